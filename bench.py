@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""bench.py — scans/sec of the MI355X-native ROLO scan-matching hot path (contract: see the task statement).
+
+One "step" = one complete registration of a synthetic OS1-128 frame pair (128 x 1024 = 131 072 points each,
+the "128k-pt frame" of BASELINE.json): per-point 20-NN covariances of both clouds, target voxel-hash build
+(UNIFORM leaf 0.5 m), SO(3) LM stage forced to exactly 20 outer iterations, continuous-time translation LM
+stage — all enqueued on one HIP stream with the two clouds already resident in HBM when the timed region starts.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode replicas|shard] [--no-cpu] [--sensor os1-128]
+
+N > 1 (launched by torch.distributed.run, one rank per GPU):
+  replicas (default) — the path partitions by frame: every rank registers its own frames, no data-path
+                       collective, "scaling": "weak"; value = total frames / max-over-ranks time.
+  shard              — one frame, source points sharded over the ranks, one RCCL all-reduce of <= 32 fp64 per LM
+                       pass; reported under "sharded" next to the replicas number.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured achievable copy rate
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--sensor", default="os1-128")
+    ap.add_argument("--leaf", type=float, default=0.5)
+    ap.add_argument("--mode", default="replicas", choices=["replicas", "shard"])
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-shard-leg", action="store_true", help="N>1: skip the extra point-sharded measurement")
+    ap.add_argument("--cpu-frames", type=int, default=1)
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import torch  # device memory, streams and torch.distributed only
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: rolo_amd has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    from rolo_amd import synth
+    from rolo_amd.rotvgicp import RotVGICP
+
+    # ---- synthetic inputs (rank-specific seed in replicas mode: independent frames) ----
+    seed = synth.SEED + (rank if args.mode == "replicas" else 0)
+    src, tgt, _ = synth.dense_pair(args.sensor, seed=seed)
+    n = src.shape[0]
+    d_src = torch.from_numpy(src).cuda()
+    d_tgt = torch.from_numpy(tgt).cuda()
+    guess = -np.asarray(synth.PREV_STEP_T, np.float64)
+    last = guess * 0.97
+
+    def new_ctx():
+        g = RotVGICP(local_rank)
+        g.setResolution(args.leaf)
+        g.setFixedIterations(20)
+        return g
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def run_steps(g, k):
+        for _ in range(k):
+            g.setInputTargetDevice(d_tgt.data_ptr(), n, 4)
+            g.setInputSourceDevice(d_src.data_ptr(), n, 4)
+            g.register_async(None, np.zeros(3), guess, last, 0.1, 0.1, 0.3)
+            g.register_wait()
+
+    def timed(g, steps, warmup):
+        run_steps(g, warmup)
+        barrier()
+        t0 = time.perf_counter()
+        run_steps(g, steps)
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    g = new_ctx()
+    if args.mode == "shard" and world > 1:
+        uid = [RotVGICP.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        g.comm_init(uid[0], rank, world)
+    dt = timed(g, args.steps, args.warmup)
+    frames_total = args.steps * (world if args.mode == "replicas" else 1)
+    value = frames_total / dt
+    rs, ts = g.last_stats, g.last_translation_stats
+    passes = rs.n_passes + ts.n_passes
+
+    out = {
+        "metric": "scans/sec (128k-pt frame, 20 GN iters)",
+        "value": value,
+        "unit": "scans/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * dt / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak" if args.mode == "replicas" else "strong",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": f"{args.sensor} dense frame pair, {n} pts/cloud, k=20 PLANE covariances, UNIFORM voxel leaf "
+                               f"{args.leaf} m, 20 SO(3) LM iterations + CT translation LM", "mode": args.mode,
+                   "parallelism": f"{args.mode}{world}", "rot_outer": rs.n_outer, "trans_outer": ts.n_outer,
+                   "passes_per_frame": passes, "n_correspondences": rs.n_correspondences},
+    }
+
+    # ---- roofline of the dominant kernel + per-kernel timing, measured live with HIP events on the ctx stream ----
+    try:
+        from rolo_amd import profile
+        out["roofline"] = profile.roofline(g, lambda: run_steps(g, 1), n, n, passes, HBM_PEAK_GBS)
+    except Exception as e:  # pragma: no cover
+        out["roofline"] = {"error": repr(e)}
+
+    # ---- optional: point-sharded leg at N>1 ----
+    if world > 1 and args.mode == "replicas" and not args.no_shard_leg:
+        src0, tgt0, _ = synth.dense_pair(args.sensor, seed=synth.SEED)
+        d_src.copy_(torch.from_numpy(src0)); d_tgt.copy_(torch.from_numpy(tgt0))
+        gs = new_ctx()
+        uid = [RotVGICP.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        gs.comm_init(uid[0], rank, world)
+        dts = timed(gs, args.steps, args.warmup)
+        out["sharded"] = {"value": args.steps / dts, "unit": "scans/s", "ms_per_step": 1e3 * dts / args.steps,
+                          "note": "one frame, source points sharded over ranks, RCCL all-reduce of 32 fp64 per LM pass"}
+
+    # ---- CPU baseline: the oracle (CPU restatement of the reference, same OpenMP structure) on this box's host cores ----
+    if rank == 0 and world == 1 and not args.no_cpu:
+        from oracle import pyorc
+        cores = os.cpu_count() or 1
+        p = pyorc.default_params(voxel_type=pyorc.VOXEL_UNIFORM, voxel_resolution=args.leaf, fixed_iterations=20, num_threads=cores)
+        t0 = time.perf_counter()
+        for _ in range(args.cpu_frames):
+            o = pyorc.Reg(p)
+            o.set_target(tgt); o.set_source(src)
+            o.align()
+            o.compute_translation(np.zeros(3), guess, last)
+        cdt = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": args.cpu_frames / cdt, "unit": "scans/s", "cores": cores, "kind": "port",
+                               "sample": f"{args.cpu_frames} frame pair(s) of the same workload, oracle/librolo_oracle.so, "
+                                         f"OMP threads = {cores}, {cdt:.1f} s"}
+
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,188 @@
+/* rolo_hip.h — C ABI of librolo_hip.so, the MI355X-native (gfx950, HIP) implementation of sdwyc/ROLO's
+ * per-frame scan-matching hot path. This is the drop-in boundary: plain pointers and sizes, no C++/torch
+ * types. Every entry point names the reference interface it replaces (paths relative to the ROLO repository).
+ *
+ * Operator API replaced: fast_gicp::RotVGICP<pcl::PointXYZI, pcl::PointXYZI> of librot_gicp.so
+ *   (include/rot_gicp/gicp/rot_vgicp.hpp:72-104, include/rot_gicp/gicp/lsq_registration.hpp:51-62), as driven by
+ *   LidarOdometry::scanRegeistration (src/lidarOdometry.cpp:460-494).
+ * Node cores replaced: ImageProjection::projectPointCloud/cloudExtraction (src/imageProjection.cpp:399-505),
+ *   FeatureExtraction::calculateSmoothness/markOccludedPoints/extractFeatures (src/featureExtraction.cpp:87-266),
+ *   LidarOdometry::cloudHandler (src/lidarOdometry.cpp:503-570).
+ *
+ * All functions return 0 on success or a negative ROLO_E* code; nothing throws or aborts. A context is
+ * single-threaded (like one RotVGICP instance); several contexts may run concurrently on one device.
+ * Host pointers unless the name ends in _device. Matrices are row-major.
+ */
+#ifndef ROLO_HIP_H
+#define ROLO_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ROLO_OK 0
+#define ROLO_EINVAL (-1)        /* bad argument */
+#define ROLO_ETOOFEW (-2)       /* cloud has fewer than k points (reference: FLANN clamps k -> UB) */
+#define ROLO_ENOCORR (-4)       /* empty correspondence set (reference: H = 0 -> NaN) */
+#define ROLO_ESTATE (-5)        /* call order: a prerequisite stage has not run */
+#define ROLO_EHIP (-6)          /* HIP runtime error; see rolo_last_error() */
+#define ROLO_EUNSUPPORTED (-7)  /* option of the reference API that this build does not implement */
+#define ROLO_EALIAS (-8)        /* reference: std::invalid_argument, rot_vgicp_impl.hpp:150-152 */
+#define ROLO_ECOMM (-9)         /* RCCL error */
+#define ROLO_EKEYRANGE (-10)    /* voxel coordinate outside +-2^20 (packed 3x21-bit key) */
+
+/* enum orders follow include/rot_gicp/gicp/gicp_settings.hpp:6-13 and lsq_registration.hpp:13 */
+enum { ROLO_REG_NONE = 0, ROLO_REG_MIN_EIG, ROLO_REG_NORMALIZED_MIN_EIG, ROLO_REG_PLANE, ROLO_REG_FROBENIUS, ROLO_REG_PLANE_S };
+enum { ROLO_DIRECT27 = 0, ROLO_DIRECT7, ROLO_DIRECT1 };
+enum { ROLO_VOXEL_POLAR = 0, ROLO_VOXEL_UNIFORM };
+enum { ROLO_OPT_GN = 0, ROLO_OPT_LM, ROLO_OPT_SO3_LM };
+
+typedef struct rolo_params {
+  int k_correspondences;         /* setCorrespondenceRandomness, rot_vgicp_impl.hpp:92-94 (20) */
+  int regularization;            /* setRegularizationMethod :97-99 (PLANE) */
+  int neighbor_search;           /* setNeighborSearchMethod :58-60 (DIRECT1) */
+  int voxel_type;                /* setResolution -> UNIFORM :44-48 ; setPolarResolution -> POLAR :51-55 */
+  double voxel_resolution;       /* setResolution (1.0) */
+  double polar_resolution[3];    /* setPolarResolution(theta, phi, r); ctor leaves (1,0,0) */
+  int optimizer;                 /* setOptimizerType, lsq_registration_impl.hpp:337-340 (SO3_LM) */
+  int max_iterations;            /* pcl::Registration::setMaximumIterations; lsq ctor :11 (64) */
+  double rotation_epsilon;       /* setRotationEpsilon :30-32 (2e-3) */
+  double transformation_epsilon; /* pcl::Registration::setTransformationEpsilon; lsq ctor :13 (5e-4) */
+  int lm_max_iterations;         /* lsq ctor :18 (10) */
+  double lm_init_lambda_factor;  /* setInitialLambdaFactor :35-37 (1e-9) */
+  int fixed_iterations;          /* harness knob: >0 runs exactly this many outer iterations of align() */
+  int q2_intended;               /* 0 as written, 1 intended continuous-time term */
+} rolo_params;
+
+typedef struct rolo_stats {
+  int n_outer;        /* outer iterations run (nr_iterations_ + 1) */
+  int converged;      /* pcl::Registration::hasConverged() */
+  int lm_failed;      /* "lm not converged!!" (lsq_registration_impl.hpp:66-69,168-171); result still returned */
+  int n_passes;       /* fused linearize/error passes over the source points */
+  int n_correspondences;
+} rolo_stats;
+
+typedef struct rolo_trace_rec { /* one LM trial; lm_debug_print_ table of lsq_registration_impl.hpp:299-305 */
+  int stage, outer, trial, accepted; /* accepted: 1 yes, 0 no, 2 rejected-but-converged */
+  double y0, yi, rho, lambda, dnorm;
+} rolo_trace_rec;
+
+typedef struct rolo_ctx rolo_ctx;
+
+const char* rolo_last_error(void);
+int rolo_device_count(void);
+
+/* RotVGICP() / ~RotVGICP(): rot_vgicp_impl.hpp:20-42. `device` = HIP device ordinal. */
+int rolo_ctx_create(int device, rolo_ctx** out);
+void rolo_ctx_destroy(rolo_ctx* ctx);
+void rolo_default_params(rolo_params* p);
+int rolo_set_params(rolo_ctx* ctx, const rolo_params* p);
+/* the HIP stream all work of this context is enqueued on (hipStream_t as void*), for event timing */
+void* rolo_ctx_stream(rolo_ctx* ctx);
+
+/* setInputTarget / setInputSource (rot_vgicp_impl.hpp:133-143 / :112-120): n records of `stride` floats with
+ * x,y,z at float offsets 0,1,2 (pcl::PointXYZI: stride 8). The cloud is copied to the device; cached
+ * covariances, voxel map and correspondences are dropped, as in the reference. */
+int rolo_set_target(rolo_ctx* ctx, const float* pts, int n, int stride);
+int rolo_set_source(rolo_ctx* ctx, const float* pts, int n, int stride);
+int rolo_set_target_device(rolo_ctx* ctx, const float* d_pts, int n, int stride);
+int rolo_set_source_device(rolo_ctx* ctx, const float* d_pts, int n, int stride);
+/* swapSourceAndTarget :69-77, clearSource :102-105, clearTarget :107-110 */
+int rolo_swap_source_and_target(rolo_ctx* ctx);
+int rolo_clear_source(rolo_ctx* ctx);
+int rolo_clear_target(rolo_ctx* ctx);
+
+/* calculate_covariances :421-496 for whichever of source/target has none. */
+int rolo_compute_covariances(rolo_ctx* ctx);
+/* getSourceCovariances / getTargetCovariances (rot_vgicp.hpp:91-97): n x 16 doubles (Matrix4d, row-major). */
+int rolo_get_source_covariances(rolo_ctx* ctx, double* covs);
+int rolo_get_target_covariances(rolo_ctx* ctx, double* covs);
+/* setSourceCovariances / setTargetCovariances :122-130 */
+int rolo_set_source_covariances(rolo_ctx* ctx, const double* covs);
+int rolo_set_target_covariances(rolo_ctx* ctx, const double* covs);
+/* debug: the k nearest neighbours (indices, squared float distances) of every source / target point */
+int rolo_get_knn(rolo_ctx* ctx, int which /*0 source, 1 target*/, int32_t* idx, float* d2);
+
+/* VmfVoxelMap::create_voxelmap (vmp_voxel.hpp:167-197) on the target. */
+int rolo_build_voxelmap(rolo_ctx* ctx);
+int rolo_num_voxels(rolo_ctx* ctx);
+/* keys V x 3, counts V, means V x 4, covs V x 16 — voxel order is unspecified (match on keys). */
+int rolo_get_voxels(rolo_ctx* ctx, int32_t* keys, int32_t* counts, double* means, double* covs);
+/* polar_coord / voxel_coord (vmp_voxel.hpp:199-211) of the target points (n x 3). */
+int rolo_get_target_voxel_keys(rolo_ctx* ctx, int32_t* keys);
+
+/* so3_linearize :293-388 / linearize :225-290 (update_correspondences :173-222 fused in), compute_error :391-417.
+ * T row-major 4x4. H/b may be NULL. */
+int rolo_so3_linearize(rolo_ctx* ctx, const double* T, double* H9, double* b3, double* err);
+int rolo_linearize(rolo_ctx* ctx, const double* T, double* H36, double* b6, double* err);
+int rolo_compute_error(rolo_ctx* ctx, const double* T, double* err);
+/* voxel_correspondences_ of the last linearize: per source point the 3-int key of its voxel, or found[i] = 0. */
+int rolo_get_correspondences(rolo_ctx* ctx, int32_t* found /* n_src * n_offsets */, int32_t* keys /* n_src * n_offsets * 3 */);
+/* t3_linearize :499-607 / compute_t_error :610-658 on the correspondences cached by the last linearize. */
+int rolo_t3_linearize(rolo_ctx* ctx, const double* t3, const double* init_guess3, const double* last_t03,
+                      double dtn, double dtn1, float ct_lambda, double* H36, double* b6, double* err);
+int rolo_compute_t_error(rolo_ctx* ctx, const double* t3, const double* init_guess3, const double* last_t03,
+                         double dtn, double dtn1, float ct_lambda, double* err);
+
+/* pcl::Registration::align(out, guess) -> RotVGICP::computeTransformation :146-160 -> LsqRegistration::
+ * computeTransformation (lsq_registration_impl.hpp:152-179). guess16 NULL = Identity. T_out_f16 =
+ * getFinalTransformation() (float); T_out_d16 (optional) the double pose it was cast from.
+ * aligned_out (optional, host): n_src x stride floats, the transformed source (pcl::transformPointCloud). */
+int rolo_align(rolo_ctx* ctx, const float* guess16, float* T_out_f16, double* T_out_d16, rolo_stats* stats);
+/* RotVGICP::computeTranslation :163-169 -> lsq :55-80. trans3_io: in = start value, out = result. */
+int rolo_compute_translation(rolo_ctx* ctx, double* trans3_io, const double* init_guess3, const double* last_t03,
+                             double dtn, double dtn1, float ct_lambda, rolo_stats* stats);
+/* Both stages back to back with no host synchronisation in between (scanRegeistration :460-500 as one enqueue).
+ * rolo_register_async only enqueues; rolo_register_wait blocks and fetches results. */
+int rolo_register_async(rolo_ctx* ctx, const float* guess16, const double* trans3_start, const double* init_guess3,
+                        const double* last_t03, double dtn, double dtn1, float ct_lambda);
+int rolo_register_wait(rolo_ctx* ctx, float* T_out_f16, double* T_out_d16, double* trans3_out,
+                       rolo_stats* rot_stats, rolo_stats* trans_stats);
+/* getFinalHessian (lsq_registration_impl.hpp:45-47): 6x6, Identity until a 6-dof LM step accepts */
+int rolo_get_final_hessian(rolo_ctx* ctx, double* H36);
+int rolo_get_trace(rolo_ctx* ctx, rolo_trace_rec* out, int cap); /* returns the number of records */
+
+/* pcl::transformPointCloud float path used at lidarOdometry.cpp:459,492 and lsq_registration_impl.hpp:78,178 */
+int rolo_transform_cloud(rolo_ctx* ctx, const float* in, float* out, int n, int stride, const float* T16);
+
+/* Multi-GPU point sharding: every rank holds the full clouds; rank r evaluates source points
+ * [r*n/W, (r+1)*n/W) in the passes and the per-pass sums are all-reduced (fp64, <= 32 values) with RCCL on the
+ * context's stream. unique_id = the 128-byte ncclUniqueId created by rank 0 (rolo_comm_unique_id) and
+ * distributed by the caller (e.g. torch.distributed broadcast). */
+int rolo_comm_unique_id(void* unique_id128);
+int rolo_comm_init(rolo_ctx* ctx, const void* unique_id128, int rank, int world);
+int rolo_comm_destroy(rolo_ctx* ctx);
+
+/* Per-kernel timing with HIP events on the context's stream (bench.py's "roofline" object). While enabled, every
+ * launch of the listed kernels is bracketed by an event pair; rolo_prof_read synchronises the stream and returns
+ * the durations (ms) of one slot in launch order, then forgets them. Returns the number of launches recorded. */
+enum { ROLO_PROF_KNN_BUILD = 0, ROLO_PROF_KNN_COV, ROLO_PROF_VOXEL_BUILD, ROLO_PROF_ROT_PASS, ROLO_PROF_TRANS_PASS, ROLO_PROF_CTRL, ROLO_PROF_N };
+int rolo_prof_enable(rolo_ctx* ctx, int on);
+int rolo_prof_read(rolo_ctx* ctx, int slot, float* ms, int cap);
+
+/* ---- front end ------------------------------------------------------------------------------------------ */
+typedef struct rolo_front_params {
+  int n_scan, horizon_scan, downsample_rate;       /* include/rolo/utility.h:310-312 */
+  float lidar_min_range, lidar_max_range;          /* :313-314 */
+  float edge_threshold, surf_threshold;            /* :318-319 */
+  float odometry_surf_leaf_size;                   /* :323 */
+} rolo_front_params;
+void rolo_front_default_params(rolo_front_params* p); /* config/params.yaml values */
+
+/* ImageProjection::projectPointCloud + cloudExtraction (src/imageProjection.cpp:399-505), deskew off.
+ * in: n_raw points (x,y,z at float offsets 0..2 of `stride`-float records) + ring[n_raw].
+ * out (host, sized n_scan*horizon_scan): extracted[N*4] (x,y,z,intensity), point_col_ind[N], point_range[N],
+ * start_ring[n_scan], end_ring[n_scan]; range_mat (optional) n_scan*horizon_scan. *n_valid = N. */
+int rolo_project_frame(rolo_ctx* ctx, const rolo_front_params* P, const float* pts, int stride, const uint16_t* ring,
+                       int n_raw, float* extracted, int32_t* point_col_ind, float* point_range, int32_t* start_ring,
+                       int32_t* end_ring, float* range_mat, int* n_valid);
+/* FeatureExtraction::calculateSmoothness + markOccludedPoints + extractFeatures (src/featureExtraction.cpp:87-266)
+ * on the arrays rolo_project_frame left on the device (call order: project, then extract).
+ * out (host): corner[nc*4], surface[ns*4] (sized for N points each); optional curvature/picked/label [N]. */
+int rolo_extract_features(rolo_ctx* ctx, const rolo_front_params* P, float* corner, int* n_corner, float* surface,
+                          int* n_surface, float* curvature, int32_t* neighbor_picked, int32_t* label);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ROLO_HIP_H */

@@ -1,0 +1,122 @@
+"""ctypes loader for rolo_amd/librolo_hip.so (the C ABI of include/rolo_hip.h).
+
+There is no CPU fallback: importing works without a GPU (so the CPU test tier can check the exported symbols),
+but every compute entry point needs a HIP device and fails loudly otherwise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "librolo_hip.so")
+
+
+class Params(C.Structure):
+    _fields_ = [("k_correspondences", C.c_int), ("regularization", C.c_int), ("neighbor_search", C.c_int),
+                ("voxel_type", C.c_int), ("voxel_resolution", C.c_double), ("polar_resolution", C.c_double * 3),
+                ("optimizer", C.c_int), ("max_iterations", C.c_int), ("rotation_epsilon", C.c_double),
+                ("transformation_epsilon", C.c_double), ("lm_max_iterations", C.c_int),
+                ("lm_init_lambda_factor", C.c_double), ("fixed_iterations", C.c_int), ("q2_intended", C.c_int)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("n_outer", C.c_int), ("converged", C.c_int), ("lm_failed", C.c_int), ("n_passes", C.c_int),
+                ("n_correspondences", C.c_int)]
+
+
+class TraceRec(C.Structure):
+    _fields_ = [("stage", C.c_int), ("outer", C.c_int), ("trial", C.c_int), ("accepted", C.c_int),
+                ("y0", C.c_double), ("yi", C.c_double), ("rho", C.c_double), ("lambda_", C.c_double),
+                ("dnorm", C.c_double)]
+
+
+class FrontParams(C.Structure):
+    _fields_ = [("n_scan", C.c_int), ("horizon_scan", C.c_int), ("downsample_rate", C.c_int),
+                ("lidar_min_range", C.c_float), ("lidar_max_range", C.c_float), ("edge_threshold", C.c_float),
+                ("surf_threshold", C.c_float), ("odometry_surf_leaf_size", C.c_float)]
+
+
+dp, fp, ip, vp = C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_int32), C.c_void_p
+
+# every symbol include/rolo_hip.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "rolo_last_error": (C.c_char_p, []),
+    "rolo_device_count": (C.c_int, []),
+    "rolo_ctx_create": (C.c_int, [C.c_int, C.POINTER(vp)]),
+    "rolo_ctx_destroy": (None, [vp]),
+    "rolo_default_params": (None, [C.POINTER(Params)]),
+    "rolo_set_params": (C.c_int, [vp, C.POINTER(Params)]),
+    "rolo_ctx_stream": (vp, [vp]),
+    "rolo_set_target": (C.c_int, [vp, fp, C.c_int, C.c_int]),
+    "rolo_set_source": (C.c_int, [vp, fp, C.c_int, C.c_int]),
+    "rolo_set_target_device": (C.c_int, [vp, vp, C.c_int, C.c_int]),
+    "rolo_set_source_device": (C.c_int, [vp, vp, C.c_int, C.c_int]),
+    "rolo_swap_source_and_target": (C.c_int, [vp]),
+    "rolo_clear_source": (C.c_int, [vp]),
+    "rolo_clear_target": (C.c_int, [vp]),
+    "rolo_compute_covariances": (C.c_int, [vp]),
+    "rolo_get_source_covariances": (C.c_int, [vp, dp]),
+    "rolo_get_target_covariances": (C.c_int, [vp, dp]),
+    "rolo_set_source_covariances": (C.c_int, [vp, dp]),
+    "rolo_set_target_covariances": (C.c_int, [vp, dp]),
+    "rolo_get_knn": (C.c_int, [vp, C.c_int, ip, fp]),
+    "rolo_build_voxelmap": (C.c_int, [vp]),
+    "rolo_num_voxels": (C.c_int, [vp]),
+    "rolo_get_voxels": (C.c_int, [vp, ip, ip, dp, dp]),
+    "rolo_get_target_voxel_keys": (C.c_int, [vp, ip]),
+    "rolo_so3_linearize": (C.c_int, [vp, dp, dp, dp, dp]),
+    "rolo_linearize": (C.c_int, [vp, dp, dp, dp, dp]),
+    "rolo_compute_error": (C.c_int, [vp, dp, dp]),
+    "rolo_get_correspondences": (C.c_int, [vp, ip, ip]),
+    "rolo_t3_linearize": (C.c_int, [vp, dp, dp, dp, C.c_double, C.c_double, C.c_float, dp, dp, dp]),
+    "rolo_compute_t_error": (C.c_int, [vp, dp, dp, dp, C.c_double, C.c_double, C.c_float, dp]),
+    "rolo_align": (C.c_int, [vp, fp, fp, dp, C.POINTER(Stats)]),
+    "rolo_compute_translation": (C.c_int, [vp, dp, dp, dp, C.c_double, C.c_double, C.c_float, C.POINTER(Stats)]),
+    "rolo_register_async": (C.c_int, [vp, fp, dp, dp, dp, C.c_double, C.c_double, C.c_float]),
+    "rolo_register_wait": (C.c_int, [vp, fp, dp, dp, C.POINTER(Stats), C.POINTER(Stats)]),
+    "rolo_get_final_hessian": (C.c_int, [vp, dp]),
+    "rolo_get_trace": (C.c_int, [vp, C.POINTER(TraceRec), C.c_int]),
+    "rolo_transform_cloud": (C.c_int, [vp, fp, fp, C.c_int, C.c_int, fp]),
+    "rolo_comm_unique_id": (C.c_int, [vp]),
+    "rolo_comm_init": (C.c_int, [vp, vp, C.c_int, C.c_int]),
+    "rolo_comm_destroy": (C.c_int, [vp]),
+    "rolo_prof_enable": (C.c_int, [vp, C.c_int]),
+    "rolo_prof_read": (C.c_int, [vp, C.c_int, fp, C.c_int]),
+    "rolo_front_default_params": (None, [C.POINTER(FrontParams)]),
+    "rolo_project_frame": (C.c_int, [vp, C.POINTER(FrontParams), fp, C.c_int, C.POINTER(C.c_uint16), C.c_int, fp, ip, fp,
+                                     ip, ip, fp, C.POINTER(C.c_int)]),
+    "rolo_extract_features": (C.c_int, [vp, C.POINTER(FrontParams), fp, C.POINTER(C.c_int), fp, C.POINTER(C.c_int), fp,
+                                        ip, ip]),
+}
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load librolo_hip.so. Raises if the extension has not been built — never falls back to anything else."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: run `python -m rolo_amd.build` (needs hipcc); "
+                               "rolo_amd has no CPU / PyTorch fallback")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            f = getattr(L, name)  # AttributeError if a declared symbol is not exported
+            f.restype = res
+            f.argtypes = args
+        _lib = L
+    return _lib
+
+
+class RoloError(RuntimeError):
+    def __init__(self, code: int, where: str):
+        msg = lib().rolo_last_error()
+        super().__init__(f"{where} failed with code {code}: {msg.decode() if msg else ''}")
+        self.code = code
+
+
+def check(code: int, where: str) -> int:
+    if code < 0:
+        raise RoloError(code, where)
+    return code

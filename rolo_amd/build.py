@@ -1,0 +1,52 @@
+"""Build librolo_hip.so (gfx950) in-tree with hipcc. Used by __graft_entry__.build() and by hand:
+
+    python -m rolo_amd.build [--force]
+"""
+from __future__ import annotations
+
+import concurrent.futures as cf
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "librolo_hip.so")
+SOURCES = ["api.hip", "knn_cov.hip", "voxelmap.hip", "passes.hip", "misc.hip", "front.hip"]
+HEADERS = ["rolo_internal.hpp", "dev_math.hpp", "voxel_dev.hpp", os.path.join("..", "..", "include", "rolo_hip.h")]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function",
+         "-Wno-unused-result"]
+
+
+def _stale(out, deps):
+    return (not os.path.exists(out)) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps if os.path.exists(d))
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    hdrs = [os.path.join(CSRC, h) for h in HEADERS]
+    objs, jobs = [], []
+    for s in SOURCES:
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(CSRC, s.replace(".hip", ".o"))
+        objs.append(obj)
+        if force or _stale(obj, [src] + hdrs):
+            jobs.append([HIPCC] + FLAGS + ["-c", src, "-o", obj])
+    if jobs:
+        with cf.ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as ex:
+            for cmd, res in zip(jobs, ex.map(lambda c: subprocess.run(c, capture_output=True, text=True), jobs)):
+                if verbose or res.returncode != 0:
+                    sys.stderr.write(" ".join(cmd) + "\n" + res.stdout + res.stderr)
+                if res.returncode != 0:
+                    raise RuntimeError("hipcc failed for " + cmd[-3])
+    if force or jobs or _stale(LIB, objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode != 0:
+            sys.stderr.write(" ".join(cmd) + "\n" + res.stdout + res.stderr)
+            raise RuntimeError("link failed")
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,814 @@
+// Host side of librolo_hip.so: the C ABI of include/rolo_hip.h. Owns the device buffers of one context (one
+// fast_gicp::RotVGICP instance in the reference's terms), enqueues the kernels of knn_cov.hip / voxelmap.hip /
+// passes.hip on the context's stream and mirrors the call semantics of the reference class
+// (include/rot_gicp/gicp/rot_vgicp.hpp:72-104, impl/rot_vgicp_impl.hpp:20-169, impl/lsq_registration_impl.hpp:55-80,
+// 152-179). No CPU fallback exists: every entry point fails with ROLO_EHIP if the HIP runtime does.
+#include "rolo_internal.hpp"
+#include <dlfcn.h>
+#include <cstdio>
+#include <cstring>
+#include <cstdlib>
+#include <string>
+#include <vector>
+#include <algorithm>
+
+using namespace rolo;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail_hip(hipError_t e, const char* what) {
+  g_err = std::string(what) + ": " + hipGetErrorString(e);
+  return ROLO_EHIP;
+}
+#define HIPCHK(x) do { hipError_t _e = (x); if (_e != hipSuccess) return fail_hip(_e, #x); } while (0)
+
+template <typename T>
+int ensure(T*& p, size_t& cap, size_t need) {
+  if (need <= cap && p) return ROLO_OK;
+  if (p) { hipError_t e = hipFree(p); if (e != hipSuccess) return fail_hip(e, "hipFree"); p = nullptr; }
+  size_t ncap = std::max<size_t>(need + need / 4, 1024);
+  hipError_t e = hipMalloc((void**)&p, ncap * sizeof(T));
+  if (e != hipSuccess) { cap = 0; return fail_hip(e, "hipMalloc"); }
+  cap = ncap;
+  return ROLO_OK;
+}
+
+// ---- RCCL through dlopen (only multi-GPU runs need it) ----
+struct Uid { char internal[128]; };
+struct Rccl {
+  void* lib = nullptr;
+  int (*GetUniqueId)(void*) = nullptr;
+  int (*CommInitRank)(void**, int, /* ncclUniqueId by value: 128 bytes */ Uid, int) = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+};
+Rccl g_rccl;
+
+int load_rccl() {
+  if (g_rccl.lib) return ROLO_OK;
+  void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+  if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+  if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+  if (!h) { g_err = std::string("dlopen librccl: ") + dlerror(); return ROLO_ECOMM; }
+  g_rccl.lib = h;
+  g_rccl.GetUniqueId = (int (*)(void*))dlsym(h, "ncclGetUniqueId");
+  g_rccl.CommInitRank = (int (*)(void**, int, Uid, int))dlsym(h, "ncclCommInitRank");
+  g_rccl.AllReduce = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(h, "ncclAllReduce");
+  g_rccl.CommDestroy = (int (*)(void*))dlsym(h, "ncclCommDestroy");
+  g_rccl.GetErrorString = (const char* (*)(int))dlsym(h, "ncclGetErrorString");
+  if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.CommDestroy) { g_err = "librccl: missing symbols"; return ROLO_ECOMM; }
+  return ROLO_OK;
+}
+constexpr int NCCL_FLOAT64 = 8;  // ncclDouble
+constexpr int NCCL_SUM = 0;
+
+}  // namespace
+
+struct rolo_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  rolo_params P;
+  CloudDev src, tgt;
+  size_t src_xyz_cap = 0, src_cov_cap = 0, tgt_xyz_cap = 0, tgt_cov_cap = 0;
+  size_t src_sorted_cap = 0, src_boxes_cap = 0, tgt_sorted_cap = 0, tgt_boxes_cap = 0;
+  size_t src_knn_cap = 0, src_knnd_cap = 0, tgt_knn_cap = 0, tgt_knnd_cap = 0;
+  bool want_knn_lists = false;
+  // kNN scratch
+  char* sort_tmp = nullptr; size_t sort_tmp_cap = 0;
+  uint32_t *keys0 = nullptr, *keys1 = nullptr, *vals0 = nullptr, *vals1 = nullptr;
+  size_t keys0_cap = 0, keys1_cap = 0, vals0_cap = 0, vals1_cap = 0;
+  int* bbox = nullptr; size_t bbox_cap = 0;
+  // voxel map
+  VoxelTable tab{};
+  size_t tab_keys_cap = 0, tab_ids_cap = 0, tab_rec_cap = 0, tab_idk_cap = 0;
+  unsigned long long* tgt_keys = nullptr; size_t tgt_keys_cap = 0;
+  int* tgt_slot = nullptr; size_t tgt_slot_cap = 0;
+  int* counters = nullptr; size_t counters_cap = 0;
+  bool have_map = false;
+  int n_voxels = 0;
+  // passes
+  int* corr[2] = {nullptr, nullptr}; size_t corr_cap[2] = {0, 0};
+  double* partials = nullptr; size_t partials_cap = 0;
+  double* sums = nullptr; size_t sums_cap = 0;
+  LmState* state = nullptr; size_t state_cap = 0;
+  rolo_trace_rec* trace = nullptr; size_t trace_cap = 0;
+  bool have_corr = false;
+  // staging
+  float* stage_in = nullptr; size_t stage_in_cap = 0;
+  float* stage_out = nullptr; size_t stage_out_cap = 0;
+  double* stage_d = nullptr; size_t stage_d_cap = 0;
+  int32_t* stage_i = nullptr; size_t stage_i_cap = 0;
+  // pinned host mirrors
+  LmState* h_state = nullptr;
+  double* h_sums = nullptr;
+  int* h_counters = nullptr;
+  // multi-GPU
+  void* comm = nullptr;
+  int rank = 0, world = 1;
+  // async registration bookkeeping
+  bool async_pending = false;
+  // per-kernel event timing (rolo_prof_*)
+  bool prof_on = false;
+  struct ProfEv { int slot; hipEvent_t a, b; };
+  std::vector<ProfEv> prof;
+  // front end (front.hip)
+  void* front = nullptr;
+};
+
+namespace {
+
+// brackets the launches issued during its lifetime with a HIP event pair on the context's stream
+struct ProfScope {
+  rolo_ctx* c; int idx = -1;
+  ProfScope(rolo_ctx* ctx, int slot) : c(ctx) {
+    if (!c->prof_on) return;
+    rolo_ctx::ProfEv e{slot, nullptr, nullptr};
+    if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) return;
+    (void)hipEventRecord(e.a, c->stream);
+    c->prof.push_back(e);
+    idx = (int)c->prof.size() - 1;
+  }
+  ~ProfScope() { if (idx >= 0) (void)hipEventRecord(c->prof[idx].b, c->stream); }
+};
+
+inline int n_offsets(const rolo_params& P) { return P.neighbor_search == ROLO_DIRECT1 ? 1 : (P.neighbor_search == ROLO_DIRECT7 ? 7 : 27); }
+
+int set_device(rolo_ctx* c) { HIPCHK(hipSetDevice(c->device)); return ROLO_OK; }
+
+int upload_cloud(rolo_ctx* c, CloudDev& cl, size_t& xyz_cap, const float* pts, int n, int stride, bool on_device) {
+  if (n < 0 || stride < 3 || (n > 0 && !pts)) { g_err = "bad cloud arguments"; return ROLO_EINVAL; }
+  int rc = ensure(cl.xyz, xyz_cap, (size_t)std::max(n, 1));
+  if (rc) return rc;
+  const float* dsrc = pts;
+  if (!on_device && n > 0) {
+    rc = ensure(c->stage_in, c->stage_in_cap, (size_t)n * stride);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(c->stage_in, pts, sizeof(float) * (size_t)n * stride, hipMemcpyHostToDevice, c->stream));
+    dsrc = c->stage_in;
+  }
+  HIPCHK(launch_pack_xyz(dsrc, stride, cl.xyz, n, c->stream));
+  cl.n = n;
+  cl.have_cov = false;
+  return ROLO_OK;
+}
+
+int build_knn_and_cov(rolo_ctx* c, CloudDev& cl, size_t& cov_cap, size_t& sorted_cap, size_t& boxes_cap, size_t& knn_cap, size_t& knnd_cap) {
+  const int n = cl.n, k = c->P.k_correspondences;
+  if (k < 1 || k > 32) { g_err = "k_correspondences must be in [1,32]"; return ROLO_EUNSUPPORTED; }
+  if (n < k) { g_err = "cloud has fewer points than k_correspondences"; return ROLO_ETOOFEW; }
+  cl.n_leaves = (n + 7) / 8;
+  int P = 2; while (P < cl.n_leaves) P <<= 1;
+  cl.P = P;
+  int rc;
+  if ((rc = ensure(cl.cov, cov_cap, 6 * (size_t)n))) return rc;
+  if ((rc = ensure(cl.sorted, sorted_cap, 8 * (size_t)cl.n_leaves))) return rc;
+  if ((rc = ensure(cl.boxes, boxes_cap, 4 * (size_t)P))) return rc;
+  if ((rc = ensure(c->keys0, c->keys0_cap, (size_t)n))) return rc;
+  if ((rc = ensure(c->keys1, c->keys1_cap, (size_t)n))) return rc;
+  if ((rc = ensure(c->vals0, c->vals0_cap, (size_t)n))) return rc;
+  if ((rc = ensure(c->vals1, c->vals1_cap, (size_t)n))) return rc;
+  if ((rc = ensure(c->bbox, c->bbox_cap, 8))) return rc;
+  size_t tmp = knn_sort_temp_bytes(n);
+  if ((rc = ensure(c->sort_tmp, c->sort_tmp_cap, tmp + 256))) return rc;
+  if (c->want_knn_lists) {
+    if ((rc = ensure(cl.knn_idx, knn_cap, (size_t)n * k))) return rc;
+    if ((rc = ensure(cl.knn_d2, knnd_cap, (size_t)n * k))) return rc;
+  }
+  { ProfScope ps(c, ROLO_PROF_KNN_BUILD); HIPCHK(launch_knn_build(cl, c->sort_tmp, tmp, c->keys0, c->keys1, c->vals0, c->vals1, c->bbox, c->stream)); }
+  { ProfScope ps(c, ROLO_PROF_KNN_COV); HIPCHK(launch_knn_cov(cl, k, c->P.regularization, c->want_knn_lists, c->stream)); }
+  cl.have_cov = true;
+  return ROLO_OK;
+}
+
+int ensure_covs(rolo_ctx* c) {
+  if (c->src.n <= 0 || c->tgt.n <= 0) { g_err = "source/target not set"; return ROLO_ESTATE; }
+  int rc;
+  if (!c->src.have_cov && (rc = build_knn_and_cov(c, c->src, c->src_cov_cap, c->src_sorted_cap, c->src_boxes_cap, c->src_knn_cap, c->src_knnd_cap))) return rc;
+  if (!c->tgt.have_cov && (rc = build_knn_and_cov(c, c->tgt, c->tgt_cov_cap, c->tgt_sorted_cap, c->tgt_boxes_cap, c->tgt_knn_cap, c->tgt_knnd_cap))) return rc;
+  return ROLO_OK;
+}
+
+void fill_table_params(rolo_ctx* c) {
+  c->tab.voxel_type = c->P.voxel_type;
+  c->tab.voxel_resolution = c->P.voxel_resolution;
+  for (int i = 0; i < 3; i++) c->tab.polar_res[i] = c->P.polar_resolution[i];
+}
+
+int ensure_map(rolo_ctx* c) {
+  int rc = ensure_covs(c);
+  if (rc) return rc;
+  if (c->have_map) return ROLO_OK;
+  const int n = c->tgt.n;
+  size_t capslots = 1024; while (capslots < 2 * (size_t)n) capslots <<= 1;
+  if ((rc = ensure(c->tab.keys, c->tab_keys_cap, capslots))) return rc;
+  if ((rc = ensure(c->tab.ids, c->tab_ids_cap, capslots))) return rc;
+  if ((rc = ensure(c->tab.rec, c->tab_rec_cap, (size_t)n * REC_DOUBLES))) return rc;
+  if ((rc = ensure(c->tab.id_keys, c->tab_idk_cap, (size_t)n))) return rc;
+  if ((rc = ensure(c->tgt_keys, c->tgt_keys_cap, (size_t)n))) return rc;
+  if ((rc = ensure(c->tgt_slot, c->tgt_slot_cap, (size_t)n))) return rc;
+  if ((rc = ensure(c->counters, c->counters_cap, 4))) return rc;
+  c->tab.mask = (unsigned)(capslots - 1);
+  fill_table_params(c);
+  { ProfScope ps(c, ROLO_PROF_VOXEL_BUILD); HIPCHK(launch_voxel_build(c->tgt, c->tab, c->tgt_keys, c->tgt_slot, c->counters, c->stream)); }
+  HIPCHK(hipMemcpyAsync(c->h_counters, c->counters, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (c->h_counters[1] != 0) { g_err = "voxel coordinate outside the packed key range"; return c->h_counters[1]; }
+  c->n_voxels = c->h_counters[0];
+  c->have_map = true;
+  c->have_corr = false;
+  return ROLO_OK;
+}
+
+void shard(const rolo_ctx* c, int& begin, int& end) {
+  const long long n = c->src.n;
+  begin = (int)(n * c->rank / c->world);
+  end = (int)(n * (c->rank + 1) / c->world);
+}
+
+int prepare_pass(rolo_ctx* c, PassArgs& a, int& grid) {
+  const int noff = n_offsets(c->P);
+  int rc;
+  for (int b = 0; b < 2; b++) if ((rc = ensure(c->corr[b], c->corr_cap[b], (size_t)c->src.n * noff))) return rc;
+  int begin, end; shard(c, begin, end);
+  grid = std::max(1, (end - begin + PASS_THREADS - 1) / PASS_THREADS);
+  if ((rc = ensure(c->partials, c->partials_cap, (size_t)grid * NV_MAX))) return rc;
+  a.src = c->src.xyz; a.cov = c->src.cov; a.n_total = c->src.n; a.begin = begin; a.end = end; a.n_off = noff;
+  a.corr[0] = c->corr[0]; a.corr[1] = c->corr[1]; a.partials = c->partials; a.tab = c->tab;
+  return ROLO_OK;
+}
+
+// one fused pass + controller, predicated on the device state
+int enqueue_pass(rolo_ctx* c, const PassArgs& a, int grid, int stage) {
+  {
+    ProfScope ps(c, stage == 1 ? ROLO_PROF_ROT_PASS : ROLO_PROF_TRANS_PASS);
+    if (stage == 1) HIPCHK(launch_rot_pass(c->P.optimizer == ROLO_OPT_SO3_LM ? 3 : 6, a, c->state, grid, c->stream));
+    else HIPCHK(launch_trans_pass(a, c->state, grid, c->stream));
+  }
+  ProfScope pc(c, ROLO_PROF_CTRL);
+  if (c->world > 1) {
+    HIPCHK(launch_reduce(c->partials, grid, c->sums, c->state, stage, c->stream));
+    int e = g_rccl.AllReduce(c->sums, c->sums, NV_MAX, NCCL_FLOAT64, NCCL_SUM, c->comm, c->stream);
+    if (e != 0) { g_err = std::string("ncclAllReduce: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "?"); return ROLO_ECOMM; }
+    HIPCHK(launch_ctrl(c->state, nullptr, 0, c->sums, c->trace, stage, c->stream));
+  } else {
+    HIPCHK(launch_ctrl(c->state, c->partials, grid, nullptr, c->trace, stage, c->stream));
+  }
+  return ROLO_OK;
+}
+
+int fetch_state(rolo_ctx* c) {
+  HIPCHK(hipMemcpyAsync(c->h_state, c->state, sizeof(LmState), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return ROLO_OK;
+}
+
+RotBegin make_rot_begin(const rolo_ctx* c, const double* R9, const double* t3, int run_trans) {
+  RotBegin b{};
+  for (int i = 0; i < 9; i++) b.R[i] = R9 ? R9[i] : ((i % 4 == 0) ? 1.0 : 0.0);
+  for (int i = 0; i < 3; i++) b.t[i] = t3 ? t3[i] : 0.0;
+  b.optimizer = c->P.optimizer; b.max_iterations = c->P.max_iterations; b.fixed_iterations = c->P.fixed_iterations;
+  b.lm_max = c->P.lm_max_iterations; b.q2_intended = c->P.q2_intended; b.rot_eps = c->P.rotation_epsilon;
+  b.trans_eps = c->P.transformation_epsilon; b.lm_init = c->P.lm_init_lambda_factor; b.run_trans = run_trans;
+  return b;
+}
+
+void guess_to_Rt(const float* g16, double* R, double* t) {
+  for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) R[i * 3 + j] = g16 ? (double)g16[i * 4 + j] : (i == j ? 1.0 : 0.0); t[i] = g16 ? (double)g16[i * 4 + 3] : 0.0; }
+}
+
+void fill_rot_outputs(const LmState* s, float* Tf, double* Td, rolo_stats* st) {
+  double T[16];
+  for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) T[i * 4 + j] = s->x0_R[i * 3 + j]; T[i * 4 + 3] = s->x0_t[i]; }
+  T[12] = T[13] = T[14] = 0; T[15] = 1;
+  if (Td) memcpy(Td, T, sizeof(T));
+  if (Tf) for (int i = 0; i < 16; i++) Tf[i] = (float)T[i];
+  if (st) { st->n_outer = s->rot_outer; st->converged = s->rot_converged; st->lm_failed = s->rot_failed; st->n_passes = s->rot_passes; st->n_correspondences = s->rot_ncorr; }
+}
+
+int rot_first_chunk(const rolo_ctx* c) { return c->P.fixed_iterations > 0 ? c->P.fixed_iterations + 3 : 8; }
+
+// drive a stage to completion: enqueue predicated passes in chunks, look at the device flags between chunks
+int run_stage(rolo_ctx* c, const PassArgs& a, int grid, int stage, int first_chunk) {
+  int chunk = first_chunk;
+  const int hard_cap = (c->P.max_iterations + 2) * (c->P.lm_max_iterations + 1) + 8;
+  int issued = 0;
+  while (true) {
+    for (int i = 0; i < chunk; i++) { int rc = enqueue_pass(c, a, grid, stage); if (rc) return rc; }
+    issued += chunk;
+    int rc = fetch_state(c);
+    if (rc) return rc;
+    const bool done = (stage == 1) ? (c->h_state->rot_done != 0) : (c->h_state->trans_done != 0);
+    if (done) return ROLO_OK;
+    if (issued > hard_cap) { g_err = "LM stage did not terminate"; return ROLO_ESTATE; }
+    chunk = 8;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* rolo_last_error(void) { return g_err.c_str(); }
+
+int rolo_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+void rolo_default_params(rolo_params* p) {
+  p->k_correspondences = 20;
+  p->regularization = ROLO_REG_PLANE;
+  p->neighbor_search = ROLO_DIRECT1;
+  p->voxel_type = ROLO_VOXEL_POLAR;
+  p->voxel_resolution = 1.0;
+  p->polar_resolution[0] = 1.0; p->polar_resolution[1] = 0.0; p->polar_resolution[2] = 0.0;
+  p->optimizer = ROLO_OPT_SO3_LM;
+  p->max_iterations = 64;
+  p->rotation_epsilon = 2e-3;
+  p->transformation_epsilon = 5e-4;
+  p->lm_max_iterations = 10;
+  p->lm_init_lambda_factor = 1e-9;
+  p->fixed_iterations = 0;
+  p->q2_intended = 0;
+}
+
+int rolo_ctx_create(int device, rolo_ctx** out) {
+  if (!out) return ROLO_EINVAL;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) { g_err = "no HIP device (librolo_hip has no CPU fallback)"; return ROLO_EHIP; }
+  if (device < 0 || device >= n) { g_err = "bad device ordinal"; return ROLO_EINVAL; }
+  rolo_ctx* c = new rolo_ctx();
+  c->device = device;
+  rolo_default_params(&c->P);
+  if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; g_err = "hipStreamCreate failed"; return ROLO_EHIP; }
+  if (hipHostMalloc((void**)&c->h_state, sizeof(LmState)) != hipSuccess || hipHostMalloc((void**)&c->h_sums, sizeof(double) * NV_MAX) != hipSuccess ||
+      hipHostMalloc((void**)&c->h_counters, sizeof(int) * 4) != hipSuccess) { delete c; g_err = "hipHostMalloc failed"; return ROLO_EHIP; }
+  memset(c->h_state, 0, sizeof(LmState));
+  int rc = ensure(c->state, c->state_cap, 1);
+  if (!rc) rc = ensure(c->sums, c->sums_cap, NV_MAX);
+  if (!rc) rc = ensure(c->trace, c->trace_cap, TRACE_CAP);
+  if (!rc && hipMemsetAsync(c->state, 0, sizeof(LmState), c->stream) != hipSuccess) rc = ROLO_EHIP;
+  if (rc) { rolo_ctx_destroy(c); return rc; }
+  *out = c;
+  return ROLO_OK;
+}
+
+void rolo_front_destroy(rolo_ctx* c);  // front.hip
+
+void rolo_ctx_destroy(rolo_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  rolo_front_destroy(c);
+  if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
+  void* bufs[] = {c->src.xyz, c->src.cov, c->src.sorted, c->src.boxes, c->src.knn_idx, c->src.knn_d2, c->tgt.xyz, c->tgt.cov, c->tgt.sorted,
+                  c->tgt.boxes, c->tgt.knn_idx, c->tgt.knn_d2, c->sort_tmp, c->keys0, c->keys1, c->vals0, c->vals1, c->bbox, c->tab.keys,
+                  c->tab.ids, c->tab.rec, c->tab.id_keys, c->tgt_keys, c->tgt_slot, c->counters, c->corr[0], c->corr[1], c->partials, c->sums,
+                  c->state, c->trace, c->stage_in, c->stage_out, c->stage_d, c->stage_i};
+  for (void* b : bufs) if (b) (void)hipFree(b);
+  if (c->h_state) (void)hipHostFree(c->h_state);
+  if (c->h_sums) (void)hipHostFree(c->h_sums);
+  if (c->h_counters) (void)hipHostFree(c->h_counters);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+void* rolo_ctx_stream(rolo_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+int rolo_set_params(rolo_ctx* c, const rolo_params* p) {
+  if (!c || !p) return ROLO_EINVAL;
+  if (p->neighbor_search < ROLO_DIRECT27 || p->neighbor_search > ROLO_DIRECT1) { g_err = "unsupported neighbor search method"; return ROLO_EUNSUPPORTED; }  // vmp_voxel.hpp:16-18 aborts
+  if (p->regularization < ROLO_REG_NONE || p->regularization > ROLO_REG_PLANE_S) { g_err = "bad regularization"; return ROLO_EINVAL; }
+  if (p->optimizer < ROLO_OPT_GN || p->optimizer > ROLO_OPT_SO3_LM) { g_err = "bad optimizer"; return ROLO_EINVAL; }
+  const bool cov_change = p->k_correspondences != c->P.k_correspondences || p->regularization != c->P.regularization;
+  const bool map_change = p->voxel_type != c->P.voxel_type || p->voxel_resolution != c->P.voxel_resolution ||
+                          memcmp(p->polar_resolution, c->P.polar_resolution, sizeof(p->polar_resolution)) != 0;
+  c->P = *p;
+  if (cov_change) { c->src.have_cov = false; c->tgt.have_cov = false; }
+  if (cov_change || map_change) { c->have_map = false; c->have_corr = false; }  // setResolution / setPolarResolution: voxelmap_.reset()
+  return ROLO_OK;
+}
+
+int rolo_set_target(rolo_ctx* c, const float* pts, int n, int stride) {
+  if (!c) return ROLO_EINVAL;
+  int rc = set_device(c); if (rc) return rc;
+  rc = upload_cloud(c, c->tgt, c->tgt_xyz_cap, pts, n, stride, false);
+  c->have_map = false; c->have_corr = false;
+  return rc;
+}
+int rolo_set_source(rolo_ctx* c, const float* pts, int n, int stride) {
+  if (!c) return ROLO_EINVAL;
+  int rc = set_device(c); if (rc) return rc;
+  rc = upload_cloud(c, c->src, c->src_xyz_cap, pts, n, stride, false);
+  c->have_corr = false;
+  return rc;
+}
+int rolo_set_target_device(rolo_ctx* c, const float* d_pts, int n, int stride) {
+  if (!c) return ROLO_EINVAL;
+  int rc = set_device(c); if (rc) return rc;
+  rc = upload_cloud(c, c->tgt, c->tgt_xyz_cap, d_pts, n, stride, true);
+  c->have_map = false; c->have_corr = false;
+  return rc;
+}
+int rolo_set_source_device(rolo_ctx* c, const float* d_pts, int n, int stride) {
+  if (!c) return ROLO_EINVAL;
+  int rc = set_device(c); if (rc) return rc;
+  rc = upload_cloud(c, c->src, c->src_xyz_cap, d_pts, n, stride, true);
+  c->have_corr = false;
+  return rc;
+}
+
+int rolo_swap_source_and_target(rolo_ctx* c) {
+  if (!c) return ROLO_EINVAL;
+  std::swap(c->src, c->tgt);
+  std::swap(c->src_xyz_cap, c->tgt_xyz_cap); std::swap(c->src_cov_cap, c->tgt_cov_cap);
+  std::swap(c->src_sorted_cap, c->tgt_sorted_cap); std::swap(c->src_boxes_cap, c->tgt_boxes_cap);
+  std::swap(c->src_knn_cap, c->tgt_knn_cap); std::swap(c->src_knnd_cap, c->tgt_knnd_cap);
+  c->have_map = false; c->have_corr = false;
+  return ROLO_OK;
+}
+int rolo_clear_source(rolo_ctx* c) { if (!c) return ROLO_EINVAL; c->src.n = 0; c->src.have_cov = false; c->have_corr = false; return ROLO_OK; }
+int rolo_clear_target(rolo_ctx* c) { if (!c) return ROLO_EINVAL; c->tgt.n = 0; c->tgt.have_cov = false; c->have_map = false; c->have_corr = false; return ROLO_OK; }
+
+int rolo_compute_covariances(rolo_ctx* c) {
+  if (!c) return ROLO_EINVAL;
+  int rc = set_device(c); if (rc) return rc;
+  return ensure_covs(c);
+}
+
+static int get_covs(rolo_ctx* c, CloudDev& cl, double* covs) {
+  if (!covs) return ROLO_EINVAL;
+  if (!cl.have_cov) { g_err = "covariances not computed"; return ROLO_ESTATE; }
+  int rc = ensure(c->stage_d, c->stage_d_cap, (size_t)cl.n * 16);
+  if (rc) return rc;
+  HIPCHK(launch_cov_unpack(cl.cov, cl.n, c->stage_d, c->stream));
+  HIPCHK(hipMemcpyAsync(covs, c->stage_d, sizeof(double) * 16 * (size_t)cl.n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return ROLO_OK;
+}
+int rolo_get_source_covariances(rolo_ctx* c, double* covs) { if (!c) return ROLO_EINVAL; int rc = set_device(c); return rc ? rc : get_covs(c, c->src, covs); }
+int rolo_get_target_covariances(rolo_ctx* c, double* covs) { if (!c) return ROLO_EINVAL; int rc = set_device(c); return rc ? rc : get_covs(c, c->tgt, covs); }
+
+static int set_covs(rolo_ctx* c, CloudDev& cl, size_t& cov_cap, const double* covs) {
+  if (!covs || cl.n <= 0) return ROLO_EINVAL;
+  int rc = ensure(cl.cov, cov_cap, 6 * (size_t)cl.n);
+  if (!rc) rc = ensure(c->stage_d, c->stage_d_cap, (size_t)cl.n * 16);
+  if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(c->stage_d, covs, sizeof(double) * 16 * (size_t)cl.n, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(launch_cov_pack(c->stage_d, cl.n, cl.cov, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  cl.have_cov = true;
+  return ROLO_OK;
+}
+int rolo_set_source_covariances(rolo_ctx* c, const double* covs) { if (!c) return ROLO_EINVAL; int rc = set_device(c); if (rc) return rc; c->have_corr = false; return set_covs(c, c->src, c->src_cov_cap, covs); }
+int rolo_set_target_covariances(rolo_ctx* c, const double* covs) { if (!c) return ROLO_EINVAL; int rc = set_device(c); if (rc) return rc; c->have_map = false; c->have_corr = false; return set_covs(c, c->tgt, c->tgt_cov_cap, covs); }
+
+int rolo_get_knn(rolo_ctx* c, int which, int32_t* idx, float* d2) {
+  if (!c || !idx || !d2) return ROLO_EINVAL;
+  int rc = set_device(c); if (rc) return rc;
+  CloudDev& cl = which == 0 ? c->src : c->tgt;
+  if (cl.n <= 0) return ROLO_ESTATE;
+  c->want_knn_lists = true;
+  cl.have_cov = false;
+  rc = which == 0 ? build_knn_and_cov(c, c->src, c->src_cov_cap, c->src_sorted_cap, c->src_boxes_cap, c->src_knn_cap, c->src_knnd_cap)
+                  : build_knn_and_cov(c, c->tgt, c->tgt_cov_cap, c->tgt_sorted_cap, c->tgt_boxes_cap, c->tgt_knn_cap, c->tgt_knnd_cap);
+  c->want_knn_lists = false;
+  if (rc) return rc;
+  const size_t m = (size_t)cl.n * c->P.k_correspondences;
+  HIPCHK(hipMemcpyAsync(idx, cl.knn_idx, sizeof(int32_t) * m, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(d2, cl.knn_d2, sizeof(float) * m, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return ROLO_OK;
+}
+
+int rolo_build_voxelmap(rolo_ctx* c) {
+  if (!c) return ROLO_EINVAL;
+  int rc = set_device(c); if (rc) return rc;
+  c->have_map = false;
+  return ensure_map(c);
+}
+int rolo_num_voxels(rolo_ctx* c) { return (c && c->have_map) ? c->n_voxels : ROLO_ESTATE; }
+
+static void unpack_key_host(unsigned long long key, int32_t* k3) {
+  k3[0] = (int)(key & 0x1fffffu) - KEY_BIAS; k3[1] = (int)((key >> 21) & 0x1fffffu) - KEY_BIAS; k3[2] = (int)((key >> 42) & 0x1fffffu) - KEY_BIAS;
+}
+
+int rolo_get_voxels(rolo_ctx* c, int32_t* keys, int32_t* counts, double* means, double* covs) {
+  if (!c) return ROLO_EINVAL;
+  if (!c->have_map) { g_err = "voxel map not built"; return ROLO_ESTATE; }
+  int rc = set_device(c); if (rc) return rc;
+  const int V = c->n_voxels;
+  std::vector<double> rec((size_t)V * REC_DOUBLES);
+  std::vector<unsigned long long> idk(V);
+  HIPCHK(hipMemcpyAsync(rec.data(), c->tab.rec, sizeof(double) * rec.size(), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(idk.data(), c->tab.id_keys, sizeof(unsigned long long) * (size_t)V, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  for (int v = 0; v < V; v++) {
+    const double* r = &rec[(size_t)v * REC_DOUBLES];
+    if (keys) unpack_key_host(idk[v], keys + 3 * (size_t)v);
+    if (counts) counts[v] = (int32_t)(r[10] + 0.5);
+    if (means) { means[4 * (size_t)v] = r[0]; means[4 * (size_t)v + 1] = r[1]; means[4 * (size_t)v + 2] = r[2]; means[4 * (size_t)v + 3] = 1.0; }
+    if (covs) {
+      double* o = covs + 16 * (size_t)v;
+      o[0] = r[3]; o[1] = r[4]; o[2] = r[5]; o[3] = 0; o[4] = r[4]; o[5] = r[6]; o[6] = r[7]; o[7] = 0;
+      o[8] = r[5]; o[9] = r[7]; o[10] = r[8]; o[11] = 0; o[12] = o[13] = o[14] = o[15] = 0;
+    }
+  }
+  return ROLO_OK;
+}
+
+int rolo_get_target_voxel_keys(rolo_ctx* c, int32_t* keys) {
+  if (!c || !keys) return ROLO_EINVAL;
+  if (c->tgt.n <= 0) return ROLO_ESTATE;
+  int rc = set_device(c); if (rc) return rc;
+  rc = ensure(c->stage_i, c->stage_i_cap, 3 * (size_t)c->tgt.n);
+  if (rc) return rc;
+  fill_table_params(c);
+  HIPCHK(launch_voxel_keys(c->tgt.xyz, c->tgt.n, c->tab, c->stage_i, c->stream));
+  HIPCHK(hipMemcpyAsync(keys, c->stage_i, sizeof(int32_t) * 3 * (size_t)c->tgt.n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return ROLO_OK;
+}
+
+// ---- stage-level evaluations ------------------------------------------------------------------------------
+static int eval_rot(rolo_ctx* c, const double* T, int dof_optimizer, int mode, double* Hout, double* bout, double* err) {
+  if (!c || !T) return ROLO_EINVAL;
+  int rc = set_device(c); if (rc) return rc;
+  if ((rc = ensure_map(c))) return rc;
+  if (mode == 1 && !c->have_corr) { g_err = "no cached correspondences: call a linearize first"; return ROLO_ESTATE; }
+  PassArgs a; int grid;
+  if ((rc = prepare_pass(c, a, grid))) return rc;
+  double R[9], t[3];
+  for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) R[i * 3 + j] = T[i * 4 + j]; t[i] = T[i * 4 + 3]; }
+  RotBegin b = make_rot_begin(c, R, t, 0);
+  b.optimizer = dof_optimizer;
+  const int dof = dof_optimizer == ROLO_OPT_SO3_LM ? 3 : 6;
+  HIPCHK(launch_eval_begin(c->state, b, mode, c->stream));
+  HIPCHK(launch_rot_pass(dof, a, c->state, grid, c->stream));
+  HIPCHK(launch_reduce(c->partials, grid, c->sums, c->state, -1, c->stream));
+  if (c->world > 1) {
+    int e = g_rccl.AllReduce(c->sums, c->sums, NV_MAX, NCCL_FLOAT64, NCCL_SUM, c->comm, c->stream);
+    if (e != 0) { g_err = "ncclAllReduce failed"; return ROLO_ECOMM; }
+  }
+  HIPCHK(launch_eval_end(c->state, c->sums, mode, c->stream));
+  HIPCHK(hipMemcpyAsync(c->h_sums, c->sums, sizeof(double) * NV_MAX, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  const double* S = c->h_sums;
+  if (mode == 0) {
+    c->have_corr = true;
+    if (err) *err = S[V_Y];
+    if (Hout) { int tt = 0; for (int i = 0; i < dof; i++) for (int j = 0; j <= i; j++) { Hout[i * dof + j] = S[V_H + tt]; Hout[j * dof + i] = S[V_H + tt]; tt++; } }
+    if (bout) for (int i = 0; i < dof; i++) bout[i] = S[V_B + i];
+    if ((int)(S[V_N] + 0.5) == 0) { g_err = "no correspondences"; return ROLO_ENOCORR; }
+  } else {
+    if (err) *err = S[V_YI];
+  }
+  return ROLO_OK;
+}
+
+int rolo_so3_linearize(rolo_ctx* c, const double* T, double* H9, double* b3, double* err) { return eval_rot(c, T, ROLO_OPT_SO3_LM, 0, H9, b3, err); }
+int rolo_linearize(rolo_ctx* c, const double* T, double* H36, double* b6, double* err) { return eval_rot(c, T, ROLO_OPT_LM, 0, H36, b6, err); }
+int rolo_compute_error(rolo_ctx* c, const double* T, double* err) { return eval_rot(c, T, ROLO_OPT_SO3_LM, 1, nullptr, nullptr, err); }
+
+int rolo_get_correspondences(rolo_ctx* c, int32_t* found, int32_t* keys) {
+  if (!c || !found) return ROLO_EINVAL;
+  if (!c->have_corr) { g_err = "no cached correspondences"; return ROLO_ESTATE; }
+  int rc = set_device(c); if (rc) return rc;
+  if ((rc = fetch_state(c))) return rc;
+  const int noff = n_offsets(c->P);
+  const size_t m = (size_t)c->src.n * noff;
+  std::vector<int> ids(m);
+  std::vector<unsigned long long> idk(std::max(c->n_voxels, 1));
+  HIPCHK(hipMemcpyAsync(ids.data(), c->corr[c->h_state->tr_cur], sizeof(int) * m, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(idk.data(), c->tab.id_keys, sizeof(unsigned long long) * (size_t)c->n_voxels, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  int b, e; shard(c, b, e);
+  for (size_t i = 0; i < m; i++) {
+    const int pt = (int)(i / noff);
+    const bool in = pt >= b && pt < e && ids[i] >= 0;
+    found[i] = in ? 1 : 0;
+    if (keys) { if (in) unpack_key_host(idk[ids[i]], keys + 3 * i); else keys[3 * i] = keys[3 * i + 1] = keys[3 * i + 2] = 0; }
+  }
+  return ROLO_OK;
+}
+
+static int eval_t3(rolo_ctx* c, const double* t3, const double* g3, const double* l3, double dtn, double dtn1, float lam, int phase, double* H36, double* b6, double* err) {
+  if (!c || !t3 || !g3 || !l3) return ROLO_EINVAL;
+  if (!c->have_corr) { g_err = "no cached correspondences: run a linearize / align first"; return ROLO_ESTATE; }
+  int rc = set_device(c); if (rc) return rc;
+  PassArgs a; int grid;
+  if ((rc = prepare_pass(c, a, grid))) return rc;
+  TransBegin tb{};
+  for (int i = 0; i < 3; i++) { tb.t0[i] = t3[i]; tb.g[i] = g3[i]; tb.l[i] = l3[i]; }
+  tb.dtn = dtn; tb.dtn1 = dtn1; tb.ct_lambda = lam; tb.direct = 0;
+  HIPCHK(launch_t3_eval_begin(c->state, tb, phase, c->stream));
+  HIPCHK(launch_trans_pass(a, c->state, grid, c->stream));
+  HIPCHK(launch_reduce(c->partials, grid, c->sums, c->state, -1, c->stream));
+  if (c->world > 1) {
+    int e = g_rccl.AllReduce(c->sums, c->sums, NV_MAX, NCCL_FLOAT64, NCCL_SUM, c->comm, c->stream);
+    if (e != 0) { g_err = "ncclAllReduce failed"; return ROLO_ECOMM; }
+  }
+  HIPCHK(launch_eval_end(c->state, c->sums, 1, c->stream));
+  HIPCHK(hipMemcpyAsync(c->h_sums, c->sums, sizeof(double) * NV_MAX, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  const double* S = c->h_sums;
+  if (phase == 0) {
+    if (err) *err = S[V_Y];
+    if (H36) { int tt = 0; for (int i = 0; i < 6; i++) for (int j = 0; j <= i; j++) { H36[i * 6 + j] = S[V_H + tt]; H36[j * 6 + i] = S[V_H + tt]; tt++; } }
+    if (b6) for (int i = 0; i < 6; i++) b6[i] = S[V_B + i];
+  } else if (err) *err = S[V_YI];
+  return ROLO_OK;
+}
+int rolo_t3_linearize(rolo_ctx* c, const double* t3, const double* g3, const double* l3, double dtn, double dtn1, float lam, double* H36, double* b6, double* err) {
+  return eval_t3(c, t3, g3, l3, dtn, dtn1, lam, 0, H36, b6, err);
+}
+int rolo_compute_t_error(rolo_ctx* c, const double* t3, const double* g3, const double* l3, double dtn, double dtn1, float lam, double* err) {
+  return eval_t3(c, t3, g3, l3, dtn, dtn1, lam, 1, nullptr, nullptr, err);
+}
+
+// ---- drivers ------------------------------------------------------------------------------------------------
+int rolo_align(rolo_ctx* c, const float* guess16, float* Tf, double* Td, rolo_stats* stats) {
+  if (!c) return ROLO_EINVAL;
+  int rc = set_device(c); if (rc) return rc;
+  c->have_map = false;  // computeTransformation: voxelmap_.reset() (rot_vgicp_impl.hpp:147)
+  if ((rc = ensure_map(c))) return rc;
+  PassArgs a; int grid;
+  if ((rc = prepare_pass(c, a, grid))) return rc;
+  double R[9], t[3]; guess_to_Rt(guess16, R, t);
+  HIPCHK(launch_rot_begin(c->state, make_rot_begin(c, R, t, 0), c->stream));
+  if ((rc = run_stage(c, a, grid, 1, rot_first_chunk(c)))) return rc;
+  c->have_corr = true;
+  fill_rot_outputs(c->h_state, Tf, Td, stats);
+  if (c->h_state->error) { g_err = "device-side error during align"; return c->h_state->error; }
+  return ROLO_OK;
+}
+
+int rolo_compute_translation(rolo_ctx* c, double* trans, const double* g3, const double* l3, double dtn, double dtn1, float lam, rolo_stats* stats) {
+  if (!c || !trans || !g3 || !l3) return ROLO_EINVAL;
+  if (!c->have_corr) { g_err = "computeTranslation needs the correspondences of a previous align"; return ROLO_ENOCORR; }
+  int rc = set_device(c); if (rc) return rc;
+  PassArgs a; int grid;
+  if ((rc = prepare_pass(c, a, grid))) return rc;
+  TransBegin tb{};
+  for (int i = 0; i < 3; i++) { tb.t0[i] = trans[i]; tb.g[i] = g3[i]; tb.l[i] = l3[i]; }
+  tb.dtn = dtn; tb.dtn1 = dtn1; tb.ct_lambda = lam; tb.direct = 1;
+  HIPCHK(launch_trans_begin(c->state, tb, c->stream));
+  if ((rc = run_stage(c, a, grid, 2, 12))) return rc;
+  const LmState* s = c->h_state;
+  for (int i = 0; i < 3; i++) trans[i] = s->t0[i];
+  if (stats) { stats->n_outer = s->trans_outer; stats->converged = s->trans_failed ? 0 : 1; stats->lm_failed = s->trans_failed; stats->n_passes = s->trans_passes; stats->n_correspondences = s->tr_n_corr; }
+  if (s->error) { g_err = "device-side error during computeTranslation"; return s->error; }
+  return ROLO_OK;
+}
+
+int rolo_register_async(rolo_ctx* c, const float* guess16, const double* trans_start, const double* g3, const double* l3, double dtn, double dtn1, float lam) {
+  if (!c || !g3 || !l3) return ROLO_EINVAL;
+  int rc = set_device(c); if (rc) return rc;
+  if ((rc = ensure_covs(c))) return rc;
+  // voxel map without the host round trip of ensure_map(): errors are picked up in rolo_register_wait
+  {
+    const int n = c->tgt.n;
+    size_t capslots = 1024; while (capslots < 2 * (size_t)n) capslots <<= 1;
+    if ((rc = ensure(c->tab.keys, c->tab_keys_cap, capslots))) return rc;
+    if ((rc = ensure(c->tab.ids, c->tab_ids_cap, capslots))) return rc;
+    if ((rc = ensure(c->tab.rec, c->tab_rec_cap, (size_t)n * REC_DOUBLES))) return rc;
+    if ((rc = ensure(c->tab.id_keys, c->tab_idk_cap, (size_t)n))) return rc;
+    if ((rc = ensure(c->tgt_keys, c->tgt_keys_cap, (size_t)n))) return rc;
+    if ((rc = ensure(c->tgt_slot, c->tgt_slot_cap, (size_t)n))) return rc;
+    if ((rc = ensure(c->counters, c->counters_cap, 4))) return rc;
+    c->tab.mask = (unsigned)(capslots - 1);
+    fill_table_params(c);
+    { ProfScope ps(c, ROLO_PROF_VOXEL_BUILD); HIPCHK(launch_voxel_build(c->tgt, c->tab, c->tgt_keys, c->tgt_slot, c->counters, c->stream)); }
+    HIPCHK(hipMemcpyAsync(c->h_counters, c->counters, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  }
+  PassArgs a; int grid;
+  if ((rc = prepare_pass(c, a, grid))) return rc;
+  double R[9], t[3]; guess_to_Rt(guess16, R, t);
+  HIPCHK(launch_rot_begin(c->state, make_rot_begin(c, R, t, 1), c->stream));
+  TransBegin tb{};
+  for (int i = 0; i < 3; i++) { tb.t0[i] = trans_start ? trans_start[i] : 0.0; tb.g[i] = g3[i]; tb.l[i] = l3[i]; }
+  tb.dtn = dtn; tb.dtn1 = dtn1; tb.ct_lambda = lam; tb.direct = 0;
+  HIPCHK(launch_trans_begin(c->state, tb, c->stream));
+  const int nrot = rot_first_chunk(c);
+  for (int i = 0; i < nrot; i++) if ((rc = enqueue_pass(c, a, grid, 1))) return rc;
+  for (int i = 0; i < 12; i++) if ((rc = enqueue_pass(c, a, grid, 2))) return rc;
+  HIPCHK(hipMemcpyAsync(c->h_state, c->state, sizeof(LmState), hipMemcpyDeviceToHost, c->stream));
+  c->async_pending = true;
+  return ROLO_OK;
+}
+
+int rolo_register_wait(rolo_ctx* c, float* Tf, double* Td, double* trans_out, rolo_stats* rs, rolo_stats* ts) {
+  if (!c) return ROLO_EINVAL;
+  if (!c->async_pending) { g_err = "no registration in flight"; return ROLO_ESTATE; }
+  int rc = set_device(c); if (rc) return rc;
+  c->async_pending = false;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (c->h_counters[1] != 0) { g_err = "voxel coordinate outside the packed key range"; return c->h_counters[1]; }
+  c->n_voxels = c->h_counters[0];
+  c->have_map = true;
+  PassArgs a; int grid;
+  if ((rc = prepare_pass(c, a, grid))) return rc;
+  // the common case finished inside the first enqueue; otherwise keep feeding predicated passes
+  if (!c->h_state->rot_done) { if ((rc = run_stage(c, a, grid, 1, 8))) return rc; }
+  if (!c->h_state->trans_done && !c->h_state->error) { if ((rc = run_stage(c, a, grid, 2, 8))) return rc; }
+  c->have_corr = true;
+  const LmState* s = c->h_state;
+  fill_rot_outputs(s, Tf, Td, rs);
+  if (trans_out) for (int i = 0; i < 3; i++) trans_out[i] = s->t0[i];
+  if (ts) { ts->n_outer = s->trans_outer; ts->converged = s->trans_failed ? 0 : 1; ts->lm_failed = s->trans_failed; ts->n_passes = s->trans_passes; ts->n_correspondences = s->tr_n_corr; }
+  if (s->error) { g_err = "device-side error during registration"; return s->error; }
+  return ROLO_OK;
+}
+
+int rolo_get_final_hessian(rolo_ctx* c, double* H36) {
+  if (!c || !H36) return ROLO_EINVAL;
+  int rc = set_device(c); if (rc) return rc;
+  if ((rc = fetch_state(c))) return rc;
+  memcpy(H36, c->h_state->final_H, sizeof(double) * 36);
+  return ROLO_OK;
+}
+
+int rolo_get_trace(rolo_ctx* c, rolo_trace_rec* out, int cap) {
+  if (!c) return ROLO_EINVAL;
+  int rc = set_device(c); if (rc) return rc;
+  if ((rc = fetch_state(c))) return rc;
+  const int n = std::min(c->h_state->trace_count, TRACE_CAP);
+  const int m = std::min(n, cap);
+  if (m > 0 && out) {
+    HIPCHK(hipMemcpyAsync(out, c->trace, sizeof(rolo_trace_rec) * (size_t)m, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+  }
+  return n;
+}
+
+int rolo_transform_cloud(rolo_ctx* c, const float* in, float* out, int n, int stride, const float* T16) {
+  if (!c || !in || !out || !T16 || n < 0 || stride < 3) return ROLO_EINVAL;
+  int rc = set_device(c); if (rc) return rc;
+  if (n == 0) return ROLO_OK;
+  if ((rc = ensure(c->stage_in, c->stage_in_cap, (size_t)n * stride))) return rc;
+  if ((rc = ensure(c->stage_out, c->stage_out_cap, (size_t)n * stride))) return rc;
+  HIPCHK(hipMemcpyAsync(c->stage_in, in, sizeof(float) * (size_t)n * stride, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(launch_transform_cloud(c->stage_in, c->stage_out, n, stride, nullptr, T16, c->stream));
+  HIPCHK(hipMemcpyAsync(out, c->stage_out, sizeof(float) * (size_t)n * stride, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return ROLO_OK;
+}
+
+int rolo_prof_enable(rolo_ctx* c, int on) {
+  if (!c) return ROLO_EINVAL;
+  c->prof_on = on != 0;
+  return ROLO_OK;
+}
+
+int rolo_prof_read(rolo_ctx* c, int slot, float* ms, int cap) {
+  if (!c || slot < 0 || slot >= ROLO_PROF_N) return ROLO_EINVAL;
+  int rc = set_device(c); if (rc) return rc;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  int n = 0;
+  std::vector<rolo_ctx::ProfEv> keep;
+  for (auto& e : c->prof) {
+    if (e.slot != slot) { keep.push_back(e); continue; }
+    float t = 0.f;
+    (void)hipEventElapsedTime(&t, e.a, e.b);
+    if (ms && n < cap) ms[n] = t;
+    n++;
+    (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b);
+  }
+  c->prof.swap(keep);
+  return n;
+}
+
+int rolo_comm_unique_id(void* uid128) {
+  if (!uid128) return ROLO_EINVAL;
+  int rc = load_rccl(); if (rc) return rc;
+  int e = g_rccl.GetUniqueId(uid128);
+  if (e != 0) { g_err = "ncclGetUniqueId failed"; return ROLO_ECOMM; }
+  return ROLO_OK;
+}
+
+int rolo_comm_init(rolo_ctx* c, const void* uid128, int rank, int world) {
+  if (!c || !uid128 || world < 1 || rank < 0 || rank >= world) return ROLO_EINVAL;
+  int rc = set_device(c); if (rc) return rc;
+  if (world == 1) { c->rank = 0; c->world = 1; return ROLO_OK; }
+  if ((rc = load_rccl())) return rc;
+  Uid id; memcpy(&id, uid128, sizeof(id));
+  int e = g_rccl.CommInitRank(&c->comm, world, id, rank);
+  if (e != 0) { g_err = std::string("ncclCommInitRank: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "?"); return ROLO_ECOMM; }
+  c->rank = rank; c->world = world;
+  c->have_corr = false;
+  return ROLO_OK;
+}
+
+int rolo_comm_destroy(rolo_ctx* c) {
+  if (!c) return ROLO_EINVAL;
+  if (c->comm && g_rccl.CommDestroy) { (void)hipStreamSynchronize(c->stream); g_rccl.CommDestroy(c->comm); }
+  c->comm = nullptr; c->rank = 0; c->world = 1;
+  return ROLO_OK;
+}
+
+}  // extern "C"

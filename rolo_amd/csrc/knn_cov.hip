@@ -1,0 +1,397 @@
+// K5 — per-point k-nearest-neighbour covariances on gfx950.
+// Replaces RotVGICP::calculate_covariances (reference include/rot_gicp/gicp/impl/rot_vgicp_impl.hpp:421-496):
+// pcl::search::KdTree::nearestKSearch (FLANN, exact, float L2, query included) + centred 4x20 outer product +
+// Eigen::JacobiSVD + regularisation.
+//
+// MI355X design: no pointer-chasing kd-tree. The cloud is sorted along a 30-bit Morton curve (rocPRIM radix
+// sort — a plain library sort), groups of 8 consecutive points become the leaves of an *implicit* complete
+// binary BVH stored in heap order (children of h are 2h, 2h+1; both child boxes sit in one 64-byte line), built
+// bottom-up in LDS, and every query walks it depth-first with a per-lane stack in LDS and a 20-entry sorted
+// candidate list in registers. Queries are issued in Morton order so the 64 lanes of a wavefront share most of
+// their path (and their cache lines). Exactness: distances are float ((dx*dx)+(dy*dy))+(dz*dz) with explicit
+// round-to-nearest ops (no FMA contraction), box bounds use the same operation order so they are true lower
+// bounds, ties are explored (<=) and broken by original point index — the neighbour set is the same pure function
+// of the cloud the oracle computes.
+#include <cstring>
+#include <string.h>
+#include "rolo_internal.hpp"
+#include "dev_math.hpp"
+#include <rocprim/rocprim.hpp>
+#include <cfloat>
+#include <climits>
+
+namespace rolo {
+
+namespace {
+
+ROLO_DEV int f2ord(float f) { int i = __float_as_int(f); return i >= 0 ? i : i ^ 0x7fffffff; }
+ROLO_DEV float ord2f(int k) { int i = k >= 0 ? k : k ^ 0x7fffffff; return __int_as_float(i); }
+
+__global__ void bbox_init_kernel(int* bbox) {
+  if (threadIdx.x < 3) bbox[threadIdx.x] = INT_MAX;
+  else if (threadIdx.x < 6) bbox[threadIdx.x] = INT_MIN;
+}
+
+__global__ __launch_bounds__(256) void bbox_kernel(const float4* __restrict__ p, int n, int* bbox) {
+  float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    float4 q = p[i];
+    mn[0] = fminf(mn[0], q.x); mn[1] = fminf(mn[1], q.y); mn[2] = fminf(mn[2], q.z);
+    mx[0] = fmaxf(mx[0], q.x); mx[1] = fmaxf(mx[1], q.y); mx[2] = fmaxf(mx[2], q.z);
+  }
+#pragma unroll
+  for (int d = 0; d < 3; d++) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      mn[d] = fminf(mn[d], __shfl_xor(mn[d], off, 64));
+      mx[d] = fmaxf(mx[d], __shfl_xor(mx[d], off, 64));
+    }
+  }
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int d = 0; d < 3; d++) { atomicMin(&bbox[d], f2ord(mn[d])); atomicMax(&bbox[3 + d], f2ord(mx[d])); }
+  }
+}
+
+ROLO_DEV uint32_t expand10(uint32_t v) {
+  v &= 0x3ffu;
+  v = (v | (v << 16)) & 0x030000ffu;
+  v = (v | (v << 8)) & 0x0300f00fu;
+  v = (v | (v << 4)) & 0x030c30c3u;
+  v = (v | (v << 2)) & 0x09249249u;
+  return v;
+}
+
+__global__ __launch_bounds__(256) void morton_kernel(const float4* __restrict__ p, int n, const int* __restrict__ bbox,
+                                                    uint32_t* keys, uint32_t* vals) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float mnx = ord2f(bbox[0]), mny = ord2f(bbox[1]), mnz = ord2f(bbox[2]);
+  float ext = fmaxf(fmaxf(ord2f(bbox[3]) - mnx, ord2f(bbox[4]) - mny), ord2f(bbox[5]) - mnz);
+  float sc = ext > 0.f ? 1024.0f / ext : 0.f;
+  float4 q = p[i];
+  int ix = min(1023, max(0, (int)((q.x - mnx) * sc)));
+  int iy = min(1023, max(0, (int)((q.y - mny) * sc)));
+  int iz = min(1023, max(0, (int)((q.z - mnz) * sc)));
+  keys[i] = expand10(ix) | (expand10(iy) << 1) | (expand10(iz) << 2);
+  vals[i] = (uint32_t)i;
+}
+
+// one thread per leaf: gather its 8 points in Morton order, write them + the leaf box
+__global__ __launch_bounds__(256) void leaf_kernel(const float4* __restrict__ p, const uint32_t* __restrict__ order, int n,
+                                                  int n_leaves, int P, float4* sorted, float4* boxes) {
+  int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= P) return;
+  float4 lo = make_float4(INFINITY, INFINITY, INFINITY, 0.f), hi = make_float4(-INFINITY, -INFINITY, -INFINITY, 0.f);
+  if (g < n_leaves) {
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      int s = 8 * g + u;
+      float4 o;
+      if (s < n) {
+        uint32_t idx = order[s];
+        float4 q = p[idx];
+        o = make_float4(q.x, q.y, q.z, __int_as_float((int)idx));
+        lo.x = fminf(lo.x, q.x); lo.y = fminf(lo.y, q.y); lo.z = fminf(lo.z, q.z);
+        hi.x = fmaxf(hi.x, q.x); hi.y = fmaxf(hi.y, q.y); hi.z = fmaxf(hi.z, q.z);
+      } else {
+        o = make_float4(INFINITY, INFINITY, INFINITY, __int_as_float(INT_MAX));
+      }
+      sorted[s] = o;
+    }
+  }
+  boxes[2 * (size_t)(P + g)] = lo;
+  boxes[2 * (size_t)(P + g) + 1] = hi;
+}
+
+// Builds log2(chunk) levels of the implicit BVH in LDS: inputs are the `count_in` nodes at heap indices
+// [count_in, 2*count_in); block b owns inputs [b*chunk, (b+1)*chunk).
+__global__ __launch_bounds__(256) void tree_reduce_kernel(float4* boxes, int count_in, int chunk) {
+  __shared__ float4 lo[512], hi[512];
+  const int b = blockIdx.x, t = threadIdx.x;
+  const size_t base_in = (size_t)count_in + (size_t)b * chunk;
+  for (int i = t; i < chunk; i += 256) { lo[i] = boxes[2 * (base_in + i)]; hi[i] = boxes[2 * (base_in + i) + 1]; }
+  __syncthreads();
+  int m = chunk, level_count = count_in;
+  while (m > 1) {
+    const int half = m >> 1;
+    level_count >>= 1;
+    float4 nlo, nhi;
+    if (t < half) {
+      float4 a = lo[2 * t], c = lo[2 * t + 1], e = hi[2 * t], f = hi[2 * t + 1];
+      nlo = make_float4(fminf(a.x, c.x), fminf(a.y, c.y), fminf(a.z, c.z), 0.f);
+      nhi = make_float4(fmaxf(e.x, f.x), fmaxf(e.y, f.y), fmaxf(e.z, f.z), 0.f);
+    }
+    __syncthreads();
+    if (t < half) {
+      lo[t] = nlo; hi[t] = nhi;
+      size_t h = (size_t)level_count + (size_t)b * half + t;
+      boxes[2 * h] = nlo; boxes[2 * h + 1] = nhi;
+    }
+    __syncthreads();
+    m = half;
+  }
+}
+
+ROLO_DEV float box_d2(const float4& lo, const float4& hi, const float4& q) {
+  float dx = fmaxf(fmaxf(__fsub_rn(lo.x, q.x), __fsub_rn(q.x, hi.x)), 0.f);
+  float dy = fmaxf(fmaxf(__fsub_rn(lo.y, q.y), __fsub_rn(q.y, hi.y)), 0.f);
+  float dz = fmaxf(fmaxf(__fsub_rn(lo.z, q.z), __fsub_rn(q.z, hi.z)), 0.f);
+  return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+}
+
+// ---- Eigen::JacobiSVD<Matrix3d> restated for one thread (rot_vgicp_impl.hpp:468) ---------------------------
+struct Rot2 { double c, s; };
+
+ROLO_DEV void make_jacobi(double x, double y, double z, Rot2& r) {
+  double deno = 2.0 * fabs(y);
+  if (deno < DBL_MIN) { r.c = 1; r.s = 0; return; }
+  double tau = (x - z) / deno;
+  double w = sqrt(tau * tau + 1.0);
+  double t = (tau > 0) ? 1.0 / (tau + w) : 1.0 / (tau - w);
+  double sign_t = t > 0 ? 1.0 : -1.0;
+  double n = 1.0 / sqrt(t * t + 1.0);
+  r.s = -sign_t * (y / fabs(y)) * fabs(t) * n;
+  r.c = n;
+}
+
+// W, U, V are 3x3 row-major in registers; p,q are compile-time so indexing stays static
+template <int P_, int Q_>
+ROLO_DEV bool jacobi_pair(double (&W)[9], double (&U)[9], double (&V)[9], double& max_diag) {
+  const double threshold = fmax(DBL_MIN, 2.0 * DBL_EPSILON * max_diag);
+  if (!(fabs(W[P_ * 3 + Q_]) > threshold || fabs(W[Q_ * 3 + P_]) > threshold)) return false;
+  double m00 = W[P_ * 3 + P_], m01 = W[P_ * 3 + Q_], m10 = W[Q_ * 3 + P_], m11 = W[Q_ * 3 + Q_];
+  Rot2 rot1;
+  double t = m00 + m11, d = m10 - m01;
+  if (fabs(d) < DBL_MIN) { rot1.s = 0; rot1.c = 1; }
+  else { double u = t / d; double tmp = sqrt(1.0 + u * u); rot1.s = 1.0 / tmp; rot1.c = u / tmp; }
+  double n00 = rot1.c * m00 + rot1.s * m10, n01 = rot1.c * m01 + rot1.s * m11, n11 = -rot1.s * m01 + rot1.c * m11;
+  Rot2 jr; make_jacobi(n00, n01, n11, jr);
+  Rot2 jl; { double c2 = jr.c, s2 = -jr.s; jl.c = rot1.c * c2 - rot1.s * s2; jl.s = rot1.c * s2 + rot1.s * c2; }
+  // W.applyOnTheLeft(p,q,jl): rows
+#pragma unroll
+  for (int k = 0; k < 3; k++) { double x = W[P_ * 3 + k], y = W[Q_ * 3 + k]; W[P_ * 3 + k] = jl.c * x + jl.s * y; W[Q_ * 3 + k] = -jl.s * x + jl.c * y; }
+  // U.applyOnTheRight(p,q,jl.transpose()) : transpose = (c,-s); right-apply of (c,s') : colp = c x - s' y ; colq = s' x + c y with s' = -s
+#pragma unroll
+  for (int k = 0; k < 3; k++) { double x = U[k * 3 + P_], y = U[k * 3 + Q_]; U[k * 3 + P_] = jl.c * x + jl.s * y; U[k * 3 + Q_] = -jl.s * x + jl.c * y; }
+  // W.applyOnTheRight(p,q,jr), V.applyOnTheRight(p,q,jr)
+#pragma unroll
+  for (int k = 0; k < 3; k++) { double x = W[k * 3 + P_], y = W[k * 3 + Q_]; W[k * 3 + P_] = jr.c * x - jr.s * y; W[k * 3 + Q_] = jr.s * x + jr.c * y; }
+#pragma unroll
+  for (int k = 0; k < 3; k++) { double x = V[k * 3 + P_], y = V[k * 3 + Q_]; V[k * 3 + P_] = jr.c * x - jr.s * y; V[k * 3 + Q_] = jr.s * x + jr.c * y; }
+  max_diag = fmax(max_diag, fmax(fabs(W[P_ * 3 + P_]), fabs(W[Q_ * 3 + Q_])));
+  return true;
+}
+
+ROLO_DEV void swap_cols(double (&M)[9], int a, int b) {
+#pragma unroll
+  for (int k = 0; k < 3; k++) { double t = M[k * 3 + a]; M[k * 3 + a] = M[k * 3 + b]; M[k * 3 + b] = t; }
+}
+
+ROLO_DEV void jacobi_svd3(const double (&A)[9], double (&U)[9], double (&sv)[3], double (&V)[9]) {
+  double scale = 0;
+#pragma unroll
+  for (int i = 0; i < 9; i++) scale = fmax(scale, fabs(A[i]));
+  if (!(scale > 0) || !isfinite(scale)) scale = 1.0;
+  double W[9];
+#pragma unroll
+  for (int i = 0; i < 9; i++) { W[i] = A[i] / scale; U[i] = (i % 4 == 0) ? 1.0 : 0.0; V[i] = (i % 4 == 0) ? 1.0 : 0.0; }
+  double max_diag = fmax(fabs(W[0]), fmax(fabs(W[4]), fabs(W[8])));
+  for (int sweep = 0; sweep < 100; sweep++) {
+    bool any = false;
+    any |= jacobi_pair<1, 0>(W, U, V, max_diag);
+    any |= jacobi_pair<2, 0>(W, U, V, max_diag);
+    any |= jacobi_pair<2, 1>(W, U, V, max_diag);
+    if (!any) break;
+  }
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    double a = fabs(W[i * 4]);
+    sv[i] = a * scale;
+    if (a != 0) { double sgn = W[i * 4] / a; U[0 * 3 + i] *= sgn; U[1 * 3 + i] *= sgn; U[2 * 3 + i] *= sgn; }
+  }
+  // sort descending with matching column swaps (3 elements: selection sort as in Eigen)
+  if (sv[1] > sv[0] && sv[1] >= sv[2]) { double t = sv[0]; sv[0] = sv[1]; sv[1] = t; swap_cols(U, 0, 1); swap_cols(V, 0, 1); }
+  else if (sv[2] > sv[0] && sv[2] > sv[1]) { double t = sv[0]; sv[0] = sv[2]; sv[2] = t; swap_cols(U, 0, 2); swap_cols(V, 0, 2); }
+  if (sv[2] > sv[1]) { double t = sv[1]; sv[1] = sv[2]; sv[2] = t; swap_cols(U, 1, 2); swap_cols(V, 1, 2); }
+}
+
+ROLO_DEV void inv3(const double (&A)[9], double (&o)[9]) {
+  double c00 = A[4] * A[8] - A[5] * A[7], c01 = A[2] * A[7] - A[1] * A[8], c02 = A[1] * A[5] - A[2] * A[4];
+  double c10 = A[5] * A[6] - A[3] * A[8], c11 = A[0] * A[8] - A[2] * A[6], c12 = A[2] * A[3] - A[0] * A[5];
+  double c20 = A[3] * A[7] - A[4] * A[6], c21 = A[1] * A[6] - A[0] * A[7], c22 = A[0] * A[4] - A[1] * A[3];
+  double det = A[0] * c00 + A[1] * c10 + A[2] * c20;
+  double inv = 1.0 / det;
+  o[0] = c00 * inv; o[1] = c01 * inv; o[2] = c02 * inv; o[3] = c10 * inv; o[4] = c11 * inv; o[5] = c12 * inv; o[6] = c20 * inv; o[7] = c21 * inv; o[8] = c22 * inv;
+}
+
+constexpr int KNN_STACK = 22;
+
+template <int KMAX>
+__global__ __launch_bounds__(256) void knn_cov_kernel(const float4* __restrict__ sorted, const float4* __restrict__ boxes,
+                                                     const float4* __restrict__ orig, int n, int n_sorted, int P, int k,
+                                                     int reg, double* __restrict__ cov, int32_t* knn_idx, float* knn_d2) {
+  __shared__ float stk_b[KNN_STACK][256];
+  __shared__ int stk_h[KNN_STACK][256];
+  const int tid = threadIdx.x;
+  const int j = blockIdx.x * 256 + tid;
+  if (j >= n_sorted) return;
+  const float4 q = sorted[j];
+  const int qi = __float_as_int(q.w);
+  if (qi == INT_MAX) return;  // padding
+  const int kk = (KMAX == 20) ? 20 : k;
+
+  float kd[KMAX];
+  int ki[KMAX];
+#pragma unroll
+  for (int u = 0; u < KMAX; u++) { kd[u] = INFINITY; ki[u] = INT_MAX; }
+  float worst_d = INFINITY;
+  int worst_i = INT_MAX;
+
+  int sp = 0;
+  int h = 1;
+  while (true) {
+    if (h < P) {
+      const float4 llo = boxes[4 * (size_t)h], lhi = boxes[4 * (size_t)h + 1], rlo = boxes[4 * (size_t)h + 2], rhi = boxes[4 * (size_t)h + 3];
+      const float bl = box_d2(llo, lhi, q), br = box_d2(rlo, rhi, q);
+      const bool okl = (bl <= worst_d) && (bl < INFINITY), okr = (br <= worst_d) && (br < INFINITY);
+      if (okl && okr) {
+        const bool lf = bl <= br;
+        stk_h[sp][tid] = lf ? 2 * h + 1 : 2 * h;
+        stk_b[sp][tid] = lf ? br : bl;
+        sp++;
+        h = lf ? 2 * h : 2 * h + 1;
+        continue;
+      }
+      if (okl) { h = 2 * h; continue; }
+      if (okr) { h = 2 * h + 1; continue; }
+    } else {
+      const int g = h - P;
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const float4 c = sorted[8 * (size_t)g + u];
+        const float dx = __fsub_rn(q.x, c.x), dy = __fsub_rn(q.y, c.y), dz = __fsub_rn(q.z, c.z);
+        float cd = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+        int ci = __float_as_int(c.w);
+        if (cd < worst_d || (cd == worst_d && ci < worst_i)) {
+          // replace the worst entry, then bubble towards the front
+#pragma unroll
+          for (int s = KMAX - 1; s >= 0; s--) if (s == kk - 1) { kd[s] = cd; ki[s] = ci; }
+#pragma unroll
+          for (int s = KMAX - 1; s >= 1; s--) {
+            if (s <= kk - 1) {
+              const bool sw = kd[s] < kd[s - 1] || (kd[s] == kd[s - 1] && ki[s] < ki[s - 1]);
+              const float td = kd[s]; const int ti = ki[s];
+              kd[s] = sw ? kd[s - 1] : td; ki[s] = sw ? ki[s - 1] : ti;
+              kd[s - 1] = sw ? td : kd[s - 1]; ki[s - 1] = sw ? ti : ki[s - 1];
+            }
+          }
+#pragma unroll
+          for (int s = KMAX - 1; s >= 0; s--) if (s == kk - 1) { worst_d = kd[s]; worst_i = ki[s]; }
+        }
+      }
+    }
+    bool got = false;
+    while (sp > 0) {
+      --sp;
+      if (stk_b[sp][tid] <= worst_d) { h = stk_h[sp][tid]; got = true; break; }
+    }
+    if (!got) break;
+  }
+
+  if (knn_idx) {
+#pragma unroll
+    for (int u = 0; u < KMAX; u++) if (u < kk) { knn_idx[(size_t)qi * kk + u] = ki[u]; knn_d2[(size_t)qi * kk + u] = kd[u]; }
+  }
+
+  // ---- covariance of the neighbourhood (rot_vgicp_impl.hpp:438-455), fp64, centred two-pass ----
+  double mx = 0, my = 0, mz = 0;
+#pragma unroll
+  for (int u = 0; u < KMAX; u++) if (u < kk) { const float4 p = orig[ki[u]]; mx += (double)p.x; my += (double)p.y; mz += (double)p.z; }
+  mx /= kk; my /= kk; mz /= kk;
+  double cxx = 0, cxy = 0, cxz = 0, cyy = 0, cyz = 0, czz = 0;
+#pragma unroll
+  for (int u = 0; u < KMAX; u++) if (u < kk) {
+    const float4 p = orig[ki[u]];
+    const double ax = (double)p.x - mx, ay = (double)p.y - my, az = (double)p.z - mz;
+    cxx += ax * ax; cxy += ax * ay; cxz += ax * az; cyy += ay * ay; cyz += ay * az; czz += az * az;
+  }
+  cxx /= kk; cxy /= kk; cxz /= kk; cyy /= kk; cyz /= kk; czz /= kk;
+
+  double out[9];
+  if (reg == ROLO_REG_NONE) {
+    out[0] = cxx; out[1] = cxy; out[2] = cxz; out[3] = cxy; out[4] = cyy; out[5] = cyz; out[6] = cxz; out[7] = cyz; out[8] = czz;
+  } else if (reg == ROLO_REG_FROBENIUS) {
+    double C[9] = {cxx + 1e-3, cxy, cxz, cxy, cyy + 1e-3, cyz, cxz, cyz, czz + 1e-3};
+    double Ci[9]; inv3(C, Ci);
+    double nrm = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) nrm += Ci[i] * Ci[i];
+    nrm = sqrt(nrm);
+#pragma unroll
+    for (int i = 0; i < 9; i++) Ci[i] /= nrm;
+    inv3(Ci, out);
+  } else {
+    const double A[9] = {cxx, cxy, cxz, cxy, cyy, cyz, cxz, cyz, czz};
+    double U[9], V[9], sv[3];
+    jacobi_svd3(A, U, sv, V);
+    double v0 = 1, v1 = 1, v2 = 1e-3;
+    if (reg == ROLO_REG_MIN_EIG) { v0 = fmax(sv[0], 1e-3); v1 = fmax(sv[1], 1e-3); v2 = fmax(sv[2], 1e-3); }
+    else if (reg == ROLO_REG_NORMALIZED_MIN_EIG) { double m = fmax(sv[0], fmax(sv[1], sv[2])); v0 = fmax(sv[0] / m, 1e-3); v1 = fmax(sv[1] / m, 1e-3); v2 = fmax(sv[2] / m, 1e-3); }
+    else if (reg == ROLO_REG_PLANE_S) { double s = sv[0] + sv[1] + sv[2]; v0 = sv[0] / s; v1 = sv[1] / s; v2 = 1e-3; }
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+      for (int b = 0; b < 3; b++) out[a * 3 + b] = (U[a * 3 + 0] * v0) * V[b * 3 + 0] + (U[a * 3 + 1] * v1) * V[b * 3 + 1] + (U[a * 3 + 2] * v2) * V[b * 3 + 2];
+  }
+  const size_t pitch = (size_t)n;
+  cov[0 * pitch + qi] = out[0];
+  cov[1 * pitch + qi] = 0.5 * (out[1] + out[3]);
+  cov[2 * pitch + qi] = 0.5 * (out[2] + out[6]);
+  cov[3 * pitch + qi] = out[4];
+  cov[4 * pitch + qi] = 0.5 * (out[5] + out[7]);
+  cov[5 * pitch + qi] = out[8];
+}
+
+}  // namespace
+
+size_t knn_sort_temp_bytes(int n) {
+  size_t bytes = 0;
+  (void)rocprim::radix_sort_pairs(nullptr, bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
+                                  (size_t)n, 0, 30, (hipStream_t)0);
+  return bytes;
+}
+
+// Morton sort + implicit BVH for one cloud. c.sorted / c.boxes must be allocated for c.n_leaves / c.P.
+hipError_t launch_knn_build(CloudDev& c, void* sort_tmp, size_t sort_tmp_bytes, uint32_t* keys0, uint32_t* keys1,
+                            uint32_t* vals0, uint32_t* vals1, int* bbox, hipStream_t s) {
+  const int n = c.n;
+  bbox_init_kernel<<<1, 64, 0, s>>>(bbox);
+  int grid = min((n + 255) / 256, 1024);
+  bbox_kernel<<<grid, 256, 0, s>>>(c.xyz, n, bbox);
+  morton_kernel<<<(n + 255) / 256, 256, 0, s>>>(c.xyz, n, bbox, keys0, vals0);
+  hipError_t e = rocprim::radix_sort_pairs(sort_tmp, sort_tmp_bytes, keys0, keys1, vals0, vals1, (size_t)n, 0, 30, s);
+  if (e != hipSuccess) return e;
+  leaf_kernel<<<(c.P + 255) / 256, 256, 0, s>>>(c.xyz, vals1, n, c.n_leaves, c.P, c.sorted, c.boxes);
+  int count = c.P;
+  while (count > 1) {
+    int chunk = count < 512 ? count : 512;
+    tree_reduce_kernel<<<count / chunk, 256, 0, s>>>(c.boxes, count, chunk);
+    count /= chunk;
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_knn_cov(CloudDev& c, int k, int regularization, bool want_lists, hipStream_t s) {
+  const int n_sorted = 8 * c.n_leaves;
+  const int grid = (n_sorted + 255) / 256;
+  int32_t* li = want_lists ? c.knn_idx : nullptr;
+  float* ld = want_lists ? c.knn_d2 : nullptr;
+  if (k == 20)
+    knn_cov_kernel<20><<<grid, 256, 0, s>>>(c.sorted, c.boxes, c.xyz, c.n, n_sorted, c.P, k, regularization, c.cov, li, ld);
+  else
+    knn_cov_kernel<32><<<grid, 256, 0, s>>>(c.sorted, c.boxes, c.xyz, c.n, n_sorted, c.P, k, regularization, c.cov, li, ld);
+  return hipGetLastError();
+}
+
+}  // namespace rolo

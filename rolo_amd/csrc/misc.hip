@@ -1,0 +1,76 @@
+// Small layout / utility kernels: strided PCL records -> float4, covariance SoA <-> Matrix4d, and the float
+// pcl::transformPointCloud used at reference src/lidarOdometry.cpp:459,492 and lsq_registration_impl.hpp:78,178.
+#include "rolo_internal.hpp"
+
+namespace rolo {
+
+namespace {
+
+__global__ __launch_bounds__(256) void pack_xyz_kernel(const float* __restrict__ in, int stride, float4* __restrict__ out, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float* p = in + (size_t)i * stride;
+  out[i] = make_float4(p[0], p[1], p[2], 1.0f);  // pcl::PointXYZI data[3] = 1
+}
+
+__global__ __launch_bounds__(256) void cov_unpack_kernel(const double* __restrict__ soa, int n, double* __restrict__ m16) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const size_t p = (size_t)n;
+  const double xx = soa[i], xy = soa[p + i], xz = soa[2 * p + i], yy = soa[3 * p + i], yz = soa[4 * p + i], zz = soa[5 * p + i];
+  double* o = m16 + (size_t)i * 16;
+  o[0] = xx; o[1] = xy; o[2] = xz; o[3] = 0;
+  o[4] = xy; o[5] = yy; o[6] = yz; o[7] = 0;
+  o[8] = xz; o[9] = yz; o[10] = zz; o[11] = 0;
+  o[12] = 0; o[13] = 0; o[14] = 0; o[15] = 0;
+}
+
+__global__ __launch_bounds__(256) void cov_pack_kernel(const double* __restrict__ m16, int n, double* __restrict__ soa) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const size_t p = (size_t)n;
+  const double* o = m16 + (size_t)i * 16;
+  soa[i] = o[0]; soa[p + i] = 0.5 * (o[1] + o[4]); soa[2 * p + i] = 0.5 * (o[2] + o[8]);
+  soa[3 * p + i] = o[5]; soa[4 * p + i] = 0.5 * (o[6] + o[9]); soa[5 * p + i] = o[10];
+}
+
+struct Mat4f { float m[16]; };
+
+// PCL >= 1.10 SSE2 Transformer::se3: p0 + (p1 + (p2 + c3)), no FMA, w <- 1, other fields copied
+__global__ __launch_bounds__(256) void transform_cloud_kernel(const float* __restrict__ in, float* __restrict__ out, int n, int stride, Mat4f T) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float* s = in + (size_t)i * stride;
+  float* d = out + (size_t)i * stride;
+  const float x = s[0], y = s[1], z = s[2];
+  float o[3];
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+    o[r] = __fadd_rn(__fmul_rn(T.m[r * 4], x), __fadd_rn(__fmul_rn(T.m[r * 4 + 1], y), __fadd_rn(__fmul_rn(T.m[r * 4 + 2], z), T.m[r * 4 + 3])));
+  for (int k = 3; k < stride; k++) d[k] = s[k];
+  d[0] = o[0]; d[1] = o[1]; d[2] = o[2];
+  if (stride > 3) d[3] = 1.0f;
+}
+
+}  // namespace
+
+hipError_t launch_pack_xyz(const float* in, int stride, float4* out, int n, hipStream_t s) {
+  if (n > 0) pack_xyz_kernel<<<(n + 255) / 256, 256, 0, s>>>(in, stride, out, n);
+  return hipGetLastError();
+}
+hipError_t launch_cov_unpack(const double* soa, int n, double* m16, hipStream_t s) {
+  if (n > 0) cov_unpack_kernel<<<(n + 255) / 256, 256, 0, s>>>(soa, n, m16);
+  return hipGetLastError();
+}
+hipError_t launch_cov_pack(const double* m16, int n, double* soa, hipStream_t s) {
+  if (n > 0) cov_pack_kernel<<<(n + 255) / 256, 256, 0, s>>>(m16, n, soa);
+  return hipGetLastError();
+}
+hipError_t launch_transform_cloud(const float* in, float* out, int n, int stride, const float*, const float* T16_host, hipStream_t s) {
+  Mat4f T;
+  for (int i = 0; i < 16; i++) T.m[i] = T16_host[i];
+  if (n > 0) transform_cloud_kernel<<<(n + 255) / 256, 256, 0, s>>>(in, out, n, stride, T);
+  return hipGetLastError();
+}
+
+}  // namespace rolo

@@ -1,0 +1,608 @@
+// K7-K12 — the Gauss-Newton / Levenberg-Marquardt iteration on gfx950.
+// Replaces (reference include/rot_gicp/gicp/impl/rot_vgicp_impl.hpp) update_correspondences :173-222,
+// so3_linearize :293-388, linearize :225-290, compute_error :391-417, t3_linearize :499-607, compute_t_error
+// :610-658, and (lsq_registration_impl.hpp) the drivers rot_step_lm :273-324, step_lm :225-270, step_gn :208-222,
+// step_t_optimize :84-139 with their convergence tests.
+//
+// MI355X design. One *fused pass* kernel per LM trial replaces the reference's separate linearize and error
+// sweeps: for every source point it (A) re-evaluates the cost at the trial pose on the correspondences and
+// Mahalanobis matrices of the current linearisation — exactly compute_error — and (B) linearises at the trial pose
+// itself (new voxel lookup, new Mahalanobis, residual, Jacobian, H, b, cost) — exactly what the reference's next
+// so3_linearize would compute if the trial is accepted. Nothing per-correspondence is cached in HBM except one
+// 4-byte voxel id: the 3x3 Mahalanobis is recomputed from the 48-byte source covariance and the 96-byte voxel
+// record instead of being stored as a 128-byte Matrix4d. Each point's contributions are summed per thread,
+// butterfly-reduced across the 64-lane wavefront, combined across the four wavefronts of the workgroup through
+// LDS, and written as one row of partials. A one-workgroup controller kernel then sums the rows in a fixed order
+// (deterministic) and runs the scalar LM logic on the device: LDLT solve, so3/se3 exponential, gain ratio,
+// damping update, convergence — so there is no host round trip inside a solve. All pass / controller launches
+// are predicated on the device-side state, so a fixed schedule of launches can be enqueued (or graph-captured)
+// without knowing how many trials the data will need.
+#include "rolo_internal.hpp"
+#include "dev_math.hpp"
+#include "voxel_dev.hpp"
+#include <cfloat>
+
+namespace rolo {
+
+namespace {
+
+// neighbor_offsets (vmp_voxel.hpp:13-47): [0] DIRECT1, [1..8) DIRECT7, [8..35) DIRECT27
+__constant__ int c_offsets[35][3] = {
+    {0, 0, 0},
+    {0, 0, 0}, {1, 0, 0}, {-1, 0, 0}, {0, 1, 0}, {0, -1, 0}, {0, 0, 1}, {0, 0, -1},
+    {-1, -1, -1}, {-1, -1, 0}, {-1, -1, 1}, {-1, 0, -1}, {-1, 0, 0}, {-1, 0, 1}, {-1, 1, -1}, {-1, 1, 0}, {-1, 1, 1},
+    {0, -1, -1},  {0, -1, 0},  {0, -1, 1},  {0, 0, -1},  {0, 0, 0},  {0, 0, 1},  {0, 1, -1},  {0, 1, 0},  {0, 1, 1},
+    {1, -1, -1},  {1, -1, 0},  {1, -1, 1},  {1, 0, -1},  {1, 0, 0},  {1, 0, 1},  {1, 1, -1},  {1, 1, 0},  {1, 1, 1}};
+
+ROLO_DEV int offset_base(int n_off) { return n_off == 1 ? 0 : (n_off == 7 ? 1 : 8); }
+
+struct Rec { Vec3 mean; Sym3 cov; double w; };
+ROLO_DEV Rec load_rec(const double* __restrict__ rec, int id) {
+  const double* r = rec + (size_t)id * REC_DOUBLES;
+  Rec o;
+  o.mean = Vec3{r[0], r[1], r[2]};
+  o.cov = Sym3{r[3], r[4], r[5], r[6], r[7], r[8]};
+  o.w = r[9];
+  return o;
+}
+
+template <int NV>
+ROLO_DEV void block_reduce_store(double (&acc)[NV], const int (&slot)[NV], double* __restrict__ out_row) {
+  __shared__ double red[PASS_THREADS / 64][NV_MAX];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int v = 0; v < NV; v++) {
+    const double s = wave_sum(acc[v]);
+    if (lane == 0) red[wv][v] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < NV) {
+    double s = 0;
+#pragma unroll
+    for (int w = 0; w < PASS_THREADS / 64; w++) s += red[w][threadIdx.x];
+    // slot[] is a compile-time table; pick by thread index
+    int sl = 0;
+#pragma unroll
+    for (int v = 0; v < NV; v++) if (threadIdx.x == v) sl = slot[v];
+    out_row[sl] = s;
+  }
+}
+
+// u_i = column i of J = [skew(a) | -I]  (rot_vgicp_impl.hpp:264-266, 353, 576-578)
+template <int DOF>
+ROLO_DEV void jacobian_cols(const Vec3& a, Vec3 (&u)[DOF]) {
+  u[0] = Vec3{0.0, a.z, -a.y};
+  u[1] = Vec3{-a.z, 0.0, a.x};
+  u[2] = Vec3{a.y, -a.x, 0.0};
+  if constexpr (DOF == 6) {
+    u[3] = Vec3{-1.0, 0.0, 0.0};
+    u[4] = Vec3{0.0, -1.0, 0.0};
+    u[5] = Vec3{0.0, 0.0, -1.0};
+  }
+}
+
+// acc layout inside the kernels: [0]=yi [1]=y [2]=n [3 .. 3+NH) H lower triangle, then b
+template <int DOF>
+ROLO_DEV void accumulate_hb(const Sym3& M, const Vec3& a, double wh, double wb_unused, const Vec3& Mv_b, double* Hacc, double* bacc) {
+  (void)wb_unused;
+  Vec3 u[DOF];
+  jacobian_cols<DOF>(a, u);
+  Vec3 Mu[DOF];
+#pragma unroll
+  for (int j = 0; j < DOF; j++) Mu[j] = sym3_mulv(M, u[j]);
+  int t = 0;
+#pragma unroll
+  for (int i = 0; i < DOF; i++) {
+#pragma unroll
+    for (int j = 0; j <= i; j++) { Hacc[t] += wh * dot3(u[i], Mu[j]); t++; }
+    bacc[i] += dot3(u[i], Mv_b);
+  }
+}
+
+template <int DOF>
+__global__ __launch_bounds__(PASS_THREADS) void rot_pass_kernel(PassArgs a, const LmState* __restrict__ st) {
+  if (st->stage != 1) return;
+  constexpr int NH = DOF * (DOF + 1) / 2;
+  constexpr int NV = 3 + NH + DOF;
+  const int phase = st->phase;
+  const int cur = st->cur;
+  const int* __restrict__ corr_old = a.corr[cur];
+  int* __restrict__ corr_new = a.corr[phase == 0 ? cur : (cur ^ 1)];
+  double R0[9], R1[9], t1[3];
+#pragma unroll
+  for (int i = 0; i < 9; i++) { R0[i] = st->x0_R[i]; R1[i] = st->xt_R[i]; }
+#pragma unroll
+  for (int i = 0; i < 3; i++) t1[i] = st->xt_t[i];
+
+  double acc[NV];
+#pragma unroll
+  for (int v = 0; v < NV; v++) acc[v] = 0.0;
+
+  const int i = a.begin + blockIdx.x * PASS_THREADS + threadIdx.x;
+  if (i < a.end) {
+    const float4 pf = a.src[i];
+    const Vec3 p{(double)pf.x, (double)pf.y, (double)pf.z};
+    const size_t pitch = (size_t)a.n_total;
+    const Sym3 CA{a.cov[i], a.cov[pitch + i], a.cov[2 * pitch + i], a.cov[3 * pitch + i], a.cov[4 * pitch + i], a.cov[5 * pitch + i]};
+    Vec3 tp = mat3_mulv(R1, p);
+    tp.x += t1[0]; tp.y += t1[1]; tp.z += t1[2];
+    const int n_off = a.n_off;
+    // (A) compute_error(xi): cached correspondences, Mahalanobis of the linearisation pose x0
+    if (phase == 1) {
+      const Sym3 RCA0 = sym3_rotate(R0, CA);
+      for (int o = 0; o < n_off; o++) {
+        const int vid = corr_old[(size_t)i * n_off + o];
+        if (vid >= 0) {
+          const Rec r = load_rec(a.tab.rec, vid);
+          const Sym3 M = sym3_inverse(sym3_add(r.cov, RCA0));
+          const Vec3 e{r.mean.x - tp.x, r.mean.y - tp.y, r.mean.z - tp.z};
+          acc[0] += r.w * dot3(e, sym3_mulv(M, e));
+        }
+      }
+    }
+    // (B) so3_linearize / linearize at xi, with update_correspondences(xi) fused in
+    int kx, ky, kz;
+    voxel_coord_dev(a.tab, tp.x, tp.y, tp.z, kx, ky, kz);
+    const Sym3 RCA1 = sym3_rotate(R1, CA);
+    const int ob = offset_base(n_off);
+    for (int o = 0; o < n_off; o++) {
+      const int vid = voxel_lookup(a.tab, kx + c_offsets[ob + o][0], ky + c_offsets[ob + o][1], kz + c_offsets[ob + o][2]);
+      corr_new[(size_t)i * n_off + o] = vid;
+      if (vid >= 0) {
+        const Rec r = load_rec(a.tab.rec, vid);
+        const Sym3 M = sym3_inverse(sym3_add(r.cov, RCA1));
+        const Vec3 e{r.mean.x - tp.x, r.mean.y - tp.y, r.mean.z - tp.z};
+        const Vec3 Me = sym3_mulv(M, e);
+        acc[1] += r.w * dot3(e, Me);
+        acc[2] += 1.0;
+        const Vec3 wMe{r.w * Me.x, r.w * Me.y, r.w * Me.z};
+        accumulate_hb<DOF>(M, tp, r.w, 0.0, wMe, &acc[3], &acc[3 + NH]);
+      }
+    }
+  }
+  int slot[NV];
+  slot[0] = V_YI; slot[1] = V_Y; slot[2] = V_N;
+#pragma unroll
+  for (int v = 0; v < NH; v++) slot[3 + v] = V_H + v;
+#pragma unroll
+  for (int v = 0; v < DOF; v++) slot[3 + NH + v] = V_B + v;
+  block_reduce_store<NV>(acc, slot, a.partials + (size_t)blockIdx.x * NV_MAX);
+}
+
+// translation stage: t3_linearize (B) + compute_t_error (A) on the correspondences of the last rotation
+// linearisation, Mahalanobis from st->tr_R.
+__global__ __launch_bounds__(PASS_THREADS) void trans_pass_kernel(PassArgs a, const LmState* __restrict__ st) {
+  if (st->stage != 2) return;
+  constexpr int NH = 21, NV = 3 + NH + 6;
+  const int phase = st->phase;
+  const int* __restrict__ corr = a.corr[st->tr_cur];
+  double R[9];
+#pragma unroll
+  for (int i = 0; i < 9; i++) R[i] = st->tr_R[i];
+  const Vec3 tt{st->tt[0], st->tt[1], st->tt[2]};
+  const Vec3 g{st->g[0], st->g[1], st->g[2]};
+  const double dtn = st->dtn, dtn1 = st->dtn1, lam_n = st->lam_over_n;
+  // last_transform keeps its initial value — Zero in t3_linearize (:539), (1,0,0,0) in compute_t_error (:637)
+  Vec3 lastA{1.0, 0.0, 0.0}, lastB{0.0, 0.0, 0.0};
+  if (st->q2_intended) { lastA = Vec3{st->l[0], st->l[1], st->l[2]}; lastB = lastA; }
+  const double inv_dtn = 1.0 / dtn;
+
+  double acc[NV];
+#pragma unroll
+  for (int v = 0; v < NV; v++) acc[v] = 0.0;
+
+  const int i = a.begin + blockIdx.x * PASS_THREADS + threadIdx.x;
+  if (i < a.end) {
+    const float4 pf = a.src[i];
+    const Vec3 p{(double)pf.x, (double)pf.y, (double)pf.z};
+    const size_t pitch = (size_t)a.n_total;
+    const Sym3 CA{a.cov[i], a.cov[pitch + i], a.cov[2 * pitch + i], a.cov[3 * pitch + i], a.cov[4 * pitch + i], a.cov[5 * pitch + i]};
+    const Sym3 RCA = sym3_rotate(R, CA);
+    const Vec3 tp{p.x + tt.x, p.y + tt.y, p.z + tt.z};
+    const Vec3 ba{p.x - g.x, p.y - g.y, p.z - g.z};
+    const Vec3 dv{(ba.x - tp.x) / dtn, (ba.y - tp.y) / dtn, (ba.z - tp.z) / dtn};
+    const Vec3 ctA{dv.x - lastA.x / dtn1, dv.y - lastA.y / dtn1, dv.z - lastA.z / dtn1};
+    const Vec3 ctB{dv.x - lastB.x / dtn1, dv.y - lastB.y / dtn1, dv.z - lastB.z / dtn1};
+    const int n_off = a.n_off;
+    for (int o = 0; o < n_off; o++) {
+      const int vid = corr[(size_t)i * n_off + o];
+      if (vid < 0) continue;
+      const Rec r = load_rec(a.tab.rec, vid);
+      const Sym3 M = sym3_inverse(sym3_add(r.cov, RCA));
+      const Vec3 e{r.mean.x - tp.x, r.mean.y - tp.y, r.mean.z - tp.z};
+      const Vec3 Me = sym3_mulv(M, e);
+      const double eMe = dot3(e, Me);
+      if (phase == 1) acc[0] += r.w * (eMe + lam_n * dot3(ctA, sym3_mulv(M, ctA)));
+      const Vec3 McB = sym3_mulv(M, ctB);
+      acc[1] += r.w * (eMe + lam_n * dot3(ctB, McB));
+      acc[2] += 1.0;
+      const double s1 = lam_n * inv_dtn;
+      const Vec3 vb{r.w * (Me.x + s1 * McB.x), r.w * (Me.y + s1 * McB.y), r.w * (Me.z + s1 * McB.z)};
+      accumulate_hb<6>(M, tp, r.w * (1.0 + lam_n * inv_dtn * inv_dtn), 0.0, vb, &acc[3], &acc[3 + NH]);
+    }
+  }
+  int slot[NV];
+  slot[0] = V_YI; slot[1] = V_Y; slot[2] = V_N;
+#pragma unroll
+  for (int v = 0; v < NH; v++) slot[3 + v] = V_H + v;
+#pragma unroll
+  for (int v = 0; v < 6; v++) slot[3 + NH + v] = V_B + v;
+  block_reduce_store<NV>(acc, slot, a.partials + (size_t)blockIdx.x * NV_MAX);
+}
+
+// fixed-order sum of the per-workgroup rows (deterministic for a given grid)
+ROLO_DEV void reduce_rows(const double* __restrict__ partials, int nblocks, double* sums /* shared, NV_MAX */) {
+  __shared__ double part[8][NV_MAX];
+  const int v = threadIdx.x & 31, q = threadIdx.x >> 5;  // 256 threads = 8 strided groups of 32 values
+  double s = 0;
+  for (int b = q; b < nblocks; b += 8) s += partials[(size_t)b * NV_MAX + v];
+  part[q][v] = s;
+  __syncthreads();
+  if (threadIdx.x < NV_MAX) {
+    double t = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) t += part[k][threadIdx.x];
+    sums[threadIdx.x] = t;
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void reduce_kernel(const double* __restrict__ partials, int nblocks, double* out, const LmState* st, int stage) {
+  if (stage >= 0 && st->stage != stage) return;
+  __shared__ double sums[NV_MAX];
+  reduce_rows(partials, nblocks, sums);
+  if (threadIdx.x < NV_MAX) out[threadIdx.x] = sums[threadIdx.x];
+}
+
+// ---- scalar LM logic (one thread) -----------------------------------------------------------------------
+template <int N>
+ROLO_DEV void ldlt_solve(const double* Hfull /* 6x6 storage, row stride 6 */, double lambda, const double* b, double* x) {
+  // Eigen::LDLT (lower, diagonal pivoting) restated; solves (H + lambda I) x = -b
+  double A[N][N];
+  int perm[N];
+  for (int i = 0; i < N; i++) { perm[i] = i; for (int j = 0; j < N; j++) { int r = i > j ? i : j, c = i > j ? j : i; A[i][j] = Hfull[r * 6 + c] + (i == j ? lambda : 0.0); } }
+  for (int k = 0; k < N; k++) {
+    int piv = k; double big = fabs(A[k][k]);
+    for (int i = k + 1; i < N; i++) if (fabs(A[i][i]) > big) { big = fabs(A[i][i]); piv = i; }
+    if (piv != k) {
+      for (int j = 0; j < N; j++) { double t = A[k][j]; A[k][j] = A[piv][j]; A[piv][j] = t; }
+      for (int i = 0; i < N; i++) { double t = A[i][k]; A[i][k] = A[i][piv]; A[i][piv] = t; }
+      int t = perm[k]; perm[k] = perm[piv]; perm[piv] = t;
+    }
+    const double d = A[k][k];
+    if (d == 0.0) continue;
+    for (int i = k + 1; i < N; i++) A[i][k] /= d;
+    for (int j = k + 1; j < N; j++) for (int i = j; i < N; i++) { A[i][j] -= A[i][k] * d * A[j][k]; A[j][i] = A[i][j]; }
+  }
+  double y[N];
+  for (int i = 0; i < N; i++) y[i] = -b[perm[i]];
+  for (int i = 0; i < N; i++) for (int j = 0; j < i; j++) y[i] -= A[i][j] * y[j];
+  for (int i = 0; i < N; i++) y[i] = (A[i][i] != 0.0) ? y[i] / A[i][i] : 0.0;
+  for (int i = N - 1; i >= 0; i--) for (int j = i + 1; j < N; j++) y[i] -= A[j][i] * y[j];
+  for (int i = 0; i < N; i++) x[perm[i]] = y[i];
+}
+
+ROLO_DEV void so3_exp_R(const double* w, double* R) {  // so3.hpp:59-77 + Quaterniond::toRotationMatrix
+  const double theta_sq = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+  double imag, real;
+  if (theta_sq < 1e-10) {
+    const double q4 = theta_sq * theta_sq;
+    imag = 0.5 - 1.0 / 48.0 * theta_sq + 1.0 / 3840.0 * q4;
+    real = 1.0 - 1.0 / 8.0 * theta_sq + 1.0 / 384.0 * q4;
+  } else {
+    const double theta = sqrt(theta_sq), half = 0.5 * theta;
+    imag = sin(half) / theta;
+    real = cos(half);
+  }
+  const double qw = real, qx = imag * w[0], qy = imag * w[1], qz = imag * w[2];
+  const double tx = 2 * qx, ty = 2 * qy, tz = 2 * qz;
+  const double twx = tx * qw, twy = ty * qw, twz = tz * qw, txx = tx * qx, txy = ty * qx, txz = tz * qx, tyy = ty * qy, tyz = tz * qy, tzz = tz * qz;
+  R[0] = 1 - (tyy + tzz); R[1] = txy - twz;       R[2] = txz + twy;
+  R[3] = txy + twz;       R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
+  R[6] = txz - twy;       R[7] = tyz + twx;       R[8] = 1 - (txx + tyy);
+}
+
+ROLO_DEV void se3_exp_Rt(const double* a, double* R, double* t) {  // so3.hpp:80-103
+  const double wx = a[0], wy = a[1], wz = a[2];
+  const double theta = sqrt(wx * wx + wy * wy + wz * wz);
+  so3_exp_R(a, R);
+  double V[9];
+  if (theta < 1e-10) {
+    for (int i = 0; i < 9; i++) V[i] = R[i];
+  } else {
+    const double O[9] = {0, -wz, wy, wz, 0, -wx, -wy, wx, 0};
+    double O2[9];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) O2[i * 3 + j] = O[i * 3] * O[j] + O[i * 3 + 1] * O[3 + j] + O[i * 3 + 2] * O[6 + j];
+    const double th2 = theta * theta;
+    const double c1 = (1.0 - cos(theta)) / th2, c2 = (theta - sin(theta)) / (th2 * theta);
+    for (int i = 0; i < 9; i++) V[i] = ((i % 4 == 0) ? 1.0 : 0.0) + c1 * O[i] + c2 * O2[i];
+  }
+  for (int i = 0; i < 3; i++) t[i] = V[i * 3] * a[3] + V[i * 3 + 1] * a[4] + V[i * 3 + 2] * a[5];
+}
+
+ROLO_DEV void unpack_hb(LmState* st, const double* S, int dof) {
+  int t = 0;
+  for (int i = 0; i < dof; i++) for (int j = 0; j <= i; j++) { st->H[i * 6 + j] = S[V_H + t]; st->H[j * 6 + i] = S[V_H + t]; t++; }
+  for (int i = 0; i < dof; i++) st->b[i] = S[V_B + i];
+  st->y0 = S[V_Y];
+  st->n_corr = (int)(S[V_N] + 0.5);
+}
+
+ROLO_DEV void trace_push(LmState* st, rolo_trace_rec* trace, int stage, int accepted, double yi, double rho, int dof) {
+  if (!trace || st->trace_count >= TRACE_CAP) { st->trace_count++; return; }
+  rolo_trace_rec& r = trace[st->trace_count++];
+  r.stage = stage; r.outer = st->outer; r.trial = st->trial; r.accepted = accepted;
+  r.y0 = st->y0; r.yi = yi; r.rho = rho; r.lambda = st->lambda;
+  double dn = 0; for (int i = 0; i < dof; i++) dn += st->d[i] * st->d[i];
+  r.dnorm = sqrt(dn);
+}
+
+// ---- rotation / 6-dof stage -------------------------------------------------------------------------------
+ROLO_DEV bool delta_converged(const LmState* st, bool rot_only) {  // lsq_registration_impl.hpp:182-191 / :328-335
+  double rmax = 0;
+  for (int i = 0; i < 9; i++) rmax = fmax(rmax, 1.0 / st->rot_eps * fabs(st->delta_R[i] - ((i % 4 == 0) ? 1.0 : 0.0)));
+  if (rot_only) return rmax < 1;
+  double tmax = 0;
+  for (int i = 0; i < 3; i++) tmax = fmax(tmax, 1.0 / st->trans_eps * fabs(st->delta_t[i]));
+  return fmax(rmax, tmax) < 1;
+}
+
+ROLO_DEV void rot_compute_step(LmState* st, int dof) {
+  if (dof == 3) {
+    ldlt_solve<3>(st->H, st->lambda, st->b, st->d);
+    st->d[3] = st->d[4] = st->d[5] = 0;
+    so3_exp_R(st->d, st->delta_R);
+    st->delta_t[0] = st->delta_t[1] = st->delta_t[2] = 0;
+  } else {
+    ldlt_solve<6>(st->H, st->lambda, st->b, st->d);
+    se3_exp_Rt(st->d, st->delta_R, st->delta_t);
+  }
+  // xi = delta * x0
+  for (int i = 0; i < 3; i++) {
+    for (int j = 0; j < 3; j++) st->xt_R[i * 3 + j] = st->delta_R[i * 3] * st->x0_R[j] + st->delta_R[i * 3 + 1] * st->x0_R[3 + j] + st->delta_R[i * 3 + 2] * st->x0_R[6 + j];
+    st->xt_t[i] = st->delta_R[i * 3] * st->x0_t[0] + st->delta_R[i * 3 + 1] * st->x0_t[1] + st->delta_R[i * 3 + 2] * st->x0_t[2] + st->delta_t[i];
+  }
+}
+
+ROLO_DEV void rot_begin_outer(LmState* st, int dof) {
+  if (st->optimizer == ROLO_OPT_GN) st->lambda = 0.0;
+  else if (st->lambda < 0.0) {
+    double m = 0; for (int i = 0; i < dof; i++) m = fmax(m, fabs(st->H[i * 7]));
+    st->lambda = st->lm_init * m;
+  }
+  st->nu = 2.0; st->trial = 0;
+  rot_compute_step(st, dof);
+}
+
+ROLO_DEV void trans_compute_step(LmState* st) {
+  ldlt_solve<6>(st->H, st->lambda, st->b, st->d);
+  double Rd[9];
+  se3_exp_Rt(st->d, Rd, st->delta_t);
+  for (int i = 0; i < 3; i++) st->tt[i] = st->delta_t[i] + st->t0[i];
+}
+ROLO_DEV void trans_begin_outer(LmState* st) {
+  if (st->lambda < 0.0) { double m = 0; for (int i = 0; i < 6; i++) m = fmax(m, fabs(st->H[i * 7])); st->lambda = st->lm_init * m; }
+  st->nu = 2.0; st->trial = 0;
+  trans_compute_step(st);
+}
+ROLO_DEV void trans_start(LmState* st) {  // lsq_registration_impl.hpp:55-61
+  st->stage = 2; st->phase = 0; st->outer = 0; st->trial = 0; st->lambda = -1.0;
+  st->trans_done = 0; st->trans_failed = 0; st->trans_outer = 0; st->trans_passes = 0;
+  for (int i = 0; i < 3; i++) st->tt[i] = st->t0[i];
+  // lambda_/pt_size: float / size_t -> float (rot_vgicp.hpp:124, rot_vgicp_impl.hpp:557)
+  st->lam_over_n = (double)(st->ct_lambda / (float)st->tr_n_corr);
+  if (st->tr_n_corr <= 0) { st->error = ROLO_ENOCORR; st->trans_failed = 1; st->trans_done = 1; st->stage = 0; }
+}
+
+ROLO_DEV void rot_finish(LmState* st, bool converged, bool failed) {
+  st->rot_done = 1; st->rot_converged = converged ? 1 : 0; st->rot_failed = failed ? 1 : 0;
+  st->rot_outer = st->outer; st->rot_ncorr = st->tr_n_corr;
+  if (st->run_trans && !st->error) trans_start(st);
+  else st->stage = 0;
+}
+
+ROLO_DEV void rot_step(LmState* st, const double* S, rolo_trace_rec* trace) {
+  const int dof = (st->optimizer == ROLO_OPT_SO3_LM) ? 3 : 6;
+  st->rot_passes++;
+  if (st->phase == 0) {
+    for (int i = 0; i < 9; i++) st->x0_R[i] = st->xt_R[i];
+    for (int i = 0; i < 3; i++) st->x0_t[i] = st->xt_t[i];
+    unpack_hb(st, S, dof);
+    st->tr_cur = st->cur; st->tr_n_corr = st->n_corr;
+    for (int i = 0; i < 9; i++) st->tr_R[i] = st->x0_R[i];
+    if (st->n_corr <= 0) { st->error = ROLO_ENOCORR; rot_finish(st, false, true); return; }
+    st->phase = 1;
+    rot_begin_outer(st, dof);
+    return;
+  }
+  const double yi = S[V_YI];
+  double den = 0;
+  for (int i = 0; i < dof; i++) den += st->d[i] * (st->lambda * st->d[i] - st->b[i]);
+  const double rho = (st->y0 - yi) / den;
+  const bool gn = st->optimizer == ROLO_OPT_GN;
+  if (!gn && rho < 0) {
+    if (delta_converged(st, dof == 3)) {  // returns true without moving x0
+      trace_push(st, trace, 0, 2, yi, rho, dof);
+      st->outer++;
+      const bool done = st->fixed_iterations > 0 ? (st->outer >= st->fixed_iterations) : true;
+      if (done) { rot_finish(st, true, false); return; }
+      rot_begin_outer(st, dof);  // the reference re-linearises at the same x0: identical H, b, y0, correspondences
+      return;
+    }
+    trace_push(st, trace, 0, 0, yi, rho, dof);
+    st->lambda = st->nu * st->lambda; st->nu = 2 * st->nu;
+    st->trial++;
+    if (st->trial >= st->lm_max) { rot_finish(st, false, true); return; }  // "lm not converged!!"
+    rot_compute_step(st, dof);
+    return;
+  }
+  trace_push(st, trace, 0, 1, gn ? NAN : yi, gn ? NAN : rho, dof);
+  for (int i = 0; i < 9; i++) st->x0_R[i] = st->xt_R[i];
+  for (int i = 0; i < 3; i++) st->x0_t[i] = st->xt_t[i];
+  if (!gn) { const double q = 2 * rho - 1; st->lambda = st->lambda * fmax(1.0 / 3.0, 1 - q * q * q); }
+  if (dof == 6) for (int i = 0; i < 36; i++) st->final_H[i] = st->H[i];  // final_hessian_ = H
+  st->outer++;
+  const bool conv = delta_converged(st, false);
+  const bool done = st->fixed_iterations > 0 ? (st->outer >= st->fixed_iterations) : (conv || st->outer >= st->max_iterations);
+  if (done) { rot_finish(st, conv, false); return; }
+  // next outer iteration: the (B) half of this pass IS so3_linearize(x0_new)
+  unpack_hb(st, S, dof);
+  st->cur ^= 1;
+  st->tr_cur = st->cur; st->tr_n_corr = st->n_corr;
+  for (int i = 0; i < 9; i++) st->tr_R[i] = st->x0_R[i];
+  if (st->n_corr <= 0) { st->error = ROLO_ENOCORR; rot_finish(st, false, true); return; }
+  rot_begin_outer(st, dof);
+}
+
+ROLO_DEV bool t_converged(const LmState* st) {  // :142-148
+  double m = 0;
+  for (int i = 0; i < 3; i++) m = fmax(m, 1.0 / st->trans_eps * fabs(st->delta_t[i]));
+  return m < 1;
+}
+ROLO_DEV void trans_finish(LmState* st, bool failed) {
+  st->trans_done = 1; st->trans_failed = failed ? 1 : 0; st->trans_outer = st->outer; st->stage = 0;
+}
+
+ROLO_DEV void trans_step(LmState* st, const double* S, rolo_trace_rec* trace) {
+  st->trans_passes++;
+  if (st->phase == 0) {
+    const int keep = st->n_corr;
+    unpack_hb(st, S, 6);
+    st->n_corr = keep;
+    st->phase = 1;
+    trans_begin_outer(st);
+    return;
+  }
+  const double yi = S[V_YI];
+  double den = 0;
+  for (int i = 0; i < 6; i++) den += st->d[i] * (st->lambda * st->d[i] - st->b[i]);
+  const double rho = (st->y0 - yi) / den;
+  if (rho < 0) {
+    if (t_converged(st)) { trace_push(st, trace, 1, 2, yi, rho, 6); st->outer++; trans_finish(st, false); return; }
+    trace_push(st, trace, 1, 0, yi, rho, 6);
+    st->lambda = st->nu * st->lambda; st->nu = 2 * st->nu;
+    st->trial++;
+    if (st->trial >= st->lm_max) { trans_finish(st, true); return; }
+    trans_compute_step(st);
+    return;
+  }
+  trace_push(st, trace, 1, 1, yi, rho, 6);
+  for (int i = 0; i < 3; i++) st->t0[i] = st->tt[i];
+  { const double q = 2 * rho - 1; st->lambda = st->lambda * fmax(1.0 / 3.0, 1 - q * q * q); }
+  st->outer++;
+  const bool conv = t_converged(st);
+  if (conv || st->outer >= st->max_iterations) { trans_finish(st, false); return; }
+  const int keep = st->n_corr;
+  unpack_hb(st, S, 6);
+  st->n_corr = keep;
+  trans_begin_outer(st);
+}
+
+__global__ __launch_bounds__(256) void ctrl_kernel(LmState* st, const double* __restrict__ partials, int nblocks,
+                                                  const double* __restrict__ sums_in, rolo_trace_rec* trace, int stage) {
+  if (st->stage != stage) return;
+  __shared__ double sums[NV_MAX];
+  if (partials) reduce_rows(partials, nblocks, sums);
+  else { if (threadIdx.x < NV_MAX) sums[threadIdx.x] = sums_in[threadIdx.x]; __syncthreads(); }
+  if (threadIdx.x == 0) {
+    if (stage == 1) rot_step(st, sums, trace);
+    else trans_step(st, sums, trace);
+  }
+}
+
+__global__ void rot_begin_kernel(LmState* st, RotBegin a) {
+  if (threadIdx.x != 0) return;
+  for (int i = 0; i < 9; i++) { st->xt_R[i] = a.R[i]; st->x0_R[i] = a.R[i]; st->tr_R[i] = a.R[i]; }
+  for (int i = 0; i < 3; i++) { st->xt_t[i] = a.t[i]; st->x0_t[i] = a.t[i]; }
+  for (int i = 0; i < 36; i++) { st->H[i] = 0; st->final_H[i] = (i % 7 == 0) ? 1.0 : 0.0; }
+  for (int i = 0; i < 6; i++) { st->b[i] = 0; st->d[i] = 0; }
+  for (int i = 0; i < 9; i++) st->delta_R[i] = (i % 4 == 0) ? 1.0 : 0.0;
+  for (int i = 0; i < 3; i++) st->delta_t[i] = 0;
+  st->y0 = 0; st->lambda = -1.0; st->nu = 2.0;
+  st->stage = 1; st->phase = 0; st->outer = 0; st->trial = 0; st->cur = 0; st->tr_cur = 0; st->n_corr = 0; st->tr_n_corr = 0;
+  st->run_trans = a.run_trans;
+  st->rot_done = 0; st->rot_converged = 0; st->rot_failed = 0; st->rot_outer = 0; st->rot_passes = 0; st->rot_ncorr = 0;
+  st->trans_done = 0; st->trans_failed = 0; st->trans_outer = 0; st->trans_passes = 0;
+  st->trace_count = 0; st->error = 0;
+  st->optimizer = a.optimizer; st->max_iterations = a.max_iterations; st->fixed_iterations = a.fixed_iterations;
+  st->lm_max = a.lm_max; st->q2_intended = a.q2_intended; st->rot_eps = a.rot_eps; st->trans_eps = a.trans_eps; st->lm_init = a.lm_init;
+}
+
+__global__ void trans_begin_kernel(LmState* st, TransBegin a) {
+  if (threadIdx.x != 0) return;
+  for (int i = 0; i < 3; i++) { st->t0[i] = a.t0[i]; st->g[i] = a.g[i]; st->l[i] = a.l[i]; }
+  st->dtn = a.dtn; st->dtn1 = a.dtn1; st->ct_lambda = a.ct_lambda;
+  if (a.direct) trans_start(st);
+}
+
+// stage-level evaluation (rolo_so3_linearize & co): mode 0 = linearise at (R,t): phase 0, correspondences into
+// buffer 0; mode 1 = error at (R,t) on the cached correspondences: phase 1.
+__global__ void eval_begin_kernel(LmState* st, RotBegin a, int mode) {
+  if (threadIdx.x != 0) return;
+  for (int i = 0; i < 9; i++) st->xt_R[i] = a.R[i];
+  for (int i = 0; i < 3; i++) st->xt_t[i] = a.t[i];
+  st->optimizer = a.optimizer; st->q2_intended = a.q2_intended;
+  st->stage = 1; st->error = 0;
+  if (mode == 0) {
+    st->phase = 0; st->cur = 0; st->tr_cur = 0;
+    for (int i = 0; i < 9; i++) { st->x0_R[i] = a.R[i]; st->tr_R[i] = a.R[i]; }
+    for (int i = 0; i < 3; i++) st->x0_t[i] = a.t[i];
+  } else {
+    st->phase = 1;
+  }
+}
+// after a mode-0 evaluation: remember the correspondence count for later t3 evaluations
+__global__ void eval_end_kernel(LmState* st, const double* sums, int mode) {
+  if (threadIdx.x != 0) return;
+  if (mode == 0) { st->n_corr = (int)(sums[V_N] + 0.5); st->tr_n_corr = st->n_corr; }
+  st->stage = 0;
+}
+__global__ void t3_eval_begin_kernel(LmState* st, TransBegin a, int phase) {
+  if (threadIdx.x != 0) return;
+  for (int i = 0; i < 3; i++) { st->tt[i] = a.t0[i]; st->t0[i] = a.t0[i]; st->g[i] = a.g[i]; st->l[i] = a.l[i]; }
+  st->dtn = a.dtn; st->dtn1 = a.dtn1; st->ct_lambda = a.ct_lambda;
+  st->lam_over_n = (double)(a.ct_lambda / (float)st->tr_n_corr);
+  st->stage = 2; st->phase = phase;
+}
+
+}  // namespace
+
+hipError_t launch_rot_pass(int dof, const PassArgs& a, const LmState* st, int grid, hipStream_t s) {
+  if (dof == 3) rot_pass_kernel<3><<<grid, PASS_THREADS, 0, s>>>(a, st);
+  else rot_pass_kernel<6><<<grid, PASS_THREADS, 0, s>>>(a, st);
+  return hipGetLastError();
+}
+hipError_t launch_trans_pass(const PassArgs& a, const LmState* st, int grid, hipStream_t s) {
+  trans_pass_kernel<<<grid, PASS_THREADS, 0, s>>>(a, st);
+  return hipGetLastError();
+}
+hipError_t launch_reduce(const double* partials, int nblocks, double* sums, const LmState* st, int stage, hipStream_t s) {
+  reduce_kernel<<<1, 256, 0, s>>>(partials, nblocks, sums, st, stage);
+  return hipGetLastError();
+}
+hipError_t launch_ctrl(LmState* st, const double* partials, int nblocks, const double* sums, rolo_trace_rec* trace, int stage, hipStream_t s) {
+  ctrl_kernel<<<1, 256, 0, s>>>(st, partials, nblocks, sums, trace, stage);
+  return hipGetLastError();
+}
+hipError_t launch_rot_begin(LmState* st, const RotBegin& a, hipStream_t s) {
+  rot_begin_kernel<<<1, 64, 0, s>>>(st, a);
+  return hipGetLastError();
+}
+hipError_t launch_trans_begin(LmState* st, const TransBegin& a, hipStream_t s) {
+  trans_begin_kernel<<<1, 64, 0, s>>>(st, a);
+  return hipGetLastError();
+}
+hipError_t launch_eval_begin(LmState* st, const RotBegin& a, int mode, hipStream_t s) {
+  eval_begin_kernel<<<1, 64, 0, s>>>(st, a, mode);
+  return hipGetLastError();
+}
+hipError_t launch_eval_end(LmState* st, const double* sums, int mode, hipStream_t s) {
+  eval_end_kernel<<<1, 64, 0, s>>>(st, sums, mode);
+  return hipGetLastError();
+}
+hipError_t launch_t3_eval_begin(LmState* st, const TransBegin& a, int phase, hipStream_t s) {
+  t3_eval_begin_kernel<<<1, 64, 0, s>>>(st, a, phase);
+  return hipGetLastError();
+}
+
+}  // namespace rolo

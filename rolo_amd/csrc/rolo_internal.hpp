@@ -1,0 +1,120 @@
+// Internal declarations shared by the HIP translation units of librolo_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/rolo_hip.h"
+
+namespace rolo {
+
+// ---- per-pass reduction layout (fp64): one row of NV_MAX values per workgroup, then one row total ----------
+constexpr int NV_MAX = 32;
+constexpr int V_YI = 0;   // cost at the trial pose on the cached correspondences (compute_error / compute_t_error)
+constexpr int V_Y = 1;    // cost of the new linearisation
+constexpr int V_N = 2;    // number of correspondences of the new linearisation
+constexpr int V_H = 3;    // lower triangle of H, row-major: (0,0) (1,0) (1,1) (2,0) ... 6 or 21 values
+constexpr int V_B = 24;   // b, 3 or 6 values
+constexpr int PASS_THREADS = 256;
+
+constexpr unsigned long long KEY_EMPTY = ~0ull;
+constexpr int KEY_BIAS = 1 << 20;
+constexpr int REC_DOUBLES = 12;  // voxel record: mean xyz, cov xx xy xz yy yz zz, sqrt(n), n, pad
+constexpr int TRACE_CAP = 2048;
+
+struct VoxelTable {
+  unsigned long long* keys;  // capacity packed keys (KEY_EMPTY = free)
+  int* ids;                  // capacity: compact voxel id of the slot
+  double* rec;               // V x REC_DOUBLES
+  unsigned long long* id_keys;  // V: packed key of each compact voxel id (for the getters)
+  unsigned mask;             // capacity - 1
+  int voxel_type;
+  double voxel_resolution;
+  double polar_res[3];
+};
+
+struct CloudDev {          // one point cloud resident in HBM
+  float4* xyz = nullptr;   // n  (x, y, z, 1)
+  double* cov = nullptr;   // 6 x n  SoA: xx | xy | xz | yy | yz | zz
+  int n = 0;
+  int cap = 0;
+  bool have_cov = false;
+  // kNN acceleration structure (Morton-ordered implicit BVH)
+  float4* sorted = nullptr;     // 8 * n_leaves, (x,y,z, bits(original index)); padding = +inf, index INT_MAX
+  float4* boxes = nullptr;      // 2 * 2P entries: node h -> boxes[2h] = lo, boxes[2h+1] = hi ; leaves h in [P, 2P)
+  int n_leaves = 0, P = 0;
+  int32_t* knn_idx = nullptr;   // debug: n x k
+  float* knn_d2 = nullptr;
+};
+
+struct LmState {
+  // poses
+  double x0_R[9], x0_t[3];  // pose of the current linearisation (x0)
+  double xt_R[9], xt_t[3];  // trial pose (xi) evaluated by the next pass
+  double tr_R[9];           // rotation of the last reference linearize call: Mahalanobis of the translation stage
+  double H[36], b[6], y0;
+  double lambda, nu;
+  double d[6];
+  double delta_R[9], delta_t[3];
+  double final_H[36];
+  // translation stage
+  double t0[3], tt[3], g[3], l[3], dtn, dtn1, lam_over_n;
+  float ct_lambda;
+  // control
+  int stage;   // 0 idle, 1 rotation / 6-dof, 2 translation
+  int phase;   // 0: first pass of the stage pending (linearise only), 1: trial pending
+  int outer, trial;
+  int cur;     // correspondence buffer that belongs to x0
+  int tr_cur;  // correspondence buffer of the last reference linearize call
+  int n_corr, tr_n_corr;
+  int run_trans;  // start the translation stage from the controller when the rotation stage ends
+  int rot_done, rot_converged, rot_failed, rot_outer, rot_passes, rot_ncorr;
+  int trans_done, trans_failed, trans_outer, trans_passes;
+  int trace_count;
+  int error;  // ROLO_E* raised on the device (key range, no correspondences)
+  // parameters
+  int optimizer, max_iterations, fixed_iterations, lm_max, q2_intended;
+  double rot_eps, trans_eps, lm_init;
+};
+
+struct PassArgs {
+  const float4* src;
+  const double* cov;  // 6 x n_total SoA
+  int n_total;        // SoA pitch
+  int begin, end;     // shard of source points evaluated by this rank
+  int n_off;          // 1, 7 or 27 neighbour offsets
+  int* corr[2];       // n_total * n_off voxel ids (-1 = none)
+  double* partials;   // gridDim.x x NV_MAX
+  VoxelTable tab;
+};
+
+// ---- launchers (defined in the .hip files) --------------------------------------------------------------
+hipError_t launch_knn_build(CloudDev& c, void* sort_tmp, size_t sort_tmp_bytes, uint32_t* keys0, uint32_t* keys1,
+                            uint32_t* vals0, uint32_t* vals1, int* bbox, hipStream_t s);
+size_t knn_sort_temp_bytes(int n);
+hipError_t launch_knn_cov(CloudDev& c, int k, int regularization, bool want_lists, hipStream_t s);
+
+hipError_t launch_voxel_build(const CloudDev& tgt, VoxelTable tab, unsigned long long* tgt_keys, int* tgt_slot,
+                              int* counters /* [0]=V, [1]=error */, hipStream_t s);
+hipError_t launch_voxel_keys(const float4* pts, int n, VoxelTable tab, int32_t* keys3, hipStream_t s);
+
+hipError_t launch_rot_pass(int dof, const PassArgs& a, const LmState* st, int grid, hipStream_t s);
+hipError_t launch_trans_pass(const PassArgs& a, const LmState* st, int grid, hipStream_t s);
+hipError_t launch_reduce(const double* partials, int nblocks, double* sums, const LmState* st, int stage, hipStream_t s);
+// controller: sums the rows of `partials` itself (single GPU) or takes all-reduced `sums` (partials == nullptr)
+hipError_t launch_ctrl(LmState* st, const double* partials, int nblocks, const double* sums, rolo_trace_rec* trace, int stage, hipStream_t s);
+
+struct RotBegin { double R[9], t[3]; int optimizer, max_iterations, fixed_iterations, lm_max, q2_intended; double rot_eps, trans_eps, lm_init; int run_trans; };
+struct TransBegin { double t0[3], g[3], l[3], dtn, dtn1; float ct_lambda; int direct; /* 1: start now (rotation already done) */ };
+hipError_t launch_rot_begin(LmState* st, const RotBegin& a, hipStream_t s);
+hipError_t launch_trans_begin(LmState* st, const TransBegin& a, hipStream_t s);
+// single evaluations for the stage-level API (rolo_so3_linearize, rolo_compute_error, rolo_t3_linearize, ...)
+hipError_t launch_eval_begin(LmState* st, const RotBegin& a, int mode, hipStream_t s);
+hipError_t launch_eval_end(LmState* st, const double* sums, int mode, hipStream_t s);
+hipError_t launch_t3_eval_begin(LmState* st, const TransBegin& a, int phase, hipStream_t s);
+
+hipError_t launch_transform_cloud(const float* in, float* out, int n, int stride, const float* T16_dev_or_null,
+                                  const float* T16_host, hipStream_t s);
+hipError_t launch_pack_xyz(const float* in, int stride, float4* out, int n, hipStream_t s);
+hipError_t launch_cov_unpack(const double* soa, int n, double* m16, hipStream_t s);   // 6 SoA -> n x 16
+hipError_t launch_cov_pack(const double* m16, int n, double* soa, hipStream_t s);     // n x 16 -> 6 SoA
+
+}  // namespace rolo

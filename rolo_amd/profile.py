@@ -1,0 +1,76 @@
+"""bench.py helper: per-kernel durations from HIP events on the context's stream, and the `roofline` object.
+
+ALGORITHMIC bytes (fixed definitions; compact records P = 16 B point, C = 24 B covariance,
+R = 48 B voxel record, S = 16 B hash slot):
+  knn_cov_kernel   (K5)      : (P + K*P + C) = 360 B per point of the cloud it is launched on
+  rot_pass_kernel  (K7+K8+K10): (P + C + S + R) = 104 B per source point per pass
+  trans_pass_kernel (K11)     : 104 B per source point per pass
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import os
+
+import numpy as np
+
+from ._lib import lib, check
+
+SLOTS = {"knn_build": 0, "knn_cov": 1, "voxel_build": 2, "rot_pass": 3, "trans_pass": 4, "ctrl": 5}
+BYTES_PER_POINT = {"knn_cov": 360.0, "rot_pass": 104.0, "trans_pass": 104.0}
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def read_slot(g, name, cap=4096):
+    buf = (C.c_float * cap)()
+    n = check(lib().rolo_prof_read(g._h, SLOTS[name], buf, cap), "rolo_prof_read")
+    return np.array(buf[:min(n, cap)], np.float64)
+
+
+def kernel_times(g, run_one_step, reps=3):
+    """Returns {slot: list of per-launch ms} accumulated over `reps` steps with event bracketing enabled."""
+    check(lib().rolo_prof_enable(g._h, 1), "rolo_prof_enable")
+    acc = {k: [] for k in SLOTS}
+    try:
+        for _ in range(reps):
+            run_one_step()
+            for k in SLOTS:
+                acc[k].append(read_slot(g, k))
+    finally:
+        lib().rolo_prof_enable(g._h, 0)
+    return acc
+
+
+def roofline(g, run_one_step, n_src, n_tgt, passes_per_frame, hbm_peak_gbs, reps=3):
+    acc = kernel_times(g, run_one_step, reps)
+    rot_real = g.last_stats.n_passes
+    trans_real = g.last_translation_stats.n_passes
+    per_frame_ms = {}
+    avg_ms = {}
+    for k, runs in acc.items():
+        real = []
+        for r in runs:
+            if k == "rot_pass":
+                r = r[:rot_real]      # the tail of the fixed schedule are predicated no-op launches
+            elif k == "trans_pass":
+                r = r[:trans_real]
+            real.append(r)
+        per_frame_ms[k] = float(np.mean([r.sum() for r in real])) if real else 0.0
+        allv = np.concatenate(real) if real else np.zeros(0)
+        avg_ms[k] = float(allv.mean()) if allv.size else 0.0
+    # dominant kernel = largest share of the frame among the HBM-streaming kernels
+    cands = {k: per_frame_ms[k] for k in BYTES_PER_POINT}
+    dom = max(cands, key=cands.get)
+    npts = n_src if dom != "knn_cov" else 0.5 * (n_src + n_tgt)
+    algo_bytes = BYTES_PER_POINT[dom] * npts
+    achieved = algo_bytes / (avg_ms[dom] * 1e-3) / 1e9 if avg_ms[dom] > 0 else 0.0
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc):
+        try:
+            traffic = json.load(open(pmc)).get(dom + "_kernel", {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    return {"bound": "hbm", "kernel": dom + "_kernel", "achieved": achieved, "peak": hbm_peak_gbs, "unit": "GB/s",
+            "frac": achieved / hbm_peak_gbs, "traffic": traffic, "algorithmic_bytes_per_launch": algo_bytes,
+            "avg_launch_ms": avg_ms[dom], "per_frame_ms": per_frame_ms, "avg_ms": avg_ms}

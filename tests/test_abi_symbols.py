@@ -1,0 +1,43 @@
+"""CPU: the C-ABI library loads (no GPU needed) and exports every function include/rolo_hip.h declares."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from rolo_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    text = open(os.path.join(ROOT, "include", "rolo_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rolo_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_and_binding_agree():
+    names = declared_functions()
+    assert len(names) >= 40
+    assert sorted(_lib.SYMBOLS) == names
+
+
+def test_library_exports_every_declared_symbol():
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.fail("rolo_amd/librolo_hip.so not built: run `python -m rolo_amd.build`")
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared_functions():
+        assert hasattr(L, name), name
+    _lib.lib()  # binds argtypes for all of them
+
+
+def test_no_gpu_is_a_loud_error_not_a_fallback():
+    L = _lib.lib()
+    if L.rolo_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    h = ctypes.c_void_p()
+    rc = L.rolo_ctx_create(0, ctypes.byref(h))
+    assert rc == -6 and b"no HIP device" in L.rolo_last_error()
+    with pytest.raises(_lib.RoloError):
+        from rolo_amd.rotvgicp import RotVGICP
+        RotVGICP()

@@ -1,0 +1,323 @@
+"""GPU parity: the HIP registration path (through the C ABI) against the oracle on the same seeded inputs, and
+against the committed golden fixtures. Bars (BASELINE.json north_star): voxel / correspondence indices
+bit-exact; rotation <= 1e-5 rad, translation <= 1e-4 m (observed: ~1e-10)."""
+import os
+
+import numpy as np
+import pytest
+from scipy.spatial.transform import Rotation
+
+from oracle import pyorc
+from rolo_amd import synth
+from rolo_amd.rotvgicp import RotVGICP, VoxelType, NeighborSearchMethod, LSQ_OPTIMIZER_TYPE, RegularizationMethod
+
+pytestmark = pytest.mark.gpu
+
+G = -np.asarray(synth.PREV_STEP_T)
+L0 = G * 0.97
+
+
+def rot_angle(Ra, Rb):
+    return float(np.linalg.norm(Rotation.from_matrix(Ra @ Rb.T).as_rotvec()))
+
+
+def make_pair(kind):
+    if kind == "vlp16_polar":
+        src, tgt, _ = synth.dense_pair("vlp16", col_stride=2)
+        return src, tgt, dict(voxel_type=0, polar=(0.175, 0.175, 2.0), leaf=1.0)
+    if kind == "os64_uniform":
+        src, tgt, _ = synth.dense_pair("os1-64", col_stride=4)
+        return src, tgt, dict(voxel_type=1, polar=(0.175, 0.175, 2.0), leaf=1.0)
+    raise KeyError(kind)
+
+
+def make_both(src, tgt, cfg, fixed=0, q2=0, optimizer=2, neighbor=2, threads=0):
+    p = pyorc.default_params(polar_resolution=cfg["polar"], voxel_type=cfg["voxel_type"], voxel_resolution=cfg["leaf"],
+                             fixed_iterations=fixed, q2_intended=q2, optimizer=optimizer, neighbor_search=neighbor,
+                             num_threads=threads)
+    o = pyorc.Reg(p)
+    o.set_target(tgt); o.set_source(src)
+    g = RotVGICP()
+    if cfg["voxel_type"] == 0:
+        g.setPolarResolution(*cfg["polar"])
+    else:
+        g.setResolution(cfg["leaf"])
+    g.setFixedIterations(fixed); g.setQ2Intended(bool(q2)); g.setOptimizerType(optimizer); g.setNeighborSearchMethod(neighbor)
+    g.setInputTarget(tgt); g.setInputSource(src)
+    return o, g
+
+
+@pytest.fixture(scope="module", params=["vlp16_polar", "os64_uniform"])
+def pair(request):
+    src, tgt, cfg = make_pair(request.param)
+    return request.param, src, tgt, cfg
+
+
+def test_knn_lists_bit_exact(pair):
+    _, src, tgt, cfg = pair
+    o, g = make_both(src, tgt, cfg)
+    idx_o, d2_o = pyorc.knn(src, 20)
+    idx_g, d2_g = g.knn(0)
+    assert np.array_equal(idx_g, idx_o)
+    assert np.array_equal(d2_g, d2_o)  # float32 distances bit-identical (no FMA contraction on either side)
+
+
+def test_covariances(pair):
+    _, src, tgt, cfg = pair
+    o, g = make_both(src, tgt, cfg)
+    assert o.compute_covariances() == 0
+    g.computeCovariances()
+    for co, cg in ((o.source_covs(), g.getSourceCovariances()), (o.target_covs(), g.getTargetCovariances())):
+        assert np.abs(cg - co).max() < 1e-9
+        assert np.all(cg[:, 3, :] == 0) and np.all(cg[:, :, 3] == 0)
+
+
+@pytest.mark.parametrize("reg", [RegularizationMethod.NONE, RegularizationMethod.MIN_EIG, RegularizationMethod.NORMALIZED_MIN_EIG,
+                                 RegularizationMethod.FROBENIUS, RegularizationMethod.PLANE_S])
+def test_other_regularizations(reg):
+    src, tgt, cfg = make_pair("vlp16_polar")
+    p = pyorc.default_params(polar_resolution=cfg["polar"], regularization=reg)
+    o = pyorc.Reg(p); o.set_target(tgt[:4000]); o.set_source(src[:4000])
+    assert o.compute_covariances() == 0
+    g = RotVGICP(); g.setPolarResolution(*cfg["polar"]); g.setRegularizationMethod(reg)
+    g.setInputTarget(tgt[:4000]); g.setInputSource(src[:4000]); g.computeCovariances()
+    co, cg = o.source_covs(), g.getSourceCovariances()
+    assert np.abs(cg - co).max() <= 1e-9 * max(1.0, np.abs(co).max())
+
+
+def test_voxel_keys_and_map(pair):
+    _, src, tgt, cfg = pair
+    o, g = make_both(src, tgt, cfg)
+    keys_o = pyorc.voxel_keys(tgt, cfg["voxel_type"], cfg["leaf"], cfg["polar"])
+    assert np.array_equal(g.targetVoxelKeys(), keys_o)  # bit-exact voxel indices
+    assert o.build_voxelmap() == 0
+    g.buildVoxelMap()
+    ko, co, mo, vo = o.voxels()
+    kg, cg, mg, vg = g.voxels()
+    assert kg.shape == ko.shape
+    so = np.lexsort(ko.T[::-1]); sg = np.lexsort(kg.T[::-1])
+    assert np.array_equal(kg[sg], ko[so])
+    assert np.array_equal(cg[sg], co[so])
+    assert np.abs(mg[sg] - mo[so]).max() < 1e-11
+    assert np.abs(vg[sg] - vo[so]).max() < 1e-9
+
+
+def test_linearize_stages(pair):
+    _, src, tgt, cfg = pair
+    o, g = make_both(src, tgt, cfg)
+    T = np.eye(4); T[:3, :3] = synth.rpy_to_R(0.004, -0.007, 0.02)
+    eo, Ho, bo = o.so3_linearize(T)
+    eg, Hg, bg = g.so3_linearize(T)
+    assert abs(eg - eo) <= 1e-9 * abs(eo)
+    assert np.abs(Hg - Ho).max() <= 1e-9 * np.abs(Ho).max()
+    assert np.abs(bg - bo).max() <= 1e-9 * np.abs(bo).max()
+    # correspondence list bit-exact: same source points, same voxel keys
+    s, v = o.correspondences()
+    vk = o.voxels()[0]
+    found, keys = g.correspondences()
+    assert np.array_equal(np.nonzero(found[:, 0])[0], np.sort(s))
+    order = np.argsort(s, kind="stable")
+    assert np.array_equal(keys[s[order], 0], vk[v[order]])
+    T2 = np.eye(4); T2[:3, :3] = synth.rpy_to_R(0.0045, -0.0065, 0.021)
+    e2o, e2g = o.compute_error(T2), g.compute_error(T2)
+    assert abs(e2g - e2o) <= 1e-9 * abs(e2o)
+    tp = np.array([0.01, -0.004, 0.002])
+    eo, Ho, bo = o.t3_linearize(tp, G, L0)
+    eg, Hg, bg = g.t3_linearize(tp, G, L0)
+    assert abs(eg - eo) <= 1e-9 * abs(eo)
+    assert np.abs(Hg - Ho).max() <= 1e-9 * np.abs(Ho).max()
+    assert np.abs(bg - bo).max() <= 1e-9 * np.abs(bo).max()
+    e3o, e3g = o.compute_t_error(tp, G, L0), g.compute_t_error(tp, G, L0)
+    assert abs(e3g - e3o) <= 1e-9 * abs(e3o)
+    T6 = T.copy(); T6[:3, 3] = (0.01, -0.02, 0.005)
+    eo, Ho, bo = o.linearize(T6)
+    eg, Hg, bg = g.linearize(T6)
+    assert abs(eg - eo) <= 1e-9 * abs(eo)
+    assert np.abs(Hg - Ho).max() <= 1e-9 * np.abs(Ho).max()
+    assert np.abs(bg - bo).max() <= 1e-9 * np.abs(bo).max()
+
+
+def check_solve(o, g, guess=None):
+    rc, Tf_o, Td_o, it_o, cv_o = o.align(guess)
+    assert rc == 0
+    Tf_g = g.align(guess)
+    Td_g = g.final_transformation_d
+    assert rot_angle(Td_g[:3, :3], Td_o[:3, :3]) <= 1e-5  # the bar
+    assert np.abs(Td_g - Td_o).max() < 1e-8             # what we actually get
+    assert np.abs(Tf_g - Tf_o).max() < 1e-6
+    st = g.last_stats
+    assert st.n_outer == it_o and bool(st.converged) == cv_o and st.lm_failed == 0
+    rc, t_o, tit_o = o.compute_translation(np.zeros(3), G, L0)
+    assert rc == 0
+    t_g = g.computeTranslation(np.zeros(3), G, L0)
+    assert np.abs(t_g - t_o).max() <= 1e-4
+    assert np.abs(t_g - t_o).max() < 1e-8
+    assert g.last_translation_stats.n_outer == tit_o
+    # LM trace: same decisions while the step is significant
+    tr_o, tr_g = o.trace(), g.trace()
+    for stage in (0, 1):
+        a = [r for r in tr_o if r["stage"] == stage]; b = [r for r in tr_g if r["stage"] == stage]
+        assert a and b
+        for ro, rg in zip(a, b):
+            if abs(ro["y0"] - ro["yi"]) <= 1e-7 * abs(ro["y0"]):
+                break
+            assert (ro["outer"], ro["trial"], ro["accepted"]) == (rg["outer"], rg["trial"], rg["accepted"])
+            assert abs(ro["y0"] - rg["y0"]) <= 1e-9 * abs(ro["y0"]) and abs(ro["yi"] - rg["yi"]) <= 1e-9 * abs(ro["yi"])
+            assert abs(ro["lam"] - rg["lam"]) <= 1e-6 * abs(ro["lam"])
+    return Td_g, t_g
+
+
+@pytest.mark.parametrize("fixed,q2", [(0, 0), (20, 0), (0, 1)])
+def test_full_solve_matches_oracle(pair, fixed, q2):
+    _, src, tgt, cfg = pair
+    o, g = make_both(src, tgt, cfg, fixed=fixed, q2=q2)
+    check_solve(o, g)
+
+
+def test_full_solve_with_guess(pair):
+    _, src, tgt, cfg = pair
+    o, g = make_both(src, tgt, cfg)
+    guess = np.eye(4, dtype=np.float32)
+    guess[:3, :3] = synth.rpy_to_R(0.002, 0.001, 0.01)
+    guess[:3, 3] = (0.02, -0.01, 0.0)
+    check_solve(o, g, guess)
+
+
+@pytest.mark.parametrize("optimizer", [LSQ_OPTIMIZER_TYPE.LevenbergMarquardt, LSQ_OPTIMIZER_TYPE.GaussNewton])
+def test_six_dof_optimizers(optimizer):
+    src, tgt, cfg = make_pair("os64_uniform")
+    o, g = make_both(src, tgt, cfg, optimizer=optimizer)
+    rc, Tf_o, Td_o, it_o, cv_o = o.align()
+    Tf_g = g.align()
+    Td_g = g.final_transformation_d
+    assert rot_angle(Td_g[:3, :3], Td_o[:3, :3]) <= 1e-5 and np.abs(Td_g[:3, 3] - Td_o[:3, 3]).max() <= 1e-4
+    assert np.abs(Td_g - Td_o).max() < 1e-7
+    assert g.last_stats.n_outer == it_o
+
+
+@pytest.mark.parametrize("neighbor", [NeighborSearchMethod.DIRECT7, NeighborSearchMethod.DIRECT27])
+def test_multi_offset_neighbor_search(neighbor):
+    src, tgt, cfg = make_pair("os64_uniform")
+    o, g = make_both(src[:6000], tgt[:6000], cfg, neighbor=neighbor)
+    T = np.eye(4); T[:3, :3] = synth.rpy_to_R(0.004, -0.007, 0.02)
+    eo, Ho, bo = o.so3_linearize(T)
+    eg, Hg, bg = g.so3_linearize(T)
+    assert o.correspondences()[0].shape[0] == int(g.correspondences()[0].sum())
+    assert abs(eg - eo) <= 1e-9 * abs(eo) and np.abs(Hg - Ho).max() <= 1e-9 * np.abs(Ho).max()
+    rc, _, Td_o, it_o, _ = o.align()
+    g.align()
+    assert np.abs(g.final_transformation_d - Td_o).max() < 1e-8
+
+
+@pytest.mark.parametrize("name", ["vlp16_polar", "os64_uniform", "vlp16_polar_fixed20", "vlp16_polar_q2"])
+def test_against_committed_golden(golden_dir, name):
+    gd = np.load(os.path.join(golden_dir, name + ".npz"))
+    g = RotVGICP()
+    if int(gd["voxel_type"]) == 0:
+        g.setPolarResolution(0.175, 0.175, 2.0)
+    else:
+        g.setResolution(float(gd["leaf"]))
+    g.setFixedIterations(int(gd["fixed_iterations"])); g.setQ2Intended(bool(gd["q2_intended"]))
+    g.setInputTarget(gd["target"]); g.setInputSource(gd["source"])
+    assert np.array_equal(g.targetVoxelKeys(), gd["tgt_keys"].astype(np.int32))
+    g.computeCovariances()
+    sub = gd["cov_sub"]
+    assert np.abs(g.getSourceCovariances()[sub][:, :3, :3] - gd["src_cov_sub"]).max() < 1e-9
+    assert np.array_equal(g.knn(0)[0][sub], gd["src_knn_sub"])
+    e, H, b = g.so3_linearize(gd["T_probe"])
+    assert abs(e - gd["so3_err"]) <= 1e-9 * abs(gd["so3_err"])
+    assert np.abs(H - gd["so3_H"]).max() <= 1e-9 * np.abs(gd["so3_H"]).max()
+    found, keys = g.correspondences()
+    assert np.array_equal(np.nonzero(found[:, 0])[0], gd["corr_src"])
+    assert np.array_equal(keys[gd["corr_src"], 0], gd["corr_vox_keys"].astype(np.int32))
+    g.align()
+    assert g.last_stats.n_outer == int(gd["align_iters"])
+    assert rot_angle(g.final_transformation_d[:3, :3], gd["align_T"][:3, :3]) <= 1e-5
+    assert np.abs(g.final_transformation_d - gd["align_T"]).max() < 1e-8
+    t = g.computeTranslation(np.zeros(3), gd["t_guess"], gd["t_last"])
+    assert np.abs(t - gd["trans_final"]).max() <= 1e-4
+    assert g.last_translation_stats.n_outer == int(gd["trans_iters"])
+
+
+def test_async_register_equals_two_calls(pair):
+    _, src, tgt, cfg = pair
+    _, g1 = make_both(src, tgt, cfg, fixed=20)
+    g1.align(); T1 = g1.final_transformation_d.copy()
+    t1 = g1.computeTranslation(np.zeros(3), G, L0)
+    _, g2 = make_both(src, tgt, cfg, fixed=20)
+    g2.register_async(None, np.zeros(3), G, L0)
+    Tf, Td, t2 = g2.register_wait()
+    # same kernels in the same order; only the fp64 atomic accumulation order of the voxel map may differ
+    assert np.abs(Td - T1).max() < 1e-12 and np.abs(t2 - t1).max() < 1e-12
+    assert g2.last_stats.n_outer == 20
+
+
+def test_errors_are_codes_not_crashes():
+    from rolo_amd._lib import RoloError
+    g = RotVGICP(); g.setPolarResolution(0.175, 0.175, 2.0)
+    pts = np.random.default_rng(0).normal(size=(10, 4)).astype(np.float32) * 5
+    g.setInputTarget(pts); g.setInputSource(pts)
+    with pytest.raises(RoloError) as ei:
+        g.align()
+    assert ei.value.code == -2  # ROLO_ETOOFEW
+    g2 = RotVGICP(); g2.setPolarResolution(0.175, 0.175, 2.0)
+    src, tgt, cfg = make_pair("vlp16_polar")
+    far = src.copy(); far[:, :3] *= 40.0  # no source point falls into an occupied target voxel
+    g2.setInputTarget(tgt); g2.setInputSource(far)
+    with pytest.raises(RoloError) as ei:
+        g2.align()
+    assert ei.value.code == -4  # ROLO_ENOCORR
+
+
+def test_transform_cloud_matches_pcl_restatement():
+    src, _, _ = make_pair("vlp16_polar")
+    pts = np.zeros((src.shape[0], 8), np.float32); pts[:, :4] = src; pts[:, 3] = 1.0; pts[:, 4] = src[:, 3]
+    T = np.eye(4, dtype=np.float32); T[:3, :3] = synth.rpy_to_R(0.01, 0.02, 0.03).astype(np.float32); T[:3, 3] = (0.3, -0.1, 0.05)
+    g = RotVGICP()
+    assert np.array_equal(g.transformPointCloud(pts, T), pyorc.transform_cloud_f(pts, T))
+
+
+# ---- full-size, size-independent properties (BASELINE configs 2 and the 128k headline frame) ----------------
+@pytest.mark.parametrize("sensor,leaf", [("os1-64", 1.0), ("os1-128", 0.5)])
+def test_full_size_properties(sensor, leaf):
+    src, tgt, (R, t) = synth.dense_pair(sensor)
+    n = src.shape[0]
+    assert n in (65536, 131072)
+    g = RotVGICP(); g.setResolution(leaf); g.setFixedIterations(20)
+    g.setInputTarget(tgt); g.setInputSource(src)
+    # (1) voxel map conserves mass: counts sum to N_t, count-weighted mean of voxel means = cloud mean
+    g.buildVoxelMap()
+    k, c, m, v = g.voxels()
+    assert c.sum() == n and len(np.unique(k, axis=0)) == k.shape[0]
+    assert np.abs((m[:, :3] * c[:, None]).sum(0) / n - tgt[:, :3].astype(np.float64).mean(0)).max() < 1e-9
+    # (2) every PLANE covariance has singular values (1, 1, 1e-3)
+    cov = g.getTargetCovariances()[::97, :3, :3]
+    sv = np.linalg.svd(cov, compute_uv=False)
+    assert np.abs(sv - np.array([1, 1, 1e-3])).max() < 1e-9
+    # (3) linearity of the reduction: H, b, err over a split of the source = sum of the parts (same target map)
+    T = np.eye(4); T[:3, :3] = synth.rpy_to_R(0.003, -0.002, 0.01)
+    e, H, b = g.so3_linearize(T)
+    parts = []
+    for sl in (slice(0, n // 2), slice(n // 2, n)):
+        gp = RotVGICP(); gp.setResolution(leaf)
+        gp.setInputTarget(tgt); gp.setInputSource(src[sl])
+        gp.computeCovariances()
+        gp.setSourceCovariances(g.getSourceCovariances()[sl])  # neighbourhoods of the full cloud
+        parts.append(gp.so3_linearize(T))
+    assert abs(parts[0][0] + parts[1][0] - e) <= 1e-11 * abs(e)
+    assert np.abs(parts[0][1] + parts[1][1] - H).max() <= 1e-11 * np.abs(H).max()
+    assert np.abs(parts[0][2] + parts[1][2] - b).max() <= 1e-11 * np.abs(b).max()
+    # (4) the solve runs exactly 20 outer iterations, returns a rotation, and re-running reproduces it
+    Tf = g.align(); T1 = g.final_transformation_d.copy()
+    assert g.last_stats.n_outer == 20
+    assert np.abs(T1[:3, :3] @ T1[:3, :3].T - np.eye(3)).max() < 1e-12 and np.all(T1[:3, 3] == 0)
+    g.align()
+    assert np.abs(g.final_transformation_d - T1).max() < 1e-12
+    # (5) and agrees with the oracle end to end at full size
+    p = pyorc.default_params(voxel_type=1, voxel_resolution=leaf, fixed_iterations=20)
+    o = pyorc.Reg(p); o.set_target(tgt); o.set_source(src)
+    rc, _, Td_o, it_o, _ = o.align()
+    assert rc == 0 and rot_angle(T1[:3, :3], Td_o[:3, :3]) <= 1e-5
+    t_g = g.computeTranslation(np.zeros(3), G, L0)
+    rc, t_o, _ = o.compute_translation(np.zeros(3), G, L0)
+    assert np.abs(t_g - t_o).max() <= 1e-4
