@@ -19,6 +19,12 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-ato
          "-Wno-unused-result"]
 
 
+# float32 paths whose results must be bit-identical to the CPU statement (kNN distances and their pruning bounds,
+# pcl::transformPointCloud, range-image projection, curvature): no FMA contraction (HIP's __fmul_rn/__fadd_rn are
+# plain operators that the compiler is otherwise free to fuse)
+EXTRA = {"knn_cov.hip": ["-ffp-contract=off"], "misc.hip": ["-ffp-contract=off"], "front.hip": ["-ffp-contract=off"]}
+
+
 def _stale(out, deps):
     return (not os.path.exists(out)) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps if os.path.exists(d))
 
@@ -31,7 +37,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         obj = os.path.join(CSRC, s.replace(".hip", ".o"))
         objs.append(obj)
         if force or _stale(obj, [src] + hdrs):
-            jobs.append([HIPCC] + FLAGS + ["-c", src, "-o", obj])
+            jobs.append([HIPCC] + FLAGS + EXTRA.get(s, []) + ["-c", src, "-o", obj])
     if jobs:
         with cf.ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as ex:
             for cmd, res in zip(jobs, ex.map(lambda c: subprocess.run(c, capture_output=True, text=True), jobs)):

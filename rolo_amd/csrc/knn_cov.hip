@@ -6,12 +6,10 @@
 // MI355X design: no pointer-chasing kd-tree. The cloud is sorted along a 30-bit Morton curve (rocPRIM radix
 // sort — a plain library sort), groups of 8 consecutive points become the leaves of an *implicit* complete
 // binary BVH stored in heap order (children of h are 2h, 2h+1; both child boxes sit in one 64-byte line), built
-// bottom-up in LDS, and every query walks it depth-first with a per-lane stack in LDS and a 20-entry sorted
-// candidate list in registers. Queries are issued in Morton order so the 64 lanes of a wavefront share most of
-// their path (and their cache lines). Exactness: distances are float ((dx*dx)+(dy*dy))+(dz*dz) with explicit
-// round-to-nearest ops (no FMA contraction), box bounds use the same operation order so they are true lower
-// bounds, ties are explored (<=) and broken by original point index — the neighbour set is the same pure function
-// of the cloud the oracle computes.
+// bottom-up in LDS. The search itself is a wavefront-wide packet traversal (knn_walk.hpp): 64 Morton-adjacent
+// queries share one walk. Exactness: distances are float ((dx*dx)+(dy*dy))+(dz*dz) with FMA contraction off,
+// box bounds use the same operation order so they are true lower bounds, ties are explored (<=) and broken by
+// original point index — the neighbour set is the same pure function of the cloud the oracle computes.
 #include <cstring>
 #include <string.h>
 #include "rolo_internal.hpp"
@@ -33,6 +31,7 @@ __global__ void bbox_init_kernel(int* bbox) {
 }
 
 __global__ __launch_bounds__(256) void bbox_kernel(const float4* __restrict__ p, int n, int* bbox) {
+  __shared__ float smn[4][3], smx[4][3];
   float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     float4 q = p[i];
@@ -47,9 +46,19 @@ __global__ __launch_bounds__(256) void bbox_kernel(const float4* __restrict__ p,
       mx[d] = fmaxf(mx[d], __shfl_xor(mx[d], off, 64));
     }
   }
+  const int wv = threadIdx.x >> 6;
   if ((threadIdx.x & 63) == 0) {
 #pragma unroll
-    for (int d = 0; d < 3; d++) { atomicMin(&bbox[d], f2ord(mn[d])); atomicMax(&bbox[3 + d], f2ord(mx[d])); }
+    for (int d = 0; d < 3; d++) { smn[wv][d] = mn[d]; smx[wv][d] = mx[d]; }
+  }
+  __syncthreads();
+  // one atomic per block and component (a per-wave atomic on 6 hot words serialised 2048 waves: 141 us)
+  if (threadIdx.x < 3) {
+    const int d = threadIdx.x;
+    const float a = fminf(fminf(smn[0][d], smn[1][d]), fminf(smn[2][d], smn[3][d]));
+    const float b = fmaxf(fmaxf(smx[0][d], smx[1][d]), fmaxf(smx[2][d], smx[3][d]));
+    atomicMin(&bbox[d], f2ord(a));
+    atomicMax(&bbox[3 + d], f2ord(b));
   }
 }
 
@@ -225,85 +234,10 @@ ROLO_DEV void inv3(const double (&A)[9], double (&o)[9]) {
   o[0] = c00 * inv; o[1] = c01 * inv; o[2] = c02 * inv; o[3] = c10 * inv; o[4] = c11 * inv; o[5] = c12 * inv; o[6] = c20 * inv; o[7] = c21 * inv; o[8] = c22 * inv;
 }
 
-constexpr int KNN_STACK = 22;
-
+// covariance of the neighbourhood + regularisation, one lane per query
 template <int KMAX>
-__global__ __launch_bounds__(256) void knn_cov_kernel(const float4* __restrict__ sorted, const float4* __restrict__ boxes,
-                                                     const float4* __restrict__ orig, int n, int n_sorted, int P, int k,
-                                                     int reg, double* __restrict__ cov, int32_t* knn_idx, float* knn_d2) {
-  __shared__ float stk_b[KNN_STACK][256];
-  __shared__ int stk_h[KNN_STACK][256];
-  const int tid = threadIdx.x;
-  const int j = blockIdx.x * 256 + tid;
-  if (j >= n_sorted) return;
-  const float4 q = sorted[j];
-  const int qi = __float_as_int(q.w);
-  if (qi == INT_MAX) return;  // padding
-  const int kk = (KMAX == 20) ? 20 : k;
-
-  float kd[KMAX];
-  int ki[KMAX];
-#pragma unroll
-  for (int u = 0; u < KMAX; u++) { kd[u] = INFINITY; ki[u] = INT_MAX; }
-  float worst_d = INFINITY;
-  int worst_i = INT_MAX;
-
-  int sp = 0;
-  int h = 1;
-  while (true) {
-    if (h < P) {
-      const float4 llo = boxes[4 * (size_t)h], lhi = boxes[4 * (size_t)h + 1], rlo = boxes[4 * (size_t)h + 2], rhi = boxes[4 * (size_t)h + 3];
-      const float bl = box_d2(llo, lhi, q), br = box_d2(rlo, rhi, q);
-      const bool okl = (bl <= worst_d) && (bl < INFINITY), okr = (br <= worst_d) && (br < INFINITY);
-      if (okl && okr) {
-        const bool lf = bl <= br;
-        stk_h[sp][tid] = lf ? 2 * h + 1 : 2 * h;
-        stk_b[sp][tid] = lf ? br : bl;
-        sp++;
-        h = lf ? 2 * h : 2 * h + 1;
-        continue;
-      }
-      if (okl) { h = 2 * h; continue; }
-      if (okr) { h = 2 * h + 1; continue; }
-    } else {
-      const int g = h - P;
-#pragma unroll
-      for (int u = 0; u < 8; u++) {
-        const float4 c = sorted[8 * (size_t)g + u];
-        const float dx = __fsub_rn(q.x, c.x), dy = __fsub_rn(q.y, c.y), dz = __fsub_rn(q.z, c.z);
-        float cd = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
-        int ci = __float_as_int(c.w);
-        if (cd < worst_d || (cd == worst_d && ci < worst_i)) {
-          // replace the worst entry, then bubble towards the front
-#pragma unroll
-          for (int s = KMAX - 1; s >= 0; s--) if (s == kk - 1) { kd[s] = cd; ki[s] = ci; }
-#pragma unroll
-          for (int s = KMAX - 1; s >= 1; s--) {
-            if (s <= kk - 1) {
-              const bool sw = kd[s] < kd[s - 1] || (kd[s] == kd[s - 1] && ki[s] < ki[s - 1]);
-              const float td = kd[s]; const int ti = ki[s];
-              kd[s] = sw ? kd[s - 1] : td; ki[s] = sw ? ki[s - 1] : ti;
-              kd[s - 1] = sw ? td : kd[s - 1]; ki[s - 1] = sw ? ti : ki[s - 1];
-            }
-          }
-#pragma unroll
-          for (int s = KMAX - 1; s >= 0; s--) if (s == kk - 1) { worst_d = kd[s]; worst_i = ki[s]; }
-        }
-      }
-    }
-    bool got = false;
-    while (sp > 0) {
-      --sp;
-      if (stk_b[sp][tid] <= worst_d) { h = stk_h[sp][tid]; got = true; break; }
-    }
-    if (!got) break;
-  }
-
-  if (knn_idx) {
-#pragma unroll
-    for (int u = 0; u < KMAX; u++) if (u < kk) { knn_idx[(size_t)qi * kk + u] = ki[u]; knn_d2[(size_t)qi * kk + u] = kd[u]; }
-  }
-
+ROLO_DEV void knn_covariance_tail(const int (&ki)[KMAX], int kk, const float4* __restrict__ orig, int n, int qi, int reg,
+                                  double* __restrict__ cov) {
   // ---- covariance of the neighbourhood (rot_vgicp_impl.hpp:438-455), fp64, centred two-pass ----
   double mx = 0, my = 0, mz = 0;
 #pragma unroll
@@ -354,6 +288,11 @@ __global__ __launch_bounds__(256) void knn_cov_kernel(const float4* __restrict__
 }
 
 }  // namespace
+}  // namespace rolo
+
+#include "knn_walk.hpp"
+
+namespace rolo {
 
 size_t knn_sort_temp_bytes(int n) {
   size_t bytes = 0;
@@ -367,7 +306,7 @@ hipError_t launch_knn_build(CloudDev& c, void* sort_tmp, size_t sort_tmp_bytes, 
                             uint32_t* vals0, uint32_t* vals1, int* bbox, hipStream_t s) {
   const int n = c.n;
   bbox_init_kernel<<<1, 64, 0, s>>>(bbox);
-  int grid = min((n + 255) / 256, 1024);
+  int grid = min((n + 255) / 256, 64);
   bbox_kernel<<<grid, 256, 0, s>>>(c.xyz, n, bbox);
   morton_kernel<<<(n + 255) / 256, 256, 0, s>>>(c.xyz, n, bbox, keys0, vals0);
   hipError_t e = rocprim::radix_sort_pairs(sort_tmp, sort_tmp_bytes, keys0, keys1, vals0, vals1, (size_t)n, 0, 30, s);
@@ -381,6 +320,15 @@ hipError_t launch_knn_build(CloudDev& c, void* sort_tmp, size_t sort_tmp_bytes, 
   }
   return hipGetLastError();
 }
+
+#ifdef ROLO_KNN_STATS
+extern "C" int rolo_debug_counters(unsigned long long* out, int reset) {
+  (void)hipDeviceSynchronize();
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_knn_stats), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+  if (reset) { unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_knn_stats), z, sizeof(z)); }
+  return 0;
+}
+#endif
 
 hipError_t launch_knn_cov(CloudDev& c, int k, int regularization, bool want_lists, hipStream_t s) {
   const int n_sorted = 8 * c.n_leaves;

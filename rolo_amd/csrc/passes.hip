@@ -234,9 +234,17 @@ __global__ __launch_bounds__(PASS_THREADS) void trans_pass_kernel(PassArgs a, co
 ROLO_DEV void reduce_rows(const double* __restrict__ partials, int nblocks, double* sums /* shared, NV_MAX */) {
   __shared__ double part[8][NV_MAX];
   const int v = threadIdx.x & 31, q = threadIdx.x >> 5;  // 256 threads = 8 strided groups of 32 values
-  double s = 0;
-  for (int b = q; b < nblocks; b += 8) s += partials[(size_t)b * NV_MAX + v];
-  part[q][v] = s;
+  // four independent accumulators keep four loads in flight; the combination order is fixed => deterministic
+  double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+  int b = q;
+  for (; b + 24 < nblocks; b += 32) {
+    s0 += partials[(size_t)b * NV_MAX + v];
+    s1 += partials[(size_t)(b + 8) * NV_MAX + v];
+    s2 += partials[(size_t)(b + 16) * NV_MAX + v];
+    s3 += partials[(size_t)(b + 24) * NV_MAX + v];
+  }
+  for (; b < nblocks; b += 8) s0 += partials[(size_t)b * NV_MAX + v];
+  part[q][v] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (threadIdx.x < NV_MAX) {
     double t = 0;
@@ -502,11 +510,27 @@ __global__ __launch_bounds__(256) void ctrl_kernel(LmState* st, const double* __
                                                   const double* __restrict__ sums_in, rolo_trace_rec* trace, int stage) {
   if (st->stage != stage) return;
   __shared__ double sums[NV_MAX];
+  // the scalar LM step touches ~150 fields: stage the whole state through LDS (one coalesced read, one write)
+  // instead of paying a global-memory round trip per field from a single lane
+  __shared__ LmState sst;
+  static_assert(sizeof(LmState) % sizeof(int) == 0, "LmState must be int-copyable");
+  constexpr int NW = sizeof(LmState) / sizeof(int);
+  {
+    const int* g = reinterpret_cast<const int*>(st);
+    int* l = reinterpret_cast<int*>(&sst);
+    for (int i = threadIdx.x; i < NW; i += blockDim.x) l[i] = g[i];
+  }
   if (partials) reduce_rows(partials, nblocks, sums);
   else { if (threadIdx.x < NV_MAX) sums[threadIdx.x] = sums_in[threadIdx.x]; __syncthreads(); }
   if (threadIdx.x == 0) {
-    if (stage == 1) rot_step(st, sums, trace);
-    else trans_step(st, sums, trace);
+    if (stage == 1) rot_step(&sst, sums, trace);
+    else trans_step(&sst, sums, trace);
+  }
+  __syncthreads();
+  {
+    int* g = reinterpret_cast<int*>(st);
+    const int* l = reinterpret_cast<const int*>(&sst);
+    for (int i = threadIdx.x; i < NW; i += blockDim.x) g[i] = l[i];
   }
 }
 
