@@ -309,6 +309,14 @@ int run_stage(rolo_ctx* c, const PassArgs& a, int grid, int stage, int first_chu
 
 }  // namespace
 
+namespace rolo {
+// accessors for front.hip / odometry.hip (the context layout is private to this file)
+void** ctx_front_slot(rolo_ctx* c) { return &c->front; }
+hipStream_t ctx_stream(rolo_ctx* c) { return c->stream; }
+int ctx_device(rolo_ctx* c) { return c->device; }
+void ctx_set_error(const char* msg) { g_err = msg ? msg : ""; }
+}  // namespace rolo
+
 extern "C" {
 
 const char* rolo_last_error(void) { return g_err.c_str(); }

@@ -1,13 +1,568 @@
-// Front end (K1-K4) — placeholder until the kernels land; see DESIGN.md.
+// K1-K4 — the front end on gfx950.
+// Replaces ImageProjection::projectPointCloud / cloudExtraction (reference src/imageProjection.cpp:399-505) and
+// FeatureExtraction::calculateSmoothness / markOccludedPoints / extractFeatures incl. pcl::VoxelGrid
+// (reference src/featureExtraction.cpp:87-266). Deskew is off (every shipped config).
+//
+// MI355X design. The reference's three serial loops become:
+//   K1  one thread per raw point; "first point to claim a pixel wins" (imageProjection.cpp:451) is an atomicMin of
+//       the raw point index on a per-pixel owner word — the smallest index is exactly the serial winner;
+//   K2  row-major stream compaction: one workgroup per ring does an LDS prefix scan of its valid pixels, a second
+//       pass adds the ring offsets and scatters (x,y,z,intensity), column and range — coalesced on both sides;
+//   K3  a stencil kernel (11-tap float sum in the reference's written order) plus a mark kernel — the marks only
+//       ever store 1 and depend only on ranges / columns, so the serial loop is order-free;
+//   K4  one workgroup per ring, everything for the ring staged in LDS: per sector a bitonic sort of packed
+//       (curvature bits << 32 | index) keys, then the inherently serial greedy corner / surface picks run on one lane
+//       against LDS (they are a few hundred LDS-latency steps), the label<=0 collection is a block compaction, and
+//       pcl::VoxelGrid is a second bitonic sort of (cell << 32 | order) keys followed by per-run centroids.
+// fp32 arithmetic follows the reference expression by expression; this file is compiled with -ffp-contract=off.
 #include "rolo_internal.hpp"
-struct rolo_ctx;
+#include "dev_math.hpp"
+#include <cfloat>
+#include <climits>
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <algorithm>
+
+namespace rolo {
+
+constexpr int FRONT_GUARD = 8;       // guard cells in front of / behind the per-point arrays (reference reads index -1.. )
+constexpr int FRONT_MAX_H = 2048;    // Horizon_SCAN limit of this build (shipped configs: 1024, 1800, 2048)
+constexpr int SORT_CAP = 2048;       // LDS bitonic capacity (elements)
+
+namespace {
+
+// ---- K1 ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void project_kernel(const float* __restrict__ pts, int stride, const unsigned short* __restrict__ ring,
+                                                     int n_raw, rolo_front_params P, int* __restrict__ owner) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_raw) return;
+  const float x = pts[(size_t)i * stride], y = pts[(size_t)i * stride + 1], z = pts[(size_t)i * stride + 2];
+  const float range = sqrtf(x * x + y * y + z * z);  // utility.h:462-465
+  if (range < P.lidar_min_range || range > P.lidar_max_range) return;
+  const int rowIdn = ring[i];
+  if (rowIdn < 0 || rowIdn >= P.n_scan) return;
+  if (rowIdn % P.downsample_rate != 0) return;
+  const int H = P.horizon_scan;
+  const float horizonAngle = atan2f(x, y) * 180 / M_PI;           // imageProjection.cpp:437
+  const float ang_res_x = 360.0 / float(H);                       // :438
+  int columnIdn = -round((horizonAngle - 90.0) / ang_res_x) + H / 2;  // :440
+  if (columnIdn >= H) columnIdn -= H;
+  if (columnIdn < 0 || columnIdn >= H) return;
+  atomicMin(&owner[rowIdn * H + columnIdn], i);  // first point wins (:451)
+}
+
+// ---- K2 pass A: per ring, local index of every valid pixel + ring count ----
+__global__ __launch_bounds__(256) void ring_scan_kernel(const int* __restrict__ owner, int H, int* __restrict__ local_idx, int* __restrict__ ring_count) {
+  __shared__ int wsum[4];
+  __shared__ int carry;
+  const int row = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  if (t == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < H; base += 256) {
+    const int j = base + t;
+    const int v = (j < H && owner[row * H + j] != INT_MAX) ? 1 : 0;
+    int inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { int o = __shfl_up(inc, off, 64); if (lane >= off) inc += o; }
+    if (lane == 63) wsum[wv] = inc;
+    __syncthreads();
+    int woff = 0;
+    for (int w = 0; w < wv; w++) woff += wsum[w];
+    const int c = carry;
+    if (j < H) local_idx[row * H + j] = v ? (c + woff + inc - 1) : -1;
+    __syncthreads();
+    if (t == 255) carry = c + woff + inc;
+    __syncthreads();
+  }
+  if (t == 0) ring_count[row] = carry;
+}
+
+// ---- K2 pass B: ring offsets, start/end ring index, scatter ----
+__global__ __launch_bounds__(256) void ring_scatter_kernel(const float* __restrict__ pts, int stride, const unsigned short* __restrict__ ring,
+                                                          const int* __restrict__ owner, const int* __restrict__ local_idx,
+                                                          const int* __restrict__ ring_count, int n_scan, int H, float4* __restrict__ extracted,
+                                                          int* __restrict__ col_ind, float* __restrict__ point_range, int* __restrict__ start_ring,
+                                                          int* __restrict__ end_ring, float* __restrict__ range_mat, int* __restrict__ n_valid) {
+  __shared__ int s_off;
+  const int row = blockIdx.x, t = threadIdx.x;
+  if (t == 0) {
+    int off = 0;
+    for (int r = 0; r < row; r++) off += ring_count[r];
+    s_off = off;
+    start_ring[row] = off - 1 + 5;                     // imageProjection.cpp:485
+    end_ring[row] = off + ring_count[row] - 1 - 5;     // :503
+    if (row == n_scan - 1) *n_valid = off + ring_count[row];
+  }
+  __syncthreads();
+  const int off = s_off;
+  for (int j = t; j < H; j += 256) {
+    const int o = owner[row * H + j];
+    float rng = FLT_MAX;
+    if (o != INT_MAX) {
+      const float x = pts[(size_t)o * stride], y = pts[(size_t)o * stride + 1], z = pts[(size_t)o * stride + 2];
+      rng = sqrtf(x * x + y * y + z * z);
+      const int dst = off + local_idx[row * H + j];
+      extracted[dst] = make_float4(x, y, z, ring[o] * z);  // intensity <- ring * z (:410)
+      col_ind[dst] = j;
+      point_range[dst] = rng;
+    }
+    if (range_mat) range_mat[row * H + j] = rng;
+  }
+}
+
+// ---- K3 ----
+__global__ __launch_bounds__(256) void smoothness_kernel(const float* __restrict__ range, int n, float* __restrict__ curv, int* __restrict__ picked,
+                                                        int* __restrict__ label) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float c = 0.f;
+  if (i >= 5 && i < n - 5) {  // featureExtraction.cpp:91-99, float sum in the written order
+    const float diffRange = range[i - 5] + range[i - 4] + range[i - 3] + range[i - 2] + range[i - 1] - range[i] * 10
+                          + range[i + 1] + range[i + 2] + range[i + 3] + range[i + 4] + range[i + 5];
+    c = diffRange * diffRange;
+  }
+  curv[i] = c; picked[i] = 0; label[i] = 0;
+}
+
+__global__ __launch_bounds__(256) void occlusion_kernel(const float* __restrict__ range, const int* __restrict__ col, int n, int* __restrict__ picked) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < 5 || i >= n - 6) return;  // featureExtraction.cpp:116
+  const float depth1 = range[i], depth2 = range[i + 1];
+  const int columnDiff = abs(col[i + 1] - col[i]);
+  if (columnDiff < 10) {
+    if (depth1 - depth2 > 0.3) { for (int k = 0; k <= 5; k++) picked[i - k] = 1; }
+    else if (depth2 - depth1 > 0.3) { for (int k = 1; k <= 6; k++) picked[i + k] = 1; }
+  }
+  const float diff1 = fabsf(float(range[i - 1] - range[i]));
+  const float diff2 = fabsf(float(range[i + 1] - range[i]));
+  if (diff1 > 0.02 * range[i] && diff2 > 0.02 * range[i]) picked[i] = 1;
+}
+
+// ---- K4 ----
+ROLO_DEV void bitonic_sort_lds(unsigned long long* key, int n_pow2) {
+  for (int k = 2; k <= n_pow2; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = threadIdx.x; i < n_pow2; i += blockDim.x) {
+        const int ixj = i ^ j;
+        if (ixj > i) {
+          const unsigned long long a = key[i], b = key[ixj];
+          const bool up = (i & k) == 0;
+          if ((a > b) == up) { key[i] = b; key[ixj] = a; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+struct FeatArgs {
+  const float4* extracted; const int* col; const float* curv; int* picked; int* label;  // global, guard-offset pointers
+  const int* start_ring; const int* end_ring;
+  int n; int n_scan; float edge_threshold, surf_threshold, leaf;
+  float4* corner_stage; int* corner_cnt;  // [n_scan][6][20], [n_scan][6]
+  float4* surf_stage; int* surf_cnt;      // [n_scan][FRONT_MAX_H], [n_scan]
+};
+
+__global__ __launch_bounds__(256) void extract_kernel(FeatArgs A) {
+  extern __shared__ unsigned char smem_raw[];
+  // layout: keys[SORT_CAP] u64 | l_picked | l_col | l_label | l_curv (ring window) | list[FRONT_MAX_H+16] | misc
+  unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem_raw);
+  const int WIN = FRONT_MAX_H + 2 * 16;
+  int* l_picked = reinterpret_cast<int*>(keys + SORT_CAP);
+  int* l_col = l_picked + WIN;
+  int* l_label = l_col + WIN;
+  float* l_curv = reinterpret_cast<float*>(l_label + WIN);
+  int* list = reinterpret_cast<int*>(l_curv + WIN);
+  __shared__ int s_cnt, s_heads, s_flag;
+  __shared__ float s_red[2][3][4];
+  __shared__ int s_wsum[4];
+
+  const int ring = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int s = A.start_ring[ring], e = A.end_ring[ring];
+  const int n = A.n;
+  // ring window in LDS: global indices [w0, w0 + wlen)
+  const int w0 = s - 16;
+  int wlen = (e - s) + 32 + 1;
+  if (wlen < 0) wlen = 0;
+  if (wlen > WIN) wlen = WIN;  // guarded by the host (ring population <= FRONT_MAX_H)
+  for (int i = t; i < wlen; i += 256) {
+    const int gi = w0 + i;
+    const bool in = gi >= -FRONT_GUARD && gi < n + FRONT_GUARD;
+    l_picked[i] = in ? A.picked[gi] : 0;
+    l_col[i] = in ? A.col[gi] : 0;
+    l_label[i] = in ? A.label[gi] : 0;
+    l_curv[i] = in ? A.curv[gi] : 0.f;
+  }
+  if (t == 0) s_cnt = 0;
+  __syncthreads();
+
+  for (int j = 0; j < 6; j++) {
+    const int sp = (s * (6 - j) + e * j) / 6;
+    const int ep = (s * (5 - j) + e * (j + 1)) / 6 - 1;
+    if (sp >= ep) { if (t == 0) A.corner_cnt[ring * 6 + j] = 0; continue; }  // uniform
+    const int len = ep - sp;  // sorted range [sp, ep)
+    int np2 = 2; while (np2 < len) np2 <<= 1;
+    for (int i = t; i < np2; i += 256) {
+      unsigned long long kv = ~0ull;
+      if (i < len) {
+        const int k = sp + i;
+        // cloudSmoothness[k] = {curvature, k} for k in [5, n-5), else the zero-initialised {0, 0}
+        const bool live = k >= 5 && k < n - 5;
+        const float cv = live ? l_curv[k - w0] : 0.f;
+        const int ind = live ? k : 0;
+        kv = ((unsigned long long)__float_as_uint(cv) << 32) | (unsigned)ind;
+      }
+      keys[i] = kv;
+    }
+    __syncthreads();
+    bitonic_sort_lds(keys, np2);  // std::sort(begin+sp, begin+ep) with the (value, ind) tie order
+    if (t == 0) {
+      // smooth[ep] is outside the sorted range but inside both loops
+      const bool live_ep = ep >= 5 && ep < n - 5;
+      const int ind_ep = live_ep ? ep : 0;
+      // corners: featureExtraction.cpp:181-211
+      int largestPickedNum = 0, ncorner = 0;
+      for (int k = ep; k >= sp; k--) {
+        const int ind = (k == ep) ? ind_ep : (int)(unsigned)(keys[k - sp] & 0xffffffffull);
+        const int li = ind - w0;
+        const bool in_win = li >= 0 && li < wlen;
+        const int pk = in_win ? l_picked[li] : A.picked[ind];
+        const float cv = in_win ? l_curv[li] : A.curv[ind];
+        if (pk == 0 && cv > A.edge_threshold) {
+          largestPickedNum++;
+          if (largestPickedNum <= 20) {
+            if (in_win) l_label[li] = 1; else A.label[ind] = 1;
+            A.corner_stage[(ring * 6 + j) * 20 + ncorner] = A.extracted[ind];
+            ncorner++;
+          } else break;
+          if (in_win) l_picked[li] = 1; else A.picked[ind] = 1;
+          for (int l = 1; l <= 5; l++) {
+            const int a = ind + l, b = ind + l - 1;
+            const int ca = (a - w0 >= 0 && a - w0 < wlen) ? l_col[a - w0] : A.col[a];
+            const int cb = (b - w0 >= 0 && b - w0 < wlen) ? l_col[b - w0] : A.col[b];
+            if (abs(ca - cb) > 10) break;
+            if (a - w0 >= 0 && a - w0 < wlen) l_picked[a - w0] = 1; else A.picked[a] = 1;
+          }
+          for (int l = -1; l >= -5; l--) {
+            const int a = ind + l, b = ind + l + 1;
+            const int ca = (a - w0 >= 0 && a - w0 < wlen) ? l_col[a - w0] : A.col[a];
+            const int cb = (b - w0 >= 0 && b - w0 < wlen) ? l_col[b - w0] : A.col[b];
+            if (abs(ca - cb) > 10) break;
+            if (a - w0 >= 0 && a - w0 < wlen) l_picked[a - w0] = 1; else A.picked[a] = 1;
+          }
+        }
+      }
+      A.corner_cnt[ring * 6 + j] = ncorner;
+      // surfaces: :213-238
+      for (int k = sp; k <= ep; k++) {
+        const int ind = (k == ep) ? ind_ep : (int)(unsigned)(keys[k - sp] & 0xffffffffull);
+        const int li = ind - w0;
+        const bool in_win = li >= 0 && li < wlen;
+        const int pk = in_win ? l_picked[li] : A.picked[ind];
+        const float cv = in_win ? l_curv[li] : A.curv[ind];
+        if (pk == 0 && cv < A.surf_threshold) {
+          if (in_win) { l_label[li] = -1; l_picked[li] = 1; } else { A.label[ind] = -1; A.picked[ind] = 1; }
+          for (int l = 1; l <= 5; l++) {
+            const int a = ind + l, b = ind + l - 1;
+            const int ca = (a - w0 >= 0 && a - w0 < wlen) ? l_col[a - w0] : A.col[a];
+            const int cb = (b - w0 >= 0 && b - w0 < wlen) ? l_col[b - w0] : A.col[b];
+            if (abs(ca - cb) > 10) break;
+            if (a - w0 >= 0 && a - w0 < wlen) l_picked[a - w0] = 1; else A.picked[a] = 1;
+          }
+          for (int l = -1; l >= -5; l--) {
+            const int a = ind + l, b = ind + l + 1;
+            const int ca = (a - w0 >= 0 && a - w0 < wlen) ? l_col[a - w0] : A.col[a];
+            const int cb = (b - w0 >= 0 && b - w0 < wlen) ? l_col[b - w0] : A.col[b];
+            if (abs(ca - cb) > 10) break;
+            if (a - w0 >= 0 && a - w0 < wlen) l_picked[a - w0] = 1; else A.picked[a] = 1;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    // every k in [sp, ep] with label <= 0 joins the ring's surface scan, in k order (:240-252): block compaction
+    const int base_cnt = s_cnt;
+    __syncthreads();
+    for (int base = sp; base <= ep; base += 256) {
+      const int k = base + t;
+      const int v = (k <= ep && l_label[k - w0] <= 0) ? 1 : 0;
+      int inc = v;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) { int o = __shfl_up(inc, off, 64); if (lane >= off) inc += o; }
+      if (lane == 63) s_wsum[wv] = inc;
+      __syncthreads();
+      int woff = 0;
+      for (int w = 0; w < wv; w++) woff += s_wsum[w];
+      const int c = s_cnt;
+      if (v) list[c + woff + inc - 1] = k;
+      __syncthreads();
+      if (t == 255) s_cnt = c + woff + inc;
+      __syncthreads();
+    }
+    (void)base_cnt;
+  }
+  // write the ring's picked / label window back (the oracle's arrays after extraction)
+  for (int i = t; i < wlen; i += 256) {
+    const int gi = w0 + i;
+    if (gi >= s - 10 && gi <= e + 10 && gi >= -FRONT_GUARD && gi < n + FRONT_GUARD) {
+      if (l_picked[i]) A.picked[gi] = 1;
+      if (gi >= s && gi <= e) A.label[gi] = l_label[i];
+      else if (l_label[i] != 0) A.label[gi] = l_label[i];
+    }
+  }
+  __syncthreads();
+
+  // ---- pcl::VoxelGrid on the ring's surface scan (featureExtraction.cpp:254-258) ----
+  const int m = s_cnt;
+  if (m == 0) { if (t == 0) A.surf_cnt[ring] = 0; return; }
+  float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  for (int i = t; i < m; i += 256) {
+    const float4 p = A.extracted[list[i]];
+    mn[0] = fminf(mn[0], p.x); mn[1] = fminf(mn[1], p.y); mn[2] = fminf(mn[2], p.z);
+    mx[0] = fmaxf(mx[0], p.x); mx[1] = fmaxf(mx[1], p.y); mx[2] = fmaxf(mx[2], p.z);
+  }
+#pragma unroll
+  for (int d = 0; d < 3; d++) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { mn[d] = fminf(mn[d], __shfl_xor(mn[d], off, 64)); mx[d] = fmaxf(mx[d], __shfl_xor(mx[d], off, 64)); }
+    if (lane == 0) { s_red[0][d][wv] = mn[d]; s_red[1][d][wv] = mx[d]; }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int d = 0; d < 3; d++) {
+    mn[d] = fminf(fminf(s_red[0][d][0], s_red[0][d][1]), fminf(s_red[0][d][2], s_red[0][d][3]));
+    mx[d] = fmaxf(fmaxf(s_red[1][d][0], s_red[1][d][1]), fmaxf(s_red[1][d][2], s_red[1][d][3]));
+  }
+  const float inv = 1.0f / A.leaf;
+  const long long dx = (long long)((mx[0] - mn[0]) * inv) + 1, dy = (long long)((mx[1] - mn[1]) * inv) + 1, dz = (long long)((mx[2] - mn[2]) * inv) + 1;
+  float4* out = A.surf_stage + (size_t)ring * FRONT_MAX_H;
+  if (dx * dy * dz > (long long)INT_MAX) {  // PCL: warn and copy the input through
+    for (int i = t; i < m; i += 256) out[i] = A.extracted[list[i]];
+    if (t == 0) A.surf_cnt[ring] = m;
+    return;
+  }
+  const int min_b0 = (int)floorf(mn[0] * inv), min_b1 = (int)floorf(mn[1] * inv), min_b2 = (int)floorf(mn[2] * inv);
+  const int div_b0 = (int)floorf(mx[0] * inv) - min_b0 + 1, div_b1 = (int)floorf(mx[1] * inv) - min_b1 + 1;
+  int np2 = 2; while (np2 < m) np2 <<= 1;
+  for (int i = t; i < np2; i += 256) {
+    unsigned long long kv = ~0ull;
+    if (i < m) {
+      const float4 p = A.extracted[list[i]];
+      const int ijk0 = (int)floorf(p.x * inv) - min_b0, ijk1 = (int)floorf(p.y * inv) - min_b1, ijk2 = (int)floorf(p.z * inv) - min_b2;
+      const int cell = ijk0 + ijk1 * div_b0 + ijk2 * div_b0 * div_b1;
+      kv = ((unsigned long long)(unsigned)cell << 32) | (unsigned)i;
+    }
+    keys[i] = kv;
+  }
+  __syncthreads();
+  bitonic_sort_lds(keys, np2);  // std::sort by cell index, ties by point order
+  // run heads -> output slot; each head accumulates its run in order with float accumulators (pcl::CentroidPoint)
+  if (t == 0) { s_heads = 0; s_flag = 0; }
+  __syncthreads();
+  for (int base = 0; base < m; base += 256) {
+    const int i = base + t;
+    const bool head = i < m && (i == 0 || (keys[i] >> 32) != (keys[i - 1] >> 32));
+    int inc = head ? 1 : 0;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { int o = __shfl_up(inc, off, 64); if (lane >= off) inc += o; }
+    if (lane == 63) s_wsum[wv] = inc;
+    __syncthreads();
+    int woff = 0;
+    for (int w = 0; w < wv; w++) woff += s_wsum[w];
+    const int c = s_heads;
+    if (head) {
+      const unsigned cell = (unsigned)(keys[i] >> 32);
+      float sx = 0, sy = 0, sz = 0, si = 0;
+      int cnt = 0;
+      for (int r = i; r < m && (unsigned)(keys[r] >> 32) == cell; r++) {
+        const float4 p = A.extracted[list[(int)(unsigned)(keys[r] & 0xffffffffull)]];
+        sx += p.x; sy += p.y; sz += p.z; si += p.w; cnt++;
+      }
+      const float fc = (float)cnt;
+      out[c + woff + inc - 1] = make_float4(sx / fc, sy / fc, sz / fc, si / fc);
+    }
+    __syncthreads();
+    if (t == 255) s_heads = c + woff + inc;
+    __syncthreads();
+  }
+  if (t == 0) A.surf_cnt[ring] = s_heads;
+}
+
+// concatenate per-ring / per-sector staging areas in order
+__global__ __launch_bounds__(256) void concat_kernel(const float4* __restrict__ stage, const int* __restrict__ cnt, int n_groups, int group_cap,
+                                                    float4* __restrict__ out, int* __restrict__ total) {
+  __shared__ int s_off;
+  const int g = blockIdx.x, t = threadIdx.x;
+  if (t == 0) {
+    int off = 0;
+    for (int r = 0; r < g; r++) off += cnt[r];
+    s_off = off;
+    if (g == n_groups - 1) *total = off + cnt[g];
+  }
+  __syncthreads();
+  const int c = cnt[g];
+  for (int i = t; i < c; i += 256) out[s_off + i] = stage[(size_t)g * group_cap + i];
+}
+
+__global__ void fill_int_kernel(int* p, int n, int v) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = v;
+}
+
+struct Front {
+  int device = 0;
+  size_t cap_raw = 0, cap_pix = 0, cap_scan = 0;
+  float* raw = nullptr; unsigned short* ring = nullptr;
+  int *owner = nullptr, *local_idx = nullptr, *ring_count = nullptr, *start_ring = nullptr, *end_ring = nullptr, *counters = nullptr;
+  float4* extracted = nullptr; int* col = nullptr; float* range = nullptr; float* range_mat = nullptr;
+  float* curv = nullptr; int *picked = nullptr, *label = nullptr;
+  float4 *corner_stage = nullptr, *surf_stage = nullptr, *corner_out = nullptr, *surf_out = nullptr;
+  int *corner_cnt = nullptr, *surf_cnt = nullptr;
+  int n_valid = 0; int n_scan = 0, H = 0;
+  bool projected = false;
+};
+
+thread_local std::string g_ferr;
+
+template <typename T>
+bool dev_alloc(T*& p, size_t count) {
+  if (p) { (void)hipFree(p); p = nullptr; }
+  return hipMalloc((void**)&p, std::max<size_t>(count, 1) * sizeof(T)) == hipSuccess;
+}
+
+void front_free(Front* f) {
+  void* bufs[] = {f->raw, f->ring, f->owner, f->local_idx, f->ring_count, f->start_ring, f->end_ring, f->counters, f->extracted, f->col, f->range,
+                  f->range_mat, f->curv, f->picked, f->label, f->corner_stage, f->surf_stage, f->corner_out, f->surf_out, f->corner_cnt, f->surf_cnt};
+  for (void* b : bufs) if (b) (void)hipFree(b);
+}
+
+}  // namespace
+
+// accessors implemented in api.hip
+void** ctx_front_slot(rolo_ctx* c);
+hipStream_t ctx_stream(rolo_ctx* c);
+int ctx_device(rolo_ctx* c);
+void ctx_set_error(const char* msg);
+
+}  // namespace rolo
+
+using namespace rolo;
+
 extern "C" {
-void rolo_front_destroy(rolo_ctx*) {}
-void rolo_front_default_params(rolo_front_params* p) {
+
+void rolo_front_destroy(rolo_ctx* c) {
+  void** slot = ctx_front_slot(c);
+  if (*slot) { Front* f = static_cast<Front*>(*slot); front_free(f); delete f; *slot = nullptr; }
+}
+
+void rolo_front_default_params(rolo_front_params* p) {  // config/params.yaml:20-36
   p->n_scan = 32; p->horizon_scan = 1024; p->downsample_rate = 1;
   p->lidar_min_range = 2.0f; p->lidar_max_range = 1000.0f;
   p->edge_threshold = 0.8f; p->surf_threshold = 0.1f; p->odometry_surf_leaf_size = 0.4f;
 }
-int rolo_project_frame(rolo_ctx*, const rolo_front_params*, const float*, int, const uint16_t*, int, float*, int32_t*, float*, int32_t*, int32_t*, float*, int*) { return ROLO_EUNSUPPORTED; }
-int rolo_extract_features(rolo_ctx*, const rolo_front_params*, float*, int*, float*, int*, float*, int32_t*, int32_t*) { return ROLO_EUNSUPPORTED; }
+
+#define FCHK(x) do { hipError_t _e = (x); if (_e != hipSuccess) { ctx_set_error((std::string(#x) + ": " + hipGetErrorString(_e)).c_str()); return ROLO_EHIP; } } while (0)
+
+int rolo_project_frame(rolo_ctx* c, const rolo_front_params* P, const float* pts, int stride, const uint16_t* ring, int n_raw,
+                       float* extracted, int32_t* point_col_ind, float* point_range, int32_t* start_ring, int32_t* end_ring,
+                       float* range_mat, int* n_valid) {
+  if (!c || !P || !pts || !ring || stride < 3 || n_raw < 0 || !n_valid) return ROLO_EINVAL;
+  if (P->n_scan <= 0 || P->horizon_scan <= 0 || P->downsample_rate <= 0) { ctx_set_error("bad front params"); return ROLO_EINVAL; }
+  if (P->horizon_scan > FRONT_MAX_H) { ctx_set_error("Horizon_SCAN above the limit of this build (2048)"); return ROLO_EUNSUPPORTED; }
+  FCHK(hipSetDevice(ctx_device(c)));
+  hipStream_t s = ctx_stream(c);
+  void** slot = ctx_front_slot(c);
+  if (!*slot) *slot = new Front();
+  Front* f = static_cast<Front*>(*slot);
+  const int NS = P->n_scan, H = P->horizon_scan;
+  const size_t npix = (size_t)NS * H;
+  bool ok = true;
+  if ((size_t)n_raw * stride > f->cap_raw || !f->raw) { ok = ok && dev_alloc(f->raw, (size_t)n_raw * stride) && dev_alloc(f->ring, (size_t)n_raw); f->cap_raw = (size_t)n_raw * stride; }
+  if (npix > f->cap_pix || !f->owner) {
+    const size_t np = npix + 2 * FRONT_GUARD;
+    ok = ok && dev_alloc(f->owner, npix) && dev_alloc(f->local_idx, npix) && dev_alloc(f->extracted, np) && dev_alloc(f->col, np) && dev_alloc(f->range, np) &&
+         dev_alloc(f->range_mat, npix) && dev_alloc(f->curv, np) && dev_alloc(f->picked, np) && dev_alloc(f->label, np) && dev_alloc(f->corner_out, npix) &&
+         dev_alloc(f->surf_out, npix);
+    f->cap_pix = npix;
+  }
+  if ((size_t)NS > f->cap_scan || !f->ring_count) {
+    ok = ok && dev_alloc(f->ring_count, NS) && dev_alloc(f->start_ring, NS) && dev_alloc(f->end_ring, NS) && dev_alloc(f->counters, 8) &&
+         dev_alloc(f->corner_stage, (size_t)NS * 6 * 20) && dev_alloc(f->corner_cnt, (size_t)NS * 6) && dev_alloc(f->surf_stage, (size_t)NS * FRONT_MAX_H) &&
+         dev_alloc(f->surf_cnt, NS);
+    f->cap_scan = NS;
+  }
+  if (!ok) { ctx_set_error("hipMalloc failed (front end)"); return ROLO_EHIP; }
+  f->n_scan = NS; f->H = H; f->projected = false;
+  FCHK(hipMemcpyAsync(f->raw, pts, sizeof(float) * (size_t)n_raw * stride, hipMemcpyHostToDevice, s));
+  FCHK(hipMemcpyAsync(f->ring, ring, sizeof(uint16_t) * (size_t)n_raw, hipMemcpyHostToDevice, s));
+  fill_int_kernel<<<256, 256, 0, s>>>(f->owner, (int)npix, INT_MAX);
+  // guard cells of the per-point arrays are zero
+  FCHK(hipMemsetAsync(f->col, 0, sizeof(int) * (npix + 2 * FRONT_GUARD), s));
+  FCHK(hipMemsetAsync(f->range, 0, sizeof(float) * (npix + 2 * FRONT_GUARD), s));
+  if (n_raw > 0) project_kernel<<<(n_raw + 255) / 256, 256, 0, s>>>(f->raw, stride, f->ring, n_raw, *P, f->owner);
+  ring_scan_kernel<<<NS, 256, 0, s>>>(f->owner, H, f->local_idx, f->ring_count);
+  ring_scatter_kernel<<<NS, 256, 0, s>>>(f->raw, stride, f->ring, f->owner, f->local_idx, f->ring_count, NS, H, f->extracted + FRONT_GUARD,
+                                        f->col + FRONT_GUARD, f->range + FRONT_GUARD, f->start_ring, f->end_ring, f->range_mat, f->counters);
+  FCHK(hipGetLastError());
+  int nv = 0;
+  FCHK(hipMemcpyAsync(&nv, f->counters, sizeof(int), hipMemcpyDeviceToHost, s));
+  FCHK(hipStreamSynchronize(s));
+  f->n_valid = nv;
+  *n_valid = nv;
+  if (extracted && nv) FCHK(hipMemcpyAsync(extracted, f->extracted + FRONT_GUARD, sizeof(float4) * (size_t)nv, hipMemcpyDeviceToHost, s));
+  if (point_col_ind && nv) FCHK(hipMemcpyAsync(point_col_ind, f->col + FRONT_GUARD, sizeof(int) * (size_t)nv, hipMemcpyDeviceToHost, s));
+  if (point_range && nv) FCHK(hipMemcpyAsync(point_range, f->range + FRONT_GUARD, sizeof(float) * (size_t)nv, hipMemcpyDeviceToHost, s));
+  if (start_ring) FCHK(hipMemcpyAsync(start_ring, f->start_ring, sizeof(int) * (size_t)NS, hipMemcpyDeviceToHost, s));
+  if (end_ring) FCHK(hipMemcpyAsync(end_ring, f->end_ring, sizeof(int) * (size_t)NS, hipMemcpyDeviceToHost, s));
+  if (range_mat) FCHK(hipMemcpyAsync(range_mat, f->range_mat, sizeof(float) * npix, hipMemcpyDeviceToHost, s));
+  FCHK(hipStreamSynchronize(s));
+  f->projected = true;
+  return ROLO_OK;
 }
+
+int rolo_extract_features(rolo_ctx* c, const rolo_front_params* P, float* corner, int* n_corner, float* surface, int* n_surface,
+                          float* curvature, int32_t* neighbor_picked, int32_t* label) {
+  if (!c || !P || !n_corner || !n_surface) return ROLO_EINVAL;
+  void** slot = ctx_front_slot(c);
+  Front* f = static_cast<Front*>(*slot);
+  if (!f || !f->projected) { ctx_set_error("rolo_extract_features needs a preceding rolo_project_frame"); return ROLO_ESTATE; }
+  FCHK(hipSetDevice(ctx_device(c)));
+  hipStream_t s = ctx_stream(c);
+  const int n = f->n_valid, NS = f->n_scan;
+  // guards of curvature / picked / label are zero; live entries are written by the smoothness kernel
+  const size_t np = (size_t)f->cap_pix + 2 * FRONT_GUARD;
+  FCHK(hipMemsetAsync(f->curv, 0, sizeof(float) * np, s));
+  FCHK(hipMemsetAsync(f->picked, 0, sizeof(int) * np, s));
+  FCHK(hipMemsetAsync(f->label, 0, sizeof(int) * np, s));
+  if (n > 0) {
+    smoothness_kernel<<<(n + 255) / 256, 256, 0, s>>>(f->range + FRONT_GUARD, n, f->curv + FRONT_GUARD, f->picked + FRONT_GUARD, f->label + FRONT_GUARD);
+    occlusion_kernel<<<(n + 255) / 256, 256, 0, s>>>(f->range + FRONT_GUARD, f->col + FRONT_GUARD, n, f->picked + FRONT_GUARD);
+  }
+  FeatArgs A;
+  A.extracted = f->extracted + FRONT_GUARD; A.col = f->col + FRONT_GUARD; A.curv = f->curv + FRONT_GUARD; A.picked = f->picked + FRONT_GUARD;
+  A.label = f->label + FRONT_GUARD; A.start_ring = f->start_ring; A.end_ring = f->end_ring; A.n = n; A.n_scan = NS;
+  A.edge_threshold = P->edge_threshold; A.surf_threshold = P->surf_threshold; A.leaf = P->odometry_surf_leaf_size;
+  A.corner_stage = f->corner_stage; A.corner_cnt = f->corner_cnt; A.surf_stage = f->surf_stage; A.surf_cnt = f->surf_cnt;
+  const size_t WIN = FRONT_MAX_H + 32;
+  const size_t lds = sizeof(unsigned long long) * SORT_CAP + sizeof(int) * WIN * 4 + sizeof(int) * (FRONT_MAX_H + 16);
+  static bool attr_set = false;
+  if (!attr_set) { FCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(extract_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set = true; }
+  extract_kernel<<<NS, 256, lds, s>>>(A);
+  concat_kernel<<<NS * 6, 256, 0, s>>>(f->corner_stage, f->corner_cnt, NS * 6, 20, f->corner_out, f->counters + 1);
+  concat_kernel<<<NS, 256, 0, s>>>(f->surf_stage, f->surf_cnt, NS, FRONT_MAX_H, f->surf_out, f->counters + 2);
+  FCHK(hipGetLastError());
+  int cnts[3] = {0, 0, 0};
+  FCHK(hipMemcpyAsync(cnts, f->counters, sizeof(int) * 3, hipMemcpyDeviceToHost, s));
+  FCHK(hipStreamSynchronize(s));
+  *n_corner = cnts[1]; *n_surface = cnts[2];
+  if (corner && cnts[1]) FCHK(hipMemcpyAsync(corner, f->corner_out, sizeof(float4) * (size_t)cnts[1], hipMemcpyDeviceToHost, s));
+  if (surface && cnts[2]) FCHK(hipMemcpyAsync(surface, f->surf_out, sizeof(float4) * (size_t)cnts[2], hipMemcpyDeviceToHost, s));
+  if (curvature && n) FCHK(hipMemcpyAsync(curvature, f->curv + FRONT_GUARD, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, s));
+  if (neighbor_picked && n) FCHK(hipMemcpyAsync(neighbor_picked, f->picked + FRONT_GUARD, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, s));
+  if (label && n) FCHK(hipMemcpyAsync(label, f->label + FRONT_GUARD, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, s));
+  FCHK(hipStreamSynchronize(s));
+  return ROLO_OK;
+}
+
+}  // extern "C"

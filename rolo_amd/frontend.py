@@ -1,0 +1,69 @@
+"""Host-side mirror of the reference front-end node cores over the C ABI:
+
+  ImageProjection.projectPointCloud + cloudExtraction   (reference src/imageProjection.cpp:399-505)
+  FeatureExtraction.calculateSmoothness / markOccludedPoints / extractFeatures (src/featureExtraction.cpp:87-266)
+
+The arrays mirror the fields of rolo/CloudInfoStamp (msg/CloudInfoStamp.msg): startRingIndex, endRingIndex,
+pointColInd, pointRange, cloud_projected, extracted_corner, extracted_surface. Plumbing only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import numpy as np
+
+from ._lib import FrontParams, check, lib
+
+
+def front_params(**kw) -> FrontParams:
+    p = FrontParams()
+    lib().rolo_front_default_params(C.byref(p))
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def _f(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _i(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+class FrontEnd:
+    """Owns nothing but a reference to a RotVGICP context (its device buffers and stream are reused)."""
+
+    def __init__(self, ctx, params: FrontParams):
+        self.ctx = ctx
+        self.p = params
+
+    def project(self, xyz, ring, want_range_mat=False):
+        xyz = np.ascontiguousarray(xyz, np.float32)
+        ring = np.ascontiguousarray(ring, np.uint16)
+        NS, H = self.p.n_scan, self.p.horizon_scan
+        ext = np.zeros((NS * H, 4), np.float32); col = np.zeros(NS * H, np.int32); rng = np.zeros(NS * H, np.float32)
+        sr = np.zeros(NS, np.int32); er = np.zeros(NS, np.int32)
+        rm = np.zeros(NS * H, np.float32) if want_range_mat else None
+        n = C.c_int(0)
+        check(lib().rolo_project_frame(self.ctx._h, C.byref(self.p), _f(xyz), xyz.shape[1], ring.ctypes.data_as(C.POINTER(C.c_uint16)),
+                                       xyz.shape[0], _f(ext), _i(col), _f(rng), _i(sr), _i(er), _f(rm) if rm is not None else None,
+                                       C.byref(n)), "rolo_project_frame")
+        n = n.value
+        out = dict(n=n, extracted=ext[:n].copy(), point_col_ind=col[:n].copy(), point_range=rng[:n].copy(), start_ring=sr, end_ring=er)
+        if rm is not None:
+            out["range_mat"] = rm.reshape(NS, H)
+        return out
+
+    def extract(self, n, debug=False):
+        corner = np.zeros((max(n, 1), 4), np.float32); surf = np.zeros((max(n, 1), 4), np.float32)
+        nc = C.c_int(0); ns = C.c_int(0)
+        curv = np.zeros(max(n, 1), np.float32) if debug else None
+        picked = np.zeros(max(n, 1), np.int32) if debug else None
+        label = np.zeros(max(n, 1), np.int32) if debug else None
+        check(lib().rolo_extract_features(self.ctx._h, C.byref(self.p), _f(corner), C.byref(nc), _f(surf), C.byref(ns),
+                                          _f(curv) if debug else None, _i(picked) if debug else None, _i(label) if debug else None),
+              "rolo_extract_features")
+        out = dict(corner=corner[:nc.value].copy(), surface=surf[:ns.value].copy())
+        if debug:
+            out.update(curvature=curv[:n], picked=picked[:n], label=label[:n])
+        return out

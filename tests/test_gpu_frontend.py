@@ -1,0 +1,95 @@
+"""GPU parity of the front end (K1-K4) against the oracle: integer / index outputs bit-exact, float outputs
+bit-exact as well (same fp32 expressions, FMA contraction off on both sides)."""
+import numpy as np
+import pytest
+
+from oracle import pyorc
+from rolo_amd import synth
+from rolo_amd.frontend import FrontEnd, front_params
+from rolo_amd.rotvgicp import RotVGICP
+
+pytestmark = pytest.mark.gpu
+
+SENSORS = {"vlp16": dict(n_scan=16, horizon_scan=1800), "os1-64": dict(n_scan=64, horizon_scan=1024),
+           "os1-128": dict(n_scan=128, horizon_scan=1024), "os1-128x2048": dict(n_scan=128, horizon_scan=2048)}
+
+
+def both(sensor, frame, **kw):
+    cfg = dict(SENSORS[sensor]); cfg.update(kw)
+    fo = pyorc.front_params(**cfg)
+    fg = front_params(**cfg)
+    ctx = RotVGICP()
+    fe = FrontEnd(ctx, fg)
+    po = pyorc.project(fo, frame.xyz, frame.ring)
+    pg = fe.project(frame.xyz, frame.ring, want_range_mat=True)
+    return fo, po, fe, pg
+
+
+def check_projection(po, pg):
+    assert pg["n"] == po["n"]
+    assert np.array_equal(pg["start_ring"], po["start_ring"]) and np.array_equal(pg["end_ring"], po["end_ring"])
+    assert np.array_equal(pg["point_col_ind"], po["point_col_ind"])       # bit-exact indices
+    assert np.array_equal(pg["point_range"], po["point_range"])           # fp32, same expression
+    assert np.array_equal(pg["extracted"], po["extracted"])
+    assert np.array_equal(pg["range_mat"], po["range_mat"])
+
+
+def check_features(fo, po, fe, pg):
+    eo = pyorc.extract_features(fo, po)
+    eg = fe.extract(pg["n"], debug=True)
+    assert np.array_equal(eg["curvature"], eo["curvature"])
+    assert np.array_equal(eg["picked"], eo["picked"])
+    assert np.array_equal(eg["label"], eo["label"])
+    assert eg["corner"].shape == eo["corner"].shape and np.array_equal(eg["corner"], eo["corner"])
+    assert eg["surface"].shape == eo["surface"].shape and np.array_equal(eg["surface"], eo["surface"])
+    return eo, eg
+
+
+@pytest.mark.parametrize("sensor", ["vlp16", "os1-64", "os1-128", "os1-128x2048"])
+def test_projection_and_features_match_oracle(sensor):
+    f0, f1, _ = synth.make_pair(sensor)
+    for fr in (f0, f1):
+        fo, po, fe, pg = both(sensor, fr)
+        check_projection(po, pg)
+        eo, eg = check_features(fo, po, fe, pg)
+        assert eo["corner"].shape[0] > 0 and eo["surface"].shape[0] > 0
+
+
+def test_duplicate_pixels_first_point_wins_and_filters():
+    f0, _, _ = synth.make_pair("vlp16")
+    rng = np.random.default_rng(3)
+    # shuffle, duplicate a slice (same pixels twice), add out-of-range / bad-ring points
+    idx = rng.permutation(f0.xyz.shape[0])
+    xyz = np.concatenate([f0.xyz[idx], f0.xyz[idx[:5000]] * 1.01, np.array([[0.5, 0.2, 0.1], [1500.0, 0, 0]], np.float32)])
+    ring = np.concatenate([f0.ring[idx], f0.ring[idx[:5000]], np.array([3, 4], np.uint16)])
+    ring[100:110] = 99  # invalid ring
+    fr = synth.Frame(xyz.astype(np.float32), np.zeros(len(xyz), np.float32), ring.astype(np.uint16), np.zeros(len(xyz), np.float32), 16, 1800)
+    fo, po, fe, pg = both("vlp16", fr)
+    check_projection(po, pg)
+    check_features(fo, po, fe, pg)
+
+
+def test_downsample_rate_and_empty_rings():
+    f0, _, _ = synth.make_pair("os1-64")
+    fo, po, fe, pg = both("os1-64", f0, downsample_rate=2)
+    check_projection(po, pg)
+    assert np.all((po["end_ring"] - po["start_ring"])[1::2] == -10)  # odd rings are empty
+    check_features(fo, po, fe, pg)
+
+
+def test_sparse_and_tiny_inputs():
+    f0, _, _ = synth.make_pair("vlp16", col_stride=16)  # 112 points per ring
+    fo, po, fe, pg = both("vlp16", f0)
+    check_projection(po, pg)
+    check_features(fo, po, fe, pg)
+    fr = synth.Frame(f0.xyz[:7], f0.intensity[:7], f0.ring[:7], f0.time[:7], 16, 1800)
+    fo, po, fe, pg = both("vlp16", fr)
+    check_projection(po, pg)
+    check_features(fo, po, fe, pg)
+
+
+def test_thresholds_change_the_selection():
+    f0, _, _ = synth.make_pair("os1-64")
+    fo, po, fe, pg = both("os1-64", f0, edge_threshold=0.1, surf_threshold=0.02, odometry_surf_leaf_size=0.2)
+    check_projection(po, pg)
+    check_features(fo, po, fe, pg)
