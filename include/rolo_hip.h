@@ -182,6 +182,22 @@ int rolo_project_frame(rolo_ctx* ctx, const rolo_front_params* P, const float* p
 int rolo_extract_features(rolo_ctx* ctx, const rolo_front_params* P, float* corner, int* n_corner, float* surface,
                           int* n_surface, float* curvature, int32_t* neighbor_picked, int32_t* label);
 
+/* ---- per-frame odometry driver -------------------------------------------------------------------------------
+ * LidarOdometry (src/lidarOdometry.cpp:325-713) between fromROSMsg and publish, on feature clouds (n x 4 floats:
+ * x, y, z, intensity). The driver keeps the node's state (previous features, LaserOdomPose, the last step for
+ * the forward prediction) and runs both registration stages on `ctx`, whose registration parameters
+ * (setPolarResolution(0.175, 0.175, 2.0) in the reference, :462) the caller sets with rolo_set_params. */
+typedef struct rolo_odom rolo_odom;
+int rolo_odom_create(rolo_ctx* ctx, float ct_lambda /* rolo/continuousTrajectoryWeight */, rolo_odom** out);
+void rolo_odom_destroy(rolo_odom* o);
+/* odometryHandler :440-446 — the back end's rolo/mapping/odometry; scan matching is gated on it (:537-541) */
+int rolo_odom_backend_odometry(rolo_odom* o, double stamp);
+/* cloudHandler :503-570. Returns 0 = first frame stored, 1 = gated (pose propagated, no registration),
+ * 2 = registered; <0 error. pose6 = LaserOdomPose (x, y, z, roll, pitch, yaw) as published on
+ * odomTopic+"_incremental"; rot9 / trans3 = Rotation / Translation of the frame-to-frame step. */
+int rolo_odom_cloud(rolo_odom* o, double stamp, const float* corner, int n_corner, const float* surface, int n_surface,
+                    float* pose6, double* rot9, double* trans3);
+
 #ifdef __cplusplus
 }
 #endif

@@ -83,6 +83,10 @@ SYMBOLS = {
     "rolo_comm_destroy": (C.c_int, [vp]),
     "rolo_prof_enable": (C.c_int, [vp, C.c_int]),
     "rolo_prof_read": (C.c_int, [vp, C.c_int, fp, C.c_int]),
+    "rolo_odom_create": (C.c_int, [vp, C.c_float, C.POINTER(vp)]),
+    "rolo_odom_destroy": (None, [vp]),
+    "rolo_odom_backend_odometry": (C.c_int, [vp, C.c_double]),
+    "rolo_odom_cloud": (C.c_int, [vp, C.c_double, fp, C.c_int, fp, C.c_int, fp, dp, dp]),
     "rolo_front_default_params": (None, [C.POINTER(FrontParams)]),
     "rolo_project_frame": (C.c_int, [vp, C.POINTER(FrontParams), fp, C.c_int, C.POINTER(C.c_uint16), C.c_int, fp, ip, fp,
                                      ip, ip, fp, C.POINTER(C.c_int)]),

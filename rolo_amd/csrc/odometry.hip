@@ -1,0 +1,163 @@
+// K13 — the per-frame odometry driver (host side).
+// Replaces LidarOdometry::cloudHandler / stateLinearPropagation / scanRegeistration / updateTransform
+// (reference src/lidarOdometry.cpp:503-570, 700-712, 448-501, 572-626) on feature clouds, i.e. everything of the
+// rolo_lidarOdometry node between "fromROSMsg" and "publish". The registration itself is the HIP path
+// (rolo_register_async / rolo_register_wait: both LM stages enqueued back to back, one host wait per frame).
+// The fp32 pose algebra restates pcl::getTransformation / getTranslationAndEulerAngles / Eigen::Affine3f products
+// (PCL, Eigen: not vendored by the reference).
+#include "rolo_internal.hpp"
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+namespace rolo {
+void ctx_set_error(const char* msg);
+}
+
+namespace {
+
+struct Aff { float m[16]; };  // row-major 4x4
+
+Aff aff_identity() { Aff a; for (int i = 0; i < 16; i++) a.m[i] = (i % 5 == 0) ? 1.f : 0.f; return a; }
+
+// pcl::getTransformation(x, y, z, roll, pitch, yaw)
+Aff get_transformation(float x, float y, float z, float roll, float pitch, float yaw) {
+  const float A = std::cos(yaw), B = std::sin(yaw), C = std::cos(pitch), D = std::sin(pitch), E = std::cos(roll), F = std::sin(roll);
+  const float DE = D * E, DF = D * F;
+  Aff t;
+  t.m[0] = A * C; t.m[1] = A * DF - B * E; t.m[2] = B * F + A * DE; t.m[3] = x;
+  t.m[4] = B * C; t.m[5] = A * E + B * DF; t.m[6] = B * DE - A * F; t.m[7] = y;
+  t.m[8] = -D;    t.m[9] = C * F;          t.m[10] = C * E;         t.m[11] = z;
+  t.m[12] = 0; t.m[13] = 0; t.m[14] = 0; t.m[15] = 1;
+  return t;
+}
+// pcl::getTranslationAndEulerAngles
+void get_translation_and_euler(const Aff& t, float* o) {
+  o[0] = t.m[3]; o[1] = t.m[7]; o[2] = t.m[11];
+  o[3] = std::atan2(t.m[9], t.m[10]);
+  o[4] = std::asin(-t.m[8]);
+  o[5] = std::atan2(t.m[4], t.m[0]);
+}
+Aff aff_mul(const Aff& a, const Aff& b) {
+  Aff c;
+  for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) { float s = 0; for (int k = 0; k < 4; k++) s += a.m[i * 4 + k] * b.m[k * 4 + j]; c.m[i * 4 + j] = s; }
+  return c;
+}
+// Eigen::Transform<float,3,Affine>::inverse(): cofactor inverse of the linear part, translation -inv * t
+Aff aff_inverse(const Aff& T) {
+  const float* a = T.m;
+  float c[9];
+  c[0] = a[5] * a[10] - a[6] * a[9]; c[1] = a[2] * a[9] - a[1] * a[10]; c[2] = a[1] * a[6] - a[2] * a[5];
+  c[3] = a[6] * a[8] - a[4] * a[10]; c[4] = a[0] * a[10] - a[2] * a[8]; c[5] = a[2] * a[4] - a[0] * a[6];
+  c[6] = a[4] * a[9] - a[5] * a[8];  c[7] = a[1] * a[8] - a[0] * a[9];  c[8] = a[0] * a[5] - a[1] * a[4];
+  const float det = a[0] * c[0] + a[1] * c[3] + a[2] * c[6];
+  const float inv = 1.0f / det;
+  Aff o;
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) o.m[i * 4 + j] = c[i * 3 + j] * inv;
+  for (int i = 0; i < 3; i++) o.m[i * 4 + 3] = -(o.m[i * 4] * a[3] + o.m[i * 4 + 1] * a[7] + o.m[i * 4 + 2] * a[11]);
+  o.m[12] = o.m[13] = o.m[14] = 0; o.m[15] = 1;
+  return o;
+}
+
+}  // namespace
+
+struct rolo_odom {
+  rolo_ctx* ctx;
+  float ct_lambda;
+  bool first = true;                       // isFirstFrame
+  double cloudTimeCur = 0, cloudTimeLast = 0;  // cloudTimeLast is read before its first assignment in the reference: 0 here
+  double lastOdomTime = -1;                // lidarOdometry.cpp:417
+  double lastMappingInterval = 9999.0;     // :419
+  Aff lidarMappingAffine = aff_identity();
+  Aff transformation_interpolated = aff_identity();
+  double Rotation[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, Translation[3] = {0, 0, 0}, TranslationOld[3] = {0, 0, 0};
+  float LaserOdomPose[6] = {0, 0, 0, 0, 0, 0};
+  std::vector<float> featureOld;           // n x 4
+  rolo_stats last_rot{}, last_trans{};
+};
+
+namespace {
+void update_transform(rolo_odom* o) {  // lidarOdometry.cpp:572-626, pose part
+  Aff step;
+  for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) step.m[i * 4 + j] = (float)o->Rotation[i * 3 + j]; step.m[i * 4 + 3] = (float)o->Translation[i]; }
+  step.m[12] = step.m[13] = step.m[14] = 0; step.m[15] = 1;
+  const Aff pose = get_transformation(o->LaserOdomPose[0], o->LaserOdomPose[1], o->LaserOdomPose[2], o->LaserOdomPose[3], o->LaserOdomPose[4], o->LaserOdomPose[5]);
+  const Aff moved = aff_mul(pose, aff_inverse(step));
+  o->lidarMappingAffine = step;
+  get_translation_and_euler(moved, o->LaserOdomPose);
+  for (int i = 0; i < 3; i++) o->TranslationOld[i] = o->Translation[i];
+}
+}  // namespace
+
+extern "C" {
+
+int rolo_odom_create(rolo_ctx* ctx, float ct_lambda, rolo_odom** out) {
+  if (!ctx || !out) return ROLO_EINVAL;
+  rolo_odom* o = new rolo_odom();
+  o->ctx = ctx; o->ct_lambda = ct_lambda;
+  *out = o;
+  return ROLO_OK;
+}
+void rolo_odom_destroy(rolo_odom* o) { delete o; }
+
+int rolo_odom_backend_odometry(rolo_odom* o, double stamp) {  // odometryHandler :440-446
+  if (!o) return ROLO_EINVAL;
+  o->lastOdomTime = stamp;
+  return ROLO_OK;
+}
+
+int rolo_odom_cloud(rolo_odom* o, double stamp, const float* corner, int n_corner, const float* surface, int n_surf,
+                    float* pose6, double* rot9, double* trans3) {
+  if (!o || n_corner < 0 || n_surf < 0 || (n_corner && !corner) || (n_surf && !surface)) return ROLO_EINVAL;
+  o->cloudTimeCur = stamp;
+  std::vector<float> featureLast((size_t)(n_corner + n_surf) * 4);  // *featureLast = *CloudCornerLast + *CloudSurfLast
+  if (n_corner) memcpy(featureLast.data(), corner, sizeof(float) * 4 * (size_t)n_corner);
+  if (n_surf) memcpy(featureLast.data() + 4 * (size_t)n_corner, surface, sizeof(float) * 4 * (size_t)n_surf);
+  int ret;
+  if (o->first) {
+    o->first = false;
+    o->featureOld.swap(featureLast);
+    ret = 0;
+  } else if (o->lastOdomTime == -1.0) {  // no scan matching until the back end has published once
+    update_transform(o);
+    o->featureOld.swap(featureLast);
+    ret = 1;
+  } else {
+    const double latestInterval = o->cloudTimeCur - o->cloudTimeLast;
+    // stateLinearPropagation :700-712
+    const double ratio = latestInterval / o->lastMappingInterval;
+    float v[6];
+    get_translation_and_euler(o->lidarMappingAffine, v);
+    v[3] = v[4] = v[5] = 0;
+    for (int i = 0; i < 6; i++) v[i] *= (float)ratio;
+    o->transformation_interpolated = get_transformation(v[0], v[1], v[2], v[3], v[4], v[5]);
+    o->cloudTimeLast = o->cloudTimeCur;
+    o->lastMappingInterval = latestInterval;
+    // scanRegeistration :448-501
+    const int nOld = (int)(o->featureOld.size() / 4);
+    std::vector<float> propagated(o->featureOld.size());
+    int rc = rolo_transform_cloud(o->ctx, o->featureOld.data(), propagated.data(), nOld, 4, o->transformation_interpolated.m);
+    if (rc) return rc;
+    if ((rc = rolo_set_target(o->ctx, featureLast.data(), n_corner + n_surf, 4))) return rc;
+    if ((rc = rolo_set_source(o->ctx, propagated.data(), nOld, 4))) return rc;
+    double guess_t[3];  // Translation after the rotation stage = translation of T_interp * T_rot = that of T_interp
+    for (int i = 0; i < 3; i++) guess_t[i] = (double)o->transformation_interpolated.m[i * 4 + 3];
+    const double zero3[3] = {0, 0, 0};
+    if ((rc = rolo_register_async(o->ctx, nullptr, zero3, guess_t, o->TranslationOld, 0.1, 0.1, o->ct_lambda))) return rc;
+    float Tf[16]; double reg_t[3];
+    if ((rc = rolo_register_wait(o->ctx, Tf, nullptr, reg_t, &o->last_rot, &o->last_trans))) return rc;
+    Aff step; memcpy(step.m, Tf, sizeof(Tf));
+    o->transformation_interpolated = aff_mul(o->transformation_interpolated, step);  // :472
+    for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) o->Rotation[i * 3 + j] = (double)o->transformation_interpolated.m[i * 4 + j]; o->Translation[i] = (double)o->transformation_interpolated.m[i * 4 + 3]; }
+    for (int i = 0; i < 3; i++) o->Translation[i] += reg_t[i];  // :500
+    update_transform(o);
+    o->featureOld.swap(featureLast);
+    ret = 2;
+  }
+  if (pose6) memcpy(pose6, o->LaserOdomPose, sizeof(float) * 6);
+  if (rot9) memcpy(rot9, o->Rotation, sizeof(double) * 9);
+  if (trans3) memcpy(trans3, o->Translation, sizeof(double) * 3);
+  return ret;
+}
+
+}  // extern "C"

@@ -1,0 +1,46 @@
+"""Host-side mirror of the reference node core `LidarOdometry` (reference src/lidarOdometry.cpp:325-713) over the
+C ABI (rolo_odom_*): same state machine — first frame stored, gated until the back end has published once
+(odometryHandler), then forward prediction + RotVGICP rotation + continuous-time translation per frame.
+Plumbing only; the pose algebra and the registration live in librolo_hip.so."""
+from __future__ import annotations
+
+import ctypes as C
+import numpy as np
+
+from ._lib import check, lib
+from .rotvgicp import RotVGICP
+
+
+class LidarOdometry:
+    def __init__(self, device: int = 0, ct_lambda: float = 0.3, polar_resolution=(0.175, 0.175, 2.0)):
+        self.reg = RotVGICP(device)
+        self.reg.setPolarResolution(*polar_resolution)  # lidarOdometry.cpp:462
+        h = C.c_void_p()
+        check(lib().rolo_odom_create(self.reg._h, ct_lambda, C.byref(h)), "rolo_odom_create")
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().rolo_odom_destroy(self._h)
+            self._h = None
+        self.reg.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def odometryHandler(self, stamp: float):
+        check(lib().rolo_odom_backend_odometry(self._h, stamp), "rolo_odom_backend_odometry")
+
+    def cloudHandler(self, stamp: float, corner: np.ndarray, surface: np.ndarray):
+        """Returns (status, LaserOdomPose[6] float32, Rotation 3x3, Translation 3)."""
+        corner = np.ascontiguousarray(corner, np.float32).reshape(-1, 4)
+        surface = np.ascontiguousarray(surface, np.float32).reshape(-1, 4)
+        pose = np.zeros(6, np.float32); R = np.zeros((3, 3)); t = np.zeros(3)
+        fp, dp = C.POINTER(C.c_float), C.POINTER(C.c_double)
+        rc = check(lib().rolo_odom_cloud(self._h, stamp, corner.ctypes.data_as(fp), corner.shape[0], surface.ctypes.data_as(fp),
+                                         surface.shape[0], pose.ctypes.data_as(fp), R.ctypes.data_as(dp), t.ctypes.data_as(dp)),
+                   "rolo_odom_cloud")
+        return rc, pose, R, t
