@@ -149,6 +149,10 @@ int rolo_transform_cloud(rolo_ctx* ctx, const float* in, float* out, int n, int 
  * [r*n/W, (r+1)*n/W) in the passes and the per-pass sums are all-reduced (fp64, <= 32 values) with RCCL on the
  * context's stream. unique_id = the 128-byte ncclUniqueId created by rank 0 (rolo_comm_unique_id) and
  * distributed by the caller (e.g. torch.distributed broadcast). */
+/* the slice of n source points rank r of `world` evaluates: [n*r/world, n*(r+1)/world) */
+void rolo_shard_range(int n, int rank, int world, int* begin, int* end);
+/* test hook: shard the passes WITHOUT a communicator — sums returned by the stage-level calls are then partial */
+int rolo_set_shard(rolo_ctx* ctx, int rank, int world);
 int rolo_comm_unique_id(void* unique_id128);
 int rolo_comm_init(rolo_ctx* ctx, const void* unique_id128, int rank, int world);
 int rolo_comm_destroy(rolo_ctx* ctx);

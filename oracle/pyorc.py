@@ -68,6 +68,7 @@ def lib():
             f.argtypes = [C.c_void_p]
         for f in (L.orc_reg_get_source_covs, L.orc_reg_get_target_covs):
             f.argtypes = [C.c_void_p, dp]
+        L.orc_reg_set_source_covs.argtypes = [C.c_void_p, dp]
         L.orc_reg_get_voxels.argtypes = [C.c_void_p, ip, ip, dp, dp]
         L.orc_reg_so3_linearize.restype = C.c_double
         L.orc_reg_so3_linearize.argtypes = [C.c_void_p, dp, dp, dp]
@@ -171,6 +172,10 @@ class Reg:
         out = np.zeros((self.ns, 4, 4))
         assert lib().orc_reg_get_source_covs(self.h, _d(out)) == 0
         return out
+
+    def set_source_covs(self, covs):
+        a = np.ascontiguousarray(covs, np.float64).reshape(self.ns, 16)
+        assert lib().orc_reg_set_source_covs(self.h, _d(a)) == 0
 
     def target_covs(self):
         out = np.zeros((self.nt, 4, 4))

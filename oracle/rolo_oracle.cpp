@@ -725,6 +725,12 @@ int orc_reg_compute_covariances(orc_reg* r) {
 }
 int orc_reg_get_source_covs(orc_reg* r, double* covs) { if (!r->have_scov) return -1; cov_out(r->source_covs, covs); return 0; }
 int orc_reg_get_target_covs(orc_reg* r, double* covs) { if (!r->have_tcov) return -1; cov_out(r->target_covs, covs); return 0; }
+int orc_reg_set_source_covs(orc_reg* r, const double* covs) {
+  r->source_covs.resize(r->source.size());
+  for (size_t i = 0; i < r->source.size(); i++) for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) r->source_covs[i].a[a][b] = covs[i * 16 + a * 4 + b];
+  r->have_scov = true;
+  return 0;
+}
 int orc_reg_build_voxelmap(orc_reg* r) { int rc = orc_reg_compute_covariances(r); if (rc) return rc; return build_map(r); }
 int orc_reg_num_voxels(orc_reg* r) { return r->have_map ? (int)r->voxels.size() : -1; }
 int orc_reg_get_voxels(orc_reg* r, int32_t* keys, int32_t* counts, double* means, double* covs) {

@@ -54,6 +54,8 @@ int orc_reg_set_source(orc_reg* r, const float* pts, int n, int stride);
 int orc_reg_compute_covariances(orc_reg* r);
 int orc_reg_get_source_covs(orc_reg* r, double* covs);
 int orc_reg_get_target_covs(orc_reg* r, double* covs);
+/* setSourceCovariances (rot_vgicp_impl.hpp:122-125): n x 16 doubles */
+int orc_reg_set_source_covs(orc_reg* r, const double* covs);
 /* K6: vmp_voxel.hpp:167-197. Builds the map from the target (needs covariances). */
 int orc_reg_build_voxelmap(orc_reg* r);
 int orc_reg_num_voxels(orc_reg* r);

@@ -67,6 +67,12 @@ constexpr int NCCL_SUM = 0;
 
 }  // namespace
 
+extern "C" void rolo_shard_range(int n, int rank, int world, int* begin, int* end) {
+  const long long N = n;
+  if (begin) *begin = (int)(N * rank / world);
+  if (end) *end = (int)(N * (rank + 1) / world);
+}
+
 struct rolo_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -222,11 +228,7 @@ int ensure_map(rolo_ctx* c) {
   return ROLO_OK;
 }
 
-void shard(const rolo_ctx* c, int& begin, int& end) {
-  const long long n = c->src.n;
-  begin = (int)(n * c->rank / c->world);
-  end = (int)(n * (c->rank + 1) / c->world);
-}
+void shard(const rolo_ctx* c, int& begin, int& end) { rolo_shard_range(c->src.n, c->rank, c->world, &begin, &end); }
 
 int prepare_pass(rolo_ctx* c, PassArgs& a, int& grid) {
   const int noff = n_offsets(c->P);
@@ -248,7 +250,7 @@ int enqueue_pass(rolo_ctx* c, const PassArgs& a, int grid, int stage) {
     else HIPCHK(launch_trans_pass(a, c->state, grid, c->stream));
   }
   ProfScope pc(c, ROLO_PROF_CTRL);
-  if (c->world > 1) {
+  if (c->comm) {
     HIPCHK(launch_reduce(c->partials, grid, c->sums, c->state, stage, c->stream));
     int e = g_rccl.AllReduce(c->sums, c->sums, NV_MAX, NCCL_FLOAT64, NCCL_SUM, c->comm, c->stream);
     if (e != 0) { g_err = std::string("ncclAllReduce: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "?"); return ROLO_ECOMM; }
@@ -559,7 +561,7 @@ static int eval_rot(rolo_ctx* c, const double* T, int dof_optimizer, int mode, d
   HIPCHK(launch_eval_begin(c->state, b, mode, c->stream));
   HIPCHK(launch_rot_pass(dof, a, c->state, grid, c->stream));
   HIPCHK(launch_reduce(c->partials, grid, c->sums, c->state, -1, c->stream));
-  if (c->world > 1) {
+  if (c->comm) {
     int e = g_rccl.AllReduce(c->sums, c->sums, NV_MAX, NCCL_FLOAT64, NCCL_SUM, c->comm, c->stream);
     if (e != 0) { g_err = "ncclAllReduce failed"; return ROLO_ECOMM; }
   }
@@ -617,7 +619,7 @@ static int eval_t3(rolo_ctx* c, const double* t3, const double* g3, const double
   HIPCHK(launch_t3_eval_begin(c->state, tb, phase, c->stream));
   HIPCHK(launch_trans_pass(a, c->state, grid, c->stream));
   HIPCHK(launch_reduce(c->partials, grid, c->sums, c->state, -1, c->stream));
-  if (c->world > 1) {
+  if (c->comm) {
     int e = g_rccl.AllReduce(c->sums, c->sums, NV_MAX, NCCL_FLOAT64, NCCL_SUM, c->comm, c->stream);
     if (e != 0) { g_err = "ncclAllReduce failed"; return ROLO_ECOMM; }
   }
@@ -789,6 +791,12 @@ int rolo_prof_read(rolo_ctx* c, int slot, float* ms, int cap) {
   }
   c->prof.swap(keep);
   return n;
+}
+
+int rolo_set_shard(rolo_ctx* c, int rank, int world) {
+  if (!c || world < 1 || rank < 0 || rank >= world) return ROLO_EINVAL;
+  c->rank = rank; c->world = world; c->have_corr = false;
+  return ROLO_OK;
 }
 
 int rolo_comm_unique_id(void* uid128) {

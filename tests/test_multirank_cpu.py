@@ -1,0 +1,99 @@
+"""CPU, world_size 2 over gloo: the host logic of the N>1 path.
+
+The GPU path shards the SOURCE points over ranks and all-reduces the <= 32 fp64 sums of every LM pass with RCCL
+inside librolo_hip. What can be checked without GPUs:
+  * rolo_shard_range (the C ABI's partition) tiles [0, n) exactly for every rank count;
+  * the algebra the collective relies on: per-rank partial (H, b, cost) of the oracle over the rank's shard,
+    summed with a real 2-process gloo all_reduce, equal the single-rank sums — and every rank then takes the same
+    LM decision;
+  * the unique-id distribution plumbing bench.py uses (broadcast_object_list) works over the process group.
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def test_shard_range_tiles_exactly():
+    import ctypes as C
+    from rolo_amd import _lib
+    L = _lib.lib()
+    for n in (0, 1, 7, 20, 131072, 262144, 1000003):
+        for world in (1, 2, 3, 4, 8):
+            prev = 0
+            for r in range(world):
+                b, e = C.c_int(), C.c_int()
+                L.rolo_shard_range(n, r, world, C.byref(b), C.byref(e))
+                assert b.value == prev and e.value >= b.value
+                prev = e.value
+            assert prev == n
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import ctypes as C
+        from oracle import pyorc
+        from rolo_amd import synth, _lib
+        src, tgt, _ = synth.dense_pair("vlp16", col_stride=8)
+        n = src.shape[0]
+        # every rank holds the full clouds (as on the GPU); covariances come from full-cloud neighbourhoods
+        full = pyorc.Reg(pyorc.default_params(polar_resolution=(0.175, 0.175, 2.0), num_threads=1))
+        full.set_target(tgt); full.set_source(src)
+        assert full.compute_covariances() == 0
+        b, e = C.c_int(), C.c_int()
+        _lib.lib().rolo_shard_range(n, rank, world, C.byref(b), C.byref(e))
+        part = pyorc.Reg(pyorc.default_params(polar_resolution=(0.175, 0.175, 2.0), num_threads=1))
+        part.set_target(tgt); part.set_source(src[b.value:e.value])
+        part.set_source_covs(full.source_covs()[b.value:e.value])
+        T = np.eye(4); T[:3, :3] = synth.rpy_to_R(0.004, -0.007, 0.02)
+        err, H, bb = part.so3_linearize(T)
+        buf = torch.zeros(32, dtype=torch.float64)
+        buf[0] = err; buf[1:10] = torch.from_numpy(H.reshape(-1)); buf[10:13] = torch.from_numpy(bb); buf[13] = part.correspondences()[0].shape[0]
+        dist.all_reduce(buf)  # the collective of one LM pass
+        ef, Hf, bf = full.so3_linearize(T)
+        ok = abs(buf[0].item() - ef) <= 1e-12 * abs(ef)
+        ok = ok and np.abs(buf[1:10].numpy().reshape(3, 3) - Hf).max() <= 1e-12 * np.abs(Hf).max()
+        ok = ok and np.abs(buf[10:13].numpy() - bf).max() <= 1e-12 * np.abs(bf).max()
+        ok = ok and int(buf[13].item()) == full.correspondences()[0].shape[0]
+        # same LM step on every rank from the reduced sums
+        lam = 1e-9 * np.abs(np.diag(buf[1:10].numpy().reshape(3, 3))).max()
+        d = np.linalg.solve(buf[1:10].numpy().reshape(3, 3) + lam * np.eye(3), -buf[10:13].numpy())
+        dd = torch.from_numpy(d.copy()); mx = dd.clone(); mn = dd.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX); dist.all_reduce(mn, op=dist.ReduceOp.MIN)
+        ok = ok and bool(torch.equal(mx, mn))  # bit-identical on all ranks
+        # unique-id plumbing used by bench.py
+        obj = [b"x" * 128 if rank == 0 else None]
+        dist.broadcast_object_list(obj, src=0)
+        ok = ok and obj[0] == b"x" * 128
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_partial_sums_allreduce_gloo():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(res) == [(0, True), (1, True)]
