@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-shard-leg", action="store_true", help="N>1: skip the extra point-sharded measurement")
     ap.add_argument("--cpu-frames", type=int, default=1)
+    ap.add_argument("--streams", type=int, default=1,
+                    help="registration contexts (HIP streams) kept in flight per GPU; a step is then one frame pair per stream")
     return ap.parse_args()
 
 
@@ -85,12 +87,19 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run_steps(g, k):
+    zero3 = np.zeros(3)
+
+    def run_steps(gs, k):
+        """k steps; one step = one frame pair on every context of `gs` (enqueue all, then wait for all)."""
+        if not isinstance(gs, (list, tuple)):
+            gs = [gs]
         for _ in range(k):
-            g.setInputTargetDevice(d_tgt.data_ptr(), n, 4)
-            g.setInputSourceDevice(d_src.data_ptr(), n, 4)
-            g.register_async(None, np.zeros(3), guess, last, 0.1, 0.1, 0.3)
-            g.register_wait()
+            for g in gs:
+                g.setInputTargetDevice(d_tgt.data_ptr(), n, 4)
+                g.setInputSourceDevice(d_src.data_ptr(), n, 4)
+                g.register_async(None, zero3, guess, last, 0.1, 0.1, 0.3)
+            for g in gs:
+                g.register_wait()
 
     def timed(g, steps, warmup):
         run_steps(g, warmup)
@@ -106,12 +115,14 @@ def main():
         return dt
 
     g = new_ctx()
+    ctxs = [g] + [new_ctx() for _ in range(max(args.streams, 1) - 1)]
     if args.mode == "shard" and world > 1:
+        ctxs = [g]
         uid = [RotVGICP.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
         g.comm_init(uid[0], rank, world)
-    dt = timed(g, args.steps, args.warmup)
-    frames_total = args.steps * (world if args.mode == "replicas" else 1)
+    dt = timed(ctxs, args.steps, args.warmup)
+    frames_total = args.steps * len(ctxs) * (world if args.mode == "replicas" else 1)
     value = frames_total / dt
     rs, ts = g.last_stats, g.last_translation_stats
     passes = rs.n_passes + ts.n_passes
@@ -124,6 +135,7 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps,
+        "frames_per_step": len(ctxs),
         "higher_is_better": True,
         "scaling": "weak" if args.mode == "replicas" else "strong",
         "vs_baseline": None,
@@ -131,7 +143,7 @@ def main():
         "data": "synthetic",
         "config": {"workload": f"{args.sensor} dense frame pair, {n} pts/cloud, k=20 PLANE covariances, UNIFORM voxel leaf "
                                f"{args.leaf} m, 20 SO(3) LM iterations + CT translation LM", "mode": args.mode,
-                   "parallelism": f"{args.mode}{world}", "rot_outer": rs.n_outer, "trans_outer": ts.n_outer,
+                   "parallelism": f"{args.mode}{world}", "streams_per_gpu": len(ctxs), "rot_outer": rs.n_outer, "trans_outer": ts.n_outer,
                    "passes_per_frame": passes, "n_correspondences": rs.n_correspondences},
     }
 

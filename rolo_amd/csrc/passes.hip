@@ -234,17 +234,21 @@ __global__ __launch_bounds__(PASS_THREADS) void trans_pass_kernel(PassArgs a, co
 ROLO_DEV void reduce_rows(const double* __restrict__ partials, int nblocks, double* sums /* shared, NV_MAX */) {
   __shared__ double part[8][NV_MAX];
   const int v = threadIdx.x & 31, q = threadIdx.x >> 5;  // 256 threads = 8 strided groups of 32 values
-  // four independent accumulators keep four loads in flight; the combination order is fixed => deterministic
-  double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-  int b = q;
-  for (; b + 24 < nblocks; b += 32) {
-    s0 += partials[(size_t)b * NV_MAX + v];
-    s1 += partials[(size_t)(b + 8) * NV_MAX + v];
-    s2 += partials[(size_t)(b + 16) * NV_MAX + v];
-    s3 += partials[(size_t)(b + 24) * NV_MAX + v];
+  // The rows were written by other CUs a moment ago, so every load is a ~1-2 us L2/fabric round trip and this
+  // reduction is pure latency: issue 16 independent loads per thread before the first add (one round trip per
+  // 128 rows instead of one per 8). The combination order is fixed => deterministic for a given grid.
+  double s0 = 0;
+  for (int b0 = q; b0 < nblocks; b0 += 8 * 16) {
+    double r[16];
+#pragma unroll
+    for (int u = 0; u < 16; u++) {
+      const int b = b0 + 8 * u;
+      r[u] = (b < nblocks) ? partials[(size_t)b * NV_MAX + v] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 16; u++) s0 += r[u];
   }
-  for (; b < nblocks; b += 8) s0 += partials[(size_t)b * NV_MAX + v];
-  part[q][v] = (s0 + s1) + (s2 + s3);
+  part[q][v] = s0;
   __syncthreads();
   if (threadIdx.x < NV_MAX) {
     double t = 0;
