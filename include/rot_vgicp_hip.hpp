@@ -1,0 +1,189 @@
+// rot_vgicp_hip.hpp — header-only C++ drop-in for `fast_gicp::RotVGICP<PointSource, PointTarget>` over the C ABI
+// of librolo_hip.so (include/rolo_hip.h). It keeps the reference's class name, method names, argument meaning
+// and error behaviour (reference include/rot_gicp/gicp/rot_vgicp.hpp:72-104, lsq_registration.hpp:51-62), so
+// src/lidarOdometry.cpp:460-494 compiles against it unchanged:
+//
+//     #include <rot_vgicp_hip.hpp>               // instead of <rot_gicp/gicp/rot_vgicp.hpp>
+//     fast_gicp::RotVGICP<PointType, PointType> rot_vgicp;
+//     rot_vgicp.setPolarResolution(0.175, 0.175, 2.0);
+//     rot_vgicp.setInputTarget(featureLast); rot_vgicp.setInputSource(feature_propagated);
+//     rot_vgicp.align(*aligned);
+//     Eigen::Matrix4f trans = rot_vgicp.getFinalTransformation();
+//     rot_vgicp.computeTranslation(*aligned, Reg_translation, Translation, TranslationOld, 0.1, 0.1, CT_lambda);
+//
+// Two build modes:
+//   * with PCL + Eigen on the include path (the ROLO catkin workspace): define ROLO_HIP_WITH_PCL before including;
+//     the class then takes pcl::PointCloud<PointT>::ConstPtr / Eigen types exactly like the reference;
+//   * without them (this repository's CI image has neither): a POD cloud `rolo::Cloud` (n x 8 floats, the
+//     pcl::PointXYZI memory layout) and plain arrays stand in, same methods.
+// The class owns one rolo_ctx (one HIP stream); like the reference object it is not thread-safe.
+#pragma once
+#include <array>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "rolo_hip.h"
+
+#ifdef ROLO_HIP_WITH_PCL
+#include <Eigen/Core>
+#include <pcl/point_cloud.h>
+#include <pcl/point_types.h>
+#endif
+
+namespace rolo {
+
+// pcl::PointXYZI memory layout: float data[4] (x, y, z, 1), float intensity, 12 bytes padding
+struct PointXYZI { float x, y, z, w, intensity, pad[3]; };
+static_assert(sizeof(PointXYZI) == 32, "pcl::PointXYZI is 32 bytes");
+struct Cloud {
+  std::vector<PointXYZI> points;
+  size_t size() const { return points.size(); }
+  using Ptr = std::shared_ptr<Cloud>;
+  using ConstPtr = std::shared_ptr<const Cloud>;
+};
+
+}  // namespace rolo
+
+namespace fast_gicp {
+
+// gicp_settings.hpp:6-13, lsq_registration.hpp:13 — same enumerators, same order
+enum class RegularizationMethod { NONE, MIN_EIG, NORMALIZED_MIN_EIG, PLANE, FROBENIUS, PLANE_S };
+enum class NeighborSearchMethod { DIRECT27, DIRECT7, DIRECT1, DIRECT_RADIUS };
+enum class VoxelAccumulationMode { ADDITIVE, ADDITIVE_WEIGHTED, MULTIPLICATIVE };
+enum class VoxelType { POLAR, UNIFORM };
+enum class LSQ_OPTIMIZER_TYPE { GaussNewton, LevenbergMarquardt, SO3_LevenbergMarquardt };
+
+#ifdef ROLO_HIP_WITH_PCL
+template <typename PointSource, typename PointTarget>
+#else
+template <typename PointSource = rolo::PointXYZI, typename PointTarget = rolo::PointXYZI>
+#endif
+class RotVGICP {
+public:
+#ifdef ROLO_HIP_WITH_PCL
+  using PointCloudSource = pcl::PointCloud<PointSource>;
+  using PointCloudTarget = pcl::PointCloud<PointTarget>;
+  using PointCloudSourceConstPtr = typename PointCloudSource::ConstPtr;
+  using PointCloudTargetConstPtr = typename PointCloudTarget::ConstPtr;
+  using Matrix4 = Eigen::Matrix4f;
+  using Vector3d = Eigen::Vector3d;
+#else
+  using PointCloudSource = rolo::Cloud;
+  using PointCloudTarget = rolo::Cloud;
+  using PointCloudSourceConstPtr = rolo::Cloud::ConstPtr;
+  using PointCloudTargetConstPtr = rolo::Cloud::ConstPtr;
+  using Matrix4 = std::array<float, 16>;   // row-major
+  using Vector3d = std::array<double, 3>;
+#endif
+  static_assert(sizeof(PointSource) % sizeof(float) == 0 && sizeof(PointTarget) % sizeof(float) == 0, "points must be float records");
+
+  explicit RotVGICP(int device = 0) {
+    if (rolo_ctx_create(device, &ctx_) != ROLO_OK) throw std::runtime_error(std::string("RotVGICP(HIP): ") + rolo_last_error());
+    rolo_default_params(&p_);
+    for (int i = 0; i < 16; i++) final_[i] = (i % 5 == 0) ? 1.f : 0.f;
+  }
+  ~RotVGICP() { rolo_ctx_destroy(ctx_); }
+  RotVGICP(const RotVGICP&) = delete;
+  RotVGICP& operator=(const RotVGICP&) = delete;
+
+  // ---- rot_vgicp_impl.hpp:44-110 ----
+  void setResolution(double resolution) { p_.voxel_resolution = resolution; p_.voxel_type = ROLO_VOXEL_UNIFORM; push(); }
+  void setPolarResolution(double theta_res, double phi_res, double r_res) {
+    p_.polar_resolution[0] = theta_res; p_.polar_resolution[1] = phi_res; p_.polar_resolution[2] = r_res;
+    p_.voxel_type = ROLO_VOXEL_POLAR; push();
+  }
+  void setNeighborSearchMethod(NeighborSearchMethod m) {
+    if (m == NeighborSearchMethod::DIRECT_RADIUS) { std::fprintf(stderr, "unsupported neighbor search method\n"); std::abort(); }  // vmp_voxel.hpp:16-18
+    p_.neighbor_search = static_cast<int>(m); push();
+  }
+  void setVoxelAccumulationMode(VoxelAccumulationMode) {}  // every mode builds AdditiveVmfVoxel (vmp_voxel.hpp:176-184)
+  void setNumThreads(int) {}                               // no host threads on the HIP path
+  void setCorrespondenceRandomness(int k) { p_.k_correspondences = k; push(); }
+  void setRegularizationMethod(RegularizationMethod m) { p_.regularization = static_cast<int>(m); push(); }
+  void setOptimizerType(LSQ_OPTIMIZER_TYPE t) { p_.optimizer = static_cast<int>(t); push(); }
+  void setRotationEpsilon(double eps) { p_.rotation_epsilon = eps; push(); }
+  void setTransformationEpsilon(double eps) { p_.transformation_epsilon = eps; push(); }
+  void setMaximumIterations(int n) { p_.max_iterations = n; push(); }
+  void setInitialLambdaFactor(double f) { p_.lm_init_lambda_factor = f; push(); }
+  void setDebugPrint(bool) {}  // the per-trial table is available through rolo_get_trace()
+
+  void clearSource() { src_.reset(); check(rolo_clear_source(ctx_)); }
+  void clearTarget() { tgt_.reset(); check(rolo_clear_target(ctx_)); }
+  void swapSourceAndTarget() { src_.swap(tgt_); check(rolo_swap_source_and_target(ctx_)); }
+
+  void setInputSource(const PointCloudSourceConstPtr& cloud) {
+    if (src_ == cloud) return;  // :113-115
+    src_ = cloud;
+    check(rolo_set_source(ctx_, reinterpret_cast<const float*>(cloud->points.data()), (int)cloud->points.size(), (int)(sizeof(PointSource) / sizeof(float))));
+  }
+  void setInputTarget(const PointCloudTargetConstPtr& cloud) {
+    if (tgt_ == cloud) return;  // :134-136
+    tgt_ = cloud;
+    check(rolo_set_target(ctx_, reinterpret_cast<const float*>(cloud->points.data()), (int)cloud->points.size(), (int)(sizeof(PointTarget) / sizeof(float))));
+  }
+
+  // pcl::Registration::align(output) -> computeTransformation (:146-160)
+  void align(PointCloudSource& output) { Matrix4 guess = identity(); align(output, guess); }
+  void align(PointCloudSource& output, const Matrix4& guess) {
+    if (!src_ || !tgt_) throw std::runtime_error("RotVGICP: source / target not set");
+    if (output.points.data() == src_->points.data() || output.points.data() == tgt_->points.data())
+      throw std::invalid_argument("RotVGICP: destination cloud cannot be identical to source or target");  // :150-152
+    float g[16]; to_rowmajor(guess, g);
+    rolo_stats st;
+    const int rc = rolo_align(ctx_, g, final_, nullptr, &st);
+    if (rc != ROLO_OK) throw std::runtime_error(std::string("RotVGICP(HIP) align: ") + rolo_last_error());
+    if (st.lm_failed) std::fprintf(stderr, "lm not converged!!\n");  // lsq_registration_impl.hpp:168-171
+    converged_ = st.converged != 0; nr_iterations_ = st.n_outer - 1;
+    transform_into(output, final_);  // lsq_registration_impl.hpp:178
+  }
+  Matrix4 getFinalTransformation() const { return from_rowmajor(final_); }
+  bool hasConverged() const { return converged_; }
+
+  // RotVGICP::computeTranslation (:163-169)
+  void computeTranslation(PointCloudSource& output, Vector3d& trans, const Vector3d& init_guess, const Vector3d& last_t0,
+                          const double interval_tn, const double interval_tn_1, const float ct_lambda) {
+    double t[3] = {trans[0], trans[1], trans[2]}, g[3] = {init_guess[0], init_guess[1], init_guess[2]}, l[3] = {last_t0[0], last_t0[1], last_t0[2]};
+    rolo_stats st;
+    const int rc = rolo_compute_translation(ctx_, t, g, l, interval_tn, interval_tn_1, ct_lambda, &st);
+    if (rc != ROLO_OK) throw std::runtime_error(std::string("RotVGICP(HIP) computeTranslation: ") + rolo_last_error());
+    if (st.lm_failed) std::fprintf(stderr, "lm not converged!!\n");
+    trans[0] = t[0]; trans[1] = t[1]; trans[2] = t[2];
+    float T[16] = {1, 0, 0, (float)t[0], 0, 1, 0, (float)t[1], 0, 0, 1, (float)t[2], 0, 0, 0, 1};
+    transform_into(output, T);  // lsq_registration_impl.hpp:75-78
+  }
+
+  rolo_ctx* handle() { return ctx_; }
+
+private:
+  void push() { check(rolo_set_params(ctx_, &p_)); }
+  static void check(int rc) { if (rc != ROLO_OK) throw std::runtime_error(std::string("RotVGICP(HIP): ") + rolo_last_error()); }
+  void transform_into(PointCloudSource& output, const float* T) {
+    output.points.resize(src_->points.size());
+    check(rolo_transform_cloud(ctx_, reinterpret_cast<const float*>(src_->points.data()), reinterpret_cast<float*>(output.points.data()),
+                               (int)src_->points.size(), (int)(sizeof(PointSource) / sizeof(float)), T));
+  }
+#ifdef ROLO_HIP_WITH_PCL
+  static Matrix4 identity() { return Matrix4::Identity(); }
+  static void to_rowmajor(const Matrix4& m, float* o) { for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) o[i * 4 + j] = m(i, j); }
+  static Matrix4 from_rowmajor(const float* o) { Matrix4 m; for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) m(i, j) = o[i * 4 + j]; return m; }
+#else
+  static Matrix4 identity() { Matrix4 m{}; for (int i = 0; i < 16; i++) m[i] = (i % 5 == 0) ? 1.f : 0.f; return m; }
+  static void to_rowmajor(const Matrix4& m, float* o) { std::memcpy(o, m.data(), sizeof(float) * 16); }
+  static Matrix4 from_rowmajor(const float* o) { Matrix4 m; std::memcpy(m.data(), o, sizeof(float) * 16); return m; }
+#endif
+
+  rolo_ctx* ctx_ = nullptr;
+  rolo_params p_;
+  PointCloudSourceConstPtr src_;
+  PointCloudTargetConstPtr tgt_;
+  float final_[16];
+  bool converged_ = false;
+  int nr_iterations_ = 0;
+};
+
+}  // namespace fast_gicp

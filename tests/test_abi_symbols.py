@@ -41,3 +41,13 @@ def test_no_gpu_is_a_loud_error_not_a_fallback():
     with pytest.raises(_lib.RoloError):
         from rolo_amd.rotvgicp import RotVGICP
         RotVGICP()
+
+
+def test_cpp_shim_compiles_and_links():
+    """The header-only RotVGICP drop-in (include/rot_vgicp_hip.hpp) builds with plain g++ against the C ABI."""
+    import subprocess, tempfile
+    out = os.path.join(tempfile.mkdtemp(), "shim_demo")
+    cmd = ["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "shim_demo.cpp"), "-o", out,
+           "-L", os.path.join(ROOT, "rolo_amd"), "-lrolo_hip", "-Wl,-rpath," + os.path.join(ROOT, "rolo_amd"), "-Wl,-rpath,/opt/rocm/lib"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr

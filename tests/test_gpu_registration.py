@@ -353,3 +353,27 @@ def test_point_sharded_passes_sum_to_the_full_result():
         e0f, H0f, b0f = g.t3_linearize(tp, G, L0, ct_lambda=0.0)
         assert abs(acc[3] - e0f) <= 1e-12 * abs(e0f) and np.abs(acc[4] - H0f).max() <= 1e-12 * np.abs(H0f).max()
         g.so3_linearize(T)  # restore the cached correspondences of the probe pose
+
+
+def test_cpp_shim_end_to_end(tmp_path):
+    """fast_gicp::RotVGICP from include/rot_vgicp_hip.hpp, driven as lidarOdometry.cpp:460-500 does, in a C++-only
+    process (no Python / torch): same result as the oracle."""
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "shim_demo")
+    cmd = ["g++", "-std=c++17", "-O1", "-I", os.path.join(root, "include"), os.path.join(root, "tests", "cpp", "shim_demo.cpp"), "-o", exe,
+           "-L", os.path.join(root, "rolo_amd"), "-lrolo_hip", "-Wl,-rpath," + os.path.join(root, "rolo_amd"), "-Wl,-rpath,/opt/rocm/lib"]
+    subprocess.run(cmd, check=True)
+    src, tgt, cfg = make_pair("vlp16_polar")
+    src.astype(np.float32).tofile(tmp_path / "s.bin"); tgt.astype(np.float32).tofile(tmp_path / "t.bin")
+    r = subprocess.run([exe, str(tmp_path / "s.bin"), str(tmp_path / "t.bin")], capture_output=True, text=True, check=True)
+    lines = r.stdout.strip().splitlines()
+    vals = [float(v) for v in lines[0].split()]
+    T = np.array(vals[:16]).reshape(4, 4); t = np.array(vals[16:19])
+    o, _ = make_both(src, tgt, cfg)
+    rc, Tf_o, Td_o, it, cv = o.align()
+    g3 = np.array([-0.28, -0.04, -0.02])
+    rc2, t_o, _ = o.compute_translation(np.zeros(3), g3, g3)
+    assert np.abs(T - Tf_o).max() < 1e-6 and np.abs(t - t_o).max() <= 1e-4
+    assert int(vals[19]) == int(cv) and int(vals[20]) == src.shape[0]
+    assert lines[1] == "invalid_argument"
