@@ -15,7 +15,7 @@ LIB = os.path.join(HERE, "librolo_hip.so")
 SOURCES = ["api.hip", "knn_cov.hip", "voxelmap.hip", "passes.hip", "misc.hip", "front.hip", "odometry.hip"]
 HEADERS = ["rolo_internal.hpp", "dev_math.hpp", "voxel_dev.hpp", "knn_walk.hpp", os.path.join("..", "..", "include", "rolo_hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function",
+FLAGS = os.environ.get("ROLO_EXTRA_FLAGS", "").split() + ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function",
          "-Wno-unused-result"]
 
 

@@ -7,8 +7,7 @@
 //   * seed: the wavefront's own 64 points (8 consecutive leaves) are scored first, so every lane starts the walk
 //     with a finite search radius;
 //   * a node is expanded if ANY lane's search sphere reaches its box (ballot); of two live children the one
-//     preferred by the lane with the largest radius goes first (its radius is what inflates the packet), the
-//     other is pushed on ONE small per-wave stack in LDS;
+//     nearer to the majority of interested lanes goes first, the other is pushed on ONE small per-wave stack in LDS;
 //   * node boxes and leaf points are fetched through wave-uniform addresses, so a leaf's 8 points are loaded
 //     once per wave, not once per lane;
 //   * each lane keeps its k best as packed 64-bit keys  (float_bits(d2) << 32) | index : for non-negative floats
@@ -49,9 +48,14 @@ ROLO_DEV float wave_max_f32(float v) {
 template <int KMAX>
 ROLO_DEV void knn_score_leaf(const float4* __restrict__ sorted, int g, const float4& q, double (&K)[KMAX], int kk, double& bkey, float& bd,
                              unsigned& n_ins) {
+  // fetch the whole leaf first: the address is wave-uniform, so these are 8 scalar loads in flight behind ONE wait
+  // (loading inside the loop serialised 8 scalar-cache round trips per leaf behind the insert branch)
+  float4 pts[8];
+#pragma unroll
+  for (int u = 0; u < 8; u++) pts[u] = sorted[8 * (size_t)g + u];
 #pragma unroll
   for (int u = 0; u < 8; u++) {
-    const float4 c = sorted[8 * (size_t)g + u];
+    const float4 c = pts[u];
     const float dx = q.x - c.x, dy = q.y - c.y, dz = q.z - c.z;
     const float cd = ((dx * dx) + (dy * dy)) + (dz * dz);  // file is compiled with -ffp-contract=off
     const double ck = key_pack(cd, __float_as_int(c.w));
@@ -111,10 +115,10 @@ __global__ __launch_bounds__(256) void knn_cov_kernel(const float4* __restrict__
       const bool okl = (bl <= bd) && (bl < INFINITY), okr = (br <= bd) && (br < INFINITY);
       const unsigned long long ml = __ballot(okl), mr = __ballot(okr);
       if (ml != 0ull && mr != 0ull) {
-        const float rad = (okl || okr) ? bd : -2.0f;
-        const float mx = wave_max_f32(rad);
-        const int lead = __ffsll((long long)__ballot(rad == mx)) - 1;
-        const bool left_first = (__ballot(bl <= br) >> lead) & 1ull;
+        // nearer child first, by majority vote of the lanes that reach either child (a "lane with the largest
+        // radius decides" rule needed a 6-step cross-lane max per node and did not reduce the nodes visited)
+        const unsigned long long pref = __ballot((okl || okr) && (bl <= br));
+        const bool left_first = 2 * __popcll(pref) >= __popcll(ml | mr);
         if (sp < WALK_STACK) { stk[wv][sp] = left_first ? 2 * h + 1 : 2 * h; sp++; }
         h = left_first ? 2 * h : 2 * h + 1;
         continue;

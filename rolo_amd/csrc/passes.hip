@@ -99,8 +99,35 @@ ROLO_DEV void accumulate_hb(const Sym3& M, const Vec3& a, double wh, double wb_u
   }
 }
 
+ROLO_DEV void ctrl_body(LmState* st, const double* partials, int nblocks, const double* sums_in, rolo_trace_rec* trace, int stage);
+
+// Fused controller: instead of a separate one-workgroup launch per LM trial, the LAST workgroup of the pass to
+// finish (arrival ticket) sums the partial rows and runs the scalar LM step. Hand-off per the gfx950 rules:
+// row stores -> __syncthreads -> lane-0 agent-scope release + drained vmcnt -> ticket atomic; the last arriver does one
+// agent-scope acquire -> __syncthreads -> plain loads. All other workgroups have read the state before they took
+// their ticket, so the last one may overwrite it.
+ROLO_DEV void fused_tail(const PassArgs& a, LmState* st, int stage) {
+  if (!a.fused) return;
+  __shared__ int s_last;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int t = atomicAdd(a.ticket, 1);
+    s_last = (t == (int)gridDim.x - 1) ? 1 : 0;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  if (threadIdx.x == 0) {
+    *a.ticket = 0;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+  __syncthreads();
+  ctrl_body(st, a.partials, (int)gridDim.x, nullptr, a.trace, stage);
+}
+
 template <int DOF>
-__global__ __launch_bounds__(PASS_THREADS) void rot_pass_kernel(PassArgs a, const LmState* __restrict__ st) {
+__global__ __launch_bounds__(PASS_THREADS) void rot_pass_kernel(PassArgs a, LmState* st) {
   if (st->stage != 1) return;
   constexpr int NH = DOF * (DOF + 1) / 2;
   constexpr int NV = 3 + NH + DOF;
@@ -167,11 +194,12 @@ __global__ __launch_bounds__(PASS_THREADS) void rot_pass_kernel(PassArgs a, cons
 #pragma unroll
   for (int v = 0; v < DOF; v++) slot[3 + NH + v] = V_B + v;
   block_reduce_store<NV>(acc, slot, a.partials + (size_t)blockIdx.x * NV_MAX);
+  fused_tail(a, st, 1);
 }
 
 // translation stage: t3_linearize (B) + compute_t_error (A) on the correspondences of the last rotation
 // linearisation, Mahalanobis from st->tr_R.
-__global__ __launch_bounds__(PASS_THREADS) void trans_pass_kernel(PassArgs a, const LmState* __restrict__ st) {
+__global__ __launch_bounds__(PASS_THREADS) void trans_pass_kernel(PassArgs a, LmState* st) {
   if (st->stage != 2) return;
   constexpr int NH = 21, NV = 3 + NH + 6;
   const int phase = st->phase;
@@ -228,6 +256,7 @@ __global__ __launch_bounds__(PASS_THREADS) void trans_pass_kernel(PassArgs a, co
 #pragma unroll
   for (int v = 0; v < 6; v++) slot[3 + NH + v] = V_B + v;
   block_reduce_store<NV>(acc, slot, a.partials + (size_t)blockIdx.x * NV_MAX);
+  fused_tail(a, st, 2);
 }
 
 // fixed-order sum of the per-workgroup rows (deterministic for a given grid)
@@ -269,29 +298,47 @@ __global__ __launch_bounds__(256) void reduce_kernel(const double* __restrict__ 
 // ---- scalar LM logic (one thread) -----------------------------------------------------------------------
 template <int N>
 ROLO_DEV void ldlt_solve(const double* Hfull /* 6x6 storage, row stride 6 */, double lambda, const double* b, double* x) {
-  // Eigen::LDLT (lower, diagonal pivoting) restated; solves (H + lambda I) x = -b
-  double A[N][N];
-  int perm[N];
-  for (int i = 0; i < N; i++) { perm[i] = i; for (int j = 0; j < N; j++) { int r = i > j ? i : j, c = i > j ? j : i; A[i][j] = Hfull[r * 6 + c] + (i == j ? lambda : 0.0); } }
-  for (int k = 0; k < N; k++) {
-    int piv = k; double big = fabs(A[k][k]);
-    for (int i = k + 1; i < N; i++) if (fabs(A[i][i]) > big) { big = fabs(A[i][i]); piv = i; }
-    if (piv != k) {
-      for (int j = 0; j < N; j++) { double t = A[k][j]; A[k][j] = A[piv][j]; A[piv][j] = t; }
-      for (int i = 0; i < N; i++) { double t = A[i][k]; A[i][k] = A[i][piv]; A[i][piv] = t; }
-      int t = perm[k]; perm[k] = perm[piv]; perm[piv] = t;
+  // Solves (H + lambda I) x = -b by an LDL^T factorisation of the lower triangle. The reference uses Eigen::LDLT
+  // (diagonal pivoting); H + lambda I is symmetric positive definite here, for which the unpivoted factorisation is
+  // backward stable as well, so the two agree to rounding (checked against the oracle's pivoted solve by the parity
+  // tests). No pivoting means no dynamic indexing: every loop unrolls and the whole solve lives in registers
+  // instead of scratch memory (the pivoted version cost ~800 scratch round trips per controller launch).
+  double L[N][N];
+  double D[N];
+#pragma unroll
+  for (int j = 0; j < N; j++) {
+    double d = Hfull[j * 6 + j] + lambda;
+#pragma unroll
+    for (int k = 0; k < j; k++) d -= L[j][k] * L[j][k] * D[k];
+    D[j] = d;
+    const double inv = (d != 0.0) ? 1.0 / d : 0.0;
+#pragma unroll
+    for (int i = j + 1; i < N; i++) {
+      double v = Hfull[i * 6 + j];
+#pragma unroll
+      for (int k = 0; k < j; k++) v -= L[i][k] * L[j][k] * D[k];
+      L[i][j] = v * inv;
     }
-    const double d = A[k][k];
-    if (d == 0.0) continue;
-    for (int i = k + 1; i < N; i++) A[i][k] /= d;
-    for (int j = k + 1; j < N; j++) for (int i = j; i < N; i++) { A[i][j] -= A[i][k] * d * A[j][k]; A[j][i] = A[i][j]; }
   }
   double y[N];
-  for (int i = 0; i < N; i++) y[i] = -b[perm[i]];
-  for (int i = 0; i < N; i++) for (int j = 0; j < i; j++) y[i] -= A[i][j] * y[j];
-  for (int i = 0; i < N; i++) y[i] = (A[i][i] != 0.0) ? y[i] / A[i][i] : 0.0;
-  for (int i = N - 1; i >= 0; i--) for (int j = i + 1; j < N; j++) y[i] -= A[j][i] * y[j];
-  for (int i = 0; i < N; i++) x[perm[i]] = y[i];
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    double v = -b[i];
+#pragma unroll
+    for (int k = 0; k < i; k++) v -= L[i][k] * y[k];
+    y[i] = v;
+  }
+#pragma unroll
+  for (int i = 0; i < N; i++) y[i] = (D[i] != 0.0) ? y[i] / D[i] : 0.0;
+#pragma unroll
+  for (int i = N - 1; i >= 0; i--) {
+    double v = y[i];
+#pragma unroll
+    for (int k = i + 1; k < N; k++) v -= L[k][i] * y[k];
+    y[i] = v;
+  }
+#pragma unroll
+  for (int i = 0; i < N; i++) x[i] = y[i];
 }
 
 ROLO_DEV void so3_exp_R(const double* w, double* R) {  // so3.hpp:59-77 + Quaterniond::toRotationMatrix
@@ -510,9 +557,7 @@ ROLO_DEV void trans_step(LmState* st, const double* S, rolo_trace_rec* trace) {
   trans_begin_outer(st);
 }
 
-__global__ __launch_bounds__(256) void ctrl_kernel(LmState* st, const double* __restrict__ partials, int nblocks,
-                                                  const double* __restrict__ sums_in, rolo_trace_rec* trace, int stage) {
-  if (st->stage != stage) return;
+ROLO_DEV void ctrl_body(LmState* st, const double* partials, int nblocks, const double* sums_in, rolo_trace_rec* trace, int stage) {
   __shared__ double sums[NV_MAX];
   // the scalar LM step touches ~150 fields: stage the whole state through LDS (one coalesced read, one write)
   // instead of paying a global-memory round trip per field from a single lane
@@ -536,6 +581,12 @@ __global__ __launch_bounds__(256) void ctrl_kernel(LmState* st, const double* __
     const int* l = reinterpret_cast<const int*>(&sst);
     for (int i = threadIdx.x; i < NW; i += blockDim.x) g[i] = l[i];
   }
+}
+
+__global__ __launch_bounds__(256) void ctrl_kernel(LmState* st, const double* __restrict__ partials, int nblocks,
+                                                  const double* __restrict__ sums_in, rolo_trace_rec* trace, int stage) {
+  if (st->stage != stage) return;
+  ctrl_body(st, partials, nblocks, sums_in, trace, stage);
 }
 
 __global__ void rot_begin_kernel(LmState* st, RotBegin a) {
@@ -595,12 +646,12 @@ __global__ void t3_eval_begin_kernel(LmState* st, TransBegin a, int phase) {
 
 }  // namespace
 
-hipError_t launch_rot_pass(int dof, const PassArgs& a, const LmState* st, int grid, hipStream_t s) {
+hipError_t launch_rot_pass(int dof, const PassArgs& a, LmState* st, int grid, hipStream_t s) {
   if (dof == 3) rot_pass_kernel<3><<<grid, PASS_THREADS, 0, s>>>(a, st);
   else rot_pass_kernel<6><<<grid, PASS_THREADS, 0, s>>>(a, st);
   return hipGetLastError();
 }
-hipError_t launch_trans_pass(const PassArgs& a, const LmState* st, int grid, hipStream_t s) {
+hipError_t launch_trans_pass(const PassArgs& a, LmState* st, int grid, hipStream_t s) {
   trans_pass_kernel<<<grid, PASS_THREADS, 0, s>>>(a, st);
   return hipGetLastError();
 }
