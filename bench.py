@@ -80,6 +80,7 @@ def main():
         g = RotVGICP(local_rank)
         g.setResolution(args.leaf)
         g.setFixedIterations(20)
+        g.setOverlapKnn(args.streams <= 1)  # with several contexts in flight the GPU is already shared between frames
         return g
 
     def barrier():
@@ -89,17 +90,25 @@ def main():
 
     zero3 = np.zeros(3)
 
+    def enqueue(g):
+        g.setInputTargetDevice(d_tgt.data_ptr(), n, 4)
+        g.setInputSourceDevice(d_src.data_ptr(), n, 4)
+        g.register_async(None, zero3, guess, last, 0.1, 0.1, 0.3)
+
     def run_steps(gs, k):
-        """k steps; one step = one frame pair on every context of `gs` (enqueue all, then wait for all)."""
+        """k steps; one step = one frame pair on every context of `gs`. Contexts are serviced round-robin
+        (wait for a context's frame, immediately enqueue its next one) so the GPU always has work queued."""
         if not isinstance(gs, (list, tuple)):
             gs = [gs]
-        for _ in range(k):
-            for g in gs:
-                g.setInputTargetDevice(d_tgt.data_ptr(), n, 4)
-                g.setInputSourceDevice(d_src.data_ptr(), n, 4)
-                g.register_async(None, zero3, guess, last, 0.1, 0.1, 0.3)
+        if k <= 0:
+            return
+        for g in gs:
+            enqueue(g)
+        for it in range(k):
             for g in gs:
                 g.register_wait()
+                if it + 1 < k:
+                    enqueue(g)
 
     def timed(g, steps, warmup):
         run_steps(g, warmup)

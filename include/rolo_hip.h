@@ -52,6 +52,8 @@ typedef struct rolo_params {
   double lm_init_lambda_factor;  /* setInitialLambdaFactor :35-37 (1e-9) */
   int fixed_iterations;          /* harness knob: >0 runs exactly this many outer iterations of align() */
   int q2_intended;               /* 0 as written, 1 intended continuous-time term */
+  int overlap_knn;               /* tuning knob (default 1): run the source / target neighbourhood searches concurrently on two
+                                    HIP streams — lowers single-frame latency; set 0 when several contexts share the GPU */
 } rolo_params;
 
 typedef struct rolo_stats {

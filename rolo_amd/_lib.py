@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "librolo_hip.so")
+LIB_PATH = os.environ.get("ROLO_HIP_LIB", os.path.join(HERE, "librolo_hip.so"))  # override: A/B experiments only
 
 
 class Params(C.Structure):
@@ -17,7 +17,8 @@ class Params(C.Structure):
                 ("voxel_type", C.c_int), ("voxel_resolution", C.c_double), ("polar_resolution", C.c_double * 3),
                 ("optimizer", C.c_int), ("max_iterations", C.c_int), ("rotation_epsilon", C.c_double),
                 ("transformation_epsilon", C.c_double), ("lm_max_iterations", C.c_int),
-                ("lm_init_lambda_factor", C.c_double), ("fixed_iterations", C.c_int), ("q2_intended", C.c_int)]
+                ("lm_init_lambda_factor", C.c_double), ("fixed_iterations", C.c_int), ("q2_intended", C.c_int),
+                ("overlap_knn", C.c_int)]
 
 
 class Stats(C.Structure):

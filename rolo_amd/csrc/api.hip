@@ -83,10 +83,15 @@ struct rolo_ctx {
   size_t src_knn_cap = 0, src_knnd_cap = 0, tgt_knn_cap = 0, tgt_knnd_cap = 0;
   bool want_knn_lists = false;
   // kNN scratch
-  char* sort_tmp = nullptr; size_t sort_tmp_cap = 0;
-  uint32_t *keys0 = nullptr, *keys1 = nullptr, *vals0 = nullptr, *vals1 = nullptr;
-  size_t keys0_cap = 0, keys1_cap = 0, vals0_cap = 0, vals1_cap = 0;
-  int* bbox = nullptr; size_t bbox_cap = 0;
+  // one scratch set per cloud: source and target neighbourhood searches run concurrently on two streams
+  struct KnnScratch {
+    char* sort_tmp = nullptr; size_t sort_tmp_cap = 0;
+    uint32_t *keys0 = nullptr, *keys1 = nullptr, *vals0 = nullptr, *vals1 = nullptr;
+    size_t keys0_cap = 0, keys1_cap = 0, vals0_cap = 0, vals1_cap = 0;
+    int* bbox = nullptr; size_t bbox_cap = 0;
+  } ks[2];
+  hipStream_t stream2 = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   // voxel map
   VoxelTable tab{};
   size_t tab_keys_cap = 0, tab_ids_cap = 0, tab_rec_cap = 0, tab_idk_cap = 0;
@@ -129,16 +134,16 @@ namespace {
 
 // brackets the launches issued during its lifetime with a HIP event pair on the context's stream
 struct ProfScope {
-  rolo_ctx* c; int idx = -1;
-  ProfScope(rolo_ctx* ctx, int slot) : c(ctx) {
+  rolo_ctx* c; int idx = -1; hipStream_t s;
+  ProfScope(rolo_ctx* ctx, int slot, hipStream_t stream = nullptr) : c(ctx), s(stream ? stream : ctx->stream) {
     if (!c->prof_on) return;
     rolo_ctx::ProfEv e{slot, nullptr, nullptr};
     if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) return;
-    (void)hipEventRecord(e.a, c->stream);
+    (void)hipEventRecord(e.a, s);
     c->prof.push_back(e);
     idx = (int)c->prof.size() - 1;
   }
-  ~ProfScope() { if (idx >= 0) (void)hipEventRecord(c->prof[idx].b, c->stream); }
+  ~ProfScope() { if (idx >= 0) (void)hipEventRecord(c->prof[idx].b, s); }
 };
 
 inline int n_offsets(const rolo_params& P) { return P.neighbor_search == ROLO_DIRECT1 ? 1 : (P.neighbor_search == ROLO_DIRECT7 ? 7 : 27); }
@@ -162,39 +167,55 @@ int upload_cloud(rolo_ctx* c, CloudDev& cl, size_t& xyz_cap, const float* pts, i
   return ROLO_OK;
 }
 
-int build_knn_and_cov(rolo_ctx* c, CloudDev& cl, size_t& cov_cap, size_t& sorted_cap, size_t& boxes_cap, size_t& knn_cap, size_t& knnd_cap) {
+int build_knn_and_cov(rolo_ctx* c, CloudDev& cl, size_t& cov_cap, size_t& sorted_cap, size_t& boxes_cap, size_t& knn_cap, size_t& knnd_cap,
+                      int which, hipStream_t stream) {
   const int n = cl.n, k = c->P.k_correspondences;
   if (k < 1 || k > 32) { g_err = "k_correspondences must be in [1,32]"; return ROLO_EUNSUPPORTED; }
   if (n < k) { g_err = "cloud has fewer points than k_correspondences"; return ROLO_ETOOFEW; }
   cl.n_leaves = (n + 7) / 8;
   int P = 2; while (P < cl.n_leaves) P <<= 1;
   cl.P = P;
+  rolo_ctx::KnnScratch& S = c->ks[which];
   int rc;
   if ((rc = ensure(cl.cov, cov_cap, 6 * (size_t)n))) return rc;
   if ((rc = ensure(cl.sorted, sorted_cap, 8 * (size_t)cl.n_leaves))) return rc;
   if ((rc = ensure(cl.boxes, boxes_cap, 4 * (size_t)P))) return rc;
-  if ((rc = ensure(c->keys0, c->keys0_cap, (size_t)n))) return rc;
-  if ((rc = ensure(c->keys1, c->keys1_cap, (size_t)n))) return rc;
-  if ((rc = ensure(c->vals0, c->vals0_cap, (size_t)n))) return rc;
-  if ((rc = ensure(c->vals1, c->vals1_cap, (size_t)n))) return rc;
-  if ((rc = ensure(c->bbox, c->bbox_cap, 8))) return rc;
+  if ((rc = ensure(S.keys0, S.keys0_cap, (size_t)n))) return rc;
+  if ((rc = ensure(S.keys1, S.keys1_cap, (size_t)n))) return rc;
+  if ((rc = ensure(S.vals0, S.vals0_cap, (size_t)n))) return rc;
+  if ((rc = ensure(S.vals1, S.vals1_cap, (size_t)n))) return rc;
+  if ((rc = ensure(S.bbox, S.bbox_cap, 8))) return rc;
   size_t tmp = knn_sort_temp_bytes(n);
-  if ((rc = ensure(c->sort_tmp, c->sort_tmp_cap, tmp + 256))) return rc;
+  if ((rc = ensure(S.sort_tmp, S.sort_tmp_cap, tmp + 256))) return rc;
   if (c->want_knn_lists) {
     if ((rc = ensure(cl.knn_idx, knn_cap, (size_t)n * k))) return rc;
     if ((rc = ensure(cl.knn_d2, knnd_cap, (size_t)n * k))) return rc;
   }
-  { ProfScope ps(c, ROLO_PROF_KNN_BUILD); HIPCHK(launch_knn_build(cl, c->sort_tmp, tmp, c->keys0, c->keys1, c->vals0, c->vals1, c->bbox, c->stream)); }
-  { ProfScope ps(c, ROLO_PROF_KNN_COV); HIPCHK(launch_knn_cov(cl, k, c->P.regularization, c->want_knn_lists, c->stream)); }
+  { ProfScope ps(c, ROLO_PROF_KNN_BUILD, stream); HIPCHK(launch_knn_build(cl, S.sort_tmp, tmp, S.keys0, S.keys1, S.vals0, S.vals1, S.bbox, stream)); }
+  { ProfScope ps(c, ROLO_PROF_KNN_COV, stream); HIPCHK(launch_knn_cov(cl, k, c->P.regularization, c->want_knn_lists, stream)); }
   cl.have_cov = true;
   return ROLO_OK;
 }
 
+int build_src(rolo_ctx* c, hipStream_t s) { return build_knn_and_cov(c, c->src, c->src_cov_cap, c->src_sorted_cap, c->src_boxes_cap, c->src_knn_cap, c->src_knnd_cap, 0, s); }
+int build_tgt(rolo_ctx* c, hipStream_t s) { return build_knn_and_cov(c, c->tgt, c->tgt_cov_cap, c->tgt_sorted_cap, c->tgt_boxes_cap, c->tgt_knn_cap, c->tgt_knnd_cap, 1, s); }
+
 int ensure_covs(rolo_ctx* c) {
   if (c->src.n <= 0 || c->tgt.n <= 0) { g_err = "source/target not set"; return ROLO_ESTATE; }
   int rc;
-  if (!c->src.have_cov && (rc = build_knn_and_cov(c, c->src, c->src_cov_cap, c->src_sorted_cap, c->src_boxes_cap, c->src_knn_cap, c->src_knnd_cap))) return rc;
-  if (!c->tgt.have_cov && (rc = build_knn_and_cov(c, c->tgt, c->tgt_cov_cap, c->tgt_sorted_cap, c->tgt_boxes_cap, c->tgt_knn_cap, c->tgt_knnd_cap))) return rc;
+  if (!c->src.have_cov && !c->tgt.have_cov && c->P.overlap_knn) {
+    // The two neighbourhood searches are independent and each is only ~2 wavefronts per SIMD wide: run the target's
+    // on a second stream (fork / join with events) so they overlap.
+    HIPCHK(hipEventRecord(c->ev_fork, c->stream));
+    HIPCHK(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+    if ((rc = build_tgt(c, c->stream2))) return rc;
+    if ((rc = build_src(c, c->stream))) return rc;
+    HIPCHK(hipEventRecord(c->ev_join, c->stream2));
+    HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join, 0));
+    return ROLO_OK;
+  }
+  if (!c->src.have_cov && (rc = build_src(c, c->stream))) return rc;
+  if (!c->tgt.have_cov && (rc = build_tgt(c, c->stream))) return rc;
   return ROLO_OK;
 }
 
@@ -353,6 +374,7 @@ void rolo_default_params(rolo_params* p) {
   p->lm_init_lambda_factor = 1e-9;
   p->fixed_iterations = 0;
   p->q2_intended = 0;
+  p->overlap_knn = 1;
 }
 
 int rolo_ctx_create(int device, rolo_ctx** out) {
@@ -364,7 +386,9 @@ int rolo_ctx_create(int device, rolo_ctx** out) {
   rolo_ctx* c = new rolo_ctx();
   c->device = device;
   rolo_default_params(&c->P);
-  if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; g_err = "hipStreamCreate failed"; return ROLO_EHIP; }
+  if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) { delete c; g_err = "hipStreamCreate failed"; return ROLO_EHIP; }
   if (hipHostMalloc((void**)&c->h_state, sizeof(LmState)) != hipSuccess || hipHostMalloc((void**)&c->h_sums, sizeof(double) * NV_MAX) != hipSuccess ||
       hipHostMalloc((void**)&c->h_counters, sizeof(int) * 4) != hipSuccess) { delete c; g_err = "hipHostMalloc failed"; return ROLO_EHIP; }
   memset(c->h_state, 0, sizeof(LmState));
@@ -388,13 +412,17 @@ void rolo_ctx_destroy(rolo_ctx* c) {
   rolo_front_destroy(c);
   if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
   void* bufs[] = {c->src.xyz, c->src.cov, c->src.sorted, c->src.boxes, c->src.knn_idx, c->src.knn_d2, c->tgt.xyz, c->tgt.cov, c->tgt.sorted,
-                  c->tgt.boxes, c->tgt.knn_idx, c->tgt.knn_d2, c->sort_tmp, c->keys0, c->keys1, c->vals0, c->vals1, c->bbox, c->tab.keys,
+                  c->tgt.boxes, c->tgt.knn_idx, c->tgt.knn_d2, c->ks[0].sort_tmp, c->ks[0].keys0, c->ks[0].keys1, c->ks[0].vals0, c->ks[0].vals1, c->ks[0].bbox,
+                  c->ks[1].sort_tmp, c->ks[1].keys0, c->ks[1].keys1, c->ks[1].vals0, c->ks[1].vals1, c->ks[1].bbox, c->tab.keys,
                   c->tab.ids, c->tab.rec, c->tab.id_keys, c->tgt_keys, c->tgt_slot, c->counters, c->ticket, c->corr[0], c->corr[1], c->partials, c->sums,
                   c->state, c->trace, c->stage_in, c->stage_out, c->stage_d, c->stage_i};
   for (void* b : bufs) if (b) (void)hipFree(b);
   if (c->h_state) (void)hipHostFree(c->h_state);
   if (c->h_sums) (void)hipHostFree(c->h_sums);
   if (c->h_counters) (void)hipHostFree(c->h_counters);
+  if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
+  if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+  if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -496,8 +524,7 @@ int rolo_get_knn(rolo_ctx* c, int which, int32_t* idx, float* d2) {
   if (cl.n <= 0) return ROLO_ESTATE;
   c->want_knn_lists = true;
   cl.have_cov = false;
-  rc = which == 0 ? build_knn_and_cov(c, c->src, c->src_cov_cap, c->src_sorted_cap, c->src_boxes_cap, c->src_knn_cap, c->src_knnd_cap)
-                  : build_knn_and_cov(c, c->tgt, c->tgt_cov_cap, c->tgt_sorted_cap, c->tgt_boxes_cap, c->tgt_knn_cap, c->tgt_knnd_cap);
+  rc = which == 0 ? build_src(c, c->stream) : build_tgt(c, c->stream);
   c->want_knn_lists = false;
   if (rc) return rc;
   const size_t m = (size_t)cl.n * c->P.k_correspondences;

@@ -73,7 +73,7 @@ ROLO_DEV void knn_score_leaf(const float4* __restrict__ sorted, int g, const flo
 }
 
 template <int KMAX>
-__global__ __launch_bounds__(256) void knn_cov_kernel(const float4* __restrict__ sorted, const float4* __restrict__ boxes,
+__global__ __launch_bounds__(256, 4) void knn_cov_kernel(const float4* __restrict__ sorted, const float4* __restrict__ boxes,
                                                      const float4* __restrict__ orig, int n, int n_sorted, int P, int k,
                                                      int reg, double* __restrict__ cov, int32_t* knn_idx, float* knn_d2) {
   __shared__ int stk[4][WALK_STACK];

@@ -122,6 +122,11 @@ class RotVGICP:
         self._p.fixed_iterations = n
         self._push()
 
+    def setOverlapKnn(self, on: bool):
+        """Tuning knob (not in the reference): overlap the source / target kNN on two streams (default on)."""
+        self._p.overlap_knn = int(on)
+        self._push()
+
     def setQ2Intended(self, on: bool):
         self._p.q2_intended = int(on)
         self._push()
