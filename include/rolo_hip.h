@@ -54,6 +54,8 @@ typedef struct rolo_params {
   int q2_intended;               /* 0 as written, 1 intended continuous-time term */
   int overlap_knn;               /* tuning knob (default 1): run the source / target neighbourhood searches concurrently on two
                                     HIP streams — lowers single-frame latency; set 0 when several contexts share the GPU */
+  int use_graph;                 /* tuning knob (default 1): rolo_register_async captures the frame's fixed launch schedule in a
+                                    hipGraph on the second frame with unchanged sizes / buffers / parameters and replays it */
 } rolo_params;
 
 typedef struct rolo_stats {

@@ -589,8 +589,7 @@ __global__ __launch_bounds__(256) void ctrl_kernel(LmState* st, const double* __
   ctrl_body(st, partials, nblocks, sums_in, trace, stage);
 }
 
-__global__ void rot_begin_kernel(LmState* st, RotBegin a) {
-  if (threadIdx.x != 0) return;
+ROLO_DEV void rot_begin_dev(LmState* st, const RotBegin& a) {
   for (int i = 0; i < 9; i++) { st->xt_R[i] = a.R[i]; st->x0_R[i] = a.R[i]; st->tr_R[i] = a.R[i]; }
   for (int i = 0; i < 3; i++) { st->xt_t[i] = a.t[i]; st->x0_t[i] = a.t[i]; }
   for (int i = 0; i < 36; i++) { st->H[i] = 0; st->final_H[i] = (i % 7 == 0) ? 1.0 : 0.0; }
@@ -607,11 +606,25 @@ __global__ void rot_begin_kernel(LmState* st, RotBegin a) {
   st->lm_max = a.lm_max; st->q2_intended = a.q2_intended; st->rot_eps = a.rot_eps; st->trans_eps = a.trans_eps; st->lm_init = a.lm_init;
 }
 
+__global__ void rot_begin_kernel(LmState* st, RotBegin a) {
+  if (threadIdx.x != 0) return;
+  rot_begin_dev(st, a);
+}
+
 __global__ void trans_begin_kernel(LmState* st, TransBegin a) {
   if (threadIdx.x != 0) return;
   for (int i = 0; i < 3; i++) { st->t0[i] = a.t0[i]; st->g[i] = a.g[i]; st->l[i] = a.l[i]; }
   st->dtn = a.dtn; st->dtn1 = a.dtn1; st->ct_lambda = a.ct_lambda;
   if (a.direct) trans_start(st);
+}
+
+__global__ void frame_begin_kernel(LmState* st, const FrameArgs* a) {
+  if (threadIdx.x != 0) return;
+  const RotBegin r = a->rot;
+  const TransBegin t = a->trans;
+  rot_begin_dev(st, r);
+  for (int i = 0; i < 3; i++) { st->t0[i] = t.t0[i]; st->g[i] = t.g[i]; st->l[i] = t.l[i]; }
+  st->dtn = t.dtn; st->dtn1 = t.dtn1; st->ct_lambda = t.ct_lambda;
 }
 
 // stage-level evaluation (rolo_so3_linearize & co): mode 0 = linearise at (R,t): phase 0, correspondences into
@@ -665,6 +678,11 @@ hipError_t launch_ctrl(LmState* st, const double* partials, int nblocks, const d
 }
 hipError_t launch_rot_begin(LmState* st, const RotBegin& a, hipStream_t s) {
   rot_begin_kernel<<<1, 64, 0, s>>>(st, a);
+  return hipGetLastError();
+}
+// graph-replayable form: both argument blocks come from a device buffer refreshed by a captured H2D copy
+hipError_t launch_frame_begin(LmState* st, const FrameArgs* a, hipStream_t s) {
+  frame_begin_kernel<<<1, 64, 0, s>>>(st, a);
   return hipGetLastError();
 }
 hipError_t launch_trans_begin(LmState* st, const TransBegin& a, hipStream_t s) {

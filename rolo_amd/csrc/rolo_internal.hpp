@@ -108,7 +108,9 @@ hipError_t launch_ctrl(LmState* st, const double* partials, int nblocks, const d
 
 struct RotBegin { double R[9], t[3]; int optimizer, max_iterations, fixed_iterations, lm_max, q2_intended; double rot_eps, trans_eps, lm_init; int run_trans; };
 struct TransBegin { double t0[3], g[3], l[3], dtn, dtn1; float ct_lambda; int direct; /* 1: start now (rotation already done) */ };
+struct FrameArgs { RotBegin rot; TransBegin trans; };
 hipError_t launch_rot_begin(LmState* st, const RotBegin& a, hipStream_t s);
+hipError_t launch_frame_begin(LmState* st, const FrameArgs* a, hipStream_t s);
 hipError_t launch_trans_begin(LmState* st, const TransBegin& a, hipStream_t s);
 // single evaluations for the stage-level API (rolo_so3_linearize, rolo_compute_error, rolo_t3_linearize, ...)
 hipError_t launch_eval_begin(LmState* st, const RotBegin& a, int mode, hipStream_t s);

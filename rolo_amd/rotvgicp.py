@@ -127,6 +127,11 @@ class RotVGICP:
         self._p.overlap_knn = int(on)
         self._push()
 
+    def setUseGraph(self, on: bool):
+        """Tuning knob (not in the reference): hipGraph capture / replay of the per-frame schedule (default on)."""
+        self._p.use_graph = int(on)
+        self._push()
+
     def setQ2Intended(self, on: bool):
         self._p.q2_intended = int(on)
         self._push()
