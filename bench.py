@@ -34,17 +34,31 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--sensor", default="os1-128")
     ap.add_argument("--leaf", type=float, default=0.5)
     ap.add_argument("--mode", default="replicas", choices=["replicas", "shard"])
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay (profiling runs)")
     ap.add_argument("--no-shard-leg", action="store_true", help="N>1: skip the extra point-sharded measurement")
-    ap.add_argument("--cpu-frames", type=int, default=1)
-    ap.add_argument("--streams", type=int, default=1,
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="length of the bounded cpu_baseline sample")
+    ap.add_argument("--streams", type=int, default=4,
                     help="registration contexts (HIP streams) kept in flight per GPU; a step is then one frame pair per stream")
     return ap.parse_args()
+
+
+def usable_cores() -> int:
+    """Host cores this process may actually use: affinity mask capped by the cgroup CPU quota (the GPU boxes show
+    256 CPUs but run under a 16-CPU quota; 256 OpenMP threads there are 60x slower than 16)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        pass
+    return max(1, n)
 
 
 def main():
@@ -76,11 +90,12 @@ def main():
     guess = -np.asarray(synth.PREV_STEP_T, np.float64)
     last = guess * 0.97
 
-    def new_ctx():
+    def new_ctx(alone=False):
         g = RotVGICP(local_rank)
         g.setResolution(args.leaf)
         g.setFixedIterations(20)
-        g.setOverlapKnn(args.streams <= 1)  # with several contexts in flight the GPU is already shared between frames
+        g.setOverlapKnn(alone or args.streams <= 1)  # with several contexts in flight the GPU is already shared between frames
+        g.setUseGraph(not args.no_graph)
         return g
 
     def barrier():
@@ -111,12 +126,18 @@ def main():
                     enqueue(g)
 
     def timed(g, steps, warmup):
+        import gc
         run_steps(g, warmup)
+        # CPython's cyclic GC walks every tracked object (torch is imported: ~40 ms per full collection) and fired once
+        # per ~140 frames in the middle of the timed loop; collect now, keep it off while timing
+        gc.collect()
+        gc.disable()
         barrier()
         t0 = time.perf_counter()
         run_steps(g, steps)
         barrier()
         dt = time.perf_counter() - t0
+        gc.enable()
         if world > 1:
             t = torch.tensor([dt], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -152,9 +173,21 @@ def main():
         "data": "synthetic",
         "config": {"workload": f"{args.sensor} dense frame pair, {n} pts/cloud, k=20 PLANE covariances, UNIFORM voxel leaf "
                                f"{args.leaf} m, 20 SO(3) LM iterations + CT translation LM", "mode": args.mode,
-                   "parallelism": f"{args.mode}{world}", "streams_per_gpu": len(ctxs), "rot_outer": rs.n_outer, "trans_outer": ts.n_outer,
+                   "parallelism": f"{args.mode}{world}", "streams_per_gpu": len(ctxs), "hip_graph": not args.no_graph, "rot_outer": rs.n_outer, "trans_outer": ts.n_outer,
                    "passes_per_frame": passes, "n_correspondences": rs.n_correspondences},
     }
+
+    # ---- single-frame latency: one context alone (source / target searches overlapped on two streams) ----
+    if len(ctxs) > 1 and args.mode == "replicas":
+        gl = new_ctx(alone=True)
+        lsteps = max(5, min(args.steps, 20))
+        run_steps(gl, 3)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run_steps(gl, lsteps)
+        torch.cuda.synchronize()
+        out["config"]["single_frame_latency_ms"] = 1e3 * (time.perf_counter() - t0) / lsteps
+        gl.close()
 
     # ---- roofline of the dominant kernel + per-kernel timing, measured live with HIP events on the ctx stream ----
     try:
@@ -178,18 +211,23 @@ def main():
     # ---- CPU baseline: the oracle (CPU restatement of the reference, same OpenMP structure) on this box's host cores ----
     if rank == 0 and world == 1 and not args.no_cpu:
         from oracle import pyorc
-        cores = os.cpu_count() or 1
+        cores = usable_cores()
         p = pyorc.default_params(voxel_type=pyorc.VOXEL_UNIFORM, voxel_resolution=args.leaf, fixed_iterations=20, num_threads=cores)
         t0 = time.perf_counter()
-        for _ in range(args.cpu_frames):
+        frames = 0
+        while True:  # bounded sample: about 10 s of CPU work
             o = pyorc.Reg(p)
             o.set_target(tgt); o.set_source(src)
             o.align()
             o.compute_translation(np.zeros(3), guess, last)
-        cdt = time.perf_counter() - t0
-        out["cpu_baseline"] = {"value": args.cpu_frames / cdt, "unit": "scans/s", "cores": cores, "kind": "port",
-                               "sample": f"{args.cpu_frames} frame pair(s) of the same workload, oracle/librolo_oracle.so, "
-                                         f"OMP threads = {cores}, {cdt:.1f} s"}
+            frames += 1
+            cdt = time.perf_counter() - t0
+            if cdt >= args.cpu_seconds or frames >= 200:
+                break
+        out["cpu_baseline"] = {"value": frames / cdt, "unit": "scans/s", "cores": cores, "kind": "port",
+                               "sample": f"{frames} frame pair(s) of the same workload (kd-tree build, 20-NN covariances, voxel map, 20 SO(3) "
+                                         f"LM iterations, CT translation) on oracle/librolo_oracle.so, OMP threads = {cores} "
+                                         f"(cgroup CPU quota of this box; os.cpu_count() = {os.cpu_count()}), {cdt:.1f} s"}
 
     if rank == 0:
         print(json.dumps(out))
