@@ -101,7 +101,6 @@ struct rolo_ctx {
   unsigned long long* tgt_keys = nullptr; size_t tgt_keys_cap = 0;
   int* tgt_slot = nullptr; size_t tgt_slot_cap = 0;
   int* counters = nullptr; size_t counters_cap = 0;
-  int* ticket = nullptr; size_t ticket_cap = 0;  // arrival ticket of the fused controller
   bool have_map = false;
   int n_voxels = 0;
   // passes
@@ -271,24 +270,16 @@ int prepare_pass(rolo_ctx* c, PassArgs& a, int& grid) {
   if ((rc = ensure(c->partials, c->partials_cap, (size_t)grid * NV_MAX))) return rc;
   a.src = c->src.xyz; a.cov = c->src.cov; a.n_total = c->src.n; a.begin = begin; a.end = end; a.n_off = noff;
   a.corr[0] = c->corr[0]; a.corr[1] = c->corr[1]; a.partials = c->partials; a.tab = c->tab;
-  a.ticket = c->ticket; a.trace = c->trace; a.fused = 0;
   return ROLO_OK;
 }
 
-// one fused pass + controller, predicated on the device state
-int enqueue_pass(rolo_ctx* c, const PassArgs& a0, int grid, int stage) {
-  PassArgs a = a0;
-  // Fused controller (last workgroup of the pass runs the LM step): measured SLOWER on MI355X — 26.2 us per trial
-  // against 11.7 (pass) + 9.9 (controller launch): 512 workgroups each pay an agent-scope release + ticket atomic.
-  // Kept selectable for experiments (ROLO_FUSED_CTRL=1); the default is the two-launch form.
-  static const bool want_fused = [] { const char* e = getenv("ROLO_FUSED_CTRL"); return e && e[0] == '1'; }();
-  a.fused = (!c->comm && want_fused) ? 1 : 0;
+// one LM trial: fused pass + controller launch, both predicated on the device state
+int enqueue_pass(rolo_ctx* c, const PassArgs& a, int grid, int stage) {
   {
     ProfScope ps(c, stage == 1 ? ROLO_PROF_ROT_PASS : ROLO_PROF_TRANS_PASS);
     if (stage == 1) HIPCHK(launch_rot_pass(c->P.optimizer == ROLO_OPT_SO3_LM ? 3 : 6, a, c->state, grid, c->stream));
     else HIPCHK(launch_trans_pass(a, c->state, grid, c->stream));
   }
-  if (a.fused) return ROLO_OK;
   ProfScope pc(c, ROLO_PROF_CTRL);
   if (c->comm) {
     HIPCHK(launch_reduce(c->partials, grid, c->sums, c->state, stage, c->stream));
@@ -406,9 +397,7 @@ int rolo_ctx_create(int device, rolo_ctx** out) {
   int rc = ensure(c->state, c->state_cap, 1);
   if (!rc) rc = ensure(c->sums, c->sums_cap, NV_MAX);
   if (!rc) rc = ensure(c->trace, c->trace_cap, TRACE_CAP);
-  if (!rc) rc = ensure(c->ticket, c->ticket_cap, 4);
   if (!rc) rc = ensure(c->d_args, c->d_args_cap, 1);
-  if (!rc && hipMemsetAsync(c->ticket, 0, 4 * sizeof(int), c->stream) != hipSuccess) rc = ROLO_EHIP;
   if (!rc && hipMemsetAsync(c->state, 0, sizeof(LmState), c->stream) != hipSuccess) rc = ROLO_EHIP;
   if (rc) { rolo_ctx_destroy(c); return rc; }
   *out = c;
@@ -426,7 +415,7 @@ void rolo_ctx_destroy(rolo_ctx* c) {
   void* bufs[] = {c->src.xyz, c->src.cov, c->src.sorted, c->src.boxes, c->src.knn_idx, c->src.knn_d2, c->tgt.xyz, c->tgt.cov, c->tgt.sorted,
                   c->tgt.boxes, c->tgt.knn_idx, c->tgt.knn_d2, c->ks[0].sort_tmp, c->ks[0].keys0, c->ks[0].keys1, c->ks[0].vals0, c->ks[0].vals1, c->ks[0].bbox,
                   c->ks[1].sort_tmp, c->ks[1].keys0, c->ks[1].keys1, c->ks[1].vals0, c->ks[1].vals1, c->ks[1].bbox, c->tab.keys,
-                  c->tab.ids, c->tab.rec, c->tab.id_keys, c->tgt_keys, c->tgt_slot, c->counters, c->ticket, c->corr[0], c->corr[1], c->partials, c->sums,
+                  c->tab.ids, c->tab.rec, c->tab.id_keys, c->tgt_keys, c->tgt_slot, c->counters, c->corr[0], c->corr[1], c->partials, c->sums,
                   c->state, c->trace, c->stage_in, c->stage_out, c->stage_d, c->stage_i};
   for (void* b : bufs) if (b) (void)hipFree(b);
   if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);

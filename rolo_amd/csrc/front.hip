@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void extract_kernel(FeatArgs A) {
   int* l_label = l_col + WIN;
   float* l_curv = reinterpret_cast<float*>(l_label + WIN);
   int* list = reinterpret_cast<int*>(l_curv + WIN);
-  __shared__ int s_cnt, s_heads, s_flag;
+  __shared__ int s_cnt, s_heads;
   __shared__ float s_red[2][3][4];
   __shared__ int s_wsum[4];
 
@@ -359,7 +359,7 @@ __global__ __launch_bounds__(256) void extract_kernel(FeatArgs A) {
   __syncthreads();
   bitonic_sort_lds(keys, np2);  // std::sort by cell index, ties by point order
   // run heads -> output slot; each head accumulates its run in order with float accumulators (pcl::CentroidPoint)
-  if (t == 0) { s_heads = 0; s_flag = 0; }
+  if (t == 0) s_heads = 0;
   __syncthreads();
   for (int base = 0; base < m; base += 256) {
     const int i = base + t;

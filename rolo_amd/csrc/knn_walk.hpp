@@ -38,12 +38,6 @@ ROLO_DEV int key_idx(double k) { return (int)(unsigned)((unsigned long long)__do
 // quieting) — our operands are never NaN by construction. Pure VALU, no memory: safe as inline asm.
 ROLO_DEV double vmin_f64(double a, double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 ROLO_DEV double vmax_f64(double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
-ROLO_DEV float wave_max_f32(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
-  return v;
-}
-
 // score the 8 points of leaf g against this lane's query and insert the ones that beat its current k-th best
 template <int KMAX>
 ROLO_DEV void knn_score_leaf(const float4* __restrict__ sorted, int g, const float4& q, double (&K)[KMAX], int kk, double& bkey, float& bd,

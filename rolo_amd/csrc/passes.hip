@@ -99,35 +99,8 @@ ROLO_DEV void accumulate_hb(const Sym3& M, const Vec3& a, double wh, double wb_u
   }
 }
 
-ROLO_DEV void ctrl_body(LmState* st, const double* partials, int nblocks, const double* sums_in, rolo_trace_rec* trace, int stage);
-
-// Fused controller: instead of a separate one-workgroup launch per LM trial, the LAST workgroup of the pass to
-// finish (arrival ticket) sums the partial rows and runs the scalar LM step. Hand-off per the gfx950 rules:
-// row stores -> __syncthreads -> lane-0 agent-scope release + drained vmcnt -> ticket atomic; the last arriver does one
-// agent-scope acquire -> __syncthreads -> plain loads. All other workgroups have read the state before they took
-// their ticket, so the last one may overwrite it.
-ROLO_DEV void fused_tail(const PassArgs& a, LmState* st, int stage) {
-  if (!a.fused) return;
-  __shared__ int s_last;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const int t = atomicAdd(a.ticket, 1);
-    s_last = (t == (int)gridDim.x - 1) ? 1 : 0;
-  }
-  __syncthreads();
-  if (!s_last) return;
-  if (threadIdx.x == 0) {
-    *a.ticket = 0;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  }
-  __syncthreads();
-  ctrl_body(st, a.partials, (int)gridDim.x, nullptr, a.trace, stage);
-}
-
 template <int DOF>
-__global__ __launch_bounds__(PASS_THREADS) void rot_pass_kernel(PassArgs a, LmState* st) {
+__global__ __launch_bounds__(PASS_THREADS) void rot_pass_kernel(PassArgs a, const LmState* __restrict__ st) {
   if (st->stage != 1) return;
   constexpr int NH = DOF * (DOF + 1) / 2;
   constexpr int NV = 3 + NH + DOF;
@@ -194,12 +167,11 @@ __global__ __launch_bounds__(PASS_THREADS) void rot_pass_kernel(PassArgs a, LmSt
 #pragma unroll
   for (int v = 0; v < DOF; v++) slot[3 + NH + v] = V_B + v;
   block_reduce_store<NV>(acc, slot, a.partials + (size_t)blockIdx.x * NV_MAX);
-  fused_tail(a, st, 1);
 }
 
 // translation stage: t3_linearize (B) + compute_t_error (A) on the correspondences of the last rotation
 // linearisation, Mahalanobis from st->tr_R.
-__global__ __launch_bounds__(PASS_THREADS) void trans_pass_kernel(PassArgs a, LmState* st) {
+__global__ __launch_bounds__(PASS_THREADS) void trans_pass_kernel(PassArgs a, const LmState* __restrict__ st) {
   if (st->stage != 2) return;
   constexpr int NH = 21, NV = 3 + NH + 6;
   const int phase = st->phase;
@@ -256,7 +228,6 @@ __global__ __launch_bounds__(PASS_THREADS) void trans_pass_kernel(PassArgs a, Lm
 #pragma unroll
   for (int v = 0; v < 6; v++) slot[3 + NH + v] = V_B + v;
   block_reduce_store<NV>(acc, slot, a.partials + (size_t)blockIdx.x * NV_MAX);
-  fused_tail(a, st, 2);
 }
 
 // fixed-order sum of the per-workgroup rows (deterministic for a given grid)
@@ -557,7 +528,14 @@ ROLO_DEV void trans_step(LmState* st, const double* S, rolo_trace_rec* trace) {
   trans_begin_outer(st);
 }
 
-ROLO_DEV void ctrl_body(LmState* st, const double* partials, int nblocks, const double* sums_in, rolo_trace_rec* trace, int stage) {
+// One workgroup: sums the partial rows in a fixed order (or takes the all-reduced sums on the multi-GPU path) and
+// runs the scalar LM step on the device. Measured alternatives that did NOT pay on MI355X: running
+// this in the last workgroup of the pass (arrival ticket + agent-scope release: 26.2 us per trial vs 11.7 + 9.9), and
+// running it redundantly in the prologue of the next pass (every workgroup re-reduces the rows: faster alone,
+// slower when four contexts share the GPU).
+__global__ __launch_bounds__(256) void ctrl_kernel(LmState* st, const double* __restrict__ partials, int nblocks,
+                                                  const double* __restrict__ sums_in, rolo_trace_rec* trace, int stage) {
+  if (st->stage != stage) return;
   __shared__ double sums[NV_MAX];
   // the scalar LM step touches ~150 fields: stage the whole state through LDS (one coalesced read, one write)
   // instead of paying a global-memory round trip per field from a single lane
@@ -581,12 +559,6 @@ ROLO_DEV void ctrl_body(LmState* st, const double* partials, int nblocks, const 
     const int* l = reinterpret_cast<const int*>(&sst);
     for (int i = threadIdx.x; i < NW; i += blockDim.x) g[i] = l[i];
   }
-}
-
-__global__ __launch_bounds__(256) void ctrl_kernel(LmState* st, const double* __restrict__ partials, int nblocks,
-                                                  const double* __restrict__ sums_in, rolo_trace_rec* trace, int stage) {
-  if (st->stage != stage) return;
-  ctrl_body(st, partials, nblocks, sums_in, trace, stage);
 }
 
 ROLO_DEV void rot_begin_dev(LmState* st, const RotBegin& a) {
@@ -659,12 +631,12 @@ __global__ void t3_eval_begin_kernel(LmState* st, TransBegin a, int phase) {
 
 }  // namespace
 
-hipError_t launch_rot_pass(int dof, const PassArgs& a, LmState* st, int grid, hipStream_t s) {
+hipError_t launch_rot_pass(int dof, const PassArgs& a, const LmState* st, int grid, hipStream_t s) {
   if (dof == 3) rot_pass_kernel<3><<<grid, PASS_THREADS, 0, s>>>(a, st);
   else rot_pass_kernel<6><<<grid, PASS_THREADS, 0, s>>>(a, st);
   return hipGetLastError();
 }
-hipError_t launch_trans_pass(const PassArgs& a, LmState* st, int grid, hipStream_t s) {
+hipError_t launch_trans_pass(const PassArgs& a, const LmState* st, int grid, hipStream_t s) {
   trans_pass_kernel<<<grid, PASS_THREADS, 0, s>>>(a, st);
   return hipGetLastError();
 }

@@ -84,10 +84,6 @@ struct PassArgs {
   int* corr[2];       // n_total * n_off voxel ids (-1 = none)
   double* partials;   // gridDim.x x NV_MAX
   VoxelTable tab;
-  // fused controller (single-GPU path): the last workgroup to finish reduces the rows and runs the LM step
-  int* ticket;
-  rolo_trace_rec* trace;
-  int fused;
 };
 
 // ---- launchers (defined in the .hip files) --------------------------------------------------------------
@@ -100,8 +96,8 @@ hipError_t launch_voxel_build(const CloudDev& tgt, VoxelTable tab, unsigned long
                               int* counters /* [0]=V, [1]=error */, hipStream_t s);
 hipError_t launch_voxel_keys(const float4* pts, int n, VoxelTable tab, int32_t* keys3, hipStream_t s);
 
-hipError_t launch_rot_pass(int dof, const PassArgs& a, LmState* st, int grid, hipStream_t s);
-hipError_t launch_trans_pass(const PassArgs& a, LmState* st, int grid, hipStream_t s);
+hipError_t launch_rot_pass(int dof, const PassArgs& a, const LmState* st, int grid, hipStream_t s);
+hipError_t launch_trans_pass(const PassArgs& a, const LmState* st, int grid, hipStream_t s);
 hipError_t launch_reduce(const double* partials, int nblocks, double* sums, const LmState* st, int stage, hipStream_t s);
 // controller: sums the rows of `partials` itself (single GPU) or takes all-reduced `sums` (partials == nullptr)
 hipError_t launch_ctrl(LmState* st, const double* partials, int nblocks, const double* sums, rolo_trace_rec* trace, int stage, hipStream_t s);
