@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="length of the bounded cpu_baseline sample")
     ap.add_argument("--streams", type=int, default=4,
                     help="registration contexts (HIP streams) kept in flight per GPU; a step is then one frame pair per stream")
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("ROLO_BENCH_BATCH", "1")),
+                    help="frame pairs per registration call (rolo_batch_*: shared LM launches); 1 = one operator per frame")
     return ap.parse_args()
 
 
@@ -79,7 +81,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from rolo_amd import synth
-    from rolo_amd.rotvgicp import RotVGICP
+    from rolo_amd.rotvgicp import RotVGICP, RotVGICPBatch
 
     # ---- synthetic inputs (rank-specific seed in replicas mode: independent frames) ----
     seed = synth.SEED + (rank if args.mode == "replicas" else 0)
@@ -90,10 +92,10 @@ def main():
     guess = -np.asarray(synth.PREV_STEP_T, np.float64)
     last = guess * 0.97
 
-    def new_ctx(alone=False):
-        g = RotVGICP(local_rank)
+    def new_ctx(alone=False, g=None):
+        g = g or RotVGICP(local_rank)
         g.setResolution(args.leaf)
-        g.setFixedIterations(20)
+        g.setFixedIterations(int(os.environ.get("ROLO_BENCH_ITERS", "20")))
         g.setOverlapKnn(alone or args.streams <= 1)  # with several contexts in flight the GPU is already shared between frames
         g.setUseGraph(not args.no_graph)
         return g
@@ -105,7 +107,27 @@ def main():
 
     zero3 = np.zeros(3)
 
+    class Batch:
+        """B frame pairs behind the enqueue / register_wait interface of one operator"""
+        def __init__(self, B):
+            self.b = RotVGICPBatch(B, local_rank)
+            for m in self.b.members:
+                new_ctx(g=m)
+            self.guess = np.tile(guess, (B, 1)); self.last = np.tile(last, (B, 1)); self.zero = np.zeros((B, 3))
+
+        def enqueue(self):
+            for m in self.b.members:
+                m.setInputTargetDevice(d_tgt.data_ptr(), n, 4)
+                m.setInputSourceDevice(d_src.data_ptr(), n, 4)
+            self.b.register_async(None, self.zero, self.guess, self.last, 0.1, 0.1, 0.3)
+
+        def register_wait(self):
+            self.b.register_wait()
+            self.last_stats = self.b.members[0].last_stats; self.last_translation_stats = self.b.members[0].last_translation_stats
+
     def enqueue(g):
+        if isinstance(g, Batch):
+            return g.enqueue()
         g.setInputTargetDevice(d_tgt.data_ptr(), n, 4)
         g.setInputSourceDevice(d_src.data_ptr(), n, 4)
         g.register_async(None, zero3, guess, last, 0.1, 0.1, 0.3)
@@ -146,15 +168,20 @@ def main():
 
     g = new_ctx()
     ctxs = [g] + [new_ctx() for _ in range(max(args.streams, 1) - 1)]
+    B = max(args.batch, 1)
+    if B > 1 and not (args.mode == "shard" and world > 1):
+        ctxs = [Batch(B) for _ in range(max(args.streams, 1))]
+    else:
+        B = 1
     if args.mode == "shard" and world > 1:
         ctxs = [g]
         uid = [RotVGICP.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
         g.comm_init(uid[0], rank, world)
     dt = timed(ctxs, args.steps, args.warmup)
-    frames_total = args.steps * len(ctxs) * (world if args.mode == "replicas" else 1)
+    frames_total = args.steps * len(ctxs) * B * (world if args.mode == "replicas" else 1)
     value = frames_total / dt
-    rs, ts = g.last_stats, g.last_translation_stats
+    rs, ts = ctxs[0].last_stats, ctxs[0].last_translation_stats
     passes = rs.n_passes + ts.n_passes
 
     out = {
@@ -165,7 +192,7 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps,
-        "frames_per_step": len(ctxs),
+        "frames_per_step": len(ctxs) * B,
         "higher_is_better": True,
         "scaling": "weak" if args.mode == "replicas" else "strong",
         "vs_baseline": None,
@@ -173,12 +200,12 @@ def main():
         "data": "synthetic",
         "config": {"workload": f"{args.sensor} dense frame pair, {n} pts/cloud, k=20 PLANE covariances, UNIFORM voxel leaf "
                                f"{args.leaf} m, 20 SO(3) LM iterations + CT translation LM", "mode": args.mode,
-                   "parallelism": f"{args.mode}{world}", "streams_per_gpu": len(ctxs), "hip_graph": not args.no_graph, "rot_outer": rs.n_outer, "trans_outer": ts.n_outer,
+                   "parallelism": f"{args.mode}{world}", "streams_per_gpu": len(ctxs), "frames_per_call": B, "hip_graph": not args.no_graph, "rot_outer": rs.n_outer, "trans_outer": ts.n_outer,
                    "passes_per_frame": passes, "n_correspondences": rs.n_correspondences},
     }
 
     # ---- single-frame latency: one context alone (source / target searches overlapped on two streams) ----
-    if len(ctxs) > 1 and args.mode == "replicas":
+    if (len(ctxs) > 1 or B > 1) and args.mode == "replicas":
         gl = new_ctx(alone=True)
         lsteps = max(5, min(args.steps, 20))
         run_steps(gl, 3)

@@ -142,6 +142,22 @@ int rolo_register_async(rolo_ctx* ctx, const float* guess16, const double* trans
                         const double* last_t03, double dtn, double dtn1, float ct_lambda);
 int rolo_register_wait(rolo_ctx* ctx, float* T_out_f16, double* T_out_d16, double* trans3_out,
                        rolo_stats* rot_stats, rolo_stats* trans_stats);
+/* Batches of independent scan pairs (BASELINE config 5 — the reference would loop scanRegeistration over them).
+ * A batch owns n member contexts that share one HIP stream; the caller configures every member through the normal
+ * API (rolo_set_params, rolo_set_source/_target[_device]) and then registers all of them with ONE call: the members'
+ * neighbourhood searches and voxel maps are enqueued back to back and their LM chains run as batched launches (one
+ * pass / controller launch per trial for the whole batch), replayed from a hipGraph when nothing changed. Array
+ * arguments hold one entry per member (guess16: n x 16 or NULL, vectors: n x 3). Members must share the optimizer
+ * and fixed_iterations settings. */
+typedef struct rolo_batch rolo_batch;
+int rolo_batch_create(int device, int n_members, rolo_batch** out);
+void rolo_batch_destroy(rolo_batch* b);
+int rolo_batch_size(rolo_batch* b);
+rolo_ctx* rolo_batch_member(rolo_batch* b, int i); /* owned by the batch: do not destroy */
+int rolo_batch_register_async(rolo_batch* b, const float* guess16, const double* trans3_start, const double* init_guess3,
+                              const double* last_t03, double dtn, double dtn1, float ct_lambda);
+int rolo_batch_register_wait(rolo_batch* b, float* T_out_f16, double* T_out_d16, double* trans3_out, rolo_stats* rot_stats,
+                             rolo_stats* trans_stats);
 /* getFinalHessian (lsq_registration_impl.hpp:45-47): 6x6, Identity until a 6-dof LM step accepts */
 int rolo_get_final_hessian(rolo_ctx* ctx, double* H36);
 int rolo_get_trace(rolo_ctx* ctx, rolo_trace_rec* out, int cap); /* returns the number of records */

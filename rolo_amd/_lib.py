@@ -76,6 +76,12 @@ SYMBOLS = {
     "rolo_compute_translation": (C.c_int, [vp, dp, dp, dp, C.c_double, C.c_double, C.c_float, C.POINTER(Stats)]),
     "rolo_register_async": (C.c_int, [vp, fp, dp, dp, dp, C.c_double, C.c_double, C.c_float]),
     "rolo_register_wait": (C.c_int, [vp, fp, dp, dp, C.POINTER(Stats), C.POINTER(Stats)]),
+    "rolo_batch_create": (C.c_int, [C.c_int, C.c_int, C.POINTER(vp)]),
+    "rolo_batch_destroy": (None, [vp]),
+    "rolo_batch_size": (C.c_int, [vp]),
+    "rolo_batch_member": (vp, [vp, C.c_int]),
+    "rolo_batch_register_async": (C.c_int, [vp, fp, dp, dp, dp, C.c_double, C.c_double, C.c_float]),
+    "rolo_batch_register_wait": (C.c_int, [vp, fp, dp, dp, C.POINTER(Stats), C.POINTER(Stats)]),
     "rolo_get_final_hessian": (C.c_int, [vp, dp]),
     "rolo_get_trace": (C.c_int, [vp, C.POINTER(TraceRec), C.c_int]),
     "rolo_transform_cloud": (C.c_int, [vp, fp, fp, C.c_int, C.c_int, fp]),

@@ -887,6 +887,226 @@ int rolo_prof_read(rolo_ctx* c, int slot, float* ms, int cap) {
   return n;
 }
 
+// ---- batches of independent scan pairs (BASELINE config 5) -------------------------------------------------------
+struct rolo_batch {
+  int device = 0, n = 0;
+  std::vector<rolo_ctx*> m;          // members: ordinary contexts; their own streams carry the per-member front work
+  hipStream_t stream = nullptr;      // the batched LM chain runs here
+  hipEvent_t ev_fork = nullptr;
+  std::vector<hipEvent_t> ev_join;   // member front work done (recorded inside the captured schedule)
+  std::vector<hipEvent_t> ev_in;     // member stream's earlier work (cloud packing) done — recorded outside the graph
+  BatchSlot* h_slots = nullptr;      // pinned
+  BatchSlot* d_slots = nullptr;
+  FrameArgs* h_args = nullptr;       // pinned, n entries
+  FrameArgs* d_args = nullptr;
+  bool pending = false;
+  int bps = 0;
+  // hipGraph of the whole batch
+  struct Key { std::vector<rolo_ctx::GraphKey> k; } gkey, gseen;
+  bool gseen_valid = false;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t graph_exec = nullptr;
+};
+
+static bool same_key(const rolo_ctx::GraphKey& a, const rolo_ctx::GraphKey& b) {
+  return a.n_src == b.n_src && a.n_tgt == b.n_tgt && a.src_xyz == b.src_xyz && a.tgt_xyz == b.tgt_xyz && a.epoch == b.epoch &&
+         memcmp(&a.P, &b.P, sizeof(rolo_params)) == 0;
+}
+static bool same_keys(const std::vector<rolo_ctx::GraphKey>& a, const std::vector<rolo_ctx::GraphKey>& b) {
+  if (a.size() != b.size()) return false;
+  for (size_t i = 0; i < a.size(); i++) if (!same_key(a[i], b[i])) return false;
+  return true;
+}
+
+int rolo_batch_create(int device, int n_members, rolo_batch** out) {
+  if (!out || n_members < 1 || n_members > 64) return ROLO_EINVAL;
+  rolo_batch* b = new rolo_batch();
+  b->device = device; b->n = n_members;
+  for (int i = 0; i < n_members; i++) {
+    rolo_ctx* c = nullptr;
+    int rc = rolo_ctx_create(device, &c);
+    if (rc) { rolo_batch_destroy(b); return rc; }
+    b->m.push_back(c);
+    hipEvent_t e = nullptr;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { g_err = "event creation failed"; rolo_batch_destroy(b); return ROLO_EHIP; }
+    b->ev_join.push_back(e);
+    e = nullptr;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { g_err = "event creation failed"; rolo_batch_destroy(b); return ROLO_EHIP; }
+    b->ev_join.push_back(e);
+    e = nullptr;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { g_err = "event creation failed"; rolo_batch_destroy(b); return ROLO_EHIP; }
+    b->ev_in.push_back(e);
+  }
+  if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming) != hipSuccess ||
+      hipHostMalloc((void**)&b->h_slots, sizeof(BatchSlot) * n_members) != hipSuccess || hipHostMalloc((void**)&b->h_args, sizeof(FrameArgs) * n_members) != hipSuccess ||
+      hipMalloc((void**)&b->d_slots, sizeof(BatchSlot) * n_members) != hipSuccess || hipMalloc((void**)&b->d_args, sizeof(FrameArgs) * n_members) != hipSuccess) {
+    g_err = "batch allocation failed"; rolo_batch_destroy(b); return ROLO_EHIP;
+  }
+  *out = b;
+  return ROLO_OK;
+}
+
+void rolo_batch_destroy(rolo_batch* b) {
+  if (!b) return;
+  (void)hipSetDevice(b->device);
+  if (b->stream) (void)hipStreamSynchronize(b->stream);
+  if (b->graph_exec) (void)hipGraphExecDestroy(b->graph_exec);
+  if (b->graph) (void)hipGraphDestroy(b->graph);
+  for (rolo_ctx* c : b->m) rolo_ctx_destroy(c);
+  for (hipEvent_t e : b->ev_join) (void)hipEventDestroy(e);
+  for (hipEvent_t e : b->ev_in) (void)hipEventDestroy(e);
+  if (b->ev_fork) (void)hipEventDestroy(b->ev_fork);
+  if (b->stream) (void)hipStreamDestroy(b->stream);
+  if (b->h_slots) (void)hipHostFree(b->h_slots);
+  if (b->h_args) (void)hipHostFree(b->h_args);
+  if (b->d_slots) (void)hipFree(b->d_slots);
+  if (b->d_args) (void)hipFree(b->d_args);
+  delete b;
+}
+
+int rolo_batch_size(rolo_batch* b) { return b ? b->n : 0; }
+rolo_ctx* rolo_batch_member(rolo_batch* b, int i) { return (b && i >= 0 && i < b->n) ? b->m[i] : nullptr; }
+
+// everything of one batch step after the clouds are on the device
+static int enqueue_batch(rolo_batch* b, bool fork) {
+  rolo_ctx* c0 = b->m[0];
+  hipStream_t st = b->stream;
+  int rc, bps = 1;
+  // Eager launches (fork): the per-member front work fans out over the members' two streams — source search on one,
+  // target search + voxel map on the other; one search launch fills about half the chip — and joins the batch stream
+  // before the shared LM chain. Both streams fork directly from the batch stream. Captured schedule (!fork): a single
+  // branch on the batch stream. ROCm 7.2's graph runtime is not safe with forked captures here: a fork of a fork sends
+  // hipStreamEndCapture into an endless recursion, and several multi-branch graphs in flight crashed hipGraphLaunch
+  // (hip::Graph::UpdateStreams); overlap between frames then comes from keeping several batches in flight.
+  if (fork) HIPCHK(hipEventRecord(b->ev_fork, st));
+  for (int i = 0; i < b->n; i++) {
+    rolo_ctx* c = b->m[i];
+    const hipStream_t s1 = fork ? c->stream : st, s2 = fork ? c->stream2 : st;
+    if (c->src.n <= 0 || c->tgt.n <= 0) { g_err = "source/target not set"; return ROLO_ESTATE; }
+    if (fork) { HIPCHK(hipStreamWaitEvent(s1, b->ev_fork, 0)); HIPCHK(hipStreamWaitEvent(s2, b->ev_fork, 0)); }
+    if (!c->src.have_cov && (rc = build_src(c, s1))) return rc;
+    if (!c->tgt.have_cov && (rc = build_tgt(c, s2))) return rc;
+    const int n = c->tgt.n;
+    size_t capslots = 1024; while (capslots < 2 * (size_t)n) capslots <<= 1;
+    if ((rc = ensure(c->tab.keys, c->tab_keys_cap, capslots))) return rc;
+    if ((rc = ensure(c->tab.ids, c->tab_ids_cap, capslots))) return rc;
+    if ((rc = ensure(c->tab.rec, c->tab_rec_cap, (size_t)n * REC_DOUBLES))) return rc;
+    if ((rc = ensure(c->tab.id_keys, c->tab_idk_cap, (size_t)n))) return rc;
+    if ((rc = ensure(c->tgt_keys, c->tgt_keys_cap, (size_t)n))) return rc;
+    if ((rc = ensure(c->tgt_slot, c->tgt_slot_cap, (size_t)n))) return rc;
+    if ((rc = ensure(c->counters, c->counters_cap, 4))) return rc;
+    c->tab.mask = (unsigned)(capslots - 1);
+    fill_table_params(c);
+    HIPCHK(launch_voxel_build(c->tgt, c->tab, c->tgt_keys, c->tgt_slot, c->counters, s2));
+    HIPCHK(hipMemcpyAsync(c->h_counters, c->counters, 2 * sizeof(int), hipMemcpyDeviceToHost, s2));
+    if (fork) { HIPCHK(hipEventRecord(b->ev_join[2 * i], s1)); HIPCHK(hipEventRecord(b->ev_join[2 * i + 1], s2)); }
+    PassArgs a; int grid;
+    if ((rc = prepare_pass(c, a, grid))) return rc;
+    BatchSlot& S = b->h_slots[i];
+    S.a = a; S.st = c->state; S.trace = c->trace; S.grid = grid; S.pad = 0;
+    bps = std::max(bps, grid);
+  }
+  b->bps = bps;
+  if (fork) for (hipEvent_t e : b->ev_join) HIPCHK(hipStreamWaitEvent(st, e, 0));
+  HIPCHK(hipMemcpyAsync(b->d_slots, b->h_slots, sizeof(BatchSlot) * b->n, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(b->d_args, b->h_args, sizeof(FrameArgs) * b->n, hipMemcpyHostToDevice, st));
+  HIPCHK(launch_batch_begin(b->d_slots, b->d_args, b->n, st));
+  const int dof = c0->P.optimizer == ROLO_OPT_SO3_LM ? 3 : 6;
+  const int nrot = rot_first_chunk(c0);
+  for (int k = 0; k < nrot; k++) { HIPCHK(launch_batch_pass(1, dof, b->d_slots, b->n, bps, st)); HIPCHK(launch_batch_ctrl(1, b->d_slots, b->n, st)); }
+  for (int k = 0; k < 12; k++) { HIPCHK(launch_batch_pass(2, dof, b->d_slots, b->n, bps, st)); HIPCHK(launch_batch_ctrl(2, b->d_slots, b->n, st)); }
+  for (int i = 0; i < b->n; i++) HIPCHK(hipMemcpyAsync(b->m[i]->h_state, b->m[i]->state, sizeof(LmState), hipMemcpyDeviceToHost, st));
+  return ROLO_OK;
+}
+
+int rolo_batch_register_async(rolo_batch* b, const float* guess16, const double* trans_start, const double* init_guess, const double* last_t0,
+                              double dtn, double dtn1, float lam) {
+  if (!b || !init_guess || !last_t0) return ROLO_EINVAL;
+  if (b->pending) { g_err = "a batch registration is already in flight"; return ROLO_ESTATE; }
+  int rc = set_device(b->m[0]); if (rc) return rc;
+  bool graphable = true;
+  std::vector<rolo_ctx::GraphKey> keys(b->n);
+  for (int i = 0; i < b->n; i++) {
+    rolo_ctx* c = b->m[i];
+    if (c->src.n <= 0 || c->tgt.n <= 0) { g_err = "batch member without source/target"; return ROLO_ESTATE; }
+    if (c->comm || c->async_pending) { g_err = "batch members must be idle single-GPU contexts"; return ROLO_ESTATE; }
+    if (c->P.optimizer != b->m[0]->P.optimizer || c->P.fixed_iterations != b->m[0]->P.fixed_iterations) { g_err = "batch members must share optimizer and iteration settings"; return ROLO_EUNSUPPORTED; }
+    double R[9], t[3]; guess_to_Rt(guess16 ? guess16 + 16 * (size_t)i : nullptr, R, t);
+    b->h_args[i].rot = make_rot_begin(c, R, t, 1);
+    TransBegin& tb = b->h_args[i].trans;
+    for (int d = 0; d < 3; d++) { tb.t0[d] = trans_start ? trans_start[3 * i + d] : 0.0; tb.g[d] = init_guess[3 * i + d]; tb.l[d] = last_t0[3 * i + d]; }
+    tb.dtn = dtn; tb.dtn1 = dtn1; tb.ct_lambda = lam; tb.direct = 0;
+    graphable = graphable && c->P.use_graph && !c->prof_on && !c->want_knn_lists && !c->src.have_cov && !c->tgt.have_cov;
+    keys[i].n_src = c->src.n; keys[i].n_tgt = c->tgt.n; keys[i].src_xyz = c->src.xyz; keys[i].tgt_xyz = c->tgt.xyz; keys[i].P = c->P; keys[i].epoch = g_alloc_epoch;
+  }
+  hipStream_t st = b->stream;
+  // whatever the caller queued on the members' streams (rolo_set_source/_target pack the clouds there) comes first
+  for (int i = 0; i < b->n; i++) { HIPCHK(hipEventRecord(b->ev_in[i], b->m[i]->stream)); HIPCHK(hipStreamWaitEvent(st, b->ev_in[i], 0)); }
+  if (graphable) {
+    if (b->graph_exec && same_keys(keys, b->gkey.k)) {
+      HIPCHK(hipGraphLaunch(b->graph_exec, st));
+      for (rolo_ctx* c : b->m) { c->src.have_cov = true; c->tgt.have_cov = true; }
+      b->pending = true;
+      return ROLO_OK;
+    }
+    if (b->gseen_valid && same_keys(keys, b->gseen.k)) {
+      if (b->graph_exec) { (void)hipGraphExecDestroy(b->graph_exec); b->graph_exec = nullptr; }
+      if (b->graph) { (void)hipGraphDestroy(b->graph); b->graph = nullptr; }
+      HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+      rc = enqueue_batch(b, false);
+      hipGraph_t gph = nullptr;
+      hipError_t e = hipStreamEndCapture(st, &gph);
+      const bool epoch_moved = keys[0].epoch != g_alloc_epoch;
+      if (rc == ROLO_OK && e == hipSuccess && gph && !epoch_moved && hipGraphInstantiate(&b->graph_exec, gph, nullptr, nullptr, 0) == hipSuccess) {
+        b->graph = gph; b->gkey.k = keys;
+        HIPCHK(hipGraphLaunch(b->graph_exec, st));
+        b->pending = true;
+        return ROLO_OK;
+      }
+      if (gph) (void)hipGraphDestroy(gph);
+      b->graph_exec = nullptr;
+      (void)hipGetLastError();
+      for (rolo_ctx* c : b->m) { c->src.have_cov = false; c->tgt.have_cov = false; }
+      b->gseen_valid = false;
+    } else {
+      b->gseen.k = keys; b->gseen_valid = true;
+    }
+  }
+  if ((rc = enqueue_batch(b, true))) return rc;
+  if (graphable) for (auto& k : b->gseen.k) k.epoch = g_alloc_epoch;
+  b->pending = true;
+  return ROLO_OK;
+}
+
+int rolo_batch_register_wait(rolo_batch* b, float* Tf, double* Td, double* trans_out, rolo_stats* rs, rolo_stats* ts) {
+  if (!b) return ROLO_EINVAL;
+  if (!b->pending) { g_err = "no batch registration in flight"; return ROLO_ESTATE; }
+  int rc = set_device(b->m[0]); if (rc) return rc;
+  b->pending = false;
+  HIPCHK(hipStreamSynchronize(b->stream));
+  int first_err = ROLO_OK;
+  for (int i = 0; i < b->n; i++) {
+    rolo_ctx* c = b->m[i];
+    if (c->h_counters[1] != 0) { g_err = "voxel coordinate outside the packed key range"; if (!first_err) first_err = c->h_counters[1]; continue; }
+    c->n_voxels = c->h_counters[0];
+    c->have_map = true;
+    // a member whose data needed more trials than the fixed schedule holds is finished on its own (rare)
+    if (!c->h_state->error && (!c->h_state->rot_done || !c->h_state->trans_done)) {
+      PassArgs a; int grid;
+      if ((rc = prepare_pass(c, a, grid))) return rc;
+      if (!c->h_state->rot_done) { if ((rc = run_stage(c, a, grid, 1, 8))) return rc; }
+      if (!c->h_state->trans_done && !c->h_state->error) { if ((rc = run_stage(c, a, grid, 2, 8))) return rc; }
+    }
+    c->have_corr = true;
+    const LmState* s = c->h_state;
+    fill_rot_outputs(s, Tf ? Tf + 16 * (size_t)i : nullptr, Td ? Td + 16 * (size_t)i : nullptr, rs ? rs + i : nullptr);
+    if (trans_out) for (int d = 0; d < 3; d++) trans_out[3 * i + d] = s->t0[d];
+    if (ts) { ts[i].n_outer = s->trans_outer; ts[i].converged = s->trans_failed ? 0 : 1; ts[i].lm_failed = s->trans_failed; ts[i].n_passes = s->trans_passes; ts[i].n_correspondences = s->tr_n_corr; }
+    if (s->error && !first_err) { g_err = "device-side error in a batch member"; first_err = s->error; }
+  }
+  return first_err;
+}
+
 int rolo_set_shard(rolo_ctx* c, int rank, int world) {
   if (!c || world < 1 || rank < 0 || rank >= world) return ROLO_EINVAL;
   c->rank = rank; c->world = world; c->have_corr = false;

@@ -41,12 +41,13 @@ ROLO_DEV double vmax_f64(double a, double b) { double r; asm("v_max_f64 %0, %1, 
 // score the 8 points of leaf g against this lane's query and insert the ones that beat its current k-th best
 template <int KMAX>
 ROLO_DEV void knn_score_leaf(const float4* __restrict__ sorted, int g, const float4& q, double (&K)[KMAX], int kk, double& bkey, float& bd,
-                             unsigned& n_ins) {
+                             unsigned& n_ins, unsigned& lane_acc, unsigned& rounds) {
   // fetch the whole leaf first: the address is wave-uniform, so these are 8 scalar loads in flight behind ONE wait
   // (loading inside the loop serialised 8 scalar-cache round trips per leaf behind the insert branch)
   float4 pts[8];
 #pragma unroll
   for (int u = 0; u < 8; u++) pts[u] = sorted[8 * (size_t)g + u];
+  KNN_STAT(const double bkey0 = bkey; int acc_leaf = 0;)
 #pragma unroll
   for (int u = 0; u < 8; u++) {
     const float4 c = pts[u];
@@ -54,6 +55,7 @@ ROLO_DEV void knn_score_leaf(const float4* __restrict__ sorted, int g, const flo
     const float cd = ((dx * dx) + (dy * dy)) + (dz * dz);  // file is compiled with -ffp-contract=off
     const double ck = key_pack(cd, __float_as_int(c.w));
     KNN_STAT(if (__any(ck < bkey)) n_ins++;)
+    KNN_STAT(if (ck < bkey0) acc_leaf++;)
     if (ck < bkey) {
       // sorted insert, descending slot order so every step reads not-yet-overwritten neighbours
 #pragma unroll
@@ -64,6 +66,12 @@ ROLO_DEV void knn_score_leaf(const float4* __restrict__ sorted, int g, const flo
       bd = key_d2(bkey);
     }
   }
+#ifdef ROLO_KNN_STATS
+  lane_acc += acc_leaf;
+  int m = acc_leaf;
+  for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o));
+  rounds += m;
+#endif
 }
 
 template <int KMAX>
@@ -80,7 +88,7 @@ __global__ __launch_bounds__(256, 4) void knn_cov_kernel(const float4* __restric
   const bool active = qi != INT_MAX;  // not padding
   const int kk = (KMAX == 20) ? 20 : k;
   const int n_leaves = n_sorted >> 3;
-  unsigned st_nodes = 0, st_leaves = 0, st_ins = 0;
+  unsigned st_nodes = 0, st_leaves = 0, st_ins = 0, st_lane = 0, st_rounds = 0;
   KNN_STAT(const long long t0 = clock64();)
 
   // K[0..KMAX) ascending; sentinel = (inf, INT_MAX)
@@ -95,7 +103,7 @@ __global__ __launch_bounds__(256, 4) void knn_cov_kernel(const float4* __restric
   // ---- seed: the wavefront's own 8 leaves ----
   const int g_own0 = __builtin_amdgcn_readfirstlane(j >> 3);  // lane 0 of the wave: j is a multiple of 64
   const int g_own1 = min(g_own0 + 8, n_leaves);
-  for (int g = g_own0; g < g_own1; g++) { knn_score_leaf<KMAX>(sorted, g, q, K, kk, bkey, bd, st_ins); st_leaves++; }
+  for (int g = g_own0; g < g_own1; g++) { knn_score_leaf<KMAX>(sorted, g, q, K, kk, bkey, bd, st_ins, st_lane, st_rounds); st_leaves++; }
 
   // ---- packet walk ----
   int sp = 0;
@@ -121,7 +129,7 @@ __global__ __launch_bounds__(256, 4) void knn_cov_kernel(const float4* __restric
       if (mr != 0ull) { h = 2 * h + 1; continue; }
     } else {
       const int g = h - P;
-      if (g < g_own0 || g >= g_own1) { knn_score_leaf<KMAX>(sorted, g, q, K, kk, bkey, bd, st_ins); st_leaves++; }
+      if (g < g_own0 || g >= g_own1) { knn_score_leaf<KMAX>(sorted, g, q, K, kk, bkey, bd, st_ins, st_lane, st_rounds); st_leaves++; }
     }
     if (sp == 0) break;
     sp--;
@@ -133,9 +141,15 @@ __global__ __launch_bounds__(256, 4) void knn_cov_kernel(const float4* __restric
     atomicAdd(&g_knn_stats[0], (unsigned long long)st_nodes); atomicAdd(&g_knn_stats[1], (unsigned long long)st_leaves);
     atomicAdd(&g_knn_stats[2], (unsigned long long)st_ins); atomicAdd(&g_knn_stats[3], (unsigned long long)(t1 - t0));
     atomicAdd(&g_knn_stats[4], 1ull);
+    atomicAdd(&g_knn_stats[6], (unsigned long long)st_rounds);
+  }
+  {
+    int m = (int)st_lane;
+    for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o));
+    if ((tid & 63) == 0) atomicAdd(&g_knn_stats[7], (unsigned long long)m);
   }
 #endif
-  (void)st_nodes; (void)st_leaves; (void)st_ins;
+  (void)st_nodes; (void)st_leaves; (void)st_ins; (void)st_lane; (void)st_rounds;
   if (!active) return;
 
   int ki[KMAX];

@@ -100,7 +100,7 @@ ROLO_DEV void accumulate_hb(const Sym3& M, const Vec3& a, double wh, double wb_u
 }
 
 template <int DOF>
-__global__ __launch_bounds__(PASS_THREADS) void rot_pass_kernel(PassArgs a, const LmState* __restrict__ st) {
+ROLO_DEV void rot_pass_body(const PassArgs& a, const LmState* __restrict__ st, const int block) {
   if (st->stage != 1) return;
   constexpr int NH = DOF * (DOF + 1) / 2;
   constexpr int NV = 3 + NH + DOF;
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(PASS_THREADS) void rot_pass_kernel(PassArgs a, cons
 #pragma unroll
   for (int v = 0; v < NV; v++) acc[v] = 0.0;
 
-  const int i = a.begin + blockIdx.x * PASS_THREADS + threadIdx.x;
+  const int i = a.begin + block * PASS_THREADS + threadIdx.x;
   if (i < a.end) {
     const float4 pf = a.src[i];
     const Vec3 p{(double)pf.x, (double)pf.y, (double)pf.z};
@@ -166,12 +166,12 @@ __global__ __launch_bounds__(PASS_THREADS) void rot_pass_kernel(PassArgs a, cons
   for (int v = 0; v < NH; v++) slot[3 + v] = V_H + v;
 #pragma unroll
   for (int v = 0; v < DOF; v++) slot[3 + NH + v] = V_B + v;
-  block_reduce_store<NV>(acc, slot, a.partials + (size_t)blockIdx.x * NV_MAX);
+  block_reduce_store<NV>(acc, slot, a.partials + (size_t)block * NV_MAX);
 }
 
 // translation stage: t3_linearize (B) + compute_t_error (A) on the correspondences of the last rotation
 // linearisation, Mahalanobis from st->tr_R.
-__global__ __launch_bounds__(PASS_THREADS) void trans_pass_kernel(PassArgs a, const LmState* __restrict__ st) {
+ROLO_DEV void trans_pass_body(const PassArgs& a, const LmState* __restrict__ st, const int block) {
   if (st->stage != 2) return;
   constexpr int NH = 21, NV = 3 + NH + 6;
   const int phase = st->phase;
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(PASS_THREADS) void trans_pass_kernel(PassArgs a, co
 #pragma unroll
   for (int v = 0; v < NV; v++) acc[v] = 0.0;
 
-  const int i = a.begin + blockIdx.x * PASS_THREADS + threadIdx.x;
+  const int i = a.begin + block * PASS_THREADS + threadIdx.x;
   if (i < a.end) {
     const float4 pf = a.src[i];
     const Vec3 p{(double)pf.x, (double)pf.y, (double)pf.z};
@@ -227,7 +227,27 @@ __global__ __launch_bounds__(PASS_THREADS) void trans_pass_kernel(PassArgs a, co
   for (int v = 0; v < NH; v++) slot[3 + v] = V_H + v;
 #pragma unroll
   for (int v = 0; v < 6; v++) slot[3 + NH + v] = V_B + v;
-  block_reduce_store<NV>(acc, slot, a.partials + (size_t)blockIdx.x * NV_MAX);
+  block_reduce_store<NV>(acc, slot, a.partials + (size_t)block * NV_MAX);
+}
+
+template <int DOF>
+__global__ __launch_bounds__(PASS_THREADS) void rot_pass_kernel(PassArgs a, const LmState* __restrict__ st) { rot_pass_body<DOF>(a, st, blockIdx.x); }
+__global__ __launch_bounds__(PASS_THREADS) void trans_pass_kernel(PassArgs a, const LmState* __restrict__ st) { trans_pass_body(a, st, blockIdx.x); }
+
+// Batched form (rolo_batch_*, BASELINE config 5): one launch evaluates the same LM trial of B independent frame
+// pairs. Workgroups [s * bps, (s + 1) * bps) belong to slot s; every slot has its own clouds, voxel table,
+// correspondence cache, partial rows and LM state, and is predicated individually. The LM chain is a string of tiny
+// latency-bound launches, so batching B frames through it costs almost the same wall time as one.
+template <int DOF>
+__global__ __launch_bounds__(PASS_THREADS) void rot_pass_batch_kernel(const BatchSlot* __restrict__ slots, int bps) {
+  const int s = blockIdx.x / bps, lb = blockIdx.x - s * bps;
+  if (lb >= slots[s].grid) return;
+  rot_pass_body<DOF>(slots[s].a, slots[s].st, lb);
+}
+__global__ __launch_bounds__(PASS_THREADS) void trans_pass_batch_kernel(const BatchSlot* __restrict__ slots, int bps) {
+  const int s = blockIdx.x / bps, lb = blockIdx.x - s * bps;
+  if (lb >= slots[s].grid) return;
+  trans_pass_body(slots[s].a, slots[s].st, lb);
 }
 
 // fixed-order sum of the per-workgroup rows (deterministic for a given grid)
@@ -533,8 +553,8 @@ ROLO_DEV void trans_step(LmState* st, const double* S, rolo_trace_rec* trace) {
 // this in the last workgroup of the pass (arrival ticket + agent-scope release: 26.2 us per trial vs 11.7 + 9.9), and
 // running it redundantly in the prologue of the next pass (every workgroup re-reduces the rows: faster alone,
 // slower when four contexts share the GPU).
-__global__ __launch_bounds__(256) void ctrl_kernel(LmState* st, const double* __restrict__ partials, int nblocks,
-                                                  const double* __restrict__ sums_in, rolo_trace_rec* trace, int stage) {
+ROLO_DEV void ctrl_body(LmState* st, const double* __restrict__ partials, int nblocks, const double* __restrict__ sums_in,
+                        rolo_trace_rec* trace, int stage) {
   if (st->stage != stage) return;
   __shared__ double sums[NV_MAX];
   // the scalar LM step touches ~150 fields: stage the whole state through LDS (one coalesced read, one write)
@@ -559,6 +579,15 @@ __global__ __launch_bounds__(256) void ctrl_kernel(LmState* st, const double* __
     const int* l = reinterpret_cast<const int*>(&sst);
     for (int i = threadIdx.x; i < NW; i += blockDim.x) g[i] = l[i];
   }
+}
+
+__global__ __launch_bounds__(256) void ctrl_kernel(LmState* st, const double* __restrict__ partials, int nblocks,
+                                                  const double* __restrict__ sums_in, rolo_trace_rec* trace, int stage) {
+  ctrl_body(st, partials, nblocks, sums_in, trace, stage);
+}
+__global__ __launch_bounds__(256) void ctrl_batch_kernel(const BatchSlot* __restrict__ slots, int stage) {
+  const BatchSlot& S = slots[blockIdx.x];
+  ctrl_body(S.st, S.a.partials, S.grid, nullptr, S.trace, stage);
 }
 
 ROLO_DEV void rot_begin_dev(LmState* st, const RotBegin& a) {
@@ -594,6 +623,17 @@ __global__ void frame_begin_kernel(LmState* st, const FrameArgs* a) {
   if (threadIdx.x != 0) return;
   const RotBegin r = a->rot;
   const TransBegin t = a->trans;
+  rot_begin_dev(st, r);
+  for (int i = 0; i < 3; i++) { st->t0[i] = t.t0[i]; st->g[i] = t.g[i]; st->l[i] = t.l[i]; }
+  st->dtn = t.dtn; st->dtn1 = t.dtn1; st->ct_lambda = t.ct_lambda;
+}
+
+__global__ void frame_begin_batch_kernel(const BatchSlot* __restrict__ slots, const FrameArgs* __restrict__ args, int n) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n) return;
+  LmState* st = slots[s].st;
+  const RotBegin r = args[s].rot;
+  const TransBegin t = args[s].trans;
   rot_begin_dev(st, r);
   for (int i = 0; i < 3; i++) { st->t0[i] = t.t0[i]; st->g[i] = t.g[i]; st->l[i] = t.l[i]; }
   st->dtn = t.dtn; st->dtn1 = t.dtn1; st->ct_lambda = t.ct_lambda;
@@ -638,6 +678,24 @@ hipError_t launch_rot_pass(int dof, const PassArgs& a, const LmState* st, int gr
 }
 hipError_t launch_trans_pass(const PassArgs& a, const LmState* st, int grid, hipStream_t s) {
   trans_pass_kernel<<<grid, PASS_THREADS, 0, s>>>(a, st);
+  return hipGetLastError();
+}
+hipError_t launch_batch_pass(int stage, int dof, const BatchSlot* slots, int n_slots, int bps, hipStream_t s) {
+  const int grid = n_slots * bps;
+  if (stage == 1) {
+    if (dof == 3) rot_pass_batch_kernel<3><<<grid, PASS_THREADS, 0, s>>>(slots, bps);
+    else rot_pass_batch_kernel<6><<<grid, PASS_THREADS, 0, s>>>(slots, bps);
+  } else {
+    trans_pass_batch_kernel<<<grid, PASS_THREADS, 0, s>>>(slots, bps);
+  }
+  return hipGetLastError();
+}
+hipError_t launch_batch_ctrl(int stage, const BatchSlot* slots, int n_slots, hipStream_t s) {
+  ctrl_batch_kernel<<<n_slots, 256, 0, s>>>(slots, stage);
+  return hipGetLastError();
+}
+hipError_t launch_batch_begin(const BatchSlot* slots, const FrameArgs* args, int n_slots, hipStream_t s) {
+  frame_begin_batch_kernel<<<(n_slots + 63) / 64, 64, 0, s>>>(slots, args, n_slots);
   return hipGetLastError();
 }
 hipError_t launch_reduce(const double* partials, int nblocks, double* sums, const LmState* st, int stage, hipStream_t s) {

@@ -86,6 +86,9 @@ struct PassArgs {
   VoxelTable tab;
 };
 
+// one member of a batch (rolo_batch_*): the arguments of its pass kernels, its LM state and trace, its row count
+struct BatchSlot { PassArgs a; LmState* st; rolo_trace_rec* trace; int grid; int pad; };
+
 // ---- launchers (defined in the .hip files) --------------------------------------------------------------
 hipError_t launch_knn_build(CloudDev& c, void* sort_tmp, size_t sort_tmp_bytes, uint32_t* keys0, uint32_t* keys1,
                             uint32_t* vals0, uint32_t* vals1, int* bbox, hipStream_t s);
@@ -107,6 +110,9 @@ struct TransBegin { double t0[3], g[3], l[3], dtn, dtn1; float ct_lambda; int di
 struct FrameArgs { RotBegin rot; TransBegin trans; };
 hipError_t launch_rot_begin(LmState* st, const RotBegin& a, hipStream_t s);
 hipError_t launch_frame_begin(LmState* st, const FrameArgs* a, hipStream_t s);
+hipError_t launch_batch_pass(int stage, int dof, const BatchSlot* slots, int n_slots, int bps, hipStream_t s);
+hipError_t launch_batch_ctrl(int stage, const BatchSlot* slots, int n_slots, hipStream_t s);
+hipError_t launch_batch_begin(const BatchSlot* slots, const FrameArgs* args, int n_slots, hipStream_t s);
 hipError_t launch_trans_begin(LmState* st, const TransBegin& a, hipStream_t s);
 // single evaluations for the stage-level API (rolo_so3_linearize, rolo_compute_error, rolo_t3_linearize, ...)
 hipError_t launch_eval_begin(LmState* st, const RotBegin& a, int mode, hipStream_t s);

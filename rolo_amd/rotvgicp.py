@@ -42,9 +42,13 @@ def _i(a):
 
 
 class RotVGICP:
-    def __init__(self, device: int = 0):
-        h = C.c_void_p()
-        check(lib().rolo_ctx_create(device, C.byref(h)), "rolo_ctx_create")
+    def __init__(self, device: int = 0, _borrowed=None):
+        if _borrowed is not None:   # member of a RotVGICPBatch: the batch owns the context
+            h = C.c_void_p(_borrowed)
+        else:
+            h = C.c_void_p()
+            check(lib().rolo_ctx_create(device, C.byref(h)), "rolo_ctx_create")
+        self._owned = _borrowed is None
         self._h = h
         self._p = Params()
         lib().rolo_default_params(C.byref(self._p))
@@ -55,7 +59,8 @@ class RotVGICP:
 
     def close(self):
         if getattr(self, "_h", None):
-            lib().rolo_ctx_destroy(self._h)
+            if self._owned:
+                lib().rolo_ctx_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -323,3 +328,49 @@ class RotVGICP:
     def comm_init(self, unique_id: bytes, rank: int, world: int):
         buf = C.create_string_buffer(unique_id, 128)
         check(lib().rolo_comm_init(self._h, buf, rank, world), "rolo_comm_init")
+
+
+class RotVGICPBatch:
+    """B independent scan pairs registered with one call (BASELINE config 5; the reference would loop
+    LidarOdometry::scanRegeistration, lidarOdometry.cpp:256-317, over them). `members[i]` is an ordinary RotVGICP
+    — set its parameters and clouds as usual — owned by the batch."""
+
+    def __init__(self, n_members: int, device: int = 0):
+        h = C.c_void_p()
+        check(lib().rolo_batch_create(device, n_members, C.byref(h)), "rolo_batch_create")
+        self._h = h
+        self.members = [RotVGICP(_borrowed=lib().rolo_batch_member(h, i)) for i in range(n_members)]
+
+    def __len__(self):
+        return len(self.members)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            for m in self.members:
+                m.close()
+            lib().rolo_batch_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def register_async(self, guesses, trans_starts, init_guesses, last_t0s, interval_tn=0.1, interval_tn_1=0.1, ct_lambda=0.3):
+        n = len(self.members)
+        g = np.ascontiguousarray(guesses, np.float32).reshape(n, 16) if guesses is not None else None
+        ts = np.ascontiguousarray(trans_starts, np.float64).reshape(n, 3) if trans_starts is not None else None
+        ig = np.ascontiguousarray(init_guesses, np.float64).reshape(n, 3)
+        l0 = np.ascontiguousarray(last_t0s, np.float64).reshape(n, 3)
+        check(lib().rolo_batch_register_async(self._h, _f(g), _d(ts), _d(ig), _d(l0), interval_tn, interval_tn_1, ct_lambda),
+              "rolo_batch_register_async")
+
+    def register_wait(self):
+        n = len(self.members)
+        Tf = np.zeros((n, 4, 4), np.float32); Td = np.zeros((n, 4, 4)); t = np.zeros((n, 3))
+        rs = (Stats * n)(); ts = (Stats * n)()
+        check(lib().rolo_batch_register_wait(self._h, _f(Tf), _d(Td), _d(t), rs, ts), "rolo_batch_register_wait")
+        for i, m in enumerate(self.members):
+            m.final_transformation_d = Td[i]; m.last_stats = rs[i]; m.last_translation_stats = ts[i]
+        return Tf, Td, t
