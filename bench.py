@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="length of the bounded cpu_baseline sample")
     ap.add_argument("--streams", type=int, default=4,
                     help="registration contexts (HIP streams) kept in flight per GPU; a step is then one frame pair per stream")
+    ap.add_argument("--no-pipeline", action="store_true", help="skip the raw-frame -> pose pipeline leg")
     ap.add_argument("--batch", type=int, default=int(os.environ.get("ROLO_BENCH_BATCH", "1")),
                     help="frame pairs per registration call (rolo_batch_*: shared LM launches); 1 = one operator per frame")
     return ap.parse_args()
@@ -61,6 +62,50 @@ def usable_cores() -> int:
     except Exception:
         pass
     return max(1, n)
+
+
+def pipeline_leg(args, torch, device):
+    """Secondary measurement, not `value`: K1 -> K13 per frame on raw OS1-128 frames resident in HBM (feature thinning,
+    POLAR voxels 0.175/0.175/2.0 — what the ROS nodes do), one frame at a time as LidarOdometry must."""
+    from rolo_amd import synth
+    from rolo_amd.frontend import front_params
+    from rolo_amd.odometry import LidarOdometry
+    sensor = args.sensor
+    S = synth.SENSORS[sensor]
+    fp = front_params(n_scan=S[0], horizon_scan=S[1])
+    R = np.eye(3); t = np.zeros(3); frames = []
+    for k in range(5):  # short trajectory, replayed back and forth so consecutive frames stay neighbours
+        fr = synth.make_frame(sensor, R, t, synth.SEED + k)
+        frames.append((torch.from_numpy(np.ascontiguousarray(fr.xyz, np.float32)).cuda(),
+                       torch.from_numpy(np.ascontiguousarray(fr.ring, np.uint16).view(np.int16)).cuda(), fr.xyz.shape[0], fr.xyz.shape[1]))
+        t = t + R @ np.array([0.3, 0.02 * k, 0.0]); R = R @ synth.rpy_to_R(np.deg2rad(0.3), np.deg2rad(-0.2), np.deg2rad(2.0))
+    order = [0, 1, 2, 3, 4, 3, 2, 1]
+    res = {"workload": f"{sensor} raw frames ({frames[0][2]} points) -> projection -> features -> RotVGICP (POLAR voxels) -> pose"}
+    for name, reuse in (("scans_per_s", 0), ("scans_per_s_reuse_covariances", 1)):
+        od = LidarOdometry(device, 0.3)
+        od.setOption(LidarOdometry.REUSE_COVARIANCES, reuse)
+        stamp = 100.0; cnt = None
+
+        def step(i):
+            nonlocal stamp, cnt
+            x, r, n_raw, stride = frames[order[i % len(order)]]
+            stamp += 0.1
+            rc, _, _, _, cnt = od.frame(fp, stamp, x.data_ptr(), r.data_ptr(), n_raw=n_raw, stride=stride)
+            return rc
+        step(0); od.odometryHandler(stamp + 0.05)
+        for i in range(1, 6):
+            step(i)
+        torch.cuda.synchronize()
+        nfr = 40
+        t0 = time.perf_counter()
+        for i in range(6, 6 + nfr):
+            rc = step(i)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        res[name] = nfr / dt
+        res["features_per_frame"] = int(cnt[1] + cnt[2]); res["valid_points"] = int(cnt[0])
+        od.close()
+    return res
 
 
 def main():
@@ -238,6 +283,13 @@ def main():
                                       "(kNN / voxel map replicated on every rank)"}
         except Exception as e:  # pragma: no cover
             out["sharded"] = {"error": repr(e)}
+
+    # ---- drop-in pipeline leg: raw frames -> pose through the fused node cores (rolo_odom_frame), production settings ----
+    if world == 1 and not args.no_pipeline:
+        try:
+            out["pipeline"] = pipeline_leg(args, torch, local_rank)
+        except Exception as e:  # pragma: no cover
+            out["pipeline"] = {"error": repr(e)}
 
     # ---- CPU baseline: the oracle (CPU restatement of the reference, same OpenMP structure) on this box's host cores ----
     if rank == 0 and world == 1 and not args.no_cpu:

@@ -93,6 +93,12 @@ int rolo_set_target_device(rolo_ctx* ctx, const float* d_pts, int n, int stride)
 int rolo_set_source_device(rolo_ctx* ctx, const float* d_pts, int n, int stride);
 /* swapSourceAndTarget :69-77, clearSource :102-105, clearTarget :107-110 */
 int rolo_swap_source_and_target(rolo_ctx* ctx);
+/* The source cloud is the previous target moved by a pure translation (LidarOdometry::stateLinearPropagation zeroes
+ * the rotation, lidarOdometry.cpp:707): its covariances are those of the target up to the float rounding of the moved
+ * points, so take them over instead of searching again. Call after rolo_set_source*, before rolo_set_target*.
+ * Not what the reference does (it recomputes both, :460-466): results differ at the 1e-7 relative level of the
+ * covariances; the drop-in default leaves it off. ROLO_ESTATE unless the target holds covariances and n matches. */
+int rolo_adopt_target_covariances(rolo_ctx* ctx);
 int rolo_clear_source(rolo_ctx* ctx);
 int rolo_clear_target(rolo_ctx* ctx);
 
@@ -221,6 +227,16 @@ int rolo_odom_backend_odometry(rolo_odom* o, double stamp);
  * odomTopic+"_incremental"; rot9 / trans3 = Rotation / Translation of the frame-to-frame step. */
 int rolo_odom_cloud(rolo_odom* o, double stamp, const float* corner, int n_corner, const float* surface, int n_surface,
                     float* pose6, double* rot9, double* trans3);
+/* The three node cores fused, device-resident: raw frame (ImageProjection::cloudHandler input, imageProjection.cpp:151)
+ * -> projection -> features -> cloudHandler of LidarOdometry, without the CloudInfoStamp hops: the feature clouds, the
+ * propagated previous features and both registration inputs never leave HBM; the host sees three counts mid-frame
+ * and the pose at the end. Same results and return codes as rolo_project_frame + rolo_extract_features +
+ * rolo_odom_cloud. pts/ring may be device pointers (pts_on_device != 0). counts3 (optional) = N, n_corner, n_surface. */
+int rolo_odom_frame(rolo_odom* o, const rolo_front_params* P, double stamp, const float* pts, int stride, const uint16_t* ring,
+                    int n_raw, int pts_on_device, float* pose6, double* rot9, double* trans3, int* counts3);
+/* options of the fused path: ROLO_ODOM_REUSE_COVARIANCES (default 0) = rolo_adopt_target_covariances between frames */
+#define ROLO_ODOM_REUSE_COVARIANCES 1
+int rolo_odom_set_option(rolo_odom* o, int option, int value);
 
 #ifdef __cplusplus
 }

@@ -54,6 +54,7 @@ SYMBOLS = {
     "rolo_set_target_device": (C.c_int, [vp, vp, C.c_int, C.c_int]),
     "rolo_set_source_device": (C.c_int, [vp, vp, C.c_int, C.c_int]),
     "rolo_swap_source_and_target": (C.c_int, [vp]),
+    "rolo_adopt_target_covariances": (C.c_int, [vp]),
     "rolo_clear_source": (C.c_int, [vp]),
     "rolo_clear_target": (C.c_int, [vp]),
     "rolo_compute_covariances": (C.c_int, [vp]),
@@ -96,6 +97,8 @@ SYMBOLS = {
     "rolo_odom_destroy": (None, [vp]),
     "rolo_odom_backend_odometry": (C.c_int, [vp, C.c_double]),
     "rolo_odom_cloud": (C.c_int, [vp, C.c_double, fp, C.c_int, fp, C.c_int, fp, dp, dp]),
+    "rolo_odom_frame": (C.c_int, [vp, C.POINTER(FrontParams), C.c_double, vp, C.c_int, vp, C.c_int, C.c_int, fp, dp, dp, C.POINTER(C.c_int)]),
+    "rolo_odom_set_option": (C.c_int, [vp, C.c_int, C.c_int]),
     "rolo_front_default_params": (None, [C.POINTER(FrontParams)]),
     "rolo_project_frame": (C.c_int, [vp, C.POINTER(FrontParams), fp, C.c_int, C.POINTER(C.c_uint16), C.c_int, fp, ip, fp,
                                      ip, ip, fp, C.POINTER(C.c_int)]),
@@ -113,6 +116,14 @@ def lib() -> C.CDLL:
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(f"{LIB_PATH} is missing: run `python -m rolo_amd.build` (needs hipcc); "
                                "rolo_amd has no CPU / PyTorch fallback")
+        # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so (same soname as /opt/rocm's, other
+        # version). Whichever loads first serves both; if this library pulled in /opt/rocm's first, a later
+        # torch.cuda.init() fails with "No HIP GPUs are available". Callers that hand over torch device pointers
+        # need torch anyway, so let it load its runtime first when it is installed.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             f = getattr(L, name)  # AttributeError if a declared symbol is not exported

@@ -486,6 +486,15 @@ int rolo_swap_source_and_target(rolo_ctx* c) {
   c->have_map = false; c->have_corr = false;
   return ROLO_OK;
 }
+int rolo_adopt_target_covariances(rolo_ctx* c) {
+  if (!c) return ROLO_EINVAL;
+  if (!c->tgt.have_cov || c->tgt.n <= 0 || c->src.n != c->tgt.n) { g_err = "no target covariances of matching size to adopt"; return ROLO_ESTATE; }
+  std::swap(c->src.cov, c->tgt.cov);
+  std::swap(c->src_cov_cap, c->tgt_cov_cap);
+  c->src.have_cov = true; c->tgt.have_cov = false;
+  c->have_map = false; c->have_corr = false;
+  return ROLO_OK;
+}
 int rolo_clear_source(rolo_ctx* c) { if (!c) return ROLO_EINVAL; c->src.n = 0; c->src.have_cov = false; c->have_corr = false; return ROLO_OK; }
 int rolo_clear_target(rolo_ctx* c) { if (!c) return ROLO_EINVAL; c->tgt.n = 0; c->tgt.have_cov = false; c->have_map = false; c->have_corr = false; return ROLO_OK; }
 

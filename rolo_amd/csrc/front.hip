@@ -113,9 +113,10 @@ __global__ __launch_bounds__(256) void ring_scatter_kernel(const float* __restri
 }
 
 // ---- K3 ----
-__global__ __launch_bounds__(256) void smoothness_kernel(const float* __restrict__ range, int n, float* __restrict__ curv, int* __restrict__ picked,
-                                                        int* __restrict__ label) {
+__global__ __launch_bounds__(256) void smoothness_kernel(const float* __restrict__ range, const int* __restrict__ n_ptr, float* __restrict__ curv,
+                                                        int* __restrict__ picked, int* __restrict__ label) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = *n_ptr;  // N of this frame stays on the device: no host round trip between projection and features
   if (i >= n) return;
   float c = 0.f;
   if (i >= 5 && i < n - 5) {  // featureExtraction.cpp:91-99, float sum in the written order
@@ -126,8 +127,10 @@ __global__ __launch_bounds__(256) void smoothness_kernel(const float* __restrict
   curv[i] = c; picked[i] = 0; label[i] = 0;
 }
 
-__global__ __launch_bounds__(256) void occlusion_kernel(const float* __restrict__ range, const int* __restrict__ col, int n, int* __restrict__ picked) {
+__global__ __launch_bounds__(256) void occlusion_kernel(const float* __restrict__ range, const int* __restrict__ col, const int* __restrict__ n_ptr,
+                                                       int* __restrict__ picked) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = *n_ptr;
   if (i < 5 || i >= n - 6) return;  // featureExtraction.cpp:116
   const float depth1 = range[i], depth2 = range[i + 1];
   const int columnDiff = abs(col[i + 1] - col[i]);
@@ -160,7 +163,7 @@ ROLO_DEV void bitonic_sort_lds(unsigned long long* key, int n_pow2) {
 struct FeatArgs {
   const float4* extracted; const int* col; const float* curv; int* picked; int* label;  // global, guard-offset pointers
   const int* start_ring; const int* end_ring;
-  int n; int n_scan; float edge_threshold, surf_threshold, leaf;
+  const int* n_ptr; int n_scan; float edge_threshold, surf_threshold, leaf;
   float4* corner_stage; int* corner_cnt;  // [n_scan][6][20], [n_scan][6]
   float4* surf_stage; int* surf_cnt;      // [n_scan][FRONT_MAX_H], [n_scan]
 };
@@ -181,7 +184,7 @@ __global__ __launch_bounds__(256) void extract_kernel(FeatArgs A) {
 
   const int ring = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
   const int s = A.start_ring[ring], e = A.end_ring[ring];
-  const int n = A.n;
+  const int n = *A.n_ptr;
   // ring window in LDS: global indices [w0, w0 + wlen)
   const int w0 = s - 16;
   int wlen = (e - s) + 32 + 1;
@@ -410,6 +413,13 @@ __global__ void fill_int_kernel(int* p, int n, int v) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = v;
 }
 
+// corner ++ surface (x, y, z, intensity) = *featureLast (lidarOdometry.cpp:521-523), counts read on the device
+__global__ __launch_bounds__(256) void feature_concat_kernel(const float4* __restrict__ corner, const float4* __restrict__ surf,
+                                                            const int* __restrict__ counters, float4* __restrict__ out) {
+  const int nc = counters[1], ns = counters[2];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nc + ns; i += gridDim.x * blockDim.x) out[i] = i < nc ? corner[i] : surf[i - nc];
+}
+
 struct Front {
   int device = 0;
   size_t cap_raw = 0, cap_pix = 0, cap_scan = 0;
@@ -445,6 +455,119 @@ hipStream_t ctx_stream(rolo_ctx* c);
 int ctx_device(rolo_ctx* c);
 void ctx_set_error(const char* msg);
 
+#define FCHK(x) do { hipError_t _e = (x); if (_e != hipSuccess) { ctx_set_error((std::string(#x) + ": " + hipGetErrorString(_e)).c_str()); return ROLO_EHIP; } } while (0)
+
+namespace {
+
+// device buffers for frames of up to n_raw points / n_scan x horizon_scan pixels
+int front_prepare(rolo_ctx* c, const rolo_front_params* P, int n_raw, int stride, bool stage_raw, Front** out) {
+  if (P->n_scan <= 0 || P->horizon_scan <= 0 || P->downsample_rate <= 0) { ctx_set_error("bad front params"); return ROLO_EINVAL; }
+  if (P->horizon_scan > FRONT_MAX_H) { ctx_set_error("Horizon_SCAN above the limit of this build (2048)"); return ROLO_EUNSUPPORTED; }
+  FCHK(hipSetDevice(ctx_device(c)));
+  void** slot = ctx_front_slot(c);
+  if (!*slot) *slot = new Front();
+  Front* f = static_cast<Front*>(*slot);
+  const int NS = P->n_scan, H = P->horizon_scan;
+  const size_t npix = (size_t)NS * H;
+  bool ok = true;
+  if (stage_raw && ((size_t)n_raw * stride > f->cap_raw || !f->raw)) {
+    ok = ok && dev_alloc(f->raw, (size_t)n_raw * stride) && dev_alloc(f->ring, (size_t)n_raw);
+    f->cap_raw = (size_t)n_raw * stride;
+  }
+  if (npix > f->cap_pix || !f->owner) {
+    const size_t np = npix + 2 * FRONT_GUARD;
+    ok = ok && dev_alloc(f->owner, npix) && dev_alloc(f->local_idx, npix) && dev_alloc(f->extracted, np) && dev_alloc(f->col, np) && dev_alloc(f->range, np) &&
+         dev_alloc(f->range_mat, npix) && dev_alloc(f->curv, np) && dev_alloc(f->picked, np) && dev_alloc(f->label, np) && dev_alloc(f->corner_out, npix) &&
+         dev_alloc(f->surf_out, npix);
+    f->cap_pix = npix;
+  }
+  if ((size_t)NS > f->cap_scan || !f->ring_count) {
+    ok = ok && dev_alloc(f->ring_count, NS) && dev_alloc(f->start_ring, NS) && dev_alloc(f->end_ring, NS) && dev_alloc(f->counters, 8) &&
+         dev_alloc(f->corner_stage, (size_t)NS * 6 * 20) && dev_alloc(f->corner_cnt, (size_t)NS * 6) && dev_alloc(f->surf_stage, (size_t)NS * FRONT_MAX_H) &&
+         dev_alloc(f->surf_cnt, NS);
+    f->cap_scan = NS;
+  }
+  if (!ok) { ctx_set_error("hipMalloc failed (front end)"); return ROLO_EHIP; }
+  f->n_scan = NS; f->H = H; f->projected = false;
+  *out = f;
+  return ROLO_OK;
+}
+
+// K1 + K2 on raw points that are on the device; N lands in counters[0]. No host synchronisation.
+int front_project_enqueue(Front* f, const rolo_front_params* P, const float* d_pts, int stride, const unsigned short* d_ring, int n_raw, bool want_range_mat,
+                          hipStream_t s) {
+  const int NS = f->n_scan, H = f->H;
+  const size_t npix = (size_t)NS * H;
+  fill_int_kernel<<<256, 256, 0, s>>>(f->owner, (int)npix, INT_MAX);
+  // guard cells of the per-point arrays are zero (SURVEY Q6)
+  FCHK(hipMemsetAsync(f->col, 0, sizeof(int) * (npix + 2 * FRONT_GUARD), s));
+  FCHK(hipMemsetAsync(f->range, 0, sizeof(float) * (npix + 2 * FRONT_GUARD), s));
+  if (n_raw > 0) project_kernel<<<(n_raw + 255) / 256, 256, 0, s>>>(d_pts, stride, d_ring, n_raw, *P, f->owner);
+  ring_scan_kernel<<<NS, 256, 0, s>>>(f->owner, H, f->local_idx, f->ring_count);
+  ring_scatter_kernel<<<NS, 256, 0, s>>>(d_pts, stride, d_ring, f->owner, f->local_idx, f->ring_count, NS, H, f->extracted + FRONT_GUARD,
+                                        f->col + FRONT_GUARD, f->range + FRONT_GUARD, f->start_ring, f->end_ring, want_range_mat ? f->range_mat : nullptr,
+                                        f->counters);
+  FCHK(hipGetLastError());
+  return ROLO_OK;
+}
+
+// K3 + K4 on what front_project_enqueue left on the device; n_corner / n_surface land in counters[1] / [2]
+int front_extract_enqueue(Front* f, const rolo_front_params* P, hipStream_t s) {
+  const int NS = f->n_scan;
+  const size_t npix = f->cap_pix;
+  // guards of curvature / picked / label are zero; live entries are written by the smoothness kernel
+  const size_t np = npix + 2 * FRONT_GUARD;
+  FCHK(hipMemsetAsync(f->curv, 0, sizeof(float) * np, s));
+  FCHK(hipMemsetAsync(f->picked, 0, sizeof(int) * np, s));
+  FCHK(hipMemsetAsync(f->label, 0, sizeof(int) * np, s));
+  const int grid = (int)(((size_t)NS * f->H + 255) / 256);  // N <= n_scan * Horizon_SCAN is only known on the device
+  smoothness_kernel<<<grid, 256, 0, s>>>(f->range + FRONT_GUARD, f->counters, f->curv + FRONT_GUARD, f->picked + FRONT_GUARD, f->label + FRONT_GUARD);
+  occlusion_kernel<<<grid, 256, 0, s>>>(f->range + FRONT_GUARD, f->col + FRONT_GUARD, f->counters, f->picked + FRONT_GUARD);
+  FeatArgs A;
+  A.extracted = f->extracted + FRONT_GUARD; A.col = f->col + FRONT_GUARD; A.curv = f->curv + FRONT_GUARD; A.picked = f->picked + FRONT_GUARD;
+  A.label = f->label + FRONT_GUARD; A.start_ring = f->start_ring; A.end_ring = f->end_ring; A.n_ptr = f->counters; A.n_scan = NS;
+  A.edge_threshold = P->edge_threshold; A.surf_threshold = P->surf_threshold; A.leaf = P->odometry_surf_leaf_size;
+  A.corner_stage = f->corner_stage; A.corner_cnt = f->corner_cnt; A.surf_stage = f->surf_stage; A.surf_cnt = f->surf_cnt;
+  const size_t WIN = FRONT_MAX_H + 32;
+  const size_t lds = sizeof(unsigned long long) * SORT_CAP + sizeof(int) * WIN * 4 + sizeof(int) * (FRONT_MAX_H + 16);
+  static bool attr_set = false;
+  if (!attr_set) { FCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(extract_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set = true; }
+  extract_kernel<<<NS, 256, lds, s>>>(A);
+  concat_kernel<<<NS * 6, 256, 0, s>>>(f->corner_stage, f->corner_cnt, NS * 6, 20, f->corner_out, f->counters + 1);
+  concat_kernel<<<NS, 256, 0, s>>>(f->surf_stage, f->surf_cnt, NS, FRONT_MAX_H, f->surf_out, f->counters + 2);
+  FCHK(hipGetLastError());
+  return ROLO_OK;
+}
+
+}  // namespace
+
+// Fused K1-K4 for the device-resident pipeline (rolo_odom_frame): raw frame -> *featureLast = corner ++ surface in
+// d_feat (capacity front_feature_capacity floats4), one host synchronisation for the three counts.
+size_t front_feature_capacity(const rolo_front_params* P) { return (size_t)P->n_scan * P->horizon_scan + (size_t)P->n_scan * 6 * 20; }
+
+int front_frame_features(rolo_ctx* c, const rolo_front_params* P, const float* pts, int stride, const uint16_t* ring, int n_raw, bool on_device,
+                         float4* d_feat, int* counts3) {
+  Front* f = nullptr;
+  int rc = front_prepare(c, P, n_raw, stride, !on_device, &f);
+  if (rc) return rc;
+  hipStream_t s = ctx_stream(c);
+  const float* d_pts = pts; const unsigned short* d_ring = ring;
+  if (!on_device) {
+    FCHK(hipMemcpyAsync(f->raw, pts, sizeof(float) * (size_t)n_raw * stride, hipMemcpyHostToDevice, s));
+    FCHK(hipMemcpyAsync(f->ring, ring, sizeof(uint16_t) * (size_t)n_raw, hipMemcpyHostToDevice, s));
+    d_pts = f->raw; d_ring = f->ring;
+  }
+  if ((rc = front_project_enqueue(f, P, d_pts, stride, d_ring, n_raw, false, s))) return rc;
+  if ((rc = front_extract_enqueue(f, P, s))) return rc;
+  feature_concat_kernel<<<256, 256, 0, s>>>(f->corner_out, f->surf_out, f->counters, d_feat);
+  FCHK(hipGetLastError());
+  FCHK(hipMemcpyAsync(counts3, f->counters, sizeof(int) * 3, hipMemcpyDeviceToHost, s));
+  FCHK(hipStreamSynchronize(s));
+  f->n_valid = counts3[0];
+  f->projected = true;
+  return ROLO_OK;
+}
+
 }  // namespace rolo
 
 using namespace rolo;
@@ -462,49 +585,19 @@ void rolo_front_default_params(rolo_front_params* p) {  // config/params.yaml:20
   p->edge_threshold = 0.8f; p->surf_threshold = 0.1f; p->odometry_surf_leaf_size = 0.4f;
 }
 
-#define FCHK(x) do { hipError_t _e = (x); if (_e != hipSuccess) { ctx_set_error((std::string(#x) + ": " + hipGetErrorString(_e)).c_str()); return ROLO_EHIP; } } while (0)
-
 int rolo_project_frame(rolo_ctx* c, const rolo_front_params* P, const float* pts, int stride, const uint16_t* ring, int n_raw,
                        float* extracted, int32_t* point_col_ind, float* point_range, int32_t* start_ring, int32_t* end_ring,
                        float* range_mat, int* n_valid) {
   if (!c || !P || !pts || !ring || stride < 3 || n_raw < 0 || !n_valid) return ROLO_EINVAL;
-  if (P->n_scan <= 0 || P->horizon_scan <= 0 || P->downsample_rate <= 0) { ctx_set_error("bad front params"); return ROLO_EINVAL; }
-  if (P->horizon_scan > FRONT_MAX_H) { ctx_set_error("Horizon_SCAN above the limit of this build (2048)"); return ROLO_EUNSUPPORTED; }
-  FCHK(hipSetDevice(ctx_device(c)));
+  Front* f = nullptr;
+  int rc = front_prepare(c, P, n_raw, stride, true, &f);
+  if (rc) return rc;
   hipStream_t s = ctx_stream(c);
-  void** slot = ctx_front_slot(c);
-  if (!*slot) *slot = new Front();
-  Front* f = static_cast<Front*>(*slot);
-  const int NS = P->n_scan, H = P->horizon_scan;
-  const size_t npix = (size_t)NS * H;
-  bool ok = true;
-  if ((size_t)n_raw * stride > f->cap_raw || !f->raw) { ok = ok && dev_alloc(f->raw, (size_t)n_raw * stride) && dev_alloc(f->ring, (size_t)n_raw); f->cap_raw = (size_t)n_raw * stride; }
-  if (npix > f->cap_pix || !f->owner) {
-    const size_t np = npix + 2 * FRONT_GUARD;
-    ok = ok && dev_alloc(f->owner, npix) && dev_alloc(f->local_idx, npix) && dev_alloc(f->extracted, np) && dev_alloc(f->col, np) && dev_alloc(f->range, np) &&
-         dev_alloc(f->range_mat, npix) && dev_alloc(f->curv, np) && dev_alloc(f->picked, np) && dev_alloc(f->label, np) && dev_alloc(f->corner_out, npix) &&
-         dev_alloc(f->surf_out, npix);
-    f->cap_pix = npix;
-  }
-  if ((size_t)NS > f->cap_scan || !f->ring_count) {
-    ok = ok && dev_alloc(f->ring_count, NS) && dev_alloc(f->start_ring, NS) && dev_alloc(f->end_ring, NS) && dev_alloc(f->counters, 8) &&
-         dev_alloc(f->corner_stage, (size_t)NS * 6 * 20) && dev_alloc(f->corner_cnt, (size_t)NS * 6) && dev_alloc(f->surf_stage, (size_t)NS * FRONT_MAX_H) &&
-         dev_alloc(f->surf_cnt, NS);
-    f->cap_scan = NS;
-  }
-  if (!ok) { ctx_set_error("hipMalloc failed (front end)"); return ROLO_EHIP; }
-  f->n_scan = NS; f->H = H; f->projected = false;
+  const int NS = P->n_scan;
+  const size_t npix = (size_t)NS * P->horizon_scan;
   FCHK(hipMemcpyAsync(f->raw, pts, sizeof(float) * (size_t)n_raw * stride, hipMemcpyHostToDevice, s));
   FCHK(hipMemcpyAsync(f->ring, ring, sizeof(uint16_t) * (size_t)n_raw, hipMemcpyHostToDevice, s));
-  fill_int_kernel<<<256, 256, 0, s>>>(f->owner, (int)npix, INT_MAX);
-  // guard cells of the per-point arrays are zero (SURVEY Q6)
-  FCHK(hipMemsetAsync(f->col, 0, sizeof(int) * (npix + 2 * FRONT_GUARD), s));
-  FCHK(hipMemsetAsync(f->range, 0, sizeof(float) * (npix + 2 * FRONT_GUARD), s));
-  if (n_raw > 0) project_kernel<<<(n_raw + 255) / 256, 256, 0, s>>>(f->raw, stride, f->ring, n_raw, *P, f->owner);
-  ring_scan_kernel<<<NS, 256, 0, s>>>(f->owner, H, f->local_idx, f->ring_count);
-  ring_scatter_kernel<<<NS, 256, 0, s>>>(f->raw, stride, f->ring, f->owner, f->local_idx, f->ring_count, NS, H, f->extracted + FRONT_GUARD,
-                                        f->col + FRONT_GUARD, f->range + FRONT_GUARD, f->start_ring, f->end_ring, f->range_mat, f->counters);
-  FCHK(hipGetLastError());
+  if ((rc = front_project_enqueue(f, P, f->raw, stride, f->ring, n_raw, true, s))) return rc;
   int nv = 0;
   FCHK(hipMemcpyAsync(&nv, f->counters, sizeof(int), hipMemcpyDeviceToHost, s));
   FCHK(hipStreamSynchronize(s));
@@ -529,29 +622,9 @@ int rolo_extract_features(rolo_ctx* c, const rolo_front_params* P, float* corner
   if (!f || !f->projected) { ctx_set_error("rolo_extract_features needs a preceding rolo_project_frame"); return ROLO_ESTATE; }
   FCHK(hipSetDevice(ctx_device(c)));
   hipStream_t s = ctx_stream(c);
-  const int n = f->n_valid, NS = f->n_scan;
-  // guards of curvature / picked / label are zero; live entries are written by the smoothness kernel
-  const size_t np = (size_t)f->cap_pix + 2 * FRONT_GUARD;
-  FCHK(hipMemsetAsync(f->curv, 0, sizeof(float) * np, s));
-  FCHK(hipMemsetAsync(f->picked, 0, sizeof(int) * np, s));
-  FCHK(hipMemsetAsync(f->label, 0, sizeof(int) * np, s));
-  if (n > 0) {
-    smoothness_kernel<<<(n + 255) / 256, 256, 0, s>>>(f->range + FRONT_GUARD, n, f->curv + FRONT_GUARD, f->picked + FRONT_GUARD, f->label + FRONT_GUARD);
-    occlusion_kernel<<<(n + 255) / 256, 256, 0, s>>>(f->range + FRONT_GUARD, f->col + FRONT_GUARD, n, f->picked + FRONT_GUARD);
-  }
-  FeatArgs A;
-  A.extracted = f->extracted + FRONT_GUARD; A.col = f->col + FRONT_GUARD; A.curv = f->curv + FRONT_GUARD; A.picked = f->picked + FRONT_GUARD;
-  A.label = f->label + FRONT_GUARD; A.start_ring = f->start_ring; A.end_ring = f->end_ring; A.n = n; A.n_scan = NS;
-  A.edge_threshold = P->edge_threshold; A.surf_threshold = P->surf_threshold; A.leaf = P->odometry_surf_leaf_size;
-  A.corner_stage = f->corner_stage; A.corner_cnt = f->corner_cnt; A.surf_stage = f->surf_stage; A.surf_cnt = f->surf_cnt;
-  const size_t WIN = FRONT_MAX_H + 32;
-  const size_t lds = sizeof(unsigned long long) * SORT_CAP + sizeof(int) * WIN * 4 + sizeof(int) * (FRONT_MAX_H + 16);
-  static bool attr_set = false;
-  if (!attr_set) { FCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(extract_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set = true; }
-  extract_kernel<<<NS, 256, lds, s>>>(A);
-  concat_kernel<<<NS * 6, 256, 0, s>>>(f->corner_stage, f->corner_cnt, NS * 6, 20, f->corner_out, f->counters + 1);
-  concat_kernel<<<NS, 256, 0, s>>>(f->surf_stage, f->surf_cnt, NS, FRONT_MAX_H, f->surf_out, f->counters + 2);
-  FCHK(hipGetLastError());
+  const int n = f->n_valid;
+  int rc = front_extract_enqueue(f, P, s);
+  if (rc) return rc;
   int cnts[3] = {0, 0, 0};
   FCHK(hipMemcpyAsync(cnts, f->counters, sizeof(int) * 3, hipMemcpyDeviceToHost, s));
   FCHK(hipStreamSynchronize(s));

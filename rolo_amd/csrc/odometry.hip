@@ -72,7 +72,12 @@ struct rolo_odom {
   Aff transformation_interpolated = aff_identity();
   double Rotation[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, Translation[3] = {0, 0, 0}, TranslationOld[3] = {0, 0, 0};
   float LaserOdomPose[6] = {0, 0, 0, 0, 0, 0};
-  std::vector<float> featureOld;           // n x 4
+  std::vector<float> featureOld;           // n x 4 (rolo_odom_cloud: host-side hand-over)
+  // rolo_odom_frame: device-resident hand-over
+  float4 *d_featOld = nullptr, *d_featNew = nullptr, *d_prop = nullptr;
+  size_t d_cap = 0;
+  int nOld = 0;
+  bool reuse_cov = false, cov_chain = false;  // cov_chain: the context's target covariances belong to d_featOld
   rolo_stats last_rot{}, last_trans{};
 };
 
@@ -98,7 +103,19 @@ int rolo_odom_create(rolo_ctx* ctx, float ct_lambda, rolo_odom** out) {
   *out = o;
   return ROLO_OK;
 }
-void rolo_odom_destroy(rolo_odom* o) { delete o; }
+void rolo_odom_destroy(rolo_odom* o) {
+  if (!o) return;
+  if (o->d_featOld) (void)hipFree(o->d_featOld);
+  if (o->d_featNew) (void)hipFree(o->d_featNew);
+  if (o->d_prop) (void)hipFree(o->d_prop);
+  delete o;
+}
+
+int rolo_odom_set_option(rolo_odom* o, int option, int value) {
+  if (!o) return ROLO_EINVAL;
+  if (option == ROLO_ODOM_REUSE_COVARIANCES) { o->reuse_cov = value != 0; o->cov_chain = false; return ROLO_OK; }
+  return ROLO_EINVAL;
+}
 
 int rolo_odom_backend_odometry(rolo_odom* o, double stamp) {  // odometryHandler :440-446
   if (!o) return ROLO_EINVAL;
@@ -154,6 +171,74 @@ int rolo_odom_cloud(rolo_odom* o, double stamp, const float* corner, int n_corne
     o->featureOld.swap(featureLast);
     ret = 2;
   }
+  if (pose6) memcpy(pose6, o->LaserOdomPose, sizeof(float) * 6);
+  if (rot9) memcpy(rot9, o->Rotation, sizeof(double) * 9);
+  if (trans3) memcpy(trans3, o->Translation, sizeof(double) * 3);
+  return ret;
+}
+
+int rolo_odom_frame(rolo_odom* o, const rolo_front_params* P, double stamp, const float* pts, int stride, const uint16_t* ring, int n_raw,
+                    int pts_on_device, float* pose6, double* rot9, double* trans3, int* counts3) {
+  if (!o || !P || !pts || !ring || stride < 3 || n_raw < 0) return ROLO_EINVAL;
+  const size_t cap = rolo::front_feature_capacity(P);
+  if (cap > o->d_cap) {
+    if (o->nOld > 0) { rolo::ctx_set_error("front parameters grew between frames"); return ROLO_ESTATE; }
+    float4** bufs[3] = {&o->d_featOld, &o->d_featNew, &o->d_prop};
+    for (float4** b : bufs) {
+      if (*b) { (void)hipFree(*b); *b = nullptr; }
+      if (hipMalloc((void**)b, sizeof(float4) * cap) != hipSuccess) { rolo::ctx_set_error("hipMalloc failed (odometry feature buffers)"); return ROLO_EHIP; }
+    }
+    o->d_cap = cap;
+  }
+  int counts[3] = {0, 0, 0};
+  int rc = rolo::front_frame_features(o->ctx, P, pts, stride, ring, n_raw, pts_on_device != 0, o->d_featNew, counts);
+  if (rc) return rc;
+  if (counts3) memcpy(counts3, counts, sizeof(counts));
+  const int nNew = counts[1] + counts[2];
+  o->cloudTimeCur = stamp;
+  int ret;
+  if (o->first) {
+    o->first = false;
+    ret = 0;
+  } else if (o->lastOdomTime == -1.0) {
+    update_transform(o);
+    ret = 1;
+  } else {
+    const double latestInterval = o->cloudTimeCur - o->cloudTimeLast;
+    const double ratio = latestInterval / o->lastMappingInterval;  // stateLinearPropagation :700-712
+    float v[6];
+    get_translation_and_euler(o->lidarMappingAffine, v);
+    v[3] = v[4] = v[5] = 0;
+    for (int i = 0; i < 6; i++) v[i] *= (float)ratio;
+    o->transformation_interpolated = get_transformation(v[0], v[1], v[2], v[3], v[4], v[5]);
+    o->cloudTimeLast = o->cloudTimeCur;
+    o->lastMappingInterval = latestInterval;
+    // scanRegeistration :448-501 on device-resident clouds
+    hipStream_t s = (hipStream_t)rolo_ctx_stream(o->ctx);
+    if (o->nOld > 0 && rolo::launch_transform_cloud(reinterpret_cast<const float*>(o->d_featOld), reinterpret_cast<float*>(o->d_prop), o->nOld, 4, nullptr,
+                                                    o->transformation_interpolated.m, s) != hipSuccess) {
+      rolo::ctx_set_error("transform kernel launch failed"); return ROLO_EHIP;
+    }
+    if ((rc = rolo_set_source_device(o->ctx, reinterpret_cast<const float*>(o->d_prop), o->nOld, 4))) return rc;
+    if (o->reuse_cov && o->cov_chain) { if ((rc = rolo_adopt_target_covariances(o->ctx))) return rc; }
+    if ((rc = rolo_set_target_device(o->ctx, reinterpret_cast<const float*>(o->d_featNew), nNew, 4))) return rc;
+    double guess_t[3];
+    for (int i = 0; i < 3; i++) guess_t[i] = (double)o->transformation_interpolated.m[i * 4 + 3];
+    const double zero3[3] = {0, 0, 0};
+    o->cov_chain = false;
+    if ((rc = rolo_register_async(o->ctx, nullptr, zero3, guess_t, o->TranslationOld, 0.1, 0.1, o->ct_lambda))) return rc;
+    float Tf[16]; double reg_t[3];
+    if ((rc = rolo_register_wait(o->ctx, Tf, nullptr, reg_t, &o->last_rot, &o->last_trans))) return rc;
+    o->cov_chain = true;  // the context now holds the covariances of d_featNew as its target's
+    Aff step; memcpy(step.m, Tf, sizeof(Tf));
+    o->transformation_interpolated = aff_mul(o->transformation_interpolated, step);  // :472
+    for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) o->Rotation[i * 3 + j] = (double)o->transformation_interpolated.m[i * 4 + j]; o->Translation[i] = (double)o->transformation_interpolated.m[i * 4 + 3]; }
+    for (int i = 0; i < 3; i++) o->Translation[i] += reg_t[i];  // :500
+    update_transform(o);
+    ret = 2;
+  }
+  std::swap(o->d_featOld, o->d_featNew);
+  o->nOld = nNew;
   if (pose6) memcpy(pose6, o->LaserOdomPose, sizeof(float) * 6);
   if (rot9) memcpy(rot9, o->Rotation, sizeof(double) * 9);
   if (trans3) memcpy(trans3, o->Translation, sizeof(double) * 3);

@@ -31,6 +31,26 @@ class LidarOdometry:
         except Exception:
             pass
 
+    REUSE_COVARIANCES = 1
+
+    def setOption(self, option: int, value: int):
+        check(lib().rolo_odom_set_option(self._h, option, value), "rolo_odom_set_option")
+
+    def frame(self, front_params, stamp: float, xyz, ring, n_raw=None, stride=None):
+        """Fused device-resident path (rolo_odom_frame): raw frame -> pose. `xyz` / `ring` are numpy arrays (host) or
+        integer device pointers (then pass n_raw and stride). Returns (status, pose6, Rotation, Translation, (N, n_corner, n_surface))."""
+        pose = np.zeros(6, np.float32); R = np.zeros((3, 3)); t = np.zeros(3); counts = (C.c_int * 3)()
+        fp, dp = C.POINTER(C.c_float), C.POINTER(C.c_double)
+        if isinstance(xyz, int):
+            pp, rp, on_dev = C.c_void_p(xyz), C.c_void_p(ring), 1
+        else:
+            xyz = np.ascontiguousarray(xyz, np.float32); ring = np.ascontiguousarray(ring, np.uint16)
+            n_raw, stride = xyz.shape[0], xyz.shape[1]
+            pp, rp, on_dev = C.c_void_p(xyz.ctypes.data), C.c_void_p(ring.ctypes.data), 0
+        rc = check(lib().rolo_odom_frame(self._h, C.byref(front_params), stamp, pp, stride, rp, n_raw, on_dev, pose.ctypes.data_as(fp),
+                                         R.ctypes.data_as(dp), t.ctypes.data_as(dp), counts), "rolo_odom_frame")
+        return rc, pose, R, t, tuple(counts)
+
     def odometryHandler(self, stamp: float):
         check(lib().rolo_odom_backend_odometry(self._h, stamp), "rolo_odom_backend_odometry")
 

@@ -178,6 +178,11 @@ class RotVGICP:
         self._ns, self._nt = self._nt, self._ns
 
     # ---- covariances ----
+    def adoptTargetCovariances(self):
+        """The source is the previous target moved by a pure translation: take over its covariances (not a reference
+        call; see rolo_adopt_target_covariances). After setInputSource*, before setInputTarget*."""
+        check(lib().rolo_adopt_target_covariances(self._h), "rolo_adopt_target_covariances")
+
     def computeCovariances(self):
         check(lib().rolo_compute_covariances(self._h), "rolo_compute_covariances")
 

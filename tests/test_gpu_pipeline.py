@@ -54,3 +54,44 @@ def test_pipeline_matches_oracle(sensor, cfg):
     Rk, tk = poses[-2]; Rn, tn = poses[-1]
     true_step = -(Rn.T @ (tn - tk))
     assert np.linalg.norm(t_g - true_step) < 0.1
+
+
+@pytest.mark.parametrize("sensor,cfg", [("vlp16", dict(n_scan=16, horizon_scan=1800)), ("os1-64", dict(n_scan=64, horizon_scan=1024))])
+def test_fused_frame_equals_staged_nodes(sensor, cfg):
+    """rolo_odom_frame (raw frame -> pose with device-resident hand-over) gives exactly what the three staged node cores
+    give — from host buffers and from device pointers — and with ROLO_ODOM_REUSE_COVARIANCES the poses stay inside the
+    north_star tolerance of the oracle chain (covariances of the propagated source taken over from the last target)."""
+    import torch
+    poses = trajectory(6)
+    fo = pyorc.front_params(**cfg)
+    fg = front_params(**cfg)
+    oo = pyorc.Odom(pyorc.default_params(polar_resolution=(0.175, 0.175, 2.0)), 0.3)
+    staged = LidarOdometry(0, 0.3); fe = FrontEnd(staged.reg, fg)
+    fused_h = LidarOdometry(0, 0.3)
+    fused_d = LidarOdometry(0, 0.3)
+    fused_r = LidarOdometry(0, 0.3); fused_r.setOption(LidarOdometry.REUSE_COVARIANCES, 1)
+    for k, (R, t) in enumerate(poses):
+        fr = synth.make_frame(sensor, R, t, synth.SEED + k)
+        stamp = 100.0 + 0.1 * k
+        if k == 2:
+            for o in (staged, fused_h, fused_d, fused_r):
+                o.odometryHandler(stamp - 0.05)
+            oo.backend_odometry(stamp - 0.05)
+        eo = pyorc.extract_features(fo, pyorc.project(fo, fr.xyz, fr.ring))
+        rco, pose_o, R_o, t_o = oo.cloud(stamp, eo["corner"], eo["surface"])
+        pg = fe.project(fr.xyz, fr.ring); eg = fe.extract(pg["n"])
+        rcs, pose_s, R_s, t_s = staged.cloudHandler(stamp, eg["corner"], eg["surface"])
+        rch, pose_h, R_h, t_h, cnt = fused_h.frame(fg, stamp, fr.xyz, fr.ring)
+        assert cnt == (pg["n"], eg["corner"].shape[0], eg["surface"].shape[0])
+        d_xyz = torch.from_numpy(np.ascontiguousarray(fr.xyz, np.float32)).cuda()
+        d_ring = torch.from_numpy(np.ascontiguousarray(fr.ring, np.uint16).view(np.int16)).cuda()
+        torch.cuda.synchronize()
+        rcd, pose_d, R_d, t_d, cnt_d = fused_d.frame(fg, stamp, d_xyz.data_ptr(), d_ring.data_ptr(), n_raw=fr.xyz.shape[0], stride=fr.xyz.shape[1])
+        assert rcs == rch == rcd == rco and cnt_d == cnt
+        for (p_, R_, t_) in ((pose_h, R_h, t_h), (pose_d, R_d, t_d)):
+            # same kernels on the same bytes; only the fp64 atomics of the voxel sums may reorder
+            assert np.abs(p_ - pose_s).max() < 1e-6 and np.abs(R_ - R_s).max() < 1e-9 and np.abs(t_ - t_s).max() < 1e-9
+        rcr, pose_r, R_r, t_r, _ = fused_r.frame(fg, stamp, fr.xyz, fr.ring)
+        assert rcr == rco
+        assert np.abs(pose_r[:3] - pose_o[:3]).max() <= 1e-4 and np.abs(pose_r[3:] - pose_o[3:]).max() <= 1e-5
+        assert np.abs(R_r - R_o).max() <= 1e-5 and np.abs(t_r - t_o).max() <= 1e-4
