@@ -29,7 +29,9 @@ namespace rolo {
 
 constexpr int FRONT_GUARD = 8;       // guard cells in front of / behind the per-point arrays (reference reads index -1.. )
 constexpr int FRONT_MAX_H = 2048;    // Horizon_SCAN limit of this build (shipped configs: 1024, 1800, 2048)
-constexpr int SORT_CAP = 2048;       // LDS bitonic capacity (elements)
+constexpr int SORT_CAP = 3072;       // LDS bitonic capacity (elements): 6 sector segments of <= 512, or one ring's surface scan (<= 2048)
+constexpr int SECTOR_CAP = 520;      // positions of one sector (<= Horizon_SCAN / 6 + 2)
+constexpr int ST_OUT = 0, ST_UNDECIDED = 1, ST_PICKED = 2;
 
 namespace {
 
@@ -170,7 +172,7 @@ struct FeatArgs {
 
 __global__ __launch_bounds__(256) void extract_kernel(FeatArgs A) {
   extern __shared__ unsigned char smem_raw[];
-  // layout: keys[SORT_CAP] u64 | l_picked | l_col | l_label | l_curv (ring window) | list[FRONT_MAX_H+16] | misc
+  // layout: keys[SORT_CAP] u64 | l_picked | l_col | l_label | l_curv (ring window) | list[FRONT_MAX_H+16] | l_brk | l_rank | l_stat (window) | l_sel
   unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem_raw);
   const int WIN = FRONT_MAX_H + 2 * 16;
   int* l_picked = reinterpret_cast<int*>(keys + SORT_CAP);
@@ -178,6 +180,10 @@ __global__ __launch_bounds__(256) void extract_kernel(FeatArgs A) {
   int* l_label = l_col + WIN;
   float* l_curv = reinterpret_cast<float*>(l_label + WIN);
   int* list = reinterpret_cast<int*>(l_curv + WIN);
+  int* l_brk = list + (FRONT_MAX_H + 16);
+  int* l_rank = l_brk + WIN;
+  int* l_stat = l_rank + WIN;
+  int* l_sel = l_stat + WIN;   // [SECTOR_CAP]
   __shared__ int s_cnt, s_heads;
   __shared__ float s_red[2][3][4];
   __shared__ int s_wsum[4];
@@ -199,36 +205,167 @@ __global__ __launch_bounds__(256) void extract_kernel(FeatArgs A) {
     l_curv[i] = in ? A.curv[gi] : 0.f;
   }
   if (t == 0) s_cnt = 0;
+  // brk[i]: the suppression marks of a pick stop between window cells i and i + 1 (|columnDiff| > 10, :199-210)
+  for (int i = t; i < wlen; i += 256) { l_rank[i] = INT_MAX; l_stat[i] = ST_OUT; }
   __syncthreads();
+  for (int i = t; i + 1 < wlen; i += 256) l_brk[i] = abs(l_col[i + 1] - l_col[i]) > 10 ? 1 : 0;
+
+  // ---- all six sector sorts at once (they depend on the curvatures only): a segmented bitonic sort, 6 x seg keys ----
+  int seg = 2;
+  {
+    int maxlen = 0;
+    for (int j = 0; j < 6; j++) {
+      const int sp = (s * (6 - j) + e * j) / 6, ep = (s * (5 - j) + e * (j + 1)) / 6 - 1;
+      maxlen = max(maxlen, ep - sp);
+    }
+    while (seg < maxlen) seg <<= 1;  // <= 512: a sector holds at most Horizon_SCAN / 6 + 1 points
+  }
+  for (int i = t; i < 6 * seg; i += 256) {
+    const int j = i / seg, li = i - j * seg;
+    const int sp = (s * (6 - j) + e * j) / 6, ep = (s * (5 - j) + e * (j + 1)) / 6 - 1;
+    unsigned long long kv = ~0ull;
+    if (li < ep - sp) {
+      const int k = sp + li;
+      // cloudSmoothness[k] = {curvature, k} for k in [5, n-5), else the zero-initialised {0, 0}
+      const bool live = k >= 5 && k < n - 5;
+      const float cv = live ? l_curv[k - w0] : 0.f;
+      const int ind = live ? k : 0;
+      kv = ((unsigned long long)__float_as_uint(cv) << 32) | (unsigned)ind;
+    }
+    keys[i] = kv;
+  }
+  __syncthreads();
+  for (int k = 2; k <= seg; k <<= 1) {   // std::sort(begin+sp, begin+ep) with the (value, ind) tie order
+    for (int jj = k >> 1; jj > 0; jj >>= 1) {
+      for (int i = t; i < 6 * seg; i += 256) {
+        const int ixj = i ^ jj;
+        if (ixj > i) {
+          const unsigned long long a = keys[i], b = keys[ixj];
+          const bool up = ((i & (seg - 1)) & k) == 0;
+          if ((a > b) == up) { keys[i] = b; keys[ixj] = a; }
+        }
+      }
+      __syncthreads();
+    }
+  }
 
   for (int j = 0; j < 6; j++) {
     const int sp = (s * (6 - j) + e * j) / 6;
     const int ep = (s * (5 - j) + e * (j + 1)) / 6 - 1;
     if (sp >= ep) { if (t == 0) A.corner_cnt[ring * 6 + j] = 0; continue; }  // uniform
-    const int len = ep - sp;  // sorted range [sp, ep)
-    int np2 = 2; while (np2 < len) np2 <<= 1;
-    for (int i = t; i < np2; i += 256) {
-      unsigned long long kv = ~0ull;
-      if (i < len) {
-        const int k = sp + i;
-        // cloudSmoothness[k] = {curvature, k} for k in [5, n-5), else the zero-initialised {0, 0}
-        const bool live = k >= 5 && k < n - 5;
-        const float cv = live ? l_curv[k - w0] : 0.f;
-        const int ind = live ? k : 0;
-        kv = ((unsigned long long)__float_as_uint(cv) << 32) | (unsigned)ind;
+    const unsigned long long* skeys = keys + j * seg;
+    const int len = ep - sp;  // sorted range [sp, ep); positions sp..ep take part in the picks
+    if (sp >= 5 && ep < n - 5 && len < 512) {
+      // ---- parallel greedy picks (every position is a live point of this ring, all distinct) ----
+      // The reference walks the sector in curvature order and a pick marks its +-5 neighbours (up to a column break) as
+      // taken. Equivalent fixed point: a candidate is picked iff no better-ranked candidate that reaches it is picked.
+      // Every round decides the candidates whose better-ranked reaching candidates are all decided; the chains are a
+      // handful of links long, so a sector takes a few rounds of ~20 LDS reads instead of ~10^3 dependent LDS steps
+      // on one lane.
+      int my_li[2], my_rank[2];
+      for (int pass = 0; pass < 2; pass++) {   // 0: corners (:181-211), 1: surfaces (:213-238)
+        const float thr = pass == 0 ? A.edge_threshold : A.surf_threshold;
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+          const int p = t + 256 * u;
+          my_li[u] = -1; my_rank[u] = INT_MAX;
+          if (p <= len) {
+            const int k = sp + p;
+            const int ind = (k == ep) ? ep : (int)(unsigned)(skeys[p] & 0xffffffffull);
+            const int li = ind - w0;
+            const int rank = pass == 0 ? ((k == ep) ? 0 : ep - k) : p;   // corners walk k = ep .. sp, surfaces k = sp .. ep
+            const float cv = l_curv[li];
+            const bool cand = l_picked[li] == 0 && (pass == 0 ? cv > thr : cv < thr);
+            my_li[u] = li; my_rank[u] = rank;
+            l_rank[li] = rank;
+            l_stat[li] = cand ? ST_UNDECIDED : ST_OUT;
+            if (pass == 0) l_sel[rank] = 0;
+          }
+        }
+        __syncthreads();
+        while (true) {
+          int nst[2] = {ST_OUT, ST_OUT};
+          int undecided = 0;
+#pragma unroll
+          for (int u = 0; u < 2; u++) {
+            const int li = my_li[u];
+            if (li < 0 || l_stat[li] != ST_UNDECIDED) continue;
+            bool any_sel = false, any_und = false;
+            for (int d = 1; d <= 5; d++) {
+              if (l_brk[li + d - 1]) break;
+              if (l_rank[li + d] < my_rank[u]) { const int st = l_stat[li + d]; any_sel |= st == ST_PICKED; any_und |= st == ST_UNDECIDED; }
+            }
+            for (int d = 1; d <= 5; d++) {
+              if (l_brk[li - d]) break;
+              if (l_rank[li - d] < my_rank[u]) { const int st = l_stat[li - d]; any_sel |= st == ST_PICKED; any_und |= st == ST_UNDECIDED; }
+            }
+            nst[u] = any_sel ? ST_OUT : (any_und ? ST_UNDECIDED : ST_PICKED);
+            undecided |= nst[u] == ST_UNDECIDED;
+          }
+          __syncthreads();
+#pragma unroll
+          for (int u = 0; u < 2; u++) {
+            const int li = my_li[u];
+            if (li >= 0 && l_stat[li] == ST_UNDECIDED) l_stat[li] = nst[u];
+          }
+          if (!__syncthreads_or(undecided)) break;
+        }
+        // apply the picks; corners: only the first 20 in walk order exist (largestPickedNum, :186-193)
+        int ordinal[2] = {0, 0};
+        if (pass == 0) {
+#pragma unroll
+          for (int u = 0; u < 2; u++) if (my_li[u] >= 0 && l_stat[my_li[u]] == ST_PICKED) l_sel[my_rank[u]] = 1;
+          __syncthreads();
+          int total = 0;
+#pragma unroll
+          for (int u = 0; u < 2; u++) {   // exclusive prefix count of picks over the rank axis, 256 ranks per step
+            const int r = t + 256 * u;
+            const int v = (r <= len) ? l_sel[r] : 0;
+            int inc = v;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) { int o = __shfl_up(inc, off, 64); if (lane >= off) inc += o; }
+            if (lane == 63) s_wsum[wv] = inc;
+            __syncthreads();
+            int woff = 0;
+            for (int w = 0; w < wv; w++) woff += s_wsum[w];
+            const int chunk = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+            if (r <= len) l_sel[r] = total + woff + inc - v;   // exclusive
+            total += chunk;
+            __syncthreads();
+          }
+#pragma unroll
+          for (int u = 0; u < 2; u++) if (my_li[u] >= 0) ordinal[u] = l_sel[my_rank[u]];
+          if (t == 0) A.corner_cnt[ring * 6 + j] = min(total, 20);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+          const int li = my_li[u];
+          if (li < 0 || l_stat[li] != ST_PICKED) continue;
+          if (pass == 0) {
+            if (ordinal[u] >= 20) continue;
+            l_label[li] = 1;
+            A.corner_stage[(ring * 6 + j) * 20 + ordinal[u]] = A.extracted[li + w0];
+          } else {
+            l_label[li] = -1;
+          }
+          l_picked[li] = 1;
+          for (int d = 1; d <= 5; d++) { if (l_brk[li + d - 1]) break; l_picked[li + d] = 1; }
+          for (int d = 1; d <= 5; d++) { if (l_brk[li - d]) break; l_picked[li - d] = 1; }
+        }
+        __syncthreads();
       }
-      keys[i] = kv;
-    }
-    __syncthreads();
-    bitonic_sort_lds(keys, np2);  // std::sort(begin+sp, begin+ep) with the (value, ind) tie order
-    if (t == 0) {
+      // leave the rank / state cells of this sector neutral for the next one
+#pragma unroll
+      for (int u = 0; u < 2; u++) if (my_li[u] >= 0) { l_rank[my_li[u]] = INT_MAX; l_stat[my_li[u]] = ST_OUT; }
+    } else if (t == 0) {
+      // sector at a cloud end (stale {0, 0} smoothness entries): the reference's serial walk as written
       // smooth[ep] is outside the sorted range but inside both loops
       const bool live_ep = ep >= 5 && ep < n - 5;
       const int ind_ep = live_ep ? ep : 0;
       // corners: featureExtraction.cpp:181-211
       int largestPickedNum = 0, ncorner = 0;
       for (int k = ep; k >= sp; k--) {
-        const int ind = (k == ep) ? ind_ep : (int)(unsigned)(keys[k - sp] & 0xffffffffull);
+        const int ind = (k == ep) ? ind_ep : (int)(unsigned)(skeys[k - sp] & 0xffffffffull);
         const int li = ind - w0;
         const bool in_win = li >= 0 && li < wlen;
         const int pk = in_win ? l_picked[li] : A.picked[ind];
@@ -260,7 +397,7 @@ __global__ __launch_bounds__(256) void extract_kernel(FeatArgs A) {
       A.corner_cnt[ring * 6 + j] = ncorner;
       // surfaces: :213-238
       for (int k = sp; k <= ep; k++) {
-        const int ind = (k == ep) ? ind_ep : (int)(unsigned)(keys[k - sp] & 0xffffffffull);
+        const int ind = (k == ep) ? ind_ep : (int)(unsigned)(skeys[k - sp] & 0xffffffffull);
         const int li = ind - w0;
         const bool in_win = li >= 0 && li < wlen;
         const int pk = in_win ? l_picked[li] : A.picked[ind];
@@ -529,7 +666,7 @@ int front_extract_enqueue(Front* f, const rolo_front_params* P, hipStream_t s) {
   A.edge_threshold = P->edge_threshold; A.surf_threshold = P->surf_threshold; A.leaf = P->odometry_surf_leaf_size;
   A.corner_stage = f->corner_stage; A.corner_cnt = f->corner_cnt; A.surf_stage = f->surf_stage; A.surf_cnt = f->surf_cnt;
   const size_t WIN = FRONT_MAX_H + 32;
-  const size_t lds = sizeof(unsigned long long) * SORT_CAP + sizeof(int) * WIN * 4 + sizeof(int) * (FRONT_MAX_H + 16);
+  const size_t lds = sizeof(unsigned long long) * SORT_CAP + sizeof(int) * WIN * 7 + sizeof(int) * (FRONT_MAX_H + 16) + sizeof(int) * SECTOR_CAP;
   static bool attr_set = false;
   if (!attr_set) { FCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(extract_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set = true; }
   extract_kernel<<<NS, 256, lds, s>>>(A);
