@@ -81,28 +81,39 @@ def pipeline_leg(args, torch, device):
         t = t + R @ np.array([0.3, 0.02 * k, 0.0]); R = R @ synth.rpy_to_R(np.deg2rad(0.3), np.deg2rad(-0.2), np.deg2rad(2.0))
     order = [0, 1, 2, 3, 4, 3, 2, 1]
     res = {"workload": f"{sensor} raw frames ({frames[0][2]} points) -> projection -> features -> RotVGICP (POLAR voxels) -> pose"}
-    for name, reuse in (("scans_per_s", 0), ("scans_per_s_reuse_covariances", 1)):
+    # frame-at-a-time (latency), pipelined (rolo_odom_submit of frame k+1 before rolo_odom_collect of frame k: K1-K4 on
+    # their own stream overlap the registration), and pipelined with covariance hand-over between frames (off by default)
+    for name, piped, reuse in (("frame_latency_ms", 0, 0), ("scans_per_s", 1, 0), ("scans_per_s_reuse_covariances", 1, 1)):
         od = LidarOdometry(device, 0.3)
         od.setOption(LidarOdometry.REUSE_COVARIANCES, reuse)
         stamp = 100.0; cnt = None
 
-        def step(i):
-            nonlocal stamp, cnt
+        def submit(i):
+            nonlocal stamp
             x, r, n_raw, stride = frames[order[i % len(order)]]
             stamp += 0.1
-            rc, _, _, _, cnt = od.frame(fp, stamp, x.data_ptr(), r.data_ptr(), n_raw=n_raw, stride=stride)
-            return rc
-        step(0); od.odometryHandler(stamp + 0.05)
-        for i in range(1, 6):
-            step(i)
+            od.submit(fp, stamp, x.data_ptr(), r.data_ptr(), n_raw=n_raw, stride=stride)
+
+        def run(i0, i1):
+            nonlocal cnt
+            if piped:
+                submit(i0)
+            for i in range(i0, i1):
+                if piped:
+                    if i + 1 < i1:
+                        submit(i + 1)
+                else:
+                    submit(i)
+                rc, _, _, _, cnt = od.collect()
+        run(0, 1); od.odometryHandler(stamp + 0.05)
+        run(1, 6)
         torch.cuda.synchronize()
         nfr = 40
         t0 = time.perf_counter()
-        for i in range(6, 6 + nfr):
-            rc = step(i)
+        run(6, 6 + nfr)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        res[name] = nfr / dt
+        res[name] = 1e3 * dt / nfr if name.endswith("_ms") else nfr / dt
         res["features_per_frame"] = int(cnt[1] + cnt[2]); res["valid_points"] = int(cnt[0])
         od.close()
     return res

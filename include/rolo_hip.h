@@ -234,6 +234,14 @@ int rolo_odom_cloud(rolo_odom* o, double stamp, const float* corner, int n_corne
  * rolo_odom_cloud. pts/ring may be device pointers (pts_on_device != 0). counts3 (optional) = N, n_corner, n_surface. */
 int rolo_odom_frame(rolo_odom* o, const rolo_front_params* P, double stamp, const float* pts, int stride, const uint16_t* ring,
                     int n_raw, int pts_on_device, float* pose6, double* rot9, double* trans3, int* counts3);
+/* The same in two halves, for throughput: rolo_odom_submit enqueues K1-K4 of a frame on the driver's own front-end
+ * stream and returns at once; rolo_odom_collect finishes the oldest submitted frame (waits for its features, registers,
+ * updates the pose). Up to two frames may be in flight, so the features of frame k+1 are extracted while frame k
+ * registers — the overlap the reference gets from running its three nodes as separate processes. With host input the
+ * caller must keep pts / ring valid until the matching collect. rolo_odom_frame = submit + collect. */
+int rolo_odom_submit(rolo_odom* o, const rolo_front_params* P, double stamp, const float* pts, int stride, const uint16_t* ring,
+                     int n_raw, int pts_on_device);
+int rolo_odom_collect(rolo_odom* o, float* pose6, double* rot9, double* trans3, int* counts3);
 /* options of the fused path: ROLO_ODOM_REUSE_COVARIANCES (default 0) = rolo_adopt_target_covariances between frames */
 #define ROLO_ODOM_REUSE_COVARIANCES 1
 int rolo_odom_set_option(rolo_odom* o, int option, int value);

@@ -98,6 +98,8 @@ SYMBOLS = {
     "rolo_odom_backend_odometry": (C.c_int, [vp, C.c_double]),
     "rolo_odom_cloud": (C.c_int, [vp, C.c_double, fp, C.c_int, fp, C.c_int, fp, dp, dp]),
     "rolo_odom_frame": (C.c_int, [vp, C.POINTER(FrontParams), C.c_double, vp, C.c_int, vp, C.c_int, C.c_int, fp, dp, dp, C.POINTER(C.c_int)]),
+    "rolo_odom_submit": (C.c_int, [vp, C.POINTER(FrontParams), C.c_double, vp, C.c_int, vp, C.c_int, C.c_int]),
+    "rolo_odom_collect": (C.c_int, [vp, fp, dp, dp, C.POINTER(C.c_int)]),
     "rolo_odom_set_option": (C.c_int, [vp, C.c_int, C.c_int]),
     "rolo_front_default_params": (None, [C.POINTER(FrontParams)]),
     "rolo_project_frame": (C.c_int, [vp, C.POINTER(FrontParams), fp, C.c_int, C.POINTER(C.c_uint16), C.c_int, fp, ip, fp,

@@ -682,8 +682,10 @@ int front_extract_enqueue(Front* f, const rolo_front_params* P, hipStream_t s) {
 // d_feat (capacity front_feature_capacity floats4), one host synchronisation for the three counts.
 size_t front_feature_capacity(const rolo_front_params* P) { return (size_t)P->n_scan * P->horizon_scan + (size_t)P->n_scan * 6 * 20; }
 
-int front_frame_features(rolo_ctx* c, const rolo_front_params* P, const float* pts, int stride, const uint16_t* ring, int n_raw, bool on_device,
-                         float4* d_feat, int* counts3) {
+// No host synchronisation: `done` is recorded on the context's stream behind the read-back of the three counts into
+// h_counts3 (pinned host memory), so the caller can keep another stream busy meanwhile.
+int front_frame_features_enqueue(rolo_ctx* c, const rolo_front_params* P, const float* pts, int stride, const uint16_t* ring, int n_raw,
+                                 bool on_device, float4* d_feat, int* h_counts3, hipEvent_t done) {
   Front* f = nullptr;
   int rc = front_prepare(c, P, n_raw, stride, !on_device, &f);
   if (rc) return rc;
@@ -698,10 +700,9 @@ int front_frame_features(rolo_ctx* c, const rolo_front_params* P, const float* p
   if ((rc = front_extract_enqueue(f, P, s))) return rc;
   feature_concat_kernel<<<256, 256, 0, s>>>(f->corner_out, f->surf_out, f->counters, d_feat);
   FCHK(hipGetLastError());
-  FCHK(hipMemcpyAsync(counts3, f->counters, sizeof(int) * 3, hipMemcpyDeviceToHost, s));
-  FCHK(hipStreamSynchronize(s));
-  f->n_valid = counts3[0];
-  f->projected = true;
+  FCHK(hipMemcpyAsync(h_counts3, f->counters, sizeof(int) * 3, hipMemcpyDeviceToHost, s));
+  if (done) FCHK(hipEventRecord(done, s));
+  f->projected = false;  // the staged rolo_extract_features must not run on top of a fused frame
   return ROLO_OK;
 }
 

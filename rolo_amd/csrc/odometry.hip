@@ -12,6 +12,7 @@
 
 namespace rolo {
 void ctx_set_error(const char* msg);
+int ctx_device(rolo_ctx* c);
 }
 
 namespace {
@@ -73,11 +74,16 @@ struct rolo_odom {
   double Rotation[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, Translation[3] = {0, 0, 0}, TranslationOld[3] = {0, 0, 0};
   float LaserOdomPose[6] = {0, 0, 0, 0, 0, 0};
   std::vector<float> featureOld;           // n x 4 (rolo_odom_cloud: host-side hand-over)
-  // rolo_odom_frame: device-resident hand-over
-  float4 *d_featOld = nullptr, *d_featNew = nullptr, *d_prop = nullptr;
+  // rolo_odom_submit / _collect / _frame: device-resident hand-over. K1-K4 run on their own context (stream + buffers),
+  // so the features of frame k+1 are extracted while frame k registers on `ctx`.
+  rolo_ctx* fctx = nullptr;
+  float4* d_feat[3] = {nullptr, nullptr, nullptr};  // ring: [old] = previous features, [old+1], [old+2] = submitted frames
+  float4* d_prop = nullptr;
   size_t d_cap = 0;
-  int nOld = 0;
-  bool reuse_cov = false, cov_chain = false;  // cov_chain: the context's target covariances belong to d_featOld
+  int old_buf = 0, nOld = 0;
+  struct Slot { double stamp = 0; int* h_counts = nullptr; hipEvent_t done = nullptr; } q[2];
+  int q_head = 0, q_len = 0;
+  bool reuse_cov = false, cov_chain = false;  // cov_chain: the context's target covariances belong to d_feat[old_buf]
   rolo_stats last_rot{}, last_trans{};
 };
 
@@ -105,9 +111,10 @@ int rolo_odom_create(rolo_ctx* ctx, float ct_lambda, rolo_odom** out) {
 }
 void rolo_odom_destroy(rolo_odom* o) {
   if (!o) return;
-  if (o->d_featOld) (void)hipFree(o->d_featOld);
-  if (o->d_featNew) (void)hipFree(o->d_featNew);
+  if (o->fctx) rolo_ctx_destroy(o->fctx);  // synchronises its stream
+  for (float4* b : o->d_feat) if (b) (void)hipFree(b);
   if (o->d_prop) (void)hipFree(o->d_prop);
+  for (auto& sl : o->q) { if (sl.h_counts) (void)hipHostFree(sl.h_counts); if (sl.done) (void)hipEventDestroy(sl.done); }
   delete o;
 }
 
@@ -177,26 +184,53 @@ int rolo_odom_cloud(rolo_odom* o, double stamp, const float* corner, int n_corne
   return ret;
 }
 
-int rolo_odom_frame(rolo_odom* o, const rolo_front_params* P, double stamp, const float* pts, int stride, const uint16_t* ring, int n_raw,
-                    int pts_on_device, float* pose6, double* rot9, double* trans3, int* counts3) {
+int rolo_odom_submit(rolo_odom* o, const rolo_front_params* P, double stamp, const float* pts, int stride, const uint16_t* ring, int n_raw,
+                     int pts_on_device) {
   if (!o || !P || !pts || !ring || stride < 3 || n_raw < 0) return ROLO_EINVAL;
+  if (o->q_len == 2) { rolo::ctx_set_error("two frames are already in flight: collect one first"); return ROLO_ESTATE; }
+  if (hipSetDevice(rolo::ctx_device(o->ctx)) != hipSuccess) { rolo::ctx_set_error("hipSetDevice failed"); return ROLO_EHIP; }
+  int rc;
+  if (!o->fctx) {
+    if ((rc = rolo_ctx_create(rolo::ctx_device(o->ctx), &o->fctx))) return rc;
+    for (auto& sl : o->q) {
+      if (hipHostMalloc((void**)&sl.h_counts, 4 * sizeof(int)) != hipSuccess || hipEventCreateWithFlags(&sl.done, hipEventDisableTiming) != hipSuccess) {
+        rolo::ctx_set_error("pinned buffer / event creation failed"); return ROLO_EHIP;
+      }
+    }
+  }
   const size_t cap = rolo::front_feature_capacity(P);
   if (cap > o->d_cap) {
-    if (o->nOld > 0) { rolo::ctx_set_error("front parameters grew between frames"); return ROLO_ESTATE; }
-    float4** bufs[3] = {&o->d_featOld, &o->d_featNew, &o->d_prop};
+    if (o->nOld > 0 || o->q_len > 0) { rolo::ctx_set_error("front parameters grew between frames"); return ROLO_ESTATE; }
+    float4** bufs[4] = {&o->d_feat[0], &o->d_feat[1], &o->d_feat[2], &o->d_prop};
     for (float4** b : bufs) {
       if (*b) { (void)hipFree(*b); *b = nullptr; }
       if (hipMalloc((void**)b, sizeof(float4) * cap) != hipSuccess) { rolo::ctx_set_error("hipMalloc failed (odometry feature buffers)"); return ROLO_EHIP; }
     }
     o->d_cap = cap;
   }
-  int counts[3] = {0, 0, 0};
-  int rc = rolo::front_frame_features(o->ctx, P, pts, stride, ring, n_raw, pts_on_device != 0, o->d_featNew, counts);
-  if (rc) return rc;
+  const int buf = (o->old_buf + 1 + o->q_len) % 3;
+  rolo_odom::Slot& sl = o->q[(o->q_head + o->q_len) % 2];
+  if ((rc = rolo::front_frame_features_enqueue(o->fctx, P, pts, stride, ring, n_raw, pts_on_device != 0, o->d_feat[buf], sl.h_counts, sl.done))) return rc;
+  sl.stamp = stamp;
+  o->q_len++;
+  return ROLO_OK;
+}
+
+int rolo_odom_collect(rolo_odom* o, float* pose6, double* rot9, double* trans3, int* counts3) {
+  if (!o) return ROLO_EINVAL;
+  if (o->q_len == 0) { rolo::ctx_set_error("no submitted frame to collect"); return ROLO_ESTATE; }
+  if (hipSetDevice(rolo::ctx_device(o->ctx)) != hipSuccess) { rolo::ctx_set_error("hipSetDevice failed"); return ROLO_EHIP; }
+  rolo_odom::Slot& sl = o->q[o->q_head];
+  o->q_head = (o->q_head + 1) % 2; o->q_len--;
+  if (hipEventSynchronize(sl.done) != hipSuccess) { rolo::ctx_set_error("front-end stream failed"); return ROLO_EHIP; }
+  int counts[3] = {sl.h_counts[0], sl.h_counts[1], sl.h_counts[2]};
   if (counts3) memcpy(counts3, counts, sizeof(counts));
+  const int buf = (o->old_buf + 1) % 3;
+  float4* d_featNew = o->d_feat[buf];
+  float4* d_featOld = o->d_feat[o->old_buf];
   const int nNew = counts[1] + counts[2];
-  o->cloudTimeCur = stamp;
-  int ret;
+  o->cloudTimeCur = sl.stamp;
+  int ret, rc;
   if (o->first) {
     o->first = false;
     ret = 0;
@@ -215,13 +249,13 @@ int rolo_odom_frame(rolo_odom* o, const rolo_front_params* P, double stamp, cons
     o->lastMappingInterval = latestInterval;
     // scanRegeistration :448-501 on device-resident clouds
     hipStream_t s = (hipStream_t)rolo_ctx_stream(o->ctx);
-    if (o->nOld > 0 && rolo::launch_transform_cloud(reinterpret_cast<const float*>(o->d_featOld), reinterpret_cast<float*>(o->d_prop), o->nOld, 4, nullptr,
+    if (o->nOld > 0 && rolo::launch_transform_cloud(reinterpret_cast<const float*>(d_featOld), reinterpret_cast<float*>(o->d_prop), o->nOld, 4, nullptr,
                                                     o->transformation_interpolated.m, s) != hipSuccess) {
       rolo::ctx_set_error("transform kernel launch failed"); return ROLO_EHIP;
     }
     if ((rc = rolo_set_source_device(o->ctx, reinterpret_cast<const float*>(o->d_prop), o->nOld, 4))) return rc;
     if (o->reuse_cov && o->cov_chain) { if ((rc = rolo_adopt_target_covariances(o->ctx))) return rc; }
-    if ((rc = rolo_set_target_device(o->ctx, reinterpret_cast<const float*>(o->d_featNew), nNew, 4))) return rc;
+    if ((rc = rolo_set_target_device(o->ctx, reinterpret_cast<const float*>(d_featNew), nNew, 4))) return rc;
     double guess_t[3];
     for (int i = 0; i < 3; i++) guess_t[i] = (double)o->transformation_interpolated.m[i * 4 + 3];
     const double zero3[3] = {0, 0, 0};
@@ -237,12 +271,21 @@ int rolo_odom_frame(rolo_odom* o, const rolo_front_params* P, double stamp, cons
     update_transform(o);
     ret = 2;
   }
-  std::swap(o->d_featOld, o->d_featNew);
+  o->old_buf = buf;
   o->nOld = nNew;
   if (pose6) memcpy(pose6, o->LaserOdomPose, sizeof(float) * 6);
   if (rot9) memcpy(rot9, o->Rotation, sizeof(double) * 9);
   if (trans3) memcpy(trans3, o->Translation, sizeof(double) * 3);
   return ret;
+}
+
+int rolo_odom_frame(rolo_odom* o, const rolo_front_params* P, double stamp, const float* pts, int stride, const uint16_t* ring, int n_raw,
+                    int pts_on_device, float* pose6, double* rot9, double* trans3, int* counts3) {
+  if (!o) return ROLO_EINVAL;
+  if (o->q_len != 0) { rolo::ctx_set_error("rolo_odom_frame with submitted frames pending: collect them first"); return ROLO_ESTATE; }
+  const int rc = rolo_odom_submit(o, P, stamp, pts, stride, ring, n_raw, pts_on_device);
+  if (rc) return rc;
+  return rolo_odom_collect(o, pose6, rot9, trans3, counts3);
 }
 
 }  // extern "C"

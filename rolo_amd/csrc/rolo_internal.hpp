@@ -125,9 +125,10 @@ hipError_t launch_pack_xyz(const float* in, int stride, float4* out, int n, hipS
 hipError_t launch_cov_unpack(const double* soa, int n, double* m16, hipStream_t s);   // 6 SoA -> n x 16
 hipError_t launch_cov_pack(const double* m16, int n, double* soa, hipStream_t s);     // n x 16 -> 6 SoA
 
-// front.hip: fused K1-K4 for the device-resident pipeline — raw frame -> corner ++ surface in d_feat; counts3 = N, n_corner, n_surface
+// front.hip: fused K1-K4 for the device-resident pipeline — raw frame -> corner ++ surface in d_feat; counts3 = N, n_corner, n_surface;
+// asynchronous on the context's stream (event `done` behind the read-back of the counts)
 size_t front_feature_capacity(const rolo_front_params* P);
-int front_frame_features(rolo_ctx* c, const rolo_front_params* P, const float* pts, int stride, const uint16_t* ring, int n_raw, bool on_device,
-                         float4* d_feat, int* counts3);
+int front_frame_features_enqueue(rolo_ctx* c, const rolo_front_params* P, const float* pts, int stride, const uint16_t* ring, int n_raw,
+                                 bool on_device, float4* d_feat, int* h_counts3_pinned, hipEvent_t done);
 
 }  // namespace rolo

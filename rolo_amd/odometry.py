@@ -51,6 +51,27 @@ class LidarOdometry:
                                          R.ctypes.data_as(dp), t.ctypes.data_as(dp), counts), "rolo_odom_frame")
         return rc, pose, R, t, tuple(counts)
 
+    def submit(self, front_params, stamp: float, xyz, ring, n_raw=None, stride=None):
+        """First half of frame(): enqueue projection + feature extraction on the driver's front-end stream (returns at once;
+        up to two frames in flight). Host arrays are kept alive until the matching collect()."""
+        if isinstance(xyz, int):
+            pp, rp, on_dev = C.c_void_p(xyz), C.c_void_p(ring), 1
+        else:
+            xyz = np.ascontiguousarray(xyz, np.float32); ring = np.ascontiguousarray(ring, np.uint16)
+            n_raw, stride = xyz.shape[0], xyz.shape[1]
+            pp, rp, on_dev = C.c_void_p(xyz.ctypes.data), C.c_void_p(ring.ctypes.data), 0
+            self._keep = getattr(self, "_keep", []) + [(xyz, ring)]
+        check(lib().rolo_odom_submit(self._h, C.byref(front_params), stamp, pp, stride, rp, n_raw, on_dev), "rolo_odom_submit")
+
+    def collect(self):
+        """Second half: finish the oldest submitted frame. Returns what frame() returns."""
+        pose = np.zeros(6, np.float32); R = np.zeros((3, 3)); t = np.zeros(3); counts = (C.c_int * 3)()
+        fp, dp = C.POINTER(C.c_float), C.POINTER(C.c_double)
+        rc = check(lib().rolo_odom_collect(self._h, pose.ctypes.data_as(fp), R.ctypes.data_as(dp), t.ctypes.data_as(dp), counts), "rolo_odom_collect")
+        if getattr(self, "_keep", None):
+            self._keep.pop(0)
+        return rc, pose, R, t, tuple(counts)
+
     def odometryHandler(self, stamp: float):
         check(lib().rolo_odom_backend_odometry(self._h, stamp), "rolo_odom_backend_odometry")
 

@@ -70,11 +70,14 @@ def test_fused_frame_equals_staged_nodes(sensor, cfg):
     fused_h = LidarOdometry(0, 0.3)
     fused_d = LidarOdometry(0, 0.3)
     fused_r = LidarOdometry(0, 0.3); fused_r.setOption(LidarOdometry.REUSE_COVARIANCES, 1)
+    fused_p = LidarOdometry(0, 0.3)   # submit / collect: K1-K4 of frame k+1 overlap the registration of frame k
+    frames = [synth.make_frame(sensor, R, t, synth.SEED + k) for k, (R, t) in enumerate(poses)]
+    fused_p.submit(fg, 100.0, frames[0].xyz, frames[0].ring)
     for k, (R, t) in enumerate(poses):
-        fr = synth.make_frame(sensor, R, t, synth.SEED + k)
+        fr = frames[k]
         stamp = 100.0 + 0.1 * k
         if k == 2:
-            for o in (staged, fused_h, fused_d, fused_r):
+            for o in (staged, fused_h, fused_d, fused_r, fused_p):
                 o.odometryHandler(stamp - 0.05)
             oo.backend_odometry(stamp - 0.05)
         eo = pyorc.extract_features(fo, pyorc.project(fo, fr.xyz, fr.ring))
@@ -91,6 +94,11 @@ def test_fused_frame_equals_staged_nodes(sensor, cfg):
         for (p_, R_, t_) in ((pose_h, R_h, t_h), (pose_d, R_d, t_d)):
             # same kernels on the same bytes; only the fp64 atomics of the voxel sums may reorder
             assert np.abs(p_ - pose_s).max() < 1e-6 and np.abs(R_ - R_s).max() < 1e-9 and np.abs(t_ - t_s).max() < 1e-9
+        if k + 1 < len(frames):
+            fused_p.submit(fg, stamp + 0.1, frames[k + 1].xyz, frames[k + 1].ring)
+        rcp, pose_p, R_p, t_p, cnt_p = fused_p.collect()
+        assert rcp == rch and cnt_p == cnt
+        assert np.abs(pose_p - pose_h).max() < 1e-6 and np.abs(R_p - R_h).max() < 1e-9 and np.abs(t_p - t_h).max() < 1e-9
         rcr, pose_r, R_r, t_r, _ = fused_r.frame(fg, stamp, fr.xyz, fr.ring)
         assert rcr == rco
         assert np.abs(pose_r[:3] - pose_o[:3]).max() <= 1e-4 and np.abs(pose_r[3:] - pose_o[3:]).max() <= 1e-5
