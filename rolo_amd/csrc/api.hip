@@ -127,7 +127,10 @@ struct rolo_ctx {
   // hipGraph of one whole frame (rolo_register_async): captured on the second frame with an unchanged key, replayed after
   FrameArgs* h_args = nullptr;   // pinned; a captured H2D copy refreshes d_args on every replay
   FrameArgs* d_args = nullptr; size_t d_args_cap = 0;
-  struct GraphKey { int n_src, n_tgt; const void *src_xyz, *tgt_xyz; rolo_params P; unsigned long long epoch; } gkey{}, gseen{};
+  struct GraphKey { int n_src, n_tgt; const void *src_xyz, *tgt_xyz; rolo_params P; unsigned long long epoch; int nrot, ntrans; } gkey{}, gseen{};
+  // passes the last frames needed per stage (+1): the next frame enqueues that many predicated pass/controller pairs up
+  // front instead of a fixed worst-case chunk; rolo_register_wait tops up if a frame needs more
+  int hint_rot = 0, hint_trans = 0;
   bool gseen_valid = false;
   hipGraph_t graph = nullptr;
   hipGraphExec_t graph_exec = nullptr;
@@ -322,6 +325,15 @@ void fill_rot_outputs(const LmState* s, float* Tf, double* Td, rolo_stats* st) {
 }
 
 int rot_first_chunk(const rolo_ctx* c) { return c->P.fixed_iterations > 0 ? c->P.fixed_iterations + 3 : 8; }
+// first chunks of a whole frame (rolo_register_async): from the hints once a frame has been seen
+void frame_chunks(const rolo_ctx* c, int& nrot, int& ntrans) {
+  nrot = c->hint_rot > 0 ? c->hint_rot : rot_first_chunk(c);
+  ntrans = c->hint_trans > 0 ? c->hint_trans : 12;
+}
+void update_hint(int& hint, int used) {
+  const int want = std::min(std::max(used + 1, 2), 96);
+  if (hint == 0 || want > hint || want < hint - 2) hint = want;  // hysteresis: a captured hipGraph stays valid while the need wobbles by one or two
+}
 
 // drive a stage to completion: enqueue predicated passes in chunks, look at the device flags between chunks
 int run_stage(rolo_ctx* c, const PassArgs& a, int grid, int stage, int first_chunk) {
@@ -752,9 +764,9 @@ static int enqueue_frame(rolo_ctx* c) {
   if ((rc = prepare_pass(c, a, grid))) return rc;
   HIPCHK(hipMemcpyAsync(c->d_args, c->h_args, sizeof(FrameArgs), hipMemcpyHostToDevice, c->stream));
   HIPCHK(launch_frame_begin(c->state, c->d_args, c->stream));
-  const int nrot = rot_first_chunk(c);
+  int nrot, ntrans; frame_chunks(c, nrot, ntrans);
   for (int i = 0; i < nrot; i++) if ((rc = enqueue_pass(c, a, grid, 1))) return rc;
-  for (int i = 0; i < 12; i++) if ((rc = enqueue_pass(c, a, grid, 2))) return rc;
+  for (int i = 0; i < ntrans; i++) if ((rc = enqueue_pass(c, a, grid, 2))) return rc;
   HIPCHK(hipMemcpyAsync(c->h_state, c->state, sizeof(LmState), hipMemcpyDeviceToHost, c->stream));
   return ROLO_OK;
 }
@@ -776,9 +788,10 @@ int rolo_register_async(rolo_ctx* c, const float* guess16, const double* trans_s
   if (graphable) {
     rolo_ctx::GraphKey key{};
     key.n_src = c->src.n; key.n_tgt = c->tgt.n; key.src_xyz = c->src.xyz; key.tgt_xyz = c->tgt.xyz; key.P = c->P; key.epoch = g_alloc_epoch;
+    frame_chunks(c, key.nrot, key.ntrans);
     auto same = [](const rolo_ctx::GraphKey& a, const rolo_ctx::GraphKey& b) {
       return a.n_src == b.n_src && a.n_tgt == b.n_tgt && a.src_xyz == b.src_xyz && a.tgt_xyz == b.tgt_xyz && a.epoch == b.epoch &&
-             memcmp(&a.P, &b.P, sizeof(rolo_params)) == 0;
+             a.nrot == b.nrot && a.ntrans == b.ntrans && memcmp(&a.P, &b.P, sizeof(rolo_params)) == 0;
     };
     if (c->graph_exec && same(key, c->gkey)) {
       HIPCHK(hipGraphLaunch(c->graph_exec, c->stream));
@@ -831,6 +844,7 @@ int rolo_register_wait(rolo_ctx* c, float* Tf, double* Td, double* trans_out, ro
   if (!c->h_state->trans_done && !c->h_state->error) { if ((rc = run_stage(c, a, grid, 2, 8))) return rc; }
   c->have_corr = true;
   const LmState* s = c->h_state;
+  if (!s->error) { update_hint(c->hint_rot, s->rot_passes); update_hint(c->hint_trans, s->trans_passes); }
   fill_rot_outputs(s, Tf, Td, rs);
   if (trans_out) for (int i = 0; i < 3; i++) trans_out[i] = s->t0[i];
   if (ts) { ts->n_outer = s->trans_outer; ts->converged = s->trans_failed ? 0 : 1; ts->lm_failed = s->trans_failed; ts->n_passes = s->trans_passes; ts->n_correspondences = s->tr_n_corr; }
