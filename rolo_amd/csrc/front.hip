@@ -30,7 +30,6 @@ namespace rolo {
 constexpr int FRONT_GUARD = 8;       // guard cells in front of / behind the per-point arrays (reference reads index -1.. )
 constexpr int FRONT_MAX_H = 2048;    // Horizon_SCAN limit of this build (shipped configs: 1024, 1800, 2048)
 constexpr int SORT_CAP = 3072;       // LDS bitonic capacity (elements): 6 sector segments of <= 512, or one ring's surface scan (<= 2048)
-constexpr int SECTOR_CAP = 520;      // positions of one sector (<= Horizon_SCAN / 6 + 2)
 constexpr int ST_OUT = 0, ST_UNDECIDED = 1, ST_PICKED = 2;
 
 namespace {
@@ -146,21 +145,46 @@ __global__ __launch_bounds__(256) void occlusion_kernel(const float* __restrict_
 }
 
 // ---- K4 ----
-ROLO_DEV void bitonic_sort_lds(unsigned long long* key, int n_pow2) {
-  for (int k = 2; k <= n_pow2; k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int i = threadIdx.x; i < n_pow2; i += blockDim.x) {
-        const int ixj = i ^ j;
+// Ascending bitonic sort of every aligned `seg`-element segment of key[0, total) in LDS (seg a power of two, total a
+// multiple of seg; 256 threads). Exchange distances >= 64 are block-wide steps with a barrier each; the distances
+// 32..1 that close every merge stage stay inside an aligned 64-element chunk, so one wavefront takes the chunk into
+// registers and finishes the stage with cross-lane exchanges — one barrier per stage instead of one per step.
+ROLO_DEV unsigned long long shfl_xor_u64(unsigned long long v, int mask) {
+  const unsigned lo = __shfl_xor((unsigned)(v & 0xffffffffull), mask, 64), hi = __shfl_xor((unsigned)(v >> 32), mask, 64);
+  return ((unsigned long long)hi << 32) | lo;
+}
+ROLO_DEV void bitonic_sort_lds_seg(unsigned long long* key, int total, int seg) {
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int n_chunks = (total + 63) >> 6;
+  for (int k = 2; k <= seg; k <<= 1) {
+    int jj = k >> 1;
+    for (; jj >= 64; jj >>= 1) {
+      for (int i = t; i < total; i += 256) {
+        const int ixj = i ^ jj;
         if (ixj > i) {
           const unsigned long long a = key[i], b = key[ixj];
-          const bool up = (i & k) == 0;
+          const bool up = ((i & (seg - 1)) & k) == 0;
           if ((a > b) == up) { key[i] = b; key[ixj] = a; }
         }
       }
       __syncthreads();
     }
+    for (int c = wv; c < n_chunks; c += 4) {
+      const int i = (c << 6) + lane;
+      unsigned long long v = i < total ? key[i] : ~0ull;
+      const bool up = ((i & (seg - 1)) & k) == 0;
+      for (int j2 = jj; j2 > 0; j2 >>= 1) {
+        const unsigned long long o = shfl_xor_u64(v, j2);
+        const bool lower = (lane & j2) == 0;          // this lane holds the smaller index of the pair
+        const bool take_min = lower == up;
+        v = take_min ? (o < v ? o : v) : (o > v ? o : v);
+      }
+      if (i < total) key[i] = v;
+    }
+    __syncthreads();
   }
 }
+ROLO_DEV void bitonic_sort_lds(unsigned long long* key, int n_pow2) { bitonic_sort_lds_seg(key, n_pow2, n_pow2); }
 
 struct FeatArgs {
   const float4* extracted; const int* col; const float* curv; int* picked; int* label;  // global, guard-offset pointers
@@ -172,7 +196,7 @@ struct FeatArgs {
 
 __global__ __launch_bounds__(256) void extract_kernel(FeatArgs A) {
   extern __shared__ unsigned char smem_raw[];
-  // layout: keys[SORT_CAP] u64 | l_picked | l_col | l_label | l_curv (ring window) | list[FRONT_MAX_H+16] | l_brk | l_rank | l_stat (window) | l_sel
+  // layout: keys[SORT_CAP] u64 | l_picked | l_col | l_label | l_curv (ring window) | list[FRONT_MAX_H+16] | l_brk | l_rank | l_stat (window)
   unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem_raw);
   const int WIN = FRONT_MAX_H + 2 * 16;
   int* l_picked = reinterpret_cast<int*>(keys + SORT_CAP);
@@ -183,8 +207,8 @@ __global__ __launch_bounds__(256) void extract_kernel(FeatArgs A) {
   int* l_brk = list + (FRONT_MAX_H + 16);
   int* l_rank = l_brk + WIN;
   int* l_stat = l_rank + WIN;
-  int* l_sel = l_stat + WIN;   // [SECTOR_CAP]
-  __shared__ int s_cnt, s_heads;
+  __shared__ int s_heads, s_ep;
+  __shared__ int s_pk[2][4], s_cw[2][4];
   __shared__ float s_red[2][3][4];
   __shared__ int s_wsum[4];
 
@@ -204,7 +228,7 @@ __global__ __launch_bounds__(256) void extract_kernel(FeatArgs A) {
     l_label[i] = in ? A.label[gi] : 0;
     l_curv[i] = in ? A.curv[gi] : 0.f;
   }
-  if (t == 0) s_cnt = 0;
+  int scan_cnt = 0, par = 0;  // surface-scan length so far (every thread keeps the same count)
   // brk[i]: the suppression marks of a pick stop between window cells i and i + 1 (|columnDiff| > 10, :199-210)
   for (int i = t; i < wlen; i += 256) { l_rank[i] = INT_MAX; l_stat[i] = ST_OUT; }
   __syncthreads();
@@ -235,19 +259,7 @@ __global__ __launch_bounds__(256) void extract_kernel(FeatArgs A) {
     keys[i] = kv;
   }
   __syncthreads();
-  for (int k = 2; k <= seg; k <<= 1) {   // std::sort(begin+sp, begin+ep) with the (value, ind) tie order
-    for (int jj = k >> 1; jj > 0; jj >>= 1) {
-      for (int i = t; i < 6 * seg; i += 256) {
-        const int ixj = i ^ jj;
-        if (ixj > i) {
-          const unsigned long long a = keys[i], b = keys[ixj];
-          const bool up = ((i & (seg - 1)) & k) == 0;
-          if ((a > b) == up) { keys[i] = b; keys[ixj] = a; }
-        }
-      }
-      __syncthreads();
-    }
-  }
+  bitonic_sort_lds_seg(keys, 6 * seg, seg);   // std::sort(begin+sp, begin+ep) with the (value, ind) tie order
 
   for (int j = 0; j < 6; j++) {
     const int sp = (s * (6 - j) + e * j) / 6;
@@ -279,12 +291,10 @@ __global__ __launch_bounds__(256) void extract_kernel(FeatArgs A) {
             my_li[u] = li; my_rank[u] = rank;
             l_rank[li] = rank;
             l_stat[li] = cand ? ST_UNDECIDED : ST_OUT;
-            if (pass == 0) l_sel[rank] = 0;
           }
         }
         __syncthreads();
-        while (true) {
-          int nst[2] = {ST_OUT, ST_OUT};
+        while (true) {   // states only ever move UNDECIDED -> final, so a neighbour's state read mid-update is either still valid
           int undecided = 0;
 #pragma unroll
           for (int u = 0; u < 2; u++) {
@@ -299,42 +309,39 @@ __global__ __launch_bounds__(256) void extract_kernel(FeatArgs A) {
               if (l_brk[li - d]) break;
               if (l_rank[li - d] < my_rank[u]) { const int st = l_stat[li - d]; any_sel |= st == ST_PICKED; any_und |= st == ST_UNDECIDED; }
             }
-            nst[u] = any_sel ? ST_OUT : (any_und ? ST_UNDECIDED : ST_PICKED);
-            undecided |= nst[u] == ST_UNDECIDED;
-          }
-          __syncthreads();
-#pragma unroll
-          for (int u = 0; u < 2; u++) {
-            const int li = my_li[u];
-            if (li >= 0 && l_stat[li] == ST_UNDECIDED) l_stat[li] = nst[u];
+            if (any_sel) l_stat[li] = ST_OUT;
+            else if (!any_und) l_stat[li] = ST_PICKED;
+            else undecided = 1;
           }
           if (!__syncthreads_or(undecided)) break;
         }
         // apply the picks; corners: only the first 20 in walk order exist (largestPickedNum, :186-193)
         int ordinal[2] = {0, 0};
         if (pass == 0) {
+          // walk order = position len first, then len - 1 .. 0: a pick's ordinal is the number of picks at higher positions
+          int higher[2];
 #pragma unroll
-          for (int u = 0; u < 2; u++) if (my_li[u] >= 0 && l_stat[my_li[u]] == ST_PICKED) l_sel[my_rank[u]] = 1;
+          for (int u = 0; u < 2; u++) {
+            const int p = t + 256 * u;
+            const bool pk = my_li[u] >= 0 && l_stat[my_li[u]] == ST_PICKED;
+            if (p == len) s_ep = pk ? 1 : 0;
+            const unsigned long long bal = __ballot(pk && p != len);
+            higher[u] = __popcll(bal & ~((2ull << lane) - 1ull));
+            if (lane == 0) s_pk[u][wv] = __popcll(bal);
+          }
           __syncthreads();
-          int total = 0;
+          int total = s_ep;
 #pragma unroll
-          for (int u = 0; u < 2; u++) {   // exclusive prefix count of picks over the rank axis, 256 ranks per step
-            const int r = t + 256 * u;
-            const int v = (r <= len) ? l_sel[r] : 0;
-            int inc = v;
+          for (int u = 0; u < 2; u++) {
 #pragma unroll
-            for (int off = 1; off < 64; off <<= 1) { int o = __shfl_up(inc, off, 64); if (lane >= off) inc += o; }
-            if (lane == 63) s_wsum[wv] = inc;
-            __syncthreads();
-            int woff = 0;
-            for (int w = 0; w < wv; w++) woff += s_wsum[w];
-            const int chunk = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
-            if (r <= len) l_sel[r] = total + woff + inc - v;   // exclusive
-            total += chunk;
-            __syncthreads();
+            for (int w = 0; w < 4; w++) {
+              total += s_pk[u][w];
+#pragma unroll
+              for (int u2 = 0; u2 < 2; u2++) if (u > u2 || (u == u2 && w > wv)) higher[u2] += s_pk[u][w];
+            }
           }
 #pragma unroll
-          for (int u = 0; u < 2; u++) if (my_li[u] >= 0) ordinal[u] = l_sel[my_rank[u]];
+          for (int u = 0; u < 2; u++) ordinal[u] = (t + 256 * u == len) ? 0 : s_ep + higher[u];
           if (t == 0) A.corner_cnt[ring * 6 + j] = min(total, 20);
         }
 #pragma unroll
@@ -422,26 +429,20 @@ __global__ __launch_bounds__(256) void extract_kernel(FeatArgs A) {
       }
     }
     __syncthreads();
-    // every k in [sp, ep] with label <= 0 joins the ring's surface scan, in k order (:240-252): block compaction
-    const int base_cnt = s_cnt;
-    __syncthreads();
+    // every k in [sp, ep] with label <= 0 joins the ring's surface scan, in k order (:240-252): ballot compaction
     for (int base = sp; base <= ep; base += 256) {
       const int k = base + t;
-      const int v = (k <= ep && l_label[k - w0] <= 0) ? 1 : 0;
-      int inc = v;
+      const bool v = k <= ep && l_label[k - w0] <= 0;
+      const unsigned long long bal = __ballot(v);
+      if (lane == 0) s_cw[par][wv] = __popcll(bal);
+      __syncthreads();
+      int woff = 0, tot = 0;
 #pragma unroll
-      for (int off = 1; off < 64; off <<= 1) { int o = __shfl_up(inc, off, 64); if (lane >= off) inc += o; }
-      if (lane == 63) s_wsum[wv] = inc;
-      __syncthreads();
-      int woff = 0;
-      for (int w = 0; w < wv; w++) woff += s_wsum[w];
-      const int c = s_cnt;
-      if (v) list[c + woff + inc - 1] = k;
-      __syncthreads();
-      if (t == 255) s_cnt = c + woff + inc;
-      __syncthreads();
+      for (int w = 0; w < 4; w++) { const int c = s_cw[par][w]; tot += c; if (w < wv) woff += c; }
+      if (v) list[scan_cnt + woff + __popcll(bal & ((1ull << lane) - 1ull))] = k;
+      scan_cnt += tot;
+      par ^= 1;
     }
-    (void)base_cnt;
   }
   // write the ring's picked / label window back (the oracle's arrays after extraction)
   for (int i = t; i < wlen; i += 256) {
@@ -455,7 +456,7 @@ __global__ __launch_bounds__(256) void extract_kernel(FeatArgs A) {
   __syncthreads();
 
   // ---- pcl::VoxelGrid on the ring's surface scan (featureExtraction.cpp:254-258) ----
-  const int m = s_cnt;
+  const int m = scan_cnt;
   if (m == 0) { if (t == 0) A.surf_cnt[ring] = 0; return; }
   float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
   for (int i = t; i < m; i += 256) {
@@ -666,7 +667,7 @@ int front_extract_enqueue(Front* f, const rolo_front_params* P, hipStream_t s) {
   A.edge_threshold = P->edge_threshold; A.surf_threshold = P->surf_threshold; A.leaf = P->odometry_surf_leaf_size;
   A.corner_stage = f->corner_stage; A.corner_cnt = f->corner_cnt; A.surf_stage = f->surf_stage; A.surf_cnt = f->surf_cnt;
   const size_t WIN = FRONT_MAX_H + 32;
-  const size_t lds = sizeof(unsigned long long) * SORT_CAP + sizeof(int) * WIN * 7 + sizeof(int) * (FRONT_MAX_H + 16) + sizeof(int) * SECTOR_CAP;
+  const size_t lds = sizeof(unsigned long long) * SORT_CAP + sizeof(int) * WIN * 7 + sizeof(int) * (FRONT_MAX_H + 16);
   static bool attr_set = false;
   if (!attr_set) { FCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(extract_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set = true; }
   extract_kernel<<<NS, 256, lds, s>>>(A);
