@@ -152,7 +152,7 @@ def main():
         g = g or RotVGICP(local_rank)
         g.setResolution(args.leaf)
         g.setFixedIterations(int(os.environ.get("ROLO_BENCH_ITERS", "20")))
-        g.setOverlapKnn(alone or args.streams <= 1)  # with several contexts in flight the GPU is already shared between frames
+        g.setOverlapKnn(alone or args.streams <= 1 or bool(os.environ.get("ROLO_BENCH_FORCE_OVERLAP")))  # with several contexts in flight the GPU is already shared between frames
         g.setUseGraph(not args.no_graph)
         return g
 
