@@ -103,3 +103,30 @@ def test_fused_frame_equals_staged_nodes(sensor, cfg):
         assert rcr == rco
         assert np.abs(pose_r[:3] - pose_o[:3]).max() <= 1e-4 and np.abs(pose_r[3:] - pose_o[3:]).max() <= 1e-5
         assert np.abs(R_r - R_o).max() <= 1e-5 and np.abs(t_r - t_o).max() <= 1e-4
+
+
+def test_submit_collect_queue_rules():
+    from rolo_amd._lib import RoloError
+    cfg = dict(n_scan=16, horizon_scan=1800)
+    fg = front_params(**cfg)
+    od = LidarOdometry(0, 0.3)
+    with pytest.raises(RoloError) as ei:
+        od.collect()                                   # nothing submitted
+    assert ei.value.code == -5
+    frames = [synth.make_frame("vlp16", R, t, synth.SEED + k) for k, (R, t) in enumerate(trajectory(3))]
+    od.submit(fg, 100.0, frames[0].xyz, frames[0].ring)
+    od.submit(fg, 100.1, frames[1].xyz, frames[1].ring)
+    with pytest.raises(RoloError) as ei:
+        od.submit(fg, 100.2, frames[2].xyz, frames[2].ring)   # at most two frames in flight
+    assert ei.value.code == -5
+    with pytest.raises(RoloError) as ei:
+        od.frame(fg, 100.2, frames[2].xyz, frames[2].ring)    # frame() needs an empty queue
+    assert ei.value.code == -5
+    assert od.collect()[0] == 0 and od.collect()[0] == 1      # first frame stored, second gated
+    od.odometryHandler(100.15)
+    assert od.frame(fg, 100.2, frames[2].xyz, frames[2].ring)[0] == 2
+    # an empty frame is an error code of the registration, not a crash
+    empty = np.zeros((0, 3), np.float32)
+    with pytest.raises(RoloError):
+        od.frame(fg, 100.3, np.full((64, 3), 0.5, np.float32), np.zeros(64, np.uint16))   # everything below lidarMinRange
+    del empty

@@ -269,6 +269,54 @@ def test_errors_are_codes_not_crashes():
     assert ei.value.code == -4  # ROLO_ENOCORR
 
 
+def test_state_errors_of_the_async_batch_and_handover_entry_points():
+    """Misuse returns ROLO_ESTATE / ROLO_EUNSUPPORTED with a message; nothing is left half-enqueued."""
+    from rolo_amd._lib import RoloError
+    from rolo_amd.rotvgicp import RotVGICPBatch
+    src, tgt, cfg = make_pair("vlp16_polar")
+    g = RotVGICP(); g.setPolarResolution(*cfg["polar"])
+    with pytest.raises(RoloError) as ei:
+        g.register_wait()                      # nothing in flight
+    assert ei.value.code == -5
+    g.setInputTarget(tgt); g.setInputSource(src)
+    with pytest.raises(RoloError) as ei:
+        g.adoptTargetCovariances()             # the target has no covariances yet
+    assert ei.value.code == -5
+    g.register_async(None, np.zeros(3), G, L0)
+    with pytest.raises(RoloError) as ei:
+        g.register_async(None, np.zeros(3), G, L0)   # one registration per context at a time
+    assert ei.value.code == -5
+    Tf, Td, t = g.register_wait()
+    # hand-over: source := old target moved by a pure translation keeps the target's covariances
+    shift = np.array([0.25, -0.1, 0.05], np.float32)
+    moved = tgt.copy(); moved[:, :3] += shift
+    ref = RotVGICP(); ref.setPolarResolution(*cfg["polar"]); ref.setInputTarget(tgt); ref.setInputSource(moved); ref.computeCovariances()
+    g.setInputSource(moved); g.adoptTargetCovariances()
+    assert np.abs(g.getSourceCovariances() - ref.getSourceCovariances()).max() < 1e-5   # equal up to the float rounding of the moved points
+    with pytest.raises(RoloError) as ei:
+        g.adoptTargetCovariances()             # already handed over
+    assert ei.value.code == -5
+
+    b = RotVGICPBatch(2)
+    with pytest.raises(RoloError) as ei:
+        b.register_async(None, None, np.tile(G, (2, 1)), np.tile(L0, (2, 1)))   # members without clouds
+    assert ei.value.code == -5
+    for m in b.members:
+        m.setPolarResolution(*cfg["polar"]); m.setInputTarget(tgt); m.setInputSource(src)
+    b.members[1].setFixedIterations(5)
+    with pytest.raises(RoloError) as ei:
+        b.register_async(None, None, np.tile(G, (2, 1)), np.tile(L0, (2, 1)))   # members must share the schedule
+    assert ei.value.code == -7
+    b.members[1].setFixedIterations(0)
+    b.register_async(None, None, np.tile(G, (2, 1)), np.tile(L0, (2, 1)))
+    with pytest.raises(RoloError) as ei:
+        b.register_async(None, None, np.tile(G, (2, 1)), np.tile(L0, (2, 1)))
+    assert ei.value.code == -5
+    Tb, Tdb, tb = b.register_wait()
+    assert np.abs(Tdb[0] - Td).max() < 1e-11 and np.abs(Tdb[1] - Td).max() < 1e-11 and np.abs(tb[0] - t).max() < 1e-11
+    b.close()
+
+
 def test_transform_cloud_matches_pcl_restatement():
     src, _, _ = make_pair("vlp16_polar")
     pts = np.zeros((src.shape[0], 8), np.float32); pts[:, :4] = src; pts[:, 3] = 1.0; pts[:, 4] = src[:, 3]
