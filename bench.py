@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--streams", type=int, default=4,
                     help="registration contexts (HIP streams) kept in flight per GPU; a step is then one frame pair per stream")
     ap.add_argument("--no-pipeline", action="store_true", help="skip the raw-frame -> pose pipeline leg")
+    ap.add_argument("--pipeline-only", action="store_true", help="run only the pipeline leg and print its dict (profiling runs)")
     ap.add_argument("--batch", type=int, default=int(os.environ.get("ROLO_BENCH_BATCH", "1")),
                     help="frame pairs per registration call (rolo_batch_*: shared LM launches); 1 = one operator per frame")
     return ap.parse_args()
@@ -138,6 +139,9 @@ def main():
 
     from rolo_amd import synth
     from rolo_amd.rotvgicp import RotVGICP, RotVGICPBatch
+    if args.pipeline_only:
+        print(json.dumps(pipeline_leg(args, torch, local_rank)))
+        return
 
     # ---- synthetic inputs (rank-specific seed in replicas mode: independent frames) ----
     seed = synth.SEED + (rank if args.mode == "replicas" else 0)
