@@ -41,7 +41,9 @@ def parse():
     ap.add_argument("--mode", default="replicas", choices=["replicas", "shard"])
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay (profiling runs)")
-    ap.add_argument("--no-shard-leg", action="store_true", help="N>1: skip the extra point-sharded measurement")
+    ap.add_argument("--shard-leg", action="store_true",
+                    help="N>1: also time ONE frame with its source points sharded over the ranks (RCCL all-reduce of 32 fp64 per LM pass); "
+                         "opt-in because this container has a single GPU and that collective path has only run in the 2-rank gloo test")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="length of the bounded cpu_baseline sample")
     ap.add_argument("--streams", type=int, default=4,
                     help="registration contexts (HIP streams) kept in flight per GPU; a step is then one frame pair per stream")
@@ -284,7 +286,7 @@ def main():
         out["roofline"] = {"error": repr(e)}
 
     # ---- optional: point-sharded leg at N>1 (never allowed to take the main number down with it) ----
-    if world > 1 and args.mode == "replicas" and not args.no_shard_leg:
+    if world > 1 and args.mode == "replicas" and args.shard_leg:
         try:
             src0, tgt0, _ = synth.dense_pair(args.sensor, seed=synth.SEED)
             d_src.copy_(torch.from_numpy(src0)); d_tgt.copy_(torch.from_numpy(tgt0))
