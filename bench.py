@@ -266,6 +266,19 @@ def main():
                    "passes_per_frame": passes, "n_correspondences": rs.n_correspondences},
     }
 
+    # ---- frame-level HBM figure of BASELINE.json's metric ("scans/sec ...; achieved HBM GB/s"): SURVEY.md 8d's ALGORITHMIC bytes of
+    # one frame (360 B/pt covariances for both clouds, 136 B/pt + 96 B/voxel map build, 104 B/pt per linearise and per error
+    # evaluation; a fused pass is one of each except the first of a stage) x scans/s. `roofline` below stays the dominant kernel.
+    try:
+        from rolo_amd._lib import lib as _rl
+        V = max(int(_rl().rolo_num_voxels(g._h)), 0)
+        n_eval = sum(2 * st.n_passes - 1 for st in (rs, ts))
+        frame_bytes = 360.0 * 2 * n + 136.0 * n + 96.0 * V + 104.0 * n * n_eval
+        out["frame_hbm"] = {"algorithmic_bytes_per_frame": frame_bytes, "achieved": frame_bytes * value / 1e9, "peak": HBM_PEAK_GBS * world,
+                            "unit": "GB/s", "frac": frame_bytes * value / 1e9 / (HBM_PEAK_GBS * world), "voxels": V, "linearise_plus_error_evaluations": n_eval}
+    except Exception as e:  # pragma: no cover
+        out["frame_hbm"] = {"error": repr(e)}
+
     # ---- single-frame latency: one context alone (source / target searches overlapped on two streams) ----
     if (len(ctxs) > 1 or B > 1) and args.mode == "replicas":
         gl = new_ctx(alone=True)

@@ -325,12 +325,12 @@ def test_transform_cloud_matches_pcl_restatement():
     assert np.array_equal(g.transformPointCloud(pts, T), pyorc.transform_cloud_f(pts, T))
 
 
-# ---- full-size, size-independent properties (BASELINE configs 2 and the 128k headline frame) ----------------
-@pytest.mark.parametrize("sensor,leaf", [("os1-64", 1.0), ("os1-128", 0.5)])
+# ---- full-size, size-independent properties (BASELINE configs[1], the 128k headline frame, configs[2] = 262k) ----
+@pytest.mark.parametrize("sensor,leaf", [("os1-64", 1.0), ("os1-128", 0.5), ("os1-128x2048", 0.5)])
 def test_full_size_properties(sensor, leaf):
     src, tgt, (R, t) = synth.dense_pair(sensor)
     n = src.shape[0]
-    assert n in (65536, 131072)
+    assert n in (65536, 131072, 262144)
     g = RotVGICP(); g.setResolution(leaf); g.setFixedIterations(20)
     g.setInputTarget(tgt); g.setInputSource(src)
     # (1) voxel map conserves mass: counts sum to N_t, count-weighted mean of voxel means = cloud mean
