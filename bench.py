@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="length of the bounded cpu_baseline sample")
     ap.add_argument("--streams", type=int, default=4,
                     help="registration contexts (HIP streams) kept in flight per GPU; a step is then one frame pair per stream")
+    ap.add_argument("--pair-search", default="on", choices=["on", "off"],
+                    help="search source and target of a frame in one chain of launches (rolo_params.overlap_knn, the library default)")
     ap.add_argument("--no-pipeline", action="store_true", help="skip the raw-frame -> pose pipeline leg")
     ap.add_argument("--pipeline-only", action="store_true", help="run only the pipeline leg and print its dict (profiling runs)")
     ap.add_argument("--batch", type=int, default=int(os.environ.get("ROLO_BENCH_BATCH", "1")),
@@ -158,7 +160,7 @@ def main():
         g = g or RotVGICP(local_rank)
         g.setResolution(args.leaf)
         g.setFixedIterations(int(os.environ.get("ROLO_BENCH_ITERS", "20")))
-        g.setOverlapKnn(alone or args.streams <= 1 or bool(os.environ.get("ROLO_BENCH_FORCE_OVERLAP")))  # with several contexts in flight the GPU is already shared between frames
+        g.setOverlapKnn(args.pair_search == "on")
         g.setUseGraph(not args.no_graph)
         return g
 
@@ -279,7 +281,7 @@ def main():
     except Exception as e:  # pragma: no cover
         out["frame_hbm"] = {"error": repr(e)}
 
-    # ---- single-frame latency: one context alone (source / target searches overlapped on two streams) ----
+    # ---- single-frame latency: one context alone ----
     if (len(ctxs) > 1 or B > 1) and args.mode == "replicas":
         gl = new_ctx(alone=True)
         lsteps = max(5, min(args.steps, 20))

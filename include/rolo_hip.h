@@ -52,8 +52,8 @@ typedef struct rolo_params {
   double lm_init_lambda_factor;  /* setInitialLambdaFactor :35-37 (1e-9) */
   int fixed_iterations;          /* harness knob: >0 runs exactly this many outer iterations of align() */
   int q2_intended;               /* 0 as written, 1 intended continuous-time term */
-  int overlap_knn;               /* tuning knob (default 1): run the source / target neighbourhood searches concurrently on two
-                                    HIP streams — lowers single-frame latency; set 0 when several contexts share the GPU */
+  int overlap_knn;               /* tuning knob (default 1): source and target go through ONE chain of search launches (every
+                                    kernel works on the pair) instead of one chain per cloud — both searches start together */
   int use_graph;                 /* tuning knob (default 1): rolo_register_async captures the frame's fixed launch schedule in a
                                     hipGraph on the second frame with unchanged sizes / buffers / parameters and replays it */
 } rolo_params;

@@ -179,53 +179,62 @@ int upload_cloud(rolo_ctx* c, CloudDev& cl, size_t& xyz_cap, const float* pts, i
   return ROLO_OK;
 }
 
-int build_knn_and_cov(rolo_ctx* c, CloudDev& cl, size_t& cov_cap, size_t& sorted_cap, size_t& boxes_cap, size_t& knn_cap, size_t& knnd_cap,
-                      int which, hipStream_t stream) {
+// search structures of one cloud: geometry + allocations
+int prepare_cloud(rolo_ctx* c, CloudDev& cl, size_t& cov_cap, size_t& sorted_cap, size_t& boxes_cap, size_t& knn_cap, size_t& knnd_cap, KnnCloud& out) {
   const int n = cl.n, k = c->P.k_correspondences;
   if (k < 1 || k > 32) { g_err = "k_correspondences must be in [1,32]"; return ROLO_EUNSUPPORTED; }
   if (n < k) { g_err = "cloud has fewer points than k_correspondences"; return ROLO_ETOOFEW; }
   cl.n_leaves = (n + 7) / 8;
   int P = 2; while (P < cl.n_leaves) P <<= 1;
   cl.P = P;
-  rolo_ctx::KnnScratch& S = c->ks[which];
   int rc;
   if ((rc = ensure(cl.cov, cov_cap, 6 * (size_t)n))) return rc;
   if ((rc = ensure(cl.sorted, sorted_cap, 8 * (size_t)cl.n_leaves))) return rc;
   if ((rc = ensure(cl.boxes, boxes_cap, 4 * (size_t)P))) return rc;
-  if ((rc = ensure(S.keys0, S.keys0_cap, (size_t)n))) return rc;
-  if ((rc = ensure(S.keys1, S.keys1_cap, (size_t)n))) return rc;
-  if ((rc = ensure(S.vals0, S.vals0_cap, (size_t)n))) return rc;
-  if ((rc = ensure(S.vals1, S.vals1_cap, (size_t)n))) return rc;
-  if ((rc = ensure(S.bbox, S.bbox_cap, 8))) return rc;
-  size_t tmp = knn_sort_temp_bytes(n);
-  if ((rc = ensure(S.sort_tmp, S.sort_tmp_cap, tmp + 256))) return rc;
   if (c->want_knn_lists) {
     if ((rc = ensure(cl.knn_idx, knn_cap, (size_t)n * k))) return rc;
     if ((rc = ensure(cl.knn_d2, knnd_cap, (size_t)n * k))) return rc;
   }
-  { ProfScope ps(c, ROLO_PROF_KNN_BUILD, stream); HIPCHK(launch_knn_build(cl, S.sort_tmp, tmp, S.keys0, S.keys1, S.vals0, S.vals1, S.bbox, stream)); }
-  { ProfScope ps(c, ROLO_PROF_KNN_COV, stream); HIPCHK(launch_knn_cov(cl, k, c->P.regularization, c->want_knn_lists, stream)); }
-  cl.have_cov = true;
+  out.xyz = cl.xyz; out.sorted = cl.sorted; out.boxes = cl.boxes; out.cov = cl.cov;
+  out.knn_idx = c->want_knn_lists ? cl.knn_idx : nullptr; out.knn_d2 = c->want_knn_lists ? cl.knn_d2 : nullptr;
+  out.n = n; out.n_leaves = cl.n_leaves; out.P = P; out.n_sorted = 8 * cl.n_leaves;
   return ROLO_OK;
 }
 
-int build_src(rolo_ctx* c, hipStream_t s) { return build_knn_and_cov(c, c->src, c->src_cov_cap, c->src_sorted_cap, c->src_boxes_cap, c->src_knn_cap, c->src_knnd_cap, 0, s); }
-int build_tgt(rolo_ctx* c, hipStream_t s) { return build_knn_and_cov(c, c->tgt, c->tgt_cov_cap, c->tgt_sorted_cap, c->tgt_boxes_cap, c->tgt_knn_cap, c->tgt_knnd_cap, 1, s); }
+// Morton sort, BVH, neighbour search and covariances of the source and / or the target in ONE chain of launches.
+// A pair shares the scratch set 0; a lone target uses set 1 so that it can run next to a lone source on another stream.
+int build_clouds(rolo_ctx* c, bool do_src, bool do_tgt, hipStream_t stream) {
+  KnnPair A{};
+  int rc, nc = 0;
+  if (do_src) { if ((rc = prepare_cloud(c, c->src, c->src_cov_cap, c->src_sorted_cap, c->src_boxes_cap, c->src_knn_cap, c->src_knnd_cap, A.c[nc]))) return rc; nc++; }
+  if (do_tgt) { if ((rc = prepare_cloud(c, c->tgt, c->tgt_cov_cap, c->tgt_sorted_cap, c->tgt_boxes_cap, c->tgt_knn_cap, c->tgt_knnd_cap, A.c[nc]))) return rc; nc++; }
+  if (nc == 0) return ROLO_OK;
+  A.n_clouds = nc;
+  const size_t n_total = (size_t)A.c[0].n + (nc > 1 ? (size_t)A.c[1].n : 0);
+  rolo_ctx::KnnScratch& S = c->ks[(do_tgt && !do_src) ? 1 : 0];
+  if ((rc = ensure(S.keys0, S.keys0_cap, n_total))) return rc;
+  if ((rc = ensure(S.keys1, S.keys1_cap, n_total))) return rc;
+  if ((rc = ensure(S.vals0, S.vals0_cap, n_total))) return rc;
+  if ((rc = ensure(S.vals1, S.vals1_cap, n_total))) return rc;
+  if ((rc = ensure(S.bbox, S.bbox_cap, 16))) return rc;
+  const size_t tmp = knn_sort_temp_bytes((int)n_total);
+  if ((rc = ensure(S.sort_tmp, S.sort_tmp_cap, tmp + 256))) return rc;
+  { ProfScope ps(c, ROLO_PROF_KNN_BUILD, stream); HIPCHK(launch_knn_build(A, S.sort_tmp, tmp, S.keys0, S.keys1, S.vals0, S.vals1, S.bbox, stream)); }
+  { ProfScope ps(c, ROLO_PROF_KNN_COV, stream); HIPCHK(launch_knn_cov(A, c->P.k_correspondences, c->P.regularization, stream)); }
+  if (do_src) c->src.have_cov = true;
+  if (do_tgt) c->tgt.have_cov = true;
+  return ROLO_OK;
+}
+
+int build_src(rolo_ctx* c, hipStream_t s) { return build_clouds(c, true, false, s); }
+int build_tgt(rolo_ctx* c, hipStream_t s) { return build_clouds(c, false, true, s); }
 
 int ensure_covs(rolo_ctx* c) {
   if (c->src.n <= 0 || c->tgt.n <= 0) { g_err = "source/target not set"; return ROLO_ESTATE; }
   int rc;
-  if (!c->src.have_cov && !c->tgt.have_cov && c->P.overlap_knn) {
-    // The two neighbourhood searches are independent and each is only ~2 wavefronts per SIMD wide: run the target's
-    // on a second stream (fork / join with events) so they overlap.
-    HIPCHK(hipEventRecord(c->ev_fork, c->stream));
-    HIPCHK(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
-    if ((rc = build_tgt(c, c->stream2))) return rc;
-    if ((rc = build_src(c, c->stream))) return rc;
-    HIPCHK(hipEventRecord(c->ev_join, c->stream2));
-    HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join, 0));
-    return ROLO_OK;
-  }
+  // overlap_knn: both clouds go through one chain of launches (every kernel works on the pair), so the two searches
+  // start together; off = one chain per cloud, back to back
+  if (!c->src.have_cov && !c->tgt.have_cov && c->P.overlap_knn) return build_clouds(c, true, true, c->stream);
   if (!c->src.have_cov && (rc = build_src(c, c->stream))) return rc;
   if (!c->tgt.have_cov && (rc = build_tgt(c, c->stream))) return rc;
   return ROLO_OK;

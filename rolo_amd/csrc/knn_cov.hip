@@ -25,15 +25,25 @@ namespace {
 ROLO_DEV int f2ord(float f) { int i = __float_as_int(f); return i >= 0 ? i : i ^ 0x7fffffff; }
 ROLO_DEV float ord2f(int k) { int i = k >= 0 ? k : k ^ 0x7fffffff; return __int_as_float(i); }
 
-__global__ void bbox_init_kernel(int* bbox) {
-  if (threadIdx.x < 3) bbox[threadIdx.x] = INT_MAX;
-  else if (threadIdx.x < 6) bbox[threadIdx.x] = INT_MIN;
+// Every kernel of the search takes a KnnPair: the source and the target cloud of a registration go through ONE chain of
+// launches (workgroups [0, split) belong to cloud 0, the rest to cloud 1) — half the launches of two separate chains,
+// both searches start together and fill the chip that one search alone leaves half empty. A single cloud is a pair
+// with n_clouds = 1.
+constexpr int BBOX_BLOCKS = 64;
+
+__global__ void bbox_init_kernel(int* bbox) {  // 2 clouds x (min xyz, max xyz)
+  const int t = threadIdx.x;
+  if (t < 12) bbox[t] = (t % 6) < 3 ? INT_MAX : INT_MIN;
 }
 
-__global__ __launch_bounds__(256) void bbox_kernel(const float4* __restrict__ p, int n, int* bbox) {
+__global__ __launch_bounds__(256) void bbox_kernel(KnnPair A, int* bbox) {
   __shared__ float smn[4][3], smx[4][3];
+  const int which = blockIdx.x / BBOX_BLOCKS, blk = blockIdx.x - which * BBOX_BLOCKS;
+  const float4* __restrict__ p = A.c[which].xyz;
+  const int n = A.c[which].n;
+  bbox += 6 * which;
   float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+  for (int i = blk * blockDim.x + threadIdx.x; i < n; i += BBOX_BLOCKS * blockDim.x) {
     float4 q = p[i];
     mn[0] = fminf(mn[0], q.x); mn[1] = fminf(mn[1], q.y); mn[2] = fminf(mn[2], q.z);
     mx[0] = fmaxf(mx[0], q.x); mx[1] = fmaxf(mx[1], q.y); mx[2] = fmaxf(mx[2], q.z);
@@ -71,9 +81,15 @@ ROLO_DEV uint32_t expand10(uint32_t v) {
   return v;
 }
 
-__global__ __launch_bounds__(256) void morton_kernel(const float4* __restrict__ p, int n, const int* __restrict__ bbox,
-                                                    uint32_t* keys, uint32_t* vals) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
+// keys: 30-bit Morton code + the cloud number in bit 30, so one sort of both clouds leaves each cloud sorted in its own
+// range [0, n0) / [n0, n0 + n1) of the arrays
+__global__ __launch_bounds__(256) void morton_kernel(KnnPair A, int split, const int* __restrict__ bbox, uint32_t* keys, uint32_t* vals) {
+  const int which = (int)blockIdx.x >= split ? 1 : 0;
+  const float4* __restrict__ p = A.c[which].xyz;
+  const int n = A.c[which].n;
+  const int off = which ? A.c[0].n : 0;
+  bbox += 6 * which; keys += off; vals += off;
+  int i = ((int)blockIdx.x - (which ? split : 0)) * blockDim.x + threadIdx.x;
   if (i >= n) return;
   float mnx = ord2f(bbox[0]), mny = ord2f(bbox[1]), mnz = ord2f(bbox[2]);
   float ext = fmaxf(fmaxf(ord2f(bbox[3]) - mnx, ord2f(bbox[4]) - mny), ord2f(bbox[5]) - mnz);
@@ -82,14 +98,18 @@ __global__ __launch_bounds__(256) void morton_kernel(const float4* __restrict__ 
   int ix = min(1023, max(0, (int)((q.x - mnx) * sc)));
   int iy = min(1023, max(0, (int)((q.y - mny) * sc)));
   int iz = min(1023, max(0, (int)((q.z - mnz) * sc)));
-  keys[i] = expand10(ix) | (expand10(iy) << 1) | (expand10(iz) << 2);
+  keys[i] = expand10(ix) | (expand10(iy) << 1) | (expand10(iz) << 2) | ((uint32_t)which << 30);
   vals[i] = (uint32_t)i;
 }
 
 // one thread per leaf: gather its 8 points in Morton order, write them + the leaf box
-__global__ __launch_bounds__(256) void leaf_kernel(const float4* __restrict__ p, const uint32_t* __restrict__ order, int n,
-                                                  int n_leaves, int P, float4* sorted, float4* boxes) {
-  int g = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void leaf_kernel(KnnPair A, int split, const uint32_t* __restrict__ order) {
+  const int which = (int)blockIdx.x >= split ? 1 : 0;
+  const float4* __restrict__ p = A.c[which].xyz;
+  const int n = A.c[which].n, n_leaves = A.c[which].n_leaves, P = A.c[which].P;
+  float4* sorted = A.c[which].sorted; float4* boxes = A.c[which].boxes;
+  order += which ? A.c[0].n : 0;
+  int g = ((int)blockIdx.x - (which ? split : 0)) * blockDim.x + threadIdx.x;
   if (g >= P) return;
   float4 lo = make_float4(INFINITY, INFINITY, INFINITY, 0.f), hi = make_float4(-INFINITY, -INFINITY, -INFINITY, 0.f);
   if (g < n_leaves) {
@@ -115,9 +135,12 @@ __global__ __launch_bounds__(256) void leaf_kernel(const float4* __restrict__ p,
 
 // Builds log2(chunk) levels of the implicit BVH in LDS: inputs are the `count_in` nodes at heap indices
 // [count_in, 2*count_in); block b owns inputs [b*chunk, (b+1)*chunk).
-__global__ __launch_bounds__(256) void tree_reduce_kernel(float4* boxes, int count_in, int chunk) {
+__global__ __launch_bounds__(256) void tree_reduce_kernel(float4* boxes0, int count_in0, int chunk0, int split, float4* boxes1, int count_in1, int chunk1) {
   __shared__ float4 lo[512], hi[512];
-  const int b = blockIdx.x, t = threadIdx.x;
+  const bool second = (int)blockIdx.x >= split;
+  float4* boxes = second ? boxes1 : boxes0;
+  const int count_in = second ? count_in1 : count_in0, chunk = second ? chunk1 : chunk0;
+  const int b = (int)blockIdx.x - (second ? split : 0), t = threadIdx.x;
   const size_t base_in = (size_t)count_in + (size_t)b * chunk;
   for (int i = t; i < chunk; i += 256) { lo[i] = boxes[2 * (base_in + i)]; hi[i] = boxes[2 * (base_in + i) + 1]; }
   __syncthreads();
@@ -294,29 +317,34 @@ ROLO_DEV void knn_covariance_tail(const int (&ki)[KMAX], int kk, const float4* _
 
 namespace rolo {
 
-size_t knn_sort_temp_bytes(int n) {
+size_t knn_sort_temp_bytes(int n) {  // for n points in total (one cloud or the sum of a pair), keys of up to 31 bits
   size_t bytes = 0;
   (void)rocprim::radix_sort_pairs(nullptr, bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
-                                  (size_t)n, 0, 30, (hipStream_t)0);
+                                  (size_t)n, 0, 31, (hipStream_t)0);
   return bytes;
 }
 
-// Morton sort + implicit BVH for one cloud. c.sorted / c.boxes must be allocated for c.n_leaves / c.P.
-hipError_t launch_knn_build(CloudDev& c, void* sort_tmp, size_t sort_tmp_bytes, uint32_t* keys0, uint32_t* keys1,
+// Morton sort + implicit BVHs of the pair's clouds. sorted / boxes must be allocated for n_leaves / P of each cloud;
+// keys / vals hold n0 + n1 entries, bbox 12 ints.
+hipError_t launch_knn_build(const KnnPair& A, void* sort_tmp, size_t sort_tmp_bytes, uint32_t* keys0, uint32_t* keys1,
                             uint32_t* vals0, uint32_t* vals1, int* bbox, hipStream_t s) {
-  const int n = c.n;
+  const int nc = A.n_clouds;
+  const int n_total = A.c[0].n + (nc > 1 ? A.c[1].n : 0);
   bbox_init_kernel<<<1, 64, 0, s>>>(bbox);
-  int grid = min((n + 255) / 256, 64);
-  bbox_kernel<<<grid, 256, 0, s>>>(c.xyz, n, bbox);
-  morton_kernel<<<(n + 255) / 256, 256, 0, s>>>(c.xyz, n, bbox, keys0, vals0);
-  hipError_t e = rocprim::radix_sort_pairs(sort_tmp, sort_tmp_bytes, keys0, keys1, vals0, vals1, (size_t)n, 0, 30, s);
+  bbox_kernel<<<BBOX_BLOCKS * nc, 256, 0, s>>>(A, bbox);
+  const int g0 = (A.c[0].n + 255) / 256, g1 = nc > 1 ? (A.c[1].n + 255) / 256 : 0;
+  morton_kernel<<<g0 + g1, 256, 0, s>>>(A, g0, bbox, keys0, vals0);
+  hipError_t e = rocprim::radix_sort_pairs(sort_tmp, sort_tmp_bytes, keys0, keys1, vals0, vals1, (size_t)n_total, 0, nc > 1 ? 31 : 30, s);
   if (e != hipSuccess) return e;
-  leaf_kernel<<<(c.P + 255) / 256, 256, 0, s>>>(c.xyz, vals1, n, c.n_leaves, c.P, c.sorted, c.boxes);
-  int count = c.P;
-  while (count > 1) {
-    int chunk = count < 512 ? count : 512;
-    tree_reduce_kernel<<<count / chunk, 256, 0, s>>>(c.boxes, count, chunk);
-    count /= chunk;
+  const int l0 = (A.c[0].P + 255) / 256, l1 = nc > 1 ? (A.c[1].P + 255) / 256 : 0;
+  leaf_kernel<<<l0 + l1, 256, 0, s>>>(A, l0, vals1);
+  int count0 = A.c[0].P, count1 = nc > 1 ? A.c[1].P : 1;
+  while (count0 > 1 || count1 > 1) {
+    const int chunk0 = count0 < 512 ? count0 : 512, chunk1 = count1 < 512 ? count1 : 512;
+    const int b0 = count0 > 1 ? count0 / chunk0 : 0, b1 = count1 > 1 ? count1 / chunk1 : 0;
+    tree_reduce_kernel<<<b0 + b1, 256, 0, s>>>(A.c[0].boxes, count0, chunk0, b0, nc > 1 ? A.c[1].boxes : nullptr, count1, chunk1);
+    if (count0 > 1) count0 /= chunk0;
+    if (count1 > 1) count1 /= chunk1;
   }
   return hipGetLastError();
 }
@@ -330,15 +358,10 @@ extern "C" int rolo_debug_counters(unsigned long long* out, int reset) {
 }
 #endif
 
-hipError_t launch_knn_cov(CloudDev& c, int k, int regularization, bool want_lists, hipStream_t s) {
-  const int n_sorted = 8 * c.n_leaves;
-  const int grid = (n_sorted + 255) / 256;
-  int32_t* li = want_lists ? c.knn_idx : nullptr;
-  float* ld = want_lists ? c.knn_d2 : nullptr;
-  if (k == 20)
-    knn_cov_kernel<20><<<grid, 256, 0, s>>>(c.sorted, c.boxes, c.xyz, c.n, n_sorted, c.P, k, regularization, c.cov, li, ld);
-  else
-    knn_cov_kernel<32><<<grid, 256, 0, s>>>(c.sorted, c.boxes, c.xyz, c.n, n_sorted, c.P, k, regularization, c.cov, li, ld);
+hipError_t launch_knn_cov(const KnnPair& A, int k, int regularization, hipStream_t s) {
+  const int g0 = (A.c[0].n_sorted + 255) / 256, g1 = A.n_clouds > 1 ? (A.c[1].n_sorted + 255) / 256 : 0;
+  if (k == 20) knn_cov_kernel<20><<<g0 + g1, 256, 0, s>>>(A, g0, k, regularization);
+  else knn_cov_kernel<32><<<g0 + g1, 256, 0, s>>>(A, g0, k, regularization);
   return hipGetLastError();
 }
 

@@ -75,13 +75,20 @@ ROLO_DEV void knn_score_leaf(const float4* __restrict__ sorted, int g, const flo
 }
 
 template <int KMAX>
-__global__ __launch_bounds__(256, 4) void knn_cov_kernel(const float4* __restrict__ sorted, const float4* __restrict__ boxes,
-                                                     const float4* __restrict__ orig, int n, int n_sorted, int P, int k,
-                                                     int reg, double* __restrict__ cov, int32_t* knn_idx, float* knn_d2) {
+__global__ __launch_bounds__(256, 4) void knn_cov_kernel(KnnPair A, int split, int k, int reg) {
   __shared__ int stk[4][WALK_STACK];
   const int tid = threadIdx.x;
   const int wv = tid >> 6;
-  const int j = blockIdx.x * 256 + tid;
+  // which cloud of the pair this workgroup searches (wave-uniform: everything below stays in scalar registers)
+  const int which = (int)blockIdx.x >= split ? 1 : 0;
+  const float4* __restrict__ sorted = A.c[which].sorted;
+  const float4* __restrict__ boxes = A.c[which].boxes;
+  const float4* __restrict__ orig = A.c[which].xyz;
+  double* __restrict__ cov = A.c[which].cov;
+  int32_t* knn_idx = A.c[which].knn_idx;
+  float* knn_d2 = A.c[which].knn_d2;
+  const int n = A.c[which].n, n_sorted = A.c[which].n_sorted, P = A.c[which].P;
+  const int j = ((int)blockIdx.x - (which ? split : 0)) * 256 + tid;
   float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
   int qi = INT_MAX;
   if (j < n_sorted) { q = sorted[j]; qi = __float_as_int(q.w); }

@@ -2,7 +2,8 @@
 
 ALGORITHMIC bytes (fixed definitions; compact records P = 16 B point, C = 24 B covariance,
 R = 48 B voxel record, S = 16 B hash slot):
-  knn_cov_kernel   (K5)      : (P + K*P + C) = 360 B per point of the cloud it is launched on
+  knn_cov_kernel   (K5)      : (P + K*P + C) = 360 B per point of the cloud(s) it is launched on (one cloud, or the
+                               source/target pair of a frame when overlap_knn is set)
   rot_pass_kernel  (K7+K8+K10): (P + C + S + R) = 104 B per source point per pass
   trans_pass_kernel (K11)     : 104 B per source point per pass
 """
@@ -61,7 +62,12 @@ def roofline(g, run_one_step, n_src, n_tgt, passes_per_frame, hbm_peak_gbs, reps
     # dominant kernel = largest share of the frame among the HBM-streaming kernels
     cands = {k: per_frame_ms[k] for k in BYTES_PER_POINT}
     dom = max(cands, key=cands.get)
-    npts = n_src if dom != "knn_cov" else 0.5 * (n_src + n_tgt)
+    if dom == "knn_cov":
+        # one launch searches one cloud, or the source/target pair of a frame (overlap_knn)
+        launches = np.mean([len(r) for r in acc["knn_cov"]]) if acc["knn_cov"] else 2.0
+        npts = (n_src + n_tgt) / max(launches, 1.0)
+    else:
+        npts = n_src
     algo_bytes = BYTES_PER_POINT[dom] * npts
     achieved = algo_bytes / (avg_ms[dom] * 1e-3) / 1e9 if avg_ms[dom] > 0 else 0.0
     traffic = None
