@@ -186,7 +186,7 @@ int rolo_comm_destroy(rolo_ctx* ctx);
 /* Per-kernel timing with HIP events on the context's stream (bench.py's "roofline" object). While enabled, every
  * launch of the listed kernels is bracketed by an event pair; rolo_prof_read synchronises the stream and returns
  * the durations (ms) of one slot in launch order, then forgets them. Returns the number of launches recorded. */
-enum { ROLO_PROF_KNN_BUILD = 0, ROLO_PROF_KNN_COV, ROLO_PROF_VOXEL_BUILD, ROLO_PROF_ROT_PASS, ROLO_PROF_TRANS_PASS, ROLO_PROF_CTRL, ROLO_PROF_N };
+enum { ROLO_PROF_KNN_BUILD = 0, ROLO_PROF_KNN_WALK, ROLO_PROF_VOXEL_BUILD, ROLO_PROF_ROT_PASS, ROLO_PROF_TRANS_PASS, ROLO_PROF_CTRL, ROLO_PROF_KNN_TAIL, ROLO_PROF_N };
 int rolo_prof_enable(rolo_ctx* ctx, int on);
 int rolo_prof_read(rolo_ctx* ctx, int slot, float* ms, int cap);
 

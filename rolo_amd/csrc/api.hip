@@ -92,6 +92,7 @@ struct rolo_ctx {
     uint32_t *keys0 = nullptr, *keys1 = nullptr, *vals0 = nullptr, *vals1 = nullptr;
     size_t keys0_cap = 0, keys1_cap = 0, vals0_cap = 0, vals1_cap = 0;
     int* bbox = nullptr; size_t bbox_cap = 0;
+    int32_t* nbr = nullptr; size_t nbr_cap = 0;   // neighbour indices between the walk and the covariance kernel
   } ks[2];
   hipStream_t stream2 = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -217,10 +218,13 @@ int build_clouds(rolo_ctx* c, bool do_src, bool do_tgt, hipStream_t stream) {
   if ((rc = ensure(S.vals0, S.vals0_cap, n_total))) return rc;
   if ((rc = ensure(S.vals1, S.vals1_cap, n_total))) return rc;
   if ((rc = ensure(S.bbox, S.bbox_cap, 16))) return rc;
+  if ((rc = ensure(S.nbr, S.nbr_cap, 32 * ((size_t)A.c[0].n_sorted + (nc > 1 ? (size_t)A.c[1].n_sorted : 0))))) return rc;
+  A.c[0].nbr = S.nbr; if (nc > 1) A.c[1].nbr = S.nbr + 32 * (size_t)A.c[0].n_sorted;
   const size_t tmp = knn_sort_temp_bytes((int)n_total);
   if ((rc = ensure(S.sort_tmp, S.sort_tmp_cap, tmp + 256))) return rc;
   { ProfScope ps(c, ROLO_PROF_KNN_BUILD, stream); HIPCHK(launch_knn_build(A, S.sort_tmp, tmp, S.keys0, S.keys1, S.vals0, S.vals1, S.bbox, stream)); }
-  { ProfScope ps(c, ROLO_PROF_KNN_COV, stream); HIPCHK(launch_knn_cov(A, c->P.k_correspondences, c->P.regularization, stream)); }
+  { ProfScope ps(c, ROLO_PROF_KNN_WALK, stream); HIPCHK(launch_knn_walk(A, c->P.k_correspondences, stream)); }
+  { ProfScope ps(c, ROLO_PROF_KNN_TAIL, stream); HIPCHK(launch_knn_tail(A, c->P.k_correspondences, c->P.regularization, stream)); }
   if (do_src) c->src.have_cov = true;
   if (do_tgt) c->tgt.have_cov = true;
   return ROLO_OK;
@@ -435,7 +439,7 @@ void rolo_ctx_destroy(rolo_ctx* c) {
   if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
   void* bufs[] = {c->src.xyz, c->src.cov, c->src.sorted, c->src.boxes, c->src.knn_idx, c->src.knn_d2, c->tgt.xyz, c->tgt.cov, c->tgt.sorted,
                   c->tgt.boxes, c->tgt.knn_idx, c->tgt.knn_d2, c->ks[0].sort_tmp, c->ks[0].keys0, c->ks[0].keys1, c->ks[0].vals0, c->ks[0].vals1, c->ks[0].bbox,
-                  c->ks[1].sort_tmp, c->ks[1].keys0, c->ks[1].keys1, c->ks[1].vals0, c->ks[1].vals1, c->ks[1].bbox, c->tab.keys,
+                  c->ks[1].sort_tmp, c->ks[1].keys0, c->ks[1].keys1, c->ks[1].vals0, c->ks[1].vals1, c->ks[1].bbox, c->ks[0].nbr, c->ks[1].nbr, c->tab.keys,
                   c->tab.ids, c->tab.rec, c->tab.id_keys, c->tgt_keys, c->tgt_slot, c->counters, c->corr[0], c->corr[1], c->partials, c->sums,
                   c->state, c->trace, c->stage_in, c->stage_out, c->stage_d, c->stage_i};
   for (void* b : bufs) if (b) (void)hipFree(b);

@@ -10,6 +10,8 @@
 // queries share one walk. Exactness: distances are float ((dx*dx)+(dy*dy))+(dz*dz) with FMA contraction off,
 // box bounds use the same operation order so they are true lower bounds, ties are explored (<=) and broken by
 // original point index — the neighbour set is the same pure function of the cloud the oracle computes.
+// Two kernels: the walk (58 VGPRs: 8 wavefronts per SIMD, so searches of several contexts share the chip) hands the
+// neighbour indices to the covariance kernel (whose 3x3 fp64 SVD needs ~150 VGPRs); fused they ran at 4 per SIMD.
 #include <cstring>
 #include <string.h>
 #include "rolo_internal.hpp"
@@ -358,10 +360,17 @@ extern "C" int rolo_debug_counters(unsigned long long* out, int reset) {
 }
 #endif
 
-hipError_t launch_knn_cov(const KnnPair& A, int k, int regularization, hipStream_t s) {
+hipError_t launch_knn_walk(const KnnPair& A, int k, hipStream_t s) {
   const int g0 = (A.c[0].n_sorted + 255) / 256, g1 = A.n_clouds > 1 ? (A.c[1].n_sorted + 255) / 256 : 0;
-  if (k == 20) knn_cov_kernel<20><<<g0 + g1, 256, 0, s>>>(A, g0, k, regularization);
-  else knn_cov_kernel<32><<<g0 + g1, 256, 0, s>>>(A, g0, k, regularization);
+  if (k == 20) knn_walk_kernel<20><<<g0 + g1, 256, 0, s>>>(A, g0, k);
+  else knn_walk_kernel<32><<<g0 + g1, 256, 0, s>>>(A, g0, k);
+  return hipGetLastError();
+}
+
+hipError_t launch_knn_tail(const KnnPair& A, int k, int regularization, hipStream_t s) {
+  const int g0 = (A.c[0].n_sorted + 255) / 256, g1 = A.n_clouds > 1 ? (A.c[1].n_sorted + 255) / 256 : 0;
+  if (k == 20) knn_tail_kernel<20><<<g0 + g1, 256, 0, s>>>(A, g0, k, regularization);
+  else knn_tail_kernel<32><<<g0 + g1, 256, 0, s>>>(A, g0, k, regularization);
   return hipGetLastError();
 }
 

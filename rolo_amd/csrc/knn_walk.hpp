@@ -1,4 +1,4 @@
-// K5 search kernel body: exact k-nearest neighbours by *packet traversal* — one wavefront walks the implicit
+// K5 search kernels: exact k-nearest neighbours by *packet traversal* — one wavefront walks the implicit
 // BVH once for its 64 Morton-adjacent queries. Included by knn_cov.hip (needs box_d2 and the covariance tail).
 //
 // Why a packet: with one independent walk per lane the wavefront executes the union of 64 divergent walks and
@@ -74,8 +74,10 @@ ROLO_DEV void knn_score_leaf(const float4* __restrict__ sorted, int g, const flo
 #endif
 }
 
+// The walk keeps only the 20 packed keys and the query live (58 VGPRs): cut for 8 wavefronts per SIMD. Neighbour indices
+// go to A.c[].nbr, slot-major so every store is coalesced; knn_tail_kernel turns them into covariances.
 template <int KMAX>
-__global__ __launch_bounds__(256, 4) void knn_cov_kernel(KnnPair A, int split, int k, int reg) {
+__global__ __launch_bounds__(256, 8) void knn_walk_kernel(KnnPair A, int split, int k) {
   __shared__ int stk[4][WALK_STACK];
   const int tid = threadIdx.x;
   const int wv = tid >> 6;
@@ -83,11 +85,9 @@ __global__ __launch_bounds__(256, 4) void knn_cov_kernel(KnnPair A, int split, i
   const int which = (int)blockIdx.x >= split ? 1 : 0;
   const float4* __restrict__ sorted = A.c[which].sorted;
   const float4* __restrict__ boxes = A.c[which].boxes;
-  const float4* __restrict__ orig = A.c[which].xyz;
-  double* __restrict__ cov = A.c[which].cov;
   int32_t* knn_idx = A.c[which].knn_idx;
   float* knn_d2 = A.c[which].knn_d2;
-  const int n = A.c[which].n, n_sorted = A.c[which].n_sorted, P = A.c[which].P;
+  const int n_sorted = A.c[which].n_sorted, P = A.c[which].P;
   const int j = ((int)blockIdx.x - (which ? split : 0)) * 256 + tid;
   float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
   int qi = INT_MAX;
@@ -166,10 +166,27 @@ __global__ __launch_bounds__(256, 4) void knn_cov_kernel(KnnPair A, int split, i
 #pragma unroll
     for (int u = 0; u < KMAX; u++) if (u < kk) { knn_idx[(size_t)qi * kk + u] = ki[u]; knn_d2[(size_t)qi * kk + u] = key_d2(K[u]); }
   }
-  knn_covariance_tail<KMAX>(ki, kk, orig, n, qi, reg, cov);
+  int32_t* __restrict__ nbr = A.c[which].nbr;
+#pragma unroll
+  for (int u = 0; u < KMAX; u++) nbr[(size_t)u * n_sorted + j] = ki[u];
 #ifdef ROLO_KNN_STATS
   if ((tid & 63) == 0) atomicAdd(&g_knn_stats[5], (unsigned long long)(clock64() - t1));
 #endif
+}
+
+template <int KMAX>
+__global__ __launch_bounds__(256) void knn_tail_kernel(KnnPair A, int split, int k, int reg) {
+  const int which = (int)blockIdx.x >= split ? 1 : 0;
+  const int n_sorted = A.c[which].n_sorted;
+  const int j = ((int)blockIdx.x - (which ? split : 0)) * 256 + threadIdx.x;
+  if (j >= n_sorted) return;
+  const int qi = __float_as_int(A.c[which].sorted[j].w);
+  if (qi == INT_MAX) return;
+  const int32_t* __restrict__ nbr = A.c[which].nbr;
+  int ki[KMAX];
+#pragma unroll
+  for (int u = 0; u < KMAX; u++) ki[u] = nbr[(size_t)u * n_sorted + j];
+  knn_covariance_tail<KMAX>(ki, (KMAX == 20) ? 20 : k, A.c[which].xyz, A.c[which].n, qi, reg, A.c[which].cov);
 }
 
 }  // namespace

@@ -91,12 +91,13 @@ struct BatchSlot { PassArgs a; LmState* st; rolo_trace_rec* trace; int grid; int
 
 // ---- launchers (defined in the .hip files) --------------------------------------------------------------
 // the clouds one chain of search launches works on (knn_cov.hip): source and target of a registration, or one cloud
-struct KnnCloud { const float4* xyz; float4* sorted; float4* boxes; double* cov; int32_t* knn_idx; float* knn_d2; int n, n_leaves, P, n_sorted; };
+struct KnnCloud { const float4* xyz; float4* sorted; float4* boxes; double* cov; int32_t* knn_idx; float* knn_d2; int32_t* nbr; int n, n_leaves, P, n_sorted; };
 struct KnnPair { KnnCloud c[2]; int n_clouds; };
 hipError_t launch_knn_build(const KnnPair& A, void* sort_tmp, size_t sort_tmp_bytes, uint32_t* keys0, uint32_t* keys1,
                             uint32_t* vals0, uint32_t* vals1, int* bbox, hipStream_t s);
 size_t knn_sort_temp_bytes(int n_total);
-hipError_t launch_knn_cov(const KnnPair& A, int k, int regularization, hipStream_t s);
+hipError_t launch_knn_walk(const KnnPair& A, int k, hipStream_t s);                       // neighbour indices -> A.c[].nbr
+hipError_t launch_knn_tail(const KnnPair& A, int k, int regularization, hipStream_t s);   // covariances from A.c[].nbr
 
 hipError_t launch_voxel_build(const CloudDev& tgt, VoxelTable tab, unsigned long long* tgt_keys, int* tgt_slot,
                               int* counters /* [0]=V, [1]=error */, hipStream_t s);

@@ -2,8 +2,9 @@
 
 ALGORITHMIC bytes (fixed definitions; compact records P = 16 B point, C = 24 B covariance,
 R = 48 B voxel record, S = 16 B hash slot):
-  knn_cov_kernel   (K5)      : (P + K*P + C) = 360 B per point of the cloud(s) it is launched on (one cloud, or the
-                               source/target pair of a frame when overlap_knn is set)
+  knn_walk_kernel  (K5)      : K5 is (P + K*P + C) = 360 B per point; the walk reads the query and its K neighbours
+                               (P + K*P = 336 B per point of the cloud(s) it is launched on: one cloud, or the source/target
+                               pair of a frame when overlap_knn is set); the C = 24 B are written by knn_tail_kernel
   rot_pass_kernel  (K7+K8+K10): (P + C + S + R) = 104 B per source point per pass
   trans_pass_kernel (K11)     : 104 B per source point per pass
 """
@@ -17,8 +18,8 @@ import numpy as np
 
 from ._lib import lib, check
 
-SLOTS = {"knn_build": 0, "knn_cov": 1, "voxel_build": 2, "rot_pass": 3, "trans_pass": 4, "ctrl": 5}
-BYTES_PER_POINT = {"knn_cov": 360.0, "rot_pass": 104.0, "trans_pass": 104.0}
+SLOTS = {"knn_build": 0, "knn_walk": 1, "voxel_build": 2, "rot_pass": 3, "trans_pass": 4, "ctrl": 5, "knn_tail": 6}
+BYTES_PER_POINT = {"knn_walk": 336.0, "rot_pass": 104.0, "trans_pass": 104.0}
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -62,9 +63,9 @@ def roofline(g, run_one_step, n_src, n_tgt, passes_per_frame, hbm_peak_gbs, reps
     # dominant kernel = largest share of the frame among the HBM-streaming kernels
     cands = {k: per_frame_ms[k] for k in BYTES_PER_POINT}
     dom = max(cands, key=cands.get)
-    if dom == "knn_cov":
+    if dom == "knn_walk":
         # one launch searches one cloud, or the source/target pair of a frame (overlap_knn)
-        launches = np.mean([len(r) for r in acc["knn_cov"]]) if acc["knn_cov"] else 2.0
+        launches = np.mean([len(r) for r in acc["knn_walk"]]) if acc["knn_walk"] else 2.0
         npts = (n_src + n_tgt) / max(launches, 1.0)
     else:
         npts = n_src
