@@ -43,11 +43,13 @@ def test_no_gpu_is_a_loud_error_not_a_fallback():
         RotVGICP()
 
 
-def test_cpp_shim_compiles_and_links():
-    """The header-only RotVGICP drop-in (include/rot_vgicp_hip.hpp) builds with plain g++ against the C ABI."""
+@pytest.mark.parametrize("demo", ["shim_demo", "nodes_demo"])
+def test_cpp_host_mirrors_compile_and_link(demo):
+    """The header-only C++ host mirrors — fast_gicp::RotVGICP (include/rot_vgicp_hip.hpp) and the node cores
+    (include/rolo_nodes_hip.hpp) — build with plain g++ against the C ABI."""
     import subprocess, tempfile
-    out = os.path.join(tempfile.mkdtemp(), "shim_demo")
-    cmd = ["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "shim_demo.cpp"), "-o", out,
+    out = os.path.join(tempfile.mkdtemp(), demo)
+    cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", demo + ".cpp"), "-o", out,
            "-L", os.path.join(ROOT, "rolo_amd"), "-lrolo_hip", "-Wl,-rpath," + os.path.join(ROOT, "rolo_amd"), "-Wl,-rpath,/opt/rocm/lib"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr

@@ -130,3 +130,40 @@ def test_submit_collect_queue_rules():
     with pytest.raises(RoloError):
         od.frame(fg, 100.3, np.full((64, 3), 0.5, np.float32), np.zeros(64, np.uint16))   # everything below lidarMinRange
     del empty
+
+
+def test_cpp_node_cores_end_to_end(tmp_path):
+    """include/rolo_nodes_hip.hpp (rolo::ImageProjection / FeatureExtraction / LidarOdometry) in a C++-only process:
+    the staged chain and the fused submit/collect path give the oracle's poses on a raw frame sequence."""
+    import os, struct, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "nodes_demo")
+    cmd = ["g++", "-std=c++17", "-O1", "-I", os.path.join(root, "include"), os.path.join(root, "tests", "cpp", "nodes_demo.cpp"), "-o", exe,
+           "-L", os.path.join(root, "rolo_amd"), "-lrolo_hip", "-Wl,-rpath," + os.path.join(root, "rolo_amd"), "-Wl,-rpath,/opt/rocm/lib"]
+    subprocess.run(cmd, check=True)
+    cfg = dict(n_scan=16, horizon_scan=1800)
+    poses = trajectory(5)
+    frames = [synth.make_frame("vlp16", R, t, synth.SEED + k) for k, (R, t) in enumerate(poses)]
+    with open(tmp_path / "frames.bin", "wb") as f:
+        f.write(struct.pack("<i", len(frames)))
+        for fr in frames:
+            f.write(struct.pack("<i", fr.xyz.shape[0]))
+            f.write(np.ascontiguousarray(fr.xyz, np.float32).tobytes()); f.write(np.ascontiguousarray(fr.ring, np.uint16).tobytes())
+    r = subprocess.run([exe, str(tmp_path / "frames.bin"), "16", "1800"], capture_output=True, text=True, check=True)
+    lines = r.stdout.strip().splitlines()
+    assert lines[-1] == "error -5"      # collect() with nothing submitted -> ROLO_ESTATE as rolo::Error
+    fo = pyorc.front_params(**cfg)
+    oo = pyorc.Odom(pyorc.default_params(polar_resolution=(0.175, 0.175, 2.0)), 0.3)
+    for k, fr in enumerate(frames):
+        stamp = 100.0 + 0.1 * k
+        if k == 2:
+            oo.backend_odometry(stamp - 0.05)
+        eo = pyorc.extract_features(fo, pyorc.project(fo, fr.xyz, fr.ring))
+        rco, pose_o, R_o, t_o = oo.cloud(stamp, eo["corner"], eo["surface"])
+        for line, tag in ((lines[2 * k], "staged"), (lines[2 * k + 1], "fused")):
+            tok = line.split()
+            assert tok[0] == tag and int(tok[1]) == rco
+            pose = np.array([float(v) for v in tok[2:8]]); t = np.array([float(v) for v in tok[8:11]])
+            assert int(tok[11]) == eo["corner"].shape[0] and int(tok[12]) == eo["surface"].shape[0]
+            assert np.abs(pose[:3] - pose_o[:3]).max() <= 1e-4 and np.abs(pose[3:] - pose_o[3:]).max() <= 1e-5
+            assert np.abs(t - t_o).max() <= 1e-4
