@@ -11,7 +11,7 @@
 // so3_linearize would compute if the trial is accepted. Nothing per-correspondence is cached in HBM except one
 // 4-byte voxel id: the 3x3 Mahalanobis is recomputed from the 48-byte source covariance and the 96-byte voxel
 // record instead of being stored as a 128-byte Matrix4d. Each point's contributions are summed per thread,
-// butterfly-reduced across the 64-lane wavefront, combined across the four wavefronts of the workgroup through
+// reduce-scattered across the 64-lane wavefront, combined across the four wavefronts of the workgroup through
 // LDS, and written as one row of partials. A one-workgroup controller kernel then sums the rows in a fixed order
 // (deterministic) and runs the scalar LM logic on the device: LDLT solve, so3/se3 exponential, gain ratio,
 // damping update, convergence — so there is no host round trip inside a solve. All pass / controller launches
@@ -46,14 +46,53 @@ ROLO_DEV Rec load_rec(const double* __restrict__ rec, int id) {
   return o;
 }
 
+// Sum NV per-lane values over the 64 lanes of the wavefront as a reduce-scatter: at every halving step a lane hands the
+// half of its values it will not own to the partner lane (offset 32, 16, ...) and adds what it receives, so the value
+// count halves with the distance — 17 cross-lane exchanges for 12..16 values, 32 for 17..32, instead of 6 per value
+// (72 / 180). With 30 values (translation and 6-dof passes) the separate butterflies were half of the kernel's
+// wavefront lifetime: 15.6 -> 9.5 us per translation pass.
+// Afterwards lane L holds the complete sum of value idx(L); the order of the additions is fixed (deterministic).
+template <int NV>
+ROLO_DEV void wave_reduce_scatter(const double (&acc)[NV], double* __restrict__ red_row /* LDS, NV_MAX */) {
+  constexpr int NP = NV <= 16 ? 16 : 32;
+  constexpr int NSTEPS = NP == 16 ? 4 : 5;
+  static_assert(NV <= 32, "at most 32 values");
+  const int lane = threadIdx.x & 63;
+  double v[NP];
+#pragma unroll
+  for (int k = 0; k < NP; k++) v[k] = k < NV ? acc[k] : 0.0;
+  int idx = 0;
+#pragma unroll
+  for (int s = 0; s < NSTEPS; s++) {
+    const int off = 32 >> s;
+    const int half = NP >> (s + 1);
+    const bool upper = (lane & off) != 0;
+    idx = (idx << 1) | (upper ? 1 : 0);
+#pragma unroll
+    for (int k = 0; k < half; k++) {
+      const double send = upper ? v[k] : v[k + half];
+      const double keep = upper ? v[k + half] : v[k];
+      v[k] = keep + __shfl_xor(send, off, 64);
+    }
+  }
+#pragma unroll
+  for (int off = 32 >> NSTEPS; off > 0; off >>= 1) v[0] += __shfl_xor(v[0], off, 64);
+  if ((lane & ((64 >> NSTEPS) - 1)) == 0 && idx < NV) red_row[idx] = v[0];
+}
+
 template <int NV>
 ROLO_DEV void block_reduce_store(double (&acc)[NV], const int (&slot)[NV], double* __restrict__ out_row) {
   __shared__ double red[PASS_THREADS / 64][NV_MAX];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int wv = threadIdx.x >> 6;
+  if constexpr (NV > 16) {
+    wave_reduce_scatter<NV>(acc, red[wv]);
+  } else {  // few values (SO(3) pass: 12): the independent butterflies pipeline well; measured 11.7 vs 13.4 us per pass
+    const int lane = threadIdx.x & 63;
 #pragma unroll
-  for (int v = 0; v < NV; v++) {
-    const double s = wave_sum(acc[v]);
-    if (lane == 0) red[wv][v] = s;
+    for (int v = 0; v < NV; v++) {
+      const double s = wave_sum(acc[v]);
+      if (lane == 0) red[wv][v] = s;
+    }
   }
   __syncthreads();
   if (threadIdx.x < NV) {

@@ -360,7 +360,7 @@ def test_full_size_properties(sensor, leaf):
     assert g.last_stats.n_outer == 20
     assert np.abs(T1[:3, :3] @ T1[:3, :3].T - np.eye(3)).max() < 1e-12 and np.all(T1[:3, 3] == 0)
     g.align()
-    assert np.abs(g.final_transformation_d - T1).max() < 1e-12
+    assert np.abs(g.final_transformation_d - T1).max() < 1e-10   # the voxel sums are fp64 atomics: the order of additions is free
     # (5) and agrees with the oracle end to end at full size
     p = pyorc.default_params(voxel_type=1, voxel_resolution=leaf, fixed_iterations=20)
     o = pyorc.Reg(p); o.set_target(tgt); o.set_source(src)
