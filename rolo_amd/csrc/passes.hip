@@ -46,6 +46,27 @@ ROLO_DEV Rec load_rec(const double* __restrict__ rec, int id) {
   return o;
 }
 
+// DPP lane moves of a double (two 32-bit halves): pure VALU, no LDS crossbar. Lanes a row_mask leaves out receive 0.0.
+template <int CTRL, int ROW_MASK = 0xf>
+ROLO_DEV double dpp_mov_f64(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+// Sum over the wavefront, result valid in lane 63: pairs, quads (quad_perm), 8 (row_half_mirror), 16 (row_mirror),
+// 32 (row_bcast:15 into rows 1 and 3), 64 (row_bcast:31 into rows 2 and 3). ds_bpermute exchanges cost ~40 cycles each
+// here (the LDS crossbar is shared by the CU's wavefronts): 144 of them were a third of the SO(3) pass.
+ROLO_DEV double wave_sum_dpp63(double v) {
+  v += dpp_mov_f64<0xB1>(v);          // quad_perm [1,0,3,2]
+  v += dpp_mov_f64<0x4E>(v);          // quad_perm [2,3,0,1]
+  v += dpp_mov_f64<0x141>(v);         // row_half_mirror
+  v += dpp_mov_f64<0x140>(v);         // row_mirror
+  v += dpp_mov_f64<0x142, 0xa>(v);    // row_bcast:15
+  v += dpp_mov_f64<0x143, 0xc>(v);    // row_bcast:31
+  return v;
+}
+
 // Sum NV per-lane values over the 64 lanes of the wavefront as a reduce-scatter: at every halving step a lane hands the
 // half of its values it will not own to the partner lane (offset 32, 16, ...) and adds what it receives, so the value
 // count halves with the distance — 17 cross-lane exchanges for 12..16 values, 32 for 17..32, instead of 6 per value
@@ -68,12 +89,12 @@ ROLO_DEV void wave_reduce_scatter(const double (&acc)[NV], double* __restrict__ 
     const int half = NP >> (s + 1);
     const bool upper = (lane & off) != 0;
     idx = (idx << 1) | (upper ? 1 : 0);
+    // all exchanges of a step are issued before the first result is used: one LDS-crossbar round trip per step
+    double got[NP / 2];
 #pragma unroll
-    for (int k = 0; k < half; k++) {
-      const double send = upper ? v[k] : v[k + half];
-      const double keep = upper ? v[k + half] : v[k];
-      v[k] = keep + __shfl_xor(send, off, 64);
-    }
+    for (int k = 0; k < half; k++) got[k] = __shfl_xor(upper ? v[k] : v[k + half], off, 64);
+#pragma unroll
+    for (int k = 0; k < half; k++) v[k] = (upper ? v[k + half] : v[k]) + got[k];
   }
 #pragma unroll
   for (int off = 32 >> NSTEPS; off > 0; off >>= 1) v[0] += __shfl_xor(v[0], off, 64);
@@ -84,14 +105,14 @@ template <int NV>
 ROLO_DEV void block_reduce_store(double (&acc)[NV], const int (&slot)[NV], double* __restrict__ out_row) {
   __shared__ double red[PASS_THREADS / 64][NV_MAX];
   const int wv = threadIdx.x >> 6;
-  if constexpr (NV > 16) {
+  if constexpr (NV > 16) {   // 30 values: reduce-scatter (9.6 us per translation pass; one DPP reduction per value: 10.7)
     wave_reduce_scatter<NV>(acc, red[wv]);
-  } else {  // few values (SO(3) pass: 12): the independent butterflies pipeline well; measured 11.7 vs 13.4 us per pass
+  } else {  // few values (SO(3) pass: 12): one DPP reduction per value
     const int lane = threadIdx.x & 63;
 #pragma unroll
-    for (int v = 0; v < NV; v++) {
-      const double s = wave_sum(acc[v]);
-      if (lane == 0) red[wv][v] = s;
+    for (int k = 0; k < NV; k++) {
+      const double t = wave_sum_dpp63(acc[k]);
+      if (lane == 63) red[wv][k] = t;
     }
   }
   __syncthreads();
