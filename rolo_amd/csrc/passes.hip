@@ -21,6 +21,7 @@
 #include "dev_math.hpp"
 #include "voxel_dev.hpp"
 #include <cfloat>
+#include <type_traits>
 
 namespace rolo {
 
@@ -67,10 +68,36 @@ ROLO_DEV double wave_sum_dpp63(double v) {
   return v;
 }
 
+// The value lane (l ^ OFF) holds, without the LDS crossbar: gfx950's v_permlane32_swap / v_permlane16_swap for the
+// cross-row distances, DPP row rotate / shifts / quad_perm inside a row of 16.
+template <int OFF>
+ROLO_DEV int lane_xor_b32(int x) {
+  if constexpr (OFF == 32) {
+    const auto r = __builtin_amdgcn_permlane32_swap((unsigned)x, (unsigned)x, false, false);  // {vdst', src'}: vdst'[32..63] = x[0..31], src'[0..31] = x[32..63]
+    return (int)((threadIdx.x & 32) ? r[0] : r[1]);
+  } else if constexpr (OFF == 16) {
+    const auto r = __builtin_amdgcn_permlane16_swap((unsigned)x, (unsigned)x, false, false);  // odd rows of vdst' <- even rows of x, even rows of src' <- odd rows of x
+    return (int)((threadIdx.x & 16) ? r[0] : r[1]);
+  } else if constexpr (OFF == 8) {
+    return __builtin_amdgcn_update_dpp(0, x, 0x128, 0xf, 0xf, false);          // row_ror:8
+  } else if constexpr (OFF == 4) {
+    const int a = __builtin_amdgcn_update_dpp(0, x, 0x104, 0xf, 0x5, false);   // row_shl:4 into banks 0 and 2 (lane <- lane + 4)
+    return __builtin_amdgcn_update_dpp(a, x, 0x114, 0xf, 0xa, false);          // row_shr:4 into banks 1 and 3 (lane <- lane - 4)
+  } else if constexpr (OFF == 2) {
+    return __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xf, 0xf, false);           // quad_perm [2,3,0,1]
+  } else {
+    return __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xf, 0xf, false);           // quad_perm [1,0,3,2]
+  }
+}
+template <int OFF>
+ROLO_DEV double lane_xor_f64(double v) {
+  return __hiloint2double(lane_xor_b32<OFF>(__double2hiint(v)), lane_xor_b32<OFF>(__double2loint(v)));
+}
+
 // Sum NV per-lane values over the 64 lanes of the wavefront as a reduce-scatter: at every halving step a lane hands the
 // half of its values it will not own to the partner lane (offset 32, 16, ...) and adds what it receives, so the value
 // count halves with the distance — 17 cross-lane exchanges for 12..16 values, 32 for 17..32, instead of 6 per value
-// (72 / 180). With 30 values (translation and 6-dof passes) the separate butterflies were half of the kernel's
+// (72 / 180), and none of them through the LDS crossbar (lane_xor_f64). With 30 values (translation and 6-dof passes) the separate butterflies were half of the kernel's
 // wavefront lifetime: 15.6 -> 9.5 us per translation pass.
 // Afterwards lane L holds the complete sum of value idx(L); the order of the additions is fixed (deterministic).
 template <int NV>
@@ -83,21 +110,28 @@ ROLO_DEV void wave_reduce_scatter(const double (&acc)[NV], double* __restrict__ 
 #pragma unroll
   for (int k = 0; k < NP; k++) v[k] = k < NV ? acc[k] : 0.0;
   int idx = 0;
-#pragma unroll
-  for (int s = 0; s < NSTEPS; s++) {
-    const int off = 32 >> s;
-    const int half = NP >> (s + 1);
+  auto step = [&](auto off_c, auto half_c) {
+    constexpr int off = decltype(off_c)::value, half = decltype(half_c)::value;
     const bool upper = (lane & off) != 0;
     idx = (idx << 1) | (upper ? 1 : 0);
-    // all exchanges of a step are issued before the first result is used: one LDS-crossbar round trip per step
-    double got[NP / 2];
+    double got[half];
 #pragma unroll
-    for (int k = 0; k < half; k++) got[k] = __shfl_xor(upper ? v[k] : v[k + half], off, 64);
+    for (int k = 0; k < half; k++) got[k] = lane_xor_f64<off>(upper ? v[k] : v[k + half]);
 #pragma unroll
     for (int k = 0; k < half; k++) v[k] = (upper ? v[k + half] : v[k]) + got[k];
+  };
+  using std::integral_constant;
+  step(integral_constant<int, 32>{}, integral_constant<int, NP / 2>{});
+  step(integral_constant<int, 16>{}, integral_constant<int, NP / 4>{});
+  step(integral_constant<int, 8>{}, integral_constant<int, NP / 8>{});
+  step(integral_constant<int, 4>{}, integral_constant<int, NP / 16>{});
+  if constexpr (NSTEPS == 5) {
+    step(integral_constant<int, 2>{}, integral_constant<int, 1>{});
+    v[0] += lane_xor_f64<1>(v[0]);
+  } else {
+    v[0] += lane_xor_f64<2>(v[0]);
+    v[0] += lane_xor_f64<1>(v[0]);
   }
-#pragma unroll
-  for (int off = 32 >> NSTEPS; off > 0; off >>= 1) v[0] += __shfl_xor(v[0], off, 64);
   if ((lane & ((64 >> NSTEPS) - 1)) == 0 && idx < NV) red_row[idx] = v[0];
 }
 
