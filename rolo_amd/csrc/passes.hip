@@ -349,18 +349,20 @@ ROLO_DEV void reduce_rows(const double* __restrict__ partials, int nblocks, doub
   __shared__ double part[8][NV_MAX];
   const int v = threadIdx.x & 31, q = threadIdx.x >> 5;  // 256 threads = 8 strided groups of 32 values
   // The rows were written by other CUs a moment ago, so every load is a ~1-2 us L2/fabric round trip and this
-  // reduction is pure latency: issue 16 independent loads per thread before the first add (one round trip per
-  // 128 rows instead of one per 8). The combination order is fixed => deterministic for a given grid.
+  // reduction is pure latency: issue 64 independent loads per thread before the first add — one round trip for the
+  // 512 rows of a 131k-point cloud (16 in flight: four round trips, half of the controller's time). The combination
+  // order is fixed => deterministic for a given grid.
+  constexpr int INFLIGHT = 64;
   double s0 = 0;
-  for (int b0 = q; b0 < nblocks; b0 += 8 * 16) {
-    double r[16];
+  for (int b0 = q; b0 < nblocks; b0 += 8 * INFLIGHT) {
+    double r[INFLIGHT];
 #pragma unroll
-    for (int u = 0; u < 16; u++) {
+    for (int u = 0; u < INFLIGHT; u++) {
       const int b = b0 + 8 * u;
       r[u] = (b < nblocks) ? partials[(size_t)b * NV_MAX + v] : 0.0;
     }
 #pragma unroll
-    for (int u = 0; u < 16; u++) s0 += r[u];
+    for (int u = 0; u < INFLIGHT; u++) s0 += r[u];
   }
   part[q][v] = s0;
   __syncthreads();
@@ -649,20 +651,60 @@ ROLO_DEV void trans_step(LmState* st, const double* S, rolo_trace_rec* trace) {
 // slower when four contexts share the GPU).
 ROLO_DEV void ctrl_body(LmState* st, const double* __restrict__ partials, int nblocks, const double* __restrict__ sums_in,
                         rolo_trace_rec* trace, int stage) {
-  if (st->stage != stage) return;
   __shared__ double sums[NV_MAX];
+  __shared__ double part[8][NV_MAX];
   // the scalar LM step touches ~150 fields: stage the whole state through LDS (one coalesced read, one write)
   // instead of paying a global-memory round trip per field from a single lane
   __shared__ LmState sst;
   static_assert(sizeof(LmState) % sizeof(int) == 0, "LmState must be int-copyable");
   constexpr int NW = sizeof(LmState) / sizeof(int);
+  constexpr int NWT = (NW + 255) / 256;
+  constexpr int INFLIGHT = 64;
+  const int v = threadIdx.x & 31, q = threadIdx.x >> 5;  // 256 threads = 8 strided groups of 32 values
+  // Everything this controller reads was written by other CUs a moment ago: every load is a ~1-2 us L2 / fabric round
+  // trip. Issue ALL of them before the first use — the state copy and 64 partial rows per thread (the 512 rows of a
+  // 131k-point cloud) — so the launch pays one round trip, not "stage flag, then state, then rows" (three).
+  int sreg[NWT];
   {
     const int* g = reinterpret_cast<const int*>(st);
-    int* l = reinterpret_cast<int*>(&sst);
-    for (int i = threadIdx.x; i < NW; i += blockDim.x) l[i] = g[i];
+#pragma unroll
+    for (int k = 0; k < NWT; k++) { const int i = threadIdx.x + 256 * k; sreg[k] = i < NW ? g[i] : 0; }
   }
-  if (partials) reduce_rows(partials, nblocks, sums);
-  else { if (threadIdx.x < NV_MAX) sums[threadIdx.x] = sums_in[threadIdx.x]; __syncthreads(); }
+  double r[INFLIGHT];
+  if (partials) {
+#pragma unroll
+    for (int u = 0; u < INFLIGHT; u++) { const int b = q + 8 * u; r[u] = (b < nblocks) ? partials[(size_t)b * NV_MAX + v] : 0.0; }
+  }
+  {
+    int* l = reinterpret_cast<int*>(&sst);
+#pragma unroll
+    for (int k = 0; k < NWT; k++) { const int i = threadIdx.x + 256 * k; if (i < NW) l[i] = sreg[k]; }
+  }
+  __syncthreads();
+  if (sst.stage != stage) return;  // predicated launch: nothing to do (uniform)
+  if (partials) {
+    // fixed combination order => deterministic for a given grid
+    double s0 = 0;
+#pragma unroll
+    for (int u = 0; u < INFLIGHT; u++) s0 += r[u];
+    for (int b0 = q + 8 * INFLIGHT; b0 < nblocks; b0 += 8 * INFLIGHT) {   // clouds above 131k points
+#pragma unroll
+      for (int u = 0; u < INFLIGHT; u++) { const int b = b0 + 8 * u; r[u] = (b < nblocks) ? partials[(size_t)b * NV_MAX + v] : 0.0; }
+#pragma unroll
+      for (int u = 0; u < INFLIGHT; u++) s0 += r[u];
+    }
+    part[q][v] = s0;
+    __syncthreads();
+    if (threadIdx.x < NV_MAX) {
+      double t = 0;
+#pragma unroll
+      for (int k = 0; k < 8; k++) t += part[k][threadIdx.x];
+      sums[threadIdx.x] = t;
+    }
+  } else if (threadIdx.x < NV_MAX) {
+    sums[threadIdx.x] = sums_in[threadIdx.x];
+  }
+  __syncthreads();
   if (threadIdx.x == 0) {
     if (stage == 1) rot_step(&sst, sums, trace);
     else trans_step(&sst, sums, trace);
@@ -671,7 +713,7 @@ ROLO_DEV void ctrl_body(LmState* st, const double* __restrict__ partials, int nb
   {
     int* g = reinterpret_cast<int*>(st);
     const int* l = reinterpret_cast<const int*>(&sst);
-    for (int i = threadIdx.x; i < NW; i += blockDim.x) g[i] = l[i];
+    for (int i = threadIdx.x; i < NW; i += 256) g[i] = l[i];
   }
 }
 
