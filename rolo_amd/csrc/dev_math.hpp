@@ -58,4 +58,36 @@ ROLO_DEV double wave_sum(double v) {
   return v;
 }
 
+// The value lane (l ^ OFF) holds, without the LDS crossbar: gfx950's v_permlane32_swap / v_permlane16_swap for the
+// cross-row distances, DPP row rotate / shifts / quad_perm inside a row of 16.
+template <int OFF>
+ROLO_DEV int lane_xor_b32(int x) {
+  if constexpr (OFF == 32) {
+    const auto r = __builtin_amdgcn_permlane32_swap((unsigned)x, (unsigned)x, false, false);  // {vdst', src'}: vdst'[32..63] = x[0..31], src'[0..31] = x[32..63]
+    return (int)((threadIdx.x & 32) ? r[0] : r[1]);
+  } else if constexpr (OFF == 16) {
+    const auto r = __builtin_amdgcn_permlane16_swap((unsigned)x, (unsigned)x, false, false);  // odd rows of vdst' <- even rows of x, even rows of src' <- odd rows of x
+    return (int)((threadIdx.x & 16) ? r[0] : r[1]);
+  } else if constexpr (OFF == 8) {
+    return __builtin_amdgcn_update_dpp(0, x, 0x128, 0xf, 0xf, false);          // row_ror:8
+  } else if constexpr (OFF == 4) {
+    const int a = __builtin_amdgcn_update_dpp(0, x, 0x104, 0xf, 0x5, false);   // row_shl:4 into banks 0 and 2 (lane <- lane + 4)
+    return __builtin_amdgcn_update_dpp(a, x, 0x114, 0xf, 0xa, false);          // row_shr:4 into banks 1 and 3 (lane <- lane - 4)
+  } else if constexpr (OFF == 2) {
+    return __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xf, 0xf, false);           // quad_perm [2,3,0,1]
+  } else {
+    return __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xf, 0xf, false);           // quad_perm [1,0,3,2]
+  }
+}
+template <int OFF>
+ROLO_DEV double lane_xor_f64(double v) {
+  return __hiloint2double(lane_xor_b32<OFF>(__double2hiint(v)), lane_xor_b32<OFF>(__double2loint(v)));
+}
+
+template <int OFF>
+ROLO_DEV unsigned long long lane_xor_u64(unsigned long long v) {
+  const unsigned lo = (unsigned)lane_xor_b32<OFF>((int)(unsigned)(v & 0xffffffffull)), hi = (unsigned)lane_xor_b32<OFF>((int)(unsigned)(v >> 32));
+  return ((unsigned long long)hi << 32) | lo;
+}
+
 }  // namespace rolo

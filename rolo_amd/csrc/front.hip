@@ -148,10 +148,13 @@ __global__ __launch_bounds__(256) void occlusion_kernel(const float* __restrict_
 // Ascending bitonic sort of every aligned `seg`-element segment of key[0, total) in LDS (seg a power of two, total a
 // multiple of seg; 256 threads). Exchange distances >= 64 are block-wide steps with a barrier each; the distances
 // 32..1 that close every merge stage stay inside an aligned 64-element chunk, so one wavefront takes the chunk into
-// registers and finishes the stage with cross-lane exchanges — one barrier per stage instead of one per step.
-ROLO_DEV unsigned long long shfl_xor_u64(unsigned long long v, int mask) {
-  const unsigned lo = __shfl_xor((unsigned)(v & 0xffffffffull), mask, 64), hi = __shfl_xor((unsigned)(v >> 32), mask, 64);
-  return ((unsigned long long)hi << 32) | lo;
+// registers and finishes the stage with cross-lane exchanges (DPP / permlane swaps) — one barrier per stage instead of
+// one per step.
+template <int J2>
+ROLO_DEV void bitonic_lane_step(unsigned long long& v, int lane, bool up) {
+  const unsigned long long o = lane_xor_u64<J2>(v);   // DPP / v_permlane*_swap: no LDS crossbar (dev_math.hpp)
+  const bool take_min = ((lane & J2) == 0) == up;     // the lane with the smaller index of the pair keeps the minimum when ascending
+  v = take_min ? (o < v ? o : v) : (o > v ? o : v);
 }
 ROLO_DEV void bitonic_sort_lds_seg(unsigned long long* key, int total, int seg) {
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
@@ -173,12 +176,12 @@ ROLO_DEV void bitonic_sort_lds_seg(unsigned long long* key, int total, int seg) 
       const int i = (c << 6) + lane;
       unsigned long long v = i < total ? key[i] : ~0ull;
       const bool up = ((i & (seg - 1)) & k) == 0;
-      for (int j2 = jj; j2 > 0; j2 >>= 1) {
-        const unsigned long long o = shfl_xor_u64(v, j2);
-        const bool lower = (lane & j2) == 0;          // this lane holds the smaller index of the pair
-        const bool take_min = lower == up;
-        v = take_min ? (o < v ? o : v) : (o > v ? o : v);
-      }
+      if (jj >= 32) bitonic_lane_step<32>(v, lane, up);
+      if (jj >= 16) bitonic_lane_step<16>(v, lane, up);
+      if (jj >= 8) bitonic_lane_step<8>(v, lane, up);
+      if (jj >= 4) bitonic_lane_step<4>(v, lane, up);
+      if (jj >= 2) bitonic_lane_step<2>(v, lane, up);
+      bitonic_lane_step<1>(v, lane, up);
       if (i < total) key[i] = v;
     }
     __syncthreads();
