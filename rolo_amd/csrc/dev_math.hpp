@@ -51,13 +51,6 @@ ROLO_DEV Vec3 sym3_mulv(const Sym3& M, const Vec3& e) {
 }
 ROLO_DEV double dot3(const Vec3& a, const Vec3& b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 
-// wave64 butterfly sum
-ROLO_DEV double wave_sum(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
-}
-
 // The value lane (l ^ OFF) holds, without the LDS crossbar: gfx950's v_permlane32_swap / v_permlane16_swap for the
 // cross-row distances, DPP row rotate / shifts / quad_perm inside a row of 16.
 template <int OFF>
