@@ -177,6 +177,7 @@ int upload_cloud(rolo_ctx* c, CloudDev& cl, size_t& xyz_cap, const float* pts, i
   HIPCHK(launch_pack_xyz(dsrc, stride, cl.xyz, n, c->stream));
   cl.n = n;
   cl.have_cov = false;
+  cl.have_sorted = false;
   return ROLO_OK;
 }
 
@@ -225,8 +226,8 @@ int build_clouds(rolo_ctx* c, bool do_src, bool do_tgt, hipStream_t stream) {
   { ProfScope ps(c, ROLO_PROF_KNN_BUILD, stream); HIPCHK(launch_knn_build(A, S.sort_tmp, tmp, S.keys0, S.keys1, S.vals0, S.vals1, S.bbox, stream)); }
   { ProfScope ps(c, ROLO_PROF_KNN_WALK, stream); HIPCHK(launch_knn_walk(A, c->P.k_correspondences, stream)); }
   { ProfScope ps(c, ROLO_PROF_KNN_TAIL, stream); HIPCHK(launch_knn_tail(A, c->P.k_correspondences, c->P.regularization, stream)); }
-  if (do_src) c->src.have_cov = true;
-  if (do_tgt) c->tgt.have_cov = true;
+  if (do_src) { c->src.have_cov = true; c->src.have_sorted = true; }
+  if (do_tgt) { c->tgt.have_cov = true; c->tgt.have_sorted = true; }
   return ROLO_OK;
 }
 
@@ -242,6 +243,13 @@ int ensure_covs(rolo_ctx* c) {
   if (!c->src.have_cov && (rc = build_src(c, c->stream))) return rc;
   if (!c->tgt.have_cov && (rc = build_tgt(c, c->stream))) return rc;
   return ROLO_OK;
+}
+
+// Morton-ordered voxel build (voxelmap.hip) pays with many points per voxel: decide from the previous map of this context,
+// before there is one from the grid type (the production POLAR grid is coarse)
+bool voxel_morton_order(const rolo_ctx* c) {
+  if (c->n_voxels > 0) return c->tgt.n / c->n_voxels >= 16;
+  return c->P.voxel_type == ROLO_VOXEL_POLAR;
 }
 
 void fill_table_params(rolo_ctx* c) {
@@ -261,11 +269,11 @@ int ensure_map(rolo_ctx* c) {
   if ((rc = ensure(c->tab.rec, c->tab_rec_cap, (size_t)n * REC_DOUBLES))) return rc;
   if ((rc = ensure(c->tab.id_keys, c->tab_idk_cap, (size_t)n))) return rc;
   if ((rc = ensure(c->tgt_keys, c->tgt_keys_cap, (size_t)n))) return rc;
-  if ((rc = ensure(c->tgt_slot, c->tgt_slot_cap, (size_t)n))) return rc;
+  if ((rc = ensure(c->tgt_slot, c->tgt_slot_cap, (size_t)n + 8))) return rc;
   if ((rc = ensure(c->counters, c->counters_cap, 4))) return rc;
   c->tab.mask = (unsigned)(capslots - 1);
   fill_table_params(c);
-  { ProfScope ps(c, ROLO_PROF_VOXEL_BUILD); HIPCHK(launch_voxel_build(c->tgt, c->tab, c->tgt_keys, c->tgt_slot, c->counters, c->stream)); }
+  { ProfScope ps(c, ROLO_PROF_VOXEL_BUILD); HIPCHK(launch_voxel_build(c->tgt, c->tab, c->tgt_keys, c->tgt_slot, c->counters, voxel_morton_order(c), c->stream)); }
   HIPCHK(hipMemcpyAsync(c->h_counters, c->counters, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   if (c->h_counters[1] != 0) { g_err = "voxel coordinate outside the packed key range"; return c->h_counters[1]; }
@@ -766,11 +774,11 @@ static int enqueue_frame(rolo_ctx* c) {
     if ((rc = ensure(c->tab.rec, c->tab_rec_cap, (size_t)n * REC_DOUBLES))) return rc;
     if ((rc = ensure(c->tab.id_keys, c->tab_idk_cap, (size_t)n))) return rc;
     if ((rc = ensure(c->tgt_keys, c->tgt_keys_cap, (size_t)n))) return rc;
-    if ((rc = ensure(c->tgt_slot, c->tgt_slot_cap, (size_t)n))) return rc;
+    if ((rc = ensure(c->tgt_slot, c->tgt_slot_cap, (size_t)n + 8))) return rc;
     if ((rc = ensure(c->counters, c->counters_cap, 4))) return rc;
     c->tab.mask = (unsigned)(capslots - 1);
     fill_table_params(c);
-    { ProfScope ps(c, ROLO_PROF_VOXEL_BUILD); HIPCHK(launch_voxel_build(c->tgt, c->tab, c->tgt_keys, c->tgt_slot, c->counters, c->stream)); }
+    { ProfScope ps(c, ROLO_PROF_VOXEL_BUILD); HIPCHK(launch_voxel_build(c->tgt, c->tab, c->tgt_keys, c->tgt_slot, c->counters, voxel_morton_order(c), c->stream)); }
     HIPCHK(hipMemcpyAsync(c->h_counters, c->counters, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
   }
   PassArgs a; int grid;
@@ -808,7 +816,7 @@ int rolo_register_async(rolo_ctx* c, const float* guess16, const double* trans_s
     };
     if (c->graph_exec && same(key, c->gkey)) {
       HIPCHK(hipGraphLaunch(c->graph_exec, c->stream));
-      c->src.have_cov = true; c->tgt.have_cov = true;
+      c->src.have_cov = true; c->tgt.have_cov = true; c->src.have_sorted = true; c->tgt.have_sorted = true;
       c->async_pending = true;
       return ROLO_OK;
     }
@@ -1029,11 +1037,11 @@ static int enqueue_batch(rolo_batch* b, bool fork) {
     if ((rc = ensure(c->tab.rec, c->tab_rec_cap, (size_t)n * REC_DOUBLES))) return rc;
     if ((rc = ensure(c->tab.id_keys, c->tab_idk_cap, (size_t)n))) return rc;
     if ((rc = ensure(c->tgt_keys, c->tgt_keys_cap, (size_t)n))) return rc;
-    if ((rc = ensure(c->tgt_slot, c->tgt_slot_cap, (size_t)n))) return rc;
+    if ((rc = ensure(c->tgt_slot, c->tgt_slot_cap, (size_t)n + 8))) return rc;
     if ((rc = ensure(c->counters, c->counters_cap, 4))) return rc;
     c->tab.mask = (unsigned)(capslots - 1);
     fill_table_params(c);
-    HIPCHK(launch_voxel_build(c->tgt, c->tab, c->tgt_keys, c->tgt_slot, c->counters, s2));
+    HIPCHK(launch_voxel_build(c->tgt, c->tab, c->tgt_keys, c->tgt_slot, c->counters, voxel_morton_order(c), s2));
     HIPCHK(hipMemcpyAsync(c->h_counters, c->counters, 2 * sizeof(int), hipMemcpyDeviceToHost, s2));
     if (fork) { HIPCHK(hipEventRecord(b->ev_join[2 * i], s1)); HIPCHK(hipEventRecord(b->ev_join[2 * i + 1], s2)); }
     PassArgs a; int grid;
@@ -1081,7 +1089,7 @@ int rolo_batch_register_async(rolo_batch* b, const float* guess16, const double*
   if (graphable) {
     if (b->graph_exec && same_keys(keys, b->gkey.k)) {
       HIPCHK(hipGraphLaunch(b->graph_exec, st));
-      for (rolo_ctx* c : b->m) { c->src.have_cov = true; c->tgt.have_cov = true; }
+      for (rolo_ctx* c : b->m) { c->src.have_cov = true; c->tgt.have_cov = true; c->src.have_sorted = true; c->tgt.have_sorted = true; }
       b->pending = true;
       return ROLO_OK;
     }

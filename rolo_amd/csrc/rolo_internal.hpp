@@ -41,6 +41,7 @@ struct CloudDev {          // one point cloud resident in HBM
   float4* sorted = nullptr;     // 8 * n_leaves, (x,y,z, bits(original index)); padding = +inf, index INT_MAX
   float4* boxes = nullptr;      // 2 * 2P entries: node h -> boxes[2h] = lo, boxes[2h+1] = hi ; leaves h in [P, 2P)
   int n_leaves = 0, P = 0;
+  bool have_sorted = false;     // sorted / boxes belong to the current xyz
   int32_t* knn_idx = nullptr;   // debug: n x k
   float* knn_d2 = nullptr;
 };
@@ -99,8 +100,8 @@ size_t knn_sort_temp_bytes(int n_total);
 hipError_t launch_knn_walk(const KnnPair& A, int k, hipStream_t s);                       // neighbour indices -> A.c[].nbr
 hipError_t launch_knn_tail(const KnnPair& A, int k, int regularization, hipStream_t s);   // covariances from A.c[].nbr
 
-hipError_t launch_voxel_build(const CloudDev& tgt, VoxelTable tab, unsigned long long* tgt_keys, int* tgt_slot,
-                              int* counters /* [0]=V, [1]=error */, hipStream_t s);
+hipError_t launch_voxel_build(const CloudDev& tgt, VoxelTable tab, unsigned long long* tgt_keys, int* tgt_slot, int* counters, bool morton_order,
+                              hipStream_t s);
 hipError_t launch_voxel_keys(const float4* pts, int n, VoxelTable tab, int32_t* keys3, hipStream_t s);
 
 hipError_t launch_rot_pass(int dof, const PassArgs& a, const LmState* st, int grid, hipStream_t s);
