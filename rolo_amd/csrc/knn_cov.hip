@@ -264,15 +264,21 @@ template <int KMAX>
 ROLO_DEV void knn_covariance_tail(const int (&ki)[KMAX], int kk, const float4* __restrict__ orig, int n, int qi, int reg,
                                   double* __restrict__ cov) {
   // ---- covariance of the neighbourhood (rot_vgicp_impl.hpp:438-455), fp64, centred two-pass ----
+  // the K neighbours are gathered once and stay in registers for both passes (this kernel is not occupancy-critical)
+  float px[KMAX], py[KMAX], pz[KMAX];
+#pragma unroll
+  for (int u = 0; u < KMAX; u++) {
+    const float4 p = (u < kk) ? orig[ki[u]] : make_float4(0.f, 0.f, 0.f, 0.f);
+    px[u] = p.x; py[u] = p.y; pz[u] = p.z;
+  }
   double mx = 0, my = 0, mz = 0;
 #pragma unroll
-  for (int u = 0; u < KMAX; u++) if (u < kk) { const float4 p = orig[ki[u]]; mx += (double)p.x; my += (double)p.y; mz += (double)p.z; }
+  for (int u = 0; u < KMAX; u++) if (u < kk) { mx += (double)px[u]; my += (double)py[u]; mz += (double)pz[u]; }
   mx /= kk; my /= kk; mz /= kk;
   double cxx = 0, cxy = 0, cxz = 0, cyy = 0, cyz = 0, czz = 0;
 #pragma unroll
   for (int u = 0; u < KMAX; u++) if (u < kk) {
-    const float4 p = orig[ki[u]];
-    const double ax = (double)p.x - mx, ay = (double)p.y - my, az = (double)p.z - mz;
+    const double ax = (double)px[u] - mx, ay = (double)py[u] - my, az = (double)pz[u] - mz;
     cxx += ax * ax; cxy += ax * ay; cxz += ax * az; cyy += ay * ay; cyz += ay * az; czz += az * az;
   }
   cxx /= kk; cxy /= kk; cxz /= kk; cyy /= kk; cyz /= kk; czz /= kk;
