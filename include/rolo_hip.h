@@ -206,6 +206,17 @@ void rolo_front_default_params(rolo_front_params* p); /* config/params.yaml valu
 int rolo_project_frame(rolo_ctx* ctx, const rolo_front_params* P, const float* pts, int stride, const uint16_t* ring,
                        int n_raw, float* extracted, int32_t* point_col_ind, float* point_range, int32_t* start_ring,
                        int32_t* end_ring, float* range_mat, int* n_valid);
+/* ImageProjection::deskewPoint (src/imageProjection.cpp:368-396; deskewCloudInfo :266-366 prepares its inputs): rotation-only
+ * de-skew of every stored point by the front-end odometry increment over the scan, `rolo/deskewEnabled` (off in every
+ * shipped config). Arms the NEXT rolo_project_frame / rolo_odom_submit on this context: rel_time[i] = fabs(point.time) of
+ * raw point i (what :358-359 stores; for clouds without a time field pass the azimuth-interpolated scanPeriod * relTime of
+ * :303-326), odom_incre_rpy = odomIncreRoll/Pitch/Yaw, odom_time_diff = odomTimeDiff (:349-351; rolo_odom_increment does
+ * the pose algebra). Range, pixel and every index still come from the raw point, as in the reference (:412-454). */
+typedef struct rolo_deskew { int enabled; float odom_incre_rpy[3]; float scan_period; double odom_time_diff; } rolo_deskew;
+int rolo_front_set_deskew(rolo_ctx* ctx, const rolo_deskew* d, const float* rel_time, int n_raw, int rel_time_on_device);
+/* lidarOdomAffineFront.inverse() * lidarOdomAffineBack -> pcl::getTranslationAndEulerAngles (:345-351); poses and increment as
+ * x, y, z, roll, pitch, yaw (float) */
+void rolo_odom_increment(const float* front6, const float* back6, float* incre6);
 /* FeatureExtraction::calculateSmoothness + markOccludedPoints + extractFeatures (src/featureExtraction.cpp:87-266)
  * on the arrays rolo_project_frame left on the device (call order: project, then extract).
  * out (host): corner[nc*4], surface[ns*4] (sized for N points each); optional curvature/picked/label [N]. */
@@ -245,6 +256,8 @@ int rolo_odom_collect(rolo_odom* o, float* pose6, double* rot9, double* trans3, 
 /* options of the fused path: ROLO_ODOM_REUSE_COVARIANCES (default 0) = rolo_adopt_target_covariances between frames */
 #define ROLO_ODOM_REUSE_COVARIANCES 1
 int rolo_odom_set_option(rolo_odom* o, int option, int value);
+/* rolo_front_set_deskew for the next rolo_odom_submit / rolo_odom_frame of the fused path */
+int rolo_odom_set_deskew(rolo_odom* o, const rolo_deskew* d, const float* rel_time, int n_raw, int rel_time_on_device);
 
 #ifdef __cplusplus
 }

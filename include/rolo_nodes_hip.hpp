@@ -62,6 +62,12 @@ struct CloudInfo {
 class ImageProjection {
 public:
   ImageProjection(Context& ctx, const FrontParams& p) : ctx_(ctx), p_(p) {}
+  // deskewCloudInfo() + deskewPoint() (:266-396) for the next projectPointCloud: odomIncreRoll/Pitch/Yaw, scanPeriod,
+  // odomTimeDiff and rel_time[i] = fabs(point.time) of raw point i (host array of n values)
+  void setDeskew(const float odomIncreRPY[3], float scanPeriod, double odomTimeDiff, const float* rel_time, int n, bool deskewEnabled = true) {
+    rolo_deskew d{deskewEnabled ? 1 : 0, {odomIncreRPY[0], odomIncreRPY[1], odomIncreRPY[2]}, scanPeriod, odomTimeDiff};
+    check(rolo_front_set_deskew(ctx_.get(), &d, rel_time, n, 0), "rolo_front_set_deskew");
+  }
   // projectPointCloud() + cloudExtraction(): `pts` = n records of `stride` floats (x, y, z first), `ring` the ring field
   const CloudInfo& projectPointCloud(const float* pts, int stride, const uint16_t* ring, int n) {
     const size_t npix = (size_t)p_.n_scan * p_.horizon_scan;
@@ -126,6 +132,11 @@ public:
     check(rolo_odom_submit(odom_, &p, stamp, pts, stride, ring, n, on_device ? 1 : 0), "rolo_odom_submit");
   }
   Status collect() { return (Status)check(rolo_odom_collect(odom_, LaserOdomPose.data(), Rotation.data(), Translation.data(), counts.data()), "rolo_odom_collect"); }
+  // de-skew of the next submit() / frame() (see ImageProjection::setDeskew)
+  void setDeskew(const float odomIncreRPY[3], float scanPeriod, double odomTimeDiff, const float* rel_time, int n, bool deskewEnabled = true) {
+    rolo_deskew d{deskewEnabled ? 1 : 0, {odomIncreRPY[0], odomIncreRPY[1], odomIncreRPY[2]}, scanPeriod, odomTimeDiff};
+    check(rolo_odom_set_deskew(odom_, &d, rel_time, n, 0), "rolo_odom_set_deskew");
+  }
   void setReuseCovariances(bool on) { check(rolo_odom_set_option(odom_, ROLO_ODOM_REUSE_COVARIANCES, on ? 1 : 0), "rolo_odom_set_option"); }
 
   std::array<float, 6> LaserOdomPose{};   // x, y, z, roll, pitch, yaw — what pubMessage publishes (:680-684)

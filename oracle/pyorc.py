@@ -298,14 +298,34 @@ def transform_cloud_f(pts, T):
     return out
 
 
-def project(fp: FrontParams, xyz, ring):
+class Deskew(C.Structure):
+    _fields_ = [("enabled", C.c_int), ("odom_incre_rpy", C.c_float * 3), ("scan_period", C.c_float), ("odom_time_diff", C.c_double)]
+
+
+def deskew(incre_rpy, scan_period=0.1, odom_time_diff=0.1, enabled=1):
+    d = Deskew(); d.enabled = enabled; d.scan_period = scan_period; d.odom_time_diff = odom_time_diff
+    for k in range(3):
+        d.odom_incre_rpy[k] = incre_rpy[k]
+    return d
+
+
+def odom_increment(front6, back6):
+    f = np.ascontiguousarray(front6, np.float32); b = np.ascontiguousarray(back6, np.float32); o = np.zeros(6, np.float32)
+    lib().orc_odom_increment(_f(f), _f(b), _f(o))
+    return o
+
+
+def project(fp: FrontParams, xyz, ring, rel_time=None, dsk=None):
     xyz = np.ascontiguousarray(xyz, np.float32); ring = np.ascontiguousarray(ring, np.uint16)
     NS, H = fp.n_scan, fp.horizon_scan
     range_mat = np.zeros(NS * H, np.float32); full = np.zeros((NS * H, 4), np.float32)
     ext = np.zeros((NS * H, 4), np.float32); col = np.zeros(NS * H, np.int32); rng = np.zeros(NS * H, np.float32)
     sr = np.zeros(NS, np.int32); er = np.zeros(NS, np.int32)
-    n = lib().orc_project(C.byref(fp), _f(xyz), xyz.shape[1], ring.ctypes.data_as(C.POINTER(C.c_uint16)),
-                          xyz.shape[0], _f(range_mat), _f(full), _f(ext), _i(col), _f(rng), _i(sr), _i(er))
+    rt = np.ascontiguousarray(rel_time, np.float32) if rel_time is not None else None
+    lib().orc_project_deskew.restype = C.c_int
+    n = lib().orc_project_deskew(C.byref(fp), _f(xyz), xyz.shape[1], ring.ctypes.data_as(C.POINTER(C.c_uint16)),
+                                 xyz.shape[0], _f(rt) if rt is not None else None, C.byref(dsk) if dsk is not None else None,
+                                 _f(range_mat), _f(full), _f(ext), _i(col), _f(rng), _i(sr), _i(er))
     assert n >= 0
     return dict(n=n, range_mat=range_mat.reshape(NS, H), full_cloud=full, extracted=ext[:n].copy(),
                 point_col_ind=col[:n].copy(), point_range=rng[:n].copy(), start_ring=sr, end_ring=er)

@@ -22,9 +22,30 @@ void orc_front_default_params(orc_front_params* p) {  // config/params.yaml:20-3
 }
 
 // imageProjection.cpp:399-460 + :477-505
+// ImageProjection::deskewPoint :368-396, rotation only
+static void deskew_point(const orc_deskew* d, float rel_time_f, float& x, float& y, float& z) {
+  const double relTime = (double)rel_time_f;           // the float stored in deskewCloud->points[i].intensity, passed as double
+  const float ratio = relTime / d->scan_period;        // :380 double / float, stored float
+  const float s1 = (float)(d->scan_period / d->odom_time_diff);  // :383 float / double; Eigen casts the scalar to the vector's float
+  const float r = d->odom_incre_rpy[0] * s1 * ratio, p = d->odom_incre_rpy[1] * s1 * ratio, w = d->odom_incre_rpy[2] * s1 * ratio;
+  float T[16];
+  orc_get_transformation(0.f, 0.f, 0.f, -r, -p, -w, T);  // :386 pcl::getTransformation (float overload)
+  const float nx = T[0] * x + T[1] * y + T[2] * z + T[3];  // :389-391
+  const float ny = T[4] * x + T[5] * y + T[6] * z + T[7];
+  const float nz = T[8] * x + T[9] * y + T[10] * z + T[11];
+  x = nx; y = ny; z = nz;
+}
+
 int orc_project(const orc_front_params* P, const float* pts, int stride, const uint16_t* ring, int n_raw,
                 float* range_mat, float* full_cloud, float* extracted, int32_t* point_col_ind,
                 float* point_range, int32_t* start_ring, int32_t* end_ring) {
+  return orc_project_deskew(P, pts, stride, ring, n_raw, nullptr, nullptr, range_mat, full_cloud, extracted, point_col_ind, point_range, start_ring, end_ring);
+}
+
+int orc_project_deskew(const orc_front_params* P, const float* pts, int stride, const uint16_t* ring, int n_raw,
+                       const float* rel_time, const orc_deskew* d,
+                       float* range_mat, float* full_cloud, float* extracted, int32_t* point_col_ind,
+                       float* point_range, int32_t* start_ring, int32_t* end_ring) {
   const int NS = P->n_scan, H = P->horizon_scan;
   if (NS <= 0 || H <= 0 || P->downsample_rate <= 0) return -1;
   for (int i = 0; i < NS * H; i++) range_mat[i] = FLT_MAX;  // :130
@@ -43,9 +64,11 @@ int orc_project(const orc_front_params* P, const float* pts, int stride, const u
     if (columnIdn >= H) columnIdn -= H;
     if (columnIdn < 0 || columnIdn >= H) continue;
     if (range_mat[rowIdn * H + columnIdn] != FLT_MAX) continue;  // first point wins :451
+    float sx = x, sy = y, sz = z;
+    if (d && d->enabled && rel_time) deskew_point(d, rel_time[i], sx, sy, sz);  // :454 (the range and the pixel come from the raw point)
     range_mat[rowIdn * H + columnIdn] = range;
     float* fc = full_cloud + 4 * ((size_t)columnIdn + (size_t)rowIdn * H);
-    fc[0] = x; fc[1] = y; fc[2] = z; fc[3] = intensity;
+    fc[0] = sx; fc[1] = sy; fc[2] = sz; fc[3] = intensity;
   }
   int count = 0;
   for (int i = 0; i < NS; i++) {
@@ -214,6 +237,15 @@ inline void affine_inverse_f(const float* T, float* out) {  // Eigen Transform<f
   out[12] = out[13] = out[14] = 0; out[15] = 1;
 }
 }  // namespace
+
+extern "C" void orc_odom_increment(const float* front6, const float* back6, float* incre6) {  // imageProjection.cpp:293-299
+  float F[16], B[16], Fi[16], I[16];
+  orc_get_transformation(front6[0], front6[1], front6[2], front6[3], front6[4], front6[5], F);
+  orc_get_transformation(back6[0], back6[1], back6[2], back6[3], back6[4], back6[5], B);
+  affine_inverse_f(F, Fi);
+  mat4f_mul(Fi, B, I);
+  orc_get_translation_and_euler(I, incre6);
+}
 
 struct orc_odom {
   orc_params RP;

@@ -33,6 +33,19 @@ int orc_project(const orc_front_params* P, const float* pts, int stride, const u
                 float* range_mat, float* full_cloud, float* extracted, int32_t* point_col_ind,
                 float* point_range, int32_t* start_ring, int32_t* end_ring);
 
+/* The same with ImageProjection::deskewPoint (imageProjection.cpp:368-396) for clouds that carry a per-point time
+ * (timeFlag == 1, deskewCloudInfo :330-361): rel_time[i] = fabs(point.time) is what :358-359 stores in
+ * deskewCloud->points[i].intensity; odom_incre_rpy / odom_time_diff are odomIncreRoll/Pitch/Yaw and odomTimeDiff of
+ * :349-351. d == NULL or !d->enabled: no de-skew (deskewPoint returns the point, :371-372). */
+typedef struct orc_deskew { int enabled; float odom_incre_rpy[3]; float scan_period; double odom_time_diff; } orc_deskew;
+int orc_project_deskew(const orc_front_params* P, const float* pts, int stride, const uint16_t* ring, int n_raw,
+                       const float* rel_time, const orc_deskew* d,
+                       float* range_mat, float* full_cloud, float* extracted, int32_t* point_col_ind,
+                       float* point_range, int32_t* start_ring, int32_t* end_ring);
+/* lidarOdomAffineFront.inverse() * lidarOdomAffineBack -> getTranslationAndEulerAngles (:293-299, 345-351); poses as
+ * x, y, z, roll, pitch, yaw (odom2affine :514-522 goes through tf's quaternion -> RPY, done by the caller) */
+void orc_odom_increment(const float* front6, const float* back6, float* incre6);
+
 /* K3 + K4: featureExtraction.cpp:87-266. Per-frame arrays are zero-initialised and the unstable
  * std::sort tie order is fixed to (curvature, index) (Q7).
  * out: curvature[N], neighbor_picked[N], label[N] (after extraction), corner[*n_corner*4], surface[*n_surf*4]

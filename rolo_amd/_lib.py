@@ -32,6 +32,10 @@ class TraceRec(C.Structure):
                 ("dnorm", C.c_double)]
 
 
+class Deskew(C.Structure):
+    _fields_ = [("enabled", C.c_int), ("odom_incre_rpy", C.c_float * 3), ("scan_period", C.c_float), ("odom_time_diff", C.c_double)]
+
+
 class FrontParams(C.Structure):
     _fields_ = [("n_scan", C.c_int), ("horizon_scan", C.c_int), ("downsample_rate", C.c_int),
                 ("lidar_min_range", C.c_float), ("lidar_max_range", C.c_float), ("edge_threshold", C.c_float),
@@ -101,6 +105,9 @@ SYMBOLS = {
     "rolo_odom_submit": (C.c_int, [vp, C.POINTER(FrontParams), C.c_double, vp, C.c_int, vp, C.c_int, C.c_int]),
     "rolo_odom_collect": (C.c_int, [vp, fp, dp, dp, C.POINTER(C.c_int)]),
     "rolo_odom_set_option": (C.c_int, [vp, C.c_int, C.c_int]),
+    "rolo_odom_set_deskew": (C.c_int, [vp, C.POINTER(Deskew), vp, C.c_int, C.c_int]),
+    "rolo_odom_increment": (None, [fp, fp, fp]),
+    "rolo_front_set_deskew": (C.c_int, [vp, C.POINTER(Deskew), vp, C.c_int, C.c_int]),
     "rolo_front_default_params": (None, [C.POINTER(FrontParams)]),
     "rolo_project_frame": (C.c_int, [vp, C.POINTER(FrontParams), fp, C.c_int, C.POINTER(C.c_uint16), C.c_int, fp, ip, fp,
                                      ip, ip, fp, C.POINTER(C.c_int)]),

@@ -1,7 +1,9 @@
 // K1-K4 — the front end on gfx950.
 // Replaces ImageProjection::projectPointCloud / cloudExtraction (reference src/imageProjection.cpp:399-505) and
 // FeatureExtraction::calculateSmoothness / markOccludedPoints / extractFeatures incl. pcl::VoxelGrid
-// (reference src/featureExtraction.cpp:87-266). Deskew is off (every shipped config).
+// (reference src/featureExtraction.cpp:87-266). De-skew (deskewPoint :368-396, off in every shipped config) is applied when
+// armed with rolo_front_set_deskew, for clouds with a per-point time; the azimuth-interpolated times of clouds without one
+// (:270-327) are left to the caller (pass them as rel_time).
 //
 // MI355X design. The reference's three serial loops become:
 //   K1  one thread per raw point; "first point to claim a pixel wins" (imageProjection.cpp:451) is an atomicMin of
@@ -81,11 +83,29 @@ __global__ __launch_bounds__(256) void ring_scan_kernel(const int* __restrict__ 
 }
 
 // ---- K2 pass B: ring offsets, start/end ring index, scatter ----
+// ImageProjection::deskewPoint (imageProjection.cpp:368-396), rotation only, for clouds with a per-point time:
+// rel_time[i] = fabs(point.time) (what deskewCloudInfo :358-359 leaves in deskewCloud->points[i].intensity)
+struct DeskewArgs { const float* rel_time; float incre_r, incre_p, incre_y, scan_period; double odom_time_diff; };
+
+ROLO_DEV void deskew_point(const DeskewArgs& d, float rel_time_f, float& x, float& y, float& z) {
+  const double relTime = (double)rel_time_f;
+  const float ratio = relTime / d.scan_period;                     // :380 double / float, stored float
+  const float s1 = (float)(d.scan_period / d.odom_time_diff);      // :383 float / double; Eigen casts the scalar to float
+  const float roll = -(d.incre_r * s1 * ratio), pitch = -(d.incre_p * s1 * ratio), yaw = -(d.incre_y * s1 * ratio);
+  // pcl::getTransformation(0, 0, 0, roll, pitch, yaw), float (:386)
+  const float A = cosf(yaw), B = sinf(yaw), C = cosf(pitch), D = sinf(pitch), E = cosf(roll), F = sinf(roll), DE = D * E, DF = D * F;
+  const float nx = (A * C) * x + (A * DF - B * E) * y + (B * F + A * DE) * z + 0.f;   // :389-391
+  const float ny = (B * C) * x + (A * E + B * DF) * y + (B * DE - A * F) * z + 0.f;
+  const float nz = (-D) * x + (C * F) * y + (C * E) * z + 0.f;
+  x = nx; y = ny; z = nz;
+}
+
 __global__ __launch_bounds__(256) void ring_scatter_kernel(const float* __restrict__ pts, int stride, const unsigned short* __restrict__ ring,
                                                           const int* __restrict__ owner, const int* __restrict__ local_idx,
                                                           const int* __restrict__ ring_count, int n_scan, int H, float4* __restrict__ extracted,
                                                           int* __restrict__ col_ind, float* __restrict__ point_range, int* __restrict__ start_ring,
-                                                          int* __restrict__ end_ring, float* __restrict__ range_mat, int* __restrict__ n_valid) {
+                                                          int* __restrict__ end_ring, float* __restrict__ range_mat, int* __restrict__ n_valid,
+                                                          DeskewArgs dsk) {
   __shared__ int s_off;
   const int row = blockIdx.x, t = threadIdx.x;
   if (t == 0) {
@@ -105,7 +125,9 @@ __global__ __launch_bounds__(256) void ring_scatter_kernel(const float* __restri
       const float x = pts[(size_t)o * stride], y = pts[(size_t)o * stride + 1], z = pts[(size_t)o * stride + 2];
       rng = sqrtf(x * x + y * y + z * z);
       const int dst = off + local_idx[row * H + j];
-      extracted[dst] = make_float4(x, y, z, ring[o] * z);  // intensity <- ring * z (:410)
+      float sx = x, sy = y, sz = z;
+      if (dsk.rel_time) deskew_point(dsk, dsk.rel_time[o], sx, sy, sz);  // :454 — range and pixel come from the raw point
+      extracted[dst] = make_float4(sx, sy, sz, ring[o] * z);  // intensity <- ring * z (:410)
       col_ind[dst] = j;
       point_range[dst] = rng;
     }
@@ -572,6 +594,10 @@ struct Front {
   int *corner_cnt = nullptr, *surf_cnt = nullptr;
   int n_valid = 0; int n_scan = 0, H = 0;
   bool projected = false;
+  // rolo_front_set_deskew: armed for the next projection only
+  bool deskew_armed = false;
+  DeskewArgs deskew{};
+  float* rel_time = nullptr; size_t cap_time = 0;   // staging when the times come from the host
 };
 
 thread_local std::string g_ferr;
@@ -584,7 +610,7 @@ bool dev_alloc(T*& p, size_t count) {
 
 void front_free(Front* f) {
   void* bufs[] = {f->raw, f->ring, f->owner, f->local_idx, f->ring_count, f->start_ring, f->end_ring, f->counters, f->extracted, f->col, f->range,
-                  f->range_mat, f->curv, f->picked, f->label, f->corner_stage, f->surf_stage, f->corner_out, f->surf_out, f->corner_cnt, f->surf_cnt};
+                  f->range_mat, f->curv, f->picked, f->label, f->corner_stage, f->surf_stage, f->corner_out, f->surf_out, f->corner_cnt, f->surf_cnt, f->rel_time};
   for (void* b : bufs) if (b) (void)hipFree(b);
 }
 
@@ -647,7 +673,8 @@ int front_project_enqueue(Front* f, const rolo_front_params* P, const float* d_p
   ring_scan_kernel<<<NS, 256, 0, s>>>(f->owner, H, f->local_idx, f->ring_count);
   ring_scatter_kernel<<<NS, 256, 0, s>>>(d_pts, stride, d_ring, f->owner, f->local_idx, f->ring_count, NS, H, f->extracted + FRONT_GUARD,
                                         f->col + FRONT_GUARD, f->range + FRONT_GUARD, f->start_ring, f->end_ring, want_range_mat ? f->range_mat : nullptr,
-                                        f->counters);
+                                        f->counters, f->deskew_armed ? f->deskew : DeskewArgs{});
+  f->deskew_armed = false;
   FCHK(hipGetLastError());
   return ROLO_OK;
 }
@@ -719,6 +746,30 @@ extern "C" {
 void rolo_front_destroy(rolo_ctx* c) {
   void** slot = ctx_front_slot(c);
   if (*slot) { Front* f = static_cast<Front*>(*slot); front_free(f); delete f; *slot = nullptr; }
+}
+
+int rolo_front_set_deskew(rolo_ctx* c, const rolo_deskew* d, const float* rel_time, int n_raw, int on_device) {
+  if (!c || !d) return ROLO_EINVAL;
+  FCHK(hipSetDevice(ctx_device(c)));
+  void** slot = ctx_front_slot(c);
+  if (!*slot) *slot = new Front();
+  Front* f = static_cast<Front*>(*slot);
+  f->deskew_armed = false;
+  if (!d->enabled) return ROLO_OK;   // deskewPoint returns the point as is (:371-372)
+  if (!rel_time || n_raw < 0) { ctx_set_error("de-skew needs the per-point times"); return ROLO_EINVAL; }
+  if (!(d->odom_time_diff != 0.0) || !(d->scan_period != 0.f)) { ctx_set_error("de-skew: zero scan period / odometry time difference"); return ROLO_EINVAL; }
+  const float* dt = rel_time;
+  if (!on_device) {
+    if ((size_t)n_raw > f->cap_time || !f->rel_time) {
+      if (!dev_alloc(f->rel_time, (size_t)n_raw)) { ctx_set_error("hipMalloc failed (de-skew times)"); return ROLO_EHIP; }
+      f->cap_time = (size_t)n_raw;
+    }
+    FCHK(hipMemcpyAsync(f->rel_time, rel_time, sizeof(float) * (size_t)n_raw, hipMemcpyHostToDevice, ctx_stream(c)));
+    dt = f->rel_time;
+  }
+  f->deskew = DeskewArgs{dt, d->odom_incre_rpy[0], d->odom_incre_rpy[1], d->odom_incre_rpy[2], d->scan_period, d->odom_time_diff};
+  f->deskew_armed = true;
+  return ROLO_OK;
 }
 
 void rolo_front_default_params(rolo_front_params* p) {  // config/params.yaml:20-36

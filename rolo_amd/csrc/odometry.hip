@@ -118,6 +118,32 @@ void rolo_odom_destroy(rolo_odom* o) {
   delete o;
 }
 
+void rolo_odom_increment(const float* front6, const float* back6, float* incre6) {  // imageProjection.cpp:345-351
+  const Aff F = get_transformation(front6[0], front6[1], front6[2], front6[3], front6[4], front6[5]);
+  const Aff B = get_transformation(back6[0], back6[1], back6[2], back6[3], back6[4], back6[5]);
+  get_translation_and_euler(aff_mul(aff_inverse(F), B), incre6);
+}
+
+static int ensure_front_ctx(rolo_odom* o) {
+  if (o->fctx) return ROLO_OK;
+  int rc = rolo_ctx_create(rolo::ctx_device(o->ctx), &o->fctx);
+  if (rc) return rc;
+  for (auto& sl : o->q) {
+    if (hipHostMalloc((void**)&sl.h_counts, 4 * sizeof(int)) != hipSuccess || hipEventCreateWithFlags(&sl.done, hipEventDisableTiming) != hipSuccess) {
+      rolo::ctx_set_error("pinned buffer / event creation failed"); return ROLO_EHIP;
+    }
+  }
+  return ROLO_OK;
+}
+
+int rolo_odom_set_deskew(rolo_odom* o, const rolo_deskew* d, const float* rel_time, int n_raw, int on_device) {
+  if (!o) return ROLO_EINVAL;
+  if (hipSetDevice(rolo::ctx_device(o->ctx)) != hipSuccess) { rolo::ctx_set_error("hipSetDevice failed"); return ROLO_EHIP; }
+  const int rc = ensure_front_ctx(o);
+  if (rc) return rc;
+  return rolo_front_set_deskew(o->fctx, d, rel_time, n_raw, on_device);
+}
+
 int rolo_odom_set_option(rolo_odom* o, int option, int value) {
   if (!o) return ROLO_EINVAL;
   if (option == ROLO_ODOM_REUSE_COVARIANCES) { o->reuse_cov = value != 0; o->cov_chain = false; return ROLO_OK; }
@@ -190,14 +216,7 @@ int rolo_odom_submit(rolo_odom* o, const rolo_front_params* P, double stamp, con
   if (o->q_len == 2) { rolo::ctx_set_error("two frames are already in flight: collect one first"); return ROLO_ESTATE; }
   if (hipSetDevice(rolo::ctx_device(o->ctx)) != hipSuccess) { rolo::ctx_set_error("hipSetDevice failed"); return ROLO_EHIP; }
   int rc;
-  if (!o->fctx) {
-    if ((rc = rolo_ctx_create(rolo::ctx_device(o->ctx), &o->fctx))) return rc;
-    for (auto& sl : o->q) {
-      if (hipHostMalloc((void**)&sl.h_counts, 4 * sizeof(int)) != hipSuccess || hipEventCreateWithFlags(&sl.done, hipEventDisableTiming) != hipSuccess) {
-        rolo::ctx_set_error("pinned buffer / event creation failed"); return ROLO_EHIP;
-      }
-    }
-  }
+  if ((rc = ensure_front_ctx(o))) return rc;
   const size_t cap = rolo::front_feature_capacity(P);
   if (cap > o->d_cap) {
     if (o->nOld > 0 || o->q_len > 0) { rolo::ctx_set_error("front parameters grew between frames"); return ROLO_ESTATE; }

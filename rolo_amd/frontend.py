@@ -11,7 +11,7 @@ from __future__ import annotations
 import ctypes as C
 import numpy as np
 
-from ._lib import FrontParams, check, lib
+from ._lib import Deskew, FrontParams, check, lib
 
 
 def front_params(**kw) -> FrontParams:
@@ -20,6 +20,21 @@ def front_params(**kw) -> FrontParams:
     for k, v in kw.items():
         setattr(p, k, v)
     return p
+
+
+def deskew_params(odom_incre_rpy, scan_period=0.1, odom_time_diff=0.1, enabled=True) -> Deskew:
+    """odomIncreRoll/Pitch/Yaw, scanPeriod, odomTimeDiff of ImageProjection (imageProjection.cpp:79-81,349-351)."""
+    d = Deskew(); d.enabled = int(enabled); d.scan_period = scan_period; d.odom_time_diff = odom_time_diff
+    for k in range(3):
+        d.odom_incre_rpy[k] = odom_incre_rpy[k]
+    return d
+
+
+def odom_increment(front6, back6):
+    """lidarOdomAffineFront.inverse() * lidarOdomAffineBack as x, y, z, roll, pitch, yaw (imageProjection.cpp:345-351)."""
+    f = np.ascontiguousarray(front6, np.float32); b = np.ascontiguousarray(back6, np.float32); o = np.zeros(6, np.float32)
+    lib().rolo_odom_increment(_f(f), _f(b), _f(o))
+    return o
 
 
 def _f(a):
@@ -36,6 +51,11 @@ class FrontEnd:
     def __init__(self, ctx, params: FrontParams):
         self.ctx = ctx
         self.p = params
+
+    def setDeskew(self, dsk: Deskew, rel_time):
+        """deskewPoint for the next project(): rel_time[i] = fabs(point.time) of raw point i (numpy array)."""
+        rt = np.ascontiguousarray(rel_time, np.float32)
+        check(lib().rolo_front_set_deskew(self.ctx._h, C.byref(dsk), C.c_void_p(rt.ctypes.data), rt.shape[0], 0), "rolo_front_set_deskew")
 
     def project(self, xyz, ring, want_range_mat=False):
         xyz = np.ascontiguousarray(xyz, np.float32)

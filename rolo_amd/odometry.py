@@ -33,6 +33,11 @@ class LidarOdometry:
 
     REUSE_COVARIANCES = 1
 
+    def setDeskew(self, dsk, rel_time):
+        """deskewPoint for the next submit() / frame(): rel_time[i] = fabs(point.time) of raw point i (numpy array)."""
+        rt = np.ascontiguousarray(rel_time, np.float32)
+        check(lib().rolo_odom_set_deskew(self._h, C.byref(dsk), C.c_void_p(rt.ctypes.data), rt.shape[0], 0), "rolo_odom_set_deskew")
+
     def setOption(self, option: int, value: int):
         check(lib().rolo_odom_set_option(self._h, option, value), "rolo_odom_set_option")
 

@@ -93,3 +93,36 @@ def test_thresholds_change_the_selection():
     fo, po, fe, pg = both("os1-64", f0, edge_threshold=0.1, surf_threshold=0.02, odometry_surf_leaf_size=0.2)
     check_projection(po, pg)
     check_features(fo, po, fe, pg)
+
+
+def test_deskew_matches_oracle():
+    """rolo_front_set_deskew = ImageProjection::deskewPoint: every index output is untouched (range, pixel and curvature come
+    from the raw point), the stored coordinates are the oracle's up to the last bit of device sinf / cosf."""
+    from rolo_amd.frontend import deskew_params, odom_increment
+    from rolo_amd.rotvgicp import RotVGICP
+    cfg = dict(n_scan=16, horizon_scan=1800)
+    fr = synth.make_frame("vlp16", np.eye(3), np.zeros(3), synth.SEED)
+    n = fr.xyz.shape[0]
+    rel_time = (np.arange(n, dtype=np.float64) / n * 0.1).astype(np.float32)     # firing order over a 0.1 s scan
+    inc_o = pyorc.odom_increment([0, 0, 0, 0, 0, 0], [0.31, 0.04, 0.01, 0.004, -0.006, 0.035])
+    inc_g = odom_increment([0, 0, 0, 0, 0, 0], [0.31, 0.04, 0.01, 0.004, -0.006, 0.035])
+    assert np.array_equal(inc_o, inc_g)
+    fo = pyorc.front_params(**cfg); fg = front_params(**cfg)
+    po = pyorc.project(fo, fr.xyz, fr.ring, rel_time, pyorc.deskew(inc_o[3:], 0.1, 0.0987))
+    eo = pyorc.extract_features(fo, po)
+    g = RotVGICP(); fe = FrontEnd(g, fg)
+    fe.setDeskew(deskew_params(inc_g[3:], 0.1, 0.0987), rel_time)
+    pg = fe.project(fr.xyz, fr.ring); eg = fe.extract(pg["n"], debug=True)
+    assert pg["n"] == po["n"] and np.array_equal(pg["point_col_ind"], po["point_col_ind"]) and np.array_equal(pg["point_range"], po["point_range"])
+    assert np.array_equal(eg["label"], eo["label"]) and np.array_equal(eg["picked"], eo["picked"])
+    raw = pyorc.project(fo, fr.xyz, fr.ring)
+    assert np.abs(po["extracted"][:, :3] - raw["extracted"][:, :3]).max() > 0.05          # the de-skew really moved the points
+    assert np.abs(pg["extracted"][:, :3] - po["extracted"][:, :3]).max() <= 4e-6          # float ulps at <= 100 m
+    assert np.array_equal(pg["extracted"][:, 3], po["extracted"][:, 3])                   # intensity = ring * raw z
+    assert eg["corner"].shape == eo["corner"].shape and np.abs(eg["corner"] - eo["corner"]).max() <= 4e-6
+    assert eg["surface"].shape == eo["surface"].shape and np.abs(eg["surface"] - eo["surface"]).max() <= 1e-5
+    # armed for one projection only; a disabled block is the plain path
+    p2 = fe.project(fr.xyz, fr.ring)
+    assert np.array_equal(p2["extracted"], raw["extracted"])
+    fe.setDeskew(deskew_params(inc_g[3:], 0.1, 0.0987, enabled=False), rel_time)
+    assert np.array_equal(fe.project(fr.xyz, fr.ring)["extracted"], raw["extracted"])

@@ -167,3 +167,26 @@ def test_cpp_node_cores_end_to_end(tmp_path):
             assert int(tok[11]) == eo["corner"].shape[0] and int(tok[12]) == eo["surface"].shape[0]
             assert np.abs(pose[:3] - pose_o[:3]).max() <= 1e-4 and np.abs(pose[3:] - pose_o[3:]).max() <= 1e-5
             assert np.abs(t - t_o).max() <= 1e-4
+
+
+def test_fused_path_with_deskew_equals_staged():
+    from rolo_amd.frontend import deskew_params
+    cfg = dict(n_scan=16, horizon_scan=1800)
+    fg = front_params(**cfg)
+    staged = LidarOdometry(0, 0.3); fe = FrontEnd(staged.reg, fg)
+    fused = LidarOdometry(0, 0.3)
+    for k, (R, t) in enumerate(trajectory(4)):
+        fr = synth.make_frame("vlp16", R, t, synth.SEED + k)
+        n = fr.xyz.shape[0]
+        rel_time = (np.arange(n, dtype=np.float64) / n * 0.1).astype(np.float32)
+        dsk = deskew_params([0.003, -0.002, 0.03], 0.1, 0.1)
+        stamp = 100.0 + 0.1 * k
+        if k == 2:
+            staged.odometryHandler(stamp - 0.05); fused.odometryHandler(stamp - 0.05)
+        fe.setDeskew(dsk, rel_time)
+        pg = fe.project(fr.xyz, fr.ring); eg = fe.extract(pg["n"])
+        rcs, pose_s, R_s, t_s = staged.cloudHandler(stamp, eg["corner"], eg["surface"])
+        fused.setDeskew(dsk, rel_time)
+        rcf, pose_f, R_f, t_f, cnt = fused.frame(fg, stamp, fr.xyz, fr.ring)
+        assert rcf == rcs and cnt == (pg["n"], eg["corner"].shape[0], eg["surface"].shape[0])
+        assert np.abs(pose_f - pose_s).max() < 1e-6 and np.abs(R_f - R_s).max() < 1e-9 and np.abs(t_f - t_s).max() < 1e-9

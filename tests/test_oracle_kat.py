@@ -115,3 +115,28 @@ def test_too_few_points_is_an_error_not_ub():
     r = pyorc.Reg(pyorc.default_params(polar_resolution=(0.175, 0.175, 2.0)))
     r.set_target(pts); r.set_source(pts)
     assert r.compute_covariances() == -2
+
+
+def test_deskew_known_answers():
+    """ImageProjection::deskewPoint restated (imageProjection.cpp:368-396): zero increment = identity; at relTime = scanPeriod
+    with odomTimeDiff = scanPeriod the stored point is the raw point rotated by -yaw about z; ranges / pixels are the raw ones."""
+    fr = synth.make_frame("vlp16", np.eye(3), np.zeros(3), synth.SEED)
+    fo = pyorc.front_params(n_scan=16, horizon_scan=1800)
+    raw = pyorc.project(fo, fr.xyz, fr.ring)
+    n = fr.xyz.shape[0]
+    full = np.full(n, 0.1, np.float32)
+    same = pyorc.project(fo, fr.xyz, fr.ring, full, pyorc.deskew([0, 0, 0], 0.1, 0.1))
+    assert np.array_equal(same["extracted"], raw["extracted"])
+    yaw = 0.05
+    rot = pyorc.project(fo, fr.xyz, fr.ring, full, pyorc.deskew([0, 0, yaw], 0.1, 0.1))
+    assert np.array_equal(rot["point_range"], raw["point_range"]) and np.array_equal(rot["point_col_ind"], raw["point_col_ind"])
+    c, s_ = np.cos(-yaw), np.sin(-yaw)
+    want = raw["extracted"][:, :3].astype(np.float64) @ np.array([[c, -s_, 0], [s_, c, 0], [0, 0, 1]]).T
+    assert np.abs(rot["extracted"][:, :3] - want).max() < 2e-5
+    assert np.array_equal(rot["extracted"][:, 3], raw["extracted"][:, 3])
+    half = pyorc.project(fo, fr.xyz, fr.ring, np.full(n, 0.05, np.float32), pyorc.deskew([0, 0, yaw], 0.1, 0.1))
+    c, s_ = np.cos(-yaw / 2), np.sin(-yaw / 2)
+    want = raw["extracted"][:, :3].astype(np.float64) @ np.array([[c, -s_, 0], [s_, c, 0], [0, 0, 1]]).T
+    assert np.abs(half["extracted"][:, :3] - want).max() < 2e-5
+    inc = pyorc.odom_increment([1.0, 2.0, 0.5, 0.0, 0.0, 0.3], [1.0, 2.0, 0.5, 0.0, 0.0, 0.35])
+    assert np.abs(inc - np.array([0, 0, 0, 0, 0, 0.05])).max() < 1e-6
