@@ -44,6 +44,9 @@ __global__ __launch_bounds__(256) void project_kernel(const float* __restrict__ 
   const float x = pts[(size_t)i * stride], y = pts[(size_t)i * stride + 1], z = pts[(size_t)i * stride + 2];
   const float range = sqrtf(x * x + y * y + z * z);  // utility.h:462-465
   if (range < P.lidar_min_range || range > P.lidar_max_range) return;
+  // NaN coordinates (the node refuses clouds that are not is_dense, :226-231): the reference's column index is then the int
+  // conversion of NaN — INT_MIN on x86, i.e. the point is dropped; the device conversion would give 0
+  if (range != range) return;
   const int rowIdn = ring[i];
   if (rowIdn < 0 || rowIdn >= P.n_scan) return;
   if (rowIdn % P.downsample_rate != 0) return;

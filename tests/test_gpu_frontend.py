@@ -126,3 +126,21 @@ def test_deskew_matches_oracle():
     assert np.array_equal(p2["extracted"], raw["extracted"])
     fe.setDeskew(deskew_params(inc_g[3:], 0.1, 0.0987, enabled=False), rel_time)
     assert np.array_equal(fe.project(fr.xyz, fr.ring)["extracted"], raw["extracted"])
+
+
+def test_nan_points_are_dropped_like_on_the_reference_cpu():
+    """Non-dense clouds are refused by the node (imageProjection.cpp:226-231); if NaNs arrive anyway the reference's column
+    index is int(NaN) = INT_MIN on x86 and the point is dropped — same here (the device's int(NaN) would be 0)."""
+    from rolo_amd.rotvgicp import RotVGICP
+    cfg = dict(n_scan=16, horizon_scan=1800)
+    fr = synth.make_frame("vlp16", np.eye(3), np.zeros(3), synth.SEED)
+    xyz = np.array(fr.xyz, np.float32); ring = np.array(fr.ring, np.uint16)
+    bad = np.arange(0, xyz.shape[0], 97)
+    xyz[bad[0::3], 0] = np.nan; xyz[bad[1::3], 1] = np.nan; xyz[bad[2::3]] = np.nan
+    fo = pyorc.front_params(**cfg); fg = front_params(**cfg)
+    po = pyorc.project(fo, xyz, ring); eo = pyorc.extract_features(fo, po)
+    g = RotVGICP(); fe = FrontEnd(g, fg)
+    pg = fe.project(xyz, ring); eg = fe.extract(pg["n"])
+    assert pg["n"] == po["n"] and np.array_equal(pg["extracted"], po["extracted"]) and np.array_equal(pg["point_col_ind"], po["point_col_ind"])
+    assert not np.isnan(pg["extracted"]).any()
+    assert np.array_equal(eg["corner"], eo["corner"]) and np.array_equal(eg["surface"], eo["surface"])
