@@ -86,7 +86,7 @@ struct rolo_ctx {
   size_t src_knn_cap = 0, src_knnd_cap = 0, tgt_knn_cap = 0, tgt_knnd_cap = 0;
   bool want_knn_lists = false;
   // kNN scratch
-  // one scratch set per cloud: source and target neighbourhood searches run concurrently on two streams
+  // scratch set 0 serves a pair search (or a lone source), set 1 a lone target — a batch's eager path runs the two on two streams
   struct KnnScratch {
     char* sort_tmp = nullptr; size_t sort_tmp_cap = 0;
     uint32_t *keys0 = nullptr, *keys1 = nullptr, *vals0 = nullptr, *vals1 = nullptr;
@@ -94,7 +94,7 @@ struct rolo_ctx {
     int* bbox = nullptr; size_t bbox_cap = 0;
     int32_t* nbr = nullptr; size_t nbr_cap = 0;   // neighbour indices between the walk and the covariance kernel
   } ks[2];
-  hipStream_t stream2 = nullptr;
+  hipStream_t stream2 = nullptr;   // second stream for the eager (uncaptured) path of rolo_batch_*
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   // voxel map
   VoxelTable tab{};

@@ -128,7 +128,7 @@ class RotVGICP:
         self._push()
 
     def setOverlapKnn(self, on: bool):
-        """Tuning knob (not in the reference): overlap the source / target kNN on two streams (default on)."""
+        """Tuning knob (not in the reference): search source and target in one chain of launches (default on)."""
         self._p.overlap_knn = int(on)
         self._push()
 
