@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256) void occlusion_kernel(const float* __restrict_
 
 // ---- K4 ----
 // Ascending bitonic sort of every aligned `seg`-element segment of key[0, total) in LDS (seg a power of two, total a
-// multiple of seg; 256 threads). Exchange distances >= 64 are block-wide steps with a barrier each; the distances
+// multiple of seg; NT threads). Exchange distances >= 64 are block-wide steps with a barrier each; the distances
 // 32..1 that close every merge stage stay inside an aligned 64-element chunk, so one wavefront takes the chunk into
 // registers and finishes the stage with cross-lane exchanges (DPP / permlane swaps) — one barrier per stage instead of
 // one per step.
@@ -181,13 +181,14 @@ ROLO_DEV void bitonic_lane_step(unsigned long long& v, int lane, bool up) {
   const bool take_min = ((lane & J2) == 0) == up;     // the lane with the smaller index of the pair keeps the minimum when ascending
   v = take_min ? (o < v ? o : v) : (o > v ? o : v);
 }
+template <int NT>
 ROLO_DEV void bitonic_sort_lds_seg(unsigned long long* key, int total, int seg) {
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
   const int n_chunks = (total + 63) >> 6;
   for (int k = 2; k <= seg; k <<= 1) {
     int jj = k >> 1;
     for (; jj >= 64; jj >>= 1) {
-      for (int i = t; i < total; i += 256) {
+      for (int i = t; i < total; i += NT) {
         const int ixj = i ^ jj;
         if (ixj > i) {
           const unsigned long long a = key[i], b = key[ixj];
@@ -197,7 +198,7 @@ ROLO_DEV void bitonic_sort_lds_seg(unsigned long long* key, int total, int seg) 
       }
       __syncthreads();
     }
-    for (int c = wv; c < n_chunks; c += 4) {
+    for (int c = wv; c < n_chunks; c += NT / 64) {
       const int i = (c << 6) + lane;
       unsigned long long v = i < total ? key[i] : ~0ull;
       const bool up = ((i & (seg - 1)) & k) == 0;
@@ -212,7 +213,8 @@ ROLO_DEV void bitonic_sort_lds_seg(unsigned long long* key, int total, int seg) 
     __syncthreads();
   }
 }
-ROLO_DEV void bitonic_sort_lds(unsigned long long* key, int n_pow2) { bitonic_sort_lds_seg(key, n_pow2, n_pow2); }
+template <int NT>
+ROLO_DEV void bitonic_sort_lds(unsigned long long* key, int n_pow2) { bitonic_sort_lds_seg<NT>(key, n_pow2, n_pow2); }
 
 struct FeatArgs {
   const float4* extracted; const int* col; const float* curv; int* picked; int* label;  // global, guard-offset pointers
@@ -222,7 +224,10 @@ struct FeatArgs {
   float4* surf_stage; int* surf_cnt;      // [n_scan][FRONT_MAX_H], [n_scan]
 };
 
-__global__ __launch_bounds__(256) void extract_kernel(FeatArgs A) {
+// One workgroup of XT = 1024 threads per ring: 128 rings are only 128 workgroups, so the parallelism has to come from inside —
+// 16 wavefronts (4 per SIMD) hide the LDS / cross-lane latency of the sorts that 4 wavefronts (1 per SIMD) exposed.
+constexpr int XT = 1024, XW = XT / 64, UP = (512 + XT - 1) / XT;   // threads, wavefronts, sector positions per thread
+__global__ __launch_bounds__(XT) void extract_kernel(FeatArgs A) {
   extern __shared__ unsigned char smem_raw[];
   // layout: keys[SORT_CAP] u64 | l_picked | l_col | l_label | l_curv (ring window) | list[FRONT_MAX_H+16] | l_brk | l_rank | l_stat (window)
   unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem_raw);
@@ -236,9 +241,9 @@ __global__ __launch_bounds__(256) void extract_kernel(FeatArgs A) {
   int* l_rank = l_brk + WIN;
   int* l_stat = l_rank + WIN;
   __shared__ int s_heads, s_ep;
-  __shared__ int s_pk[2][4], s_cw[2][4];
-  __shared__ float s_red[2][3][4];
-  __shared__ int s_wsum[4];
+  __shared__ int s_pk[UP][XW], s_cw[2][XW];
+  __shared__ float s_red[2][3][XW];
+  __shared__ int s_wsum[XW];
 
   const int ring = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
   const int s = A.start_ring[ring], e = A.end_ring[ring];
@@ -248,7 +253,7 @@ __global__ __launch_bounds__(256) void extract_kernel(FeatArgs A) {
   int wlen = (e - s) + 32 + 1;
   if (wlen < 0) wlen = 0;
   if (wlen > WIN) wlen = WIN;  // guarded by the host (ring population <= FRONT_MAX_H)
-  for (int i = t; i < wlen; i += 256) {
+  for (int i = t; i < wlen; i += XT) {
     const int gi = w0 + i;
     const bool in = gi >= -FRONT_GUARD && gi < n + FRONT_GUARD;
     l_picked[i] = in ? A.picked[gi] : 0;
@@ -258,9 +263,9 @@ __global__ __launch_bounds__(256) void extract_kernel(FeatArgs A) {
   }
   int scan_cnt = 0, par = 0;  // surface-scan length so far (every thread keeps the same count)
   // brk[i]: the suppression marks of a pick stop between window cells i and i + 1 (|columnDiff| > 10, :199-210)
-  for (int i = t; i < wlen; i += 256) { l_rank[i] = INT_MAX; l_stat[i] = ST_OUT; }
+  for (int i = t; i < wlen; i += XT) { l_rank[i] = INT_MAX; l_stat[i] = ST_OUT; }
   __syncthreads();
-  for (int i = t; i + 1 < wlen; i += 256) l_brk[i] = abs(l_col[i + 1] - l_col[i]) > 10 ? 1 : 0;
+  for (int i = t; i + 1 < wlen; i += XT) l_brk[i] = abs(l_col[i + 1] - l_col[i]) > 10 ? 1 : 0;
 
   // ---- all six sector sorts at once (they depend on the curvatures only): a segmented bitonic sort, 6 x seg keys ----
   int seg = 2;
@@ -272,7 +277,7 @@ __global__ __launch_bounds__(256) void extract_kernel(FeatArgs A) {
     }
     while (seg < maxlen) seg <<= 1;  // <= 512: a sector holds at most Horizon_SCAN / 6 + 1 points
   }
-  for (int i = t; i < 6 * seg; i += 256) {
+  for (int i = t; i < 6 * seg; i += XT) {
     const int j = i / seg, li = i - j * seg;
     const int sp = (s * (6 - j) + e * j) / 6, ep = (s * (5 - j) + e * (j + 1)) / 6 - 1;
     unsigned long long kv = ~0ull;
@@ -287,7 +292,7 @@ __global__ __launch_bounds__(256) void extract_kernel(FeatArgs A) {
     keys[i] = kv;
   }
   __syncthreads();
-  bitonic_sort_lds_seg(keys, 6 * seg, seg);   // std::sort(begin+sp, begin+ep) with the (value, ind) tie order
+  bitonic_sort_lds_seg<XT>(keys, 6 * seg, seg);   // std::sort(begin+sp, begin+ep) with the (value, ind) tie order
 
   for (int j = 0; j < 6; j++) {
     const int sp = (s * (6 - j) + e * j) / 6;
@@ -302,12 +307,12 @@ __global__ __launch_bounds__(256) void extract_kernel(FeatArgs A) {
       // Every round decides the candidates whose better-ranked reaching candidates are all decided; the chains are a
       // handful of links long, so a sector takes a few rounds of ~20 LDS reads instead of ~10^3 dependent LDS steps
       // on one lane.
-      int my_li[2], my_rank[2];
+      int my_li[UP], my_rank[UP];
       for (int pass = 0; pass < 2; pass++) {   // 0: corners (:181-211), 1: surfaces (:213-238)
         const float thr = pass == 0 ? A.edge_threshold : A.surf_threshold;
 #pragma unroll
-        for (int u = 0; u < 2; u++) {
-          const int p = t + 256 * u;
+        for (int u = 0; u < UP; u++) {
+          const int p = t + XT * u;
           my_li[u] = -1; my_rank[u] = INT_MAX;
           if (p <= len) {
             const int k = sp + p;
@@ -325,7 +330,7 @@ __global__ __launch_bounds__(256) void extract_kernel(FeatArgs A) {
         while (true) {   // states only ever move UNDECIDED -> final, so a neighbour's state read mid-update is either still valid
           int undecided = 0;
 #pragma unroll
-          for (int u = 0; u < 2; u++) {
+          for (int u = 0; u < UP; u++) {
             const int li = my_li[u];
             if (li < 0 || l_stat[li] != ST_UNDECIDED) continue;
             bool any_sel = false, any_und = false;
@@ -344,13 +349,13 @@ __global__ __launch_bounds__(256) void extract_kernel(FeatArgs A) {
           if (!__syncthreads_or(undecided)) break;
         }
         // apply the picks; corners: only the first 20 in walk order exist (largestPickedNum, :186-193)
-        int ordinal[2] = {0, 0};
+        int ordinal[UP] = {};
         if (pass == 0) {
           // walk order = position len first, then len - 1 .. 0: a pick's ordinal is the number of picks at higher positions
-          int higher[2];
+          int higher[UP];
 #pragma unroll
-          for (int u = 0; u < 2; u++) {
-            const int p = t + 256 * u;
+          for (int u = 0; u < UP; u++) {
+            const int p = t + XT * u;
             const bool pk = my_li[u] >= 0 && l_stat[my_li[u]] == ST_PICKED;
             if (p == len) s_ep = pk ? 1 : 0;
             const unsigned long long bal = __ballot(pk && p != len);
@@ -360,20 +365,20 @@ __global__ __launch_bounds__(256) void extract_kernel(FeatArgs A) {
           __syncthreads();
           int total = s_ep;
 #pragma unroll
-          for (int u = 0; u < 2; u++) {
+          for (int u = 0; u < UP; u++) {
 #pragma unroll
-            for (int w = 0; w < 4; w++) {
+            for (int w = 0; w < XW; w++) {
               total += s_pk[u][w];
 #pragma unroll
-              for (int u2 = 0; u2 < 2; u2++) if (u > u2 || (u == u2 && w > wv)) higher[u2] += s_pk[u][w];
+              for (int u2 = 0; u2 < UP; u2++) if (u > u2 || (u == u2 && w > wv)) higher[u2] += s_pk[u][w];
             }
           }
 #pragma unroll
-          for (int u = 0; u < 2; u++) ordinal[u] = (t + 256 * u == len) ? 0 : s_ep + higher[u];
+          for (int u = 0; u < UP; u++) ordinal[u] = (t + XT * u == len) ? 0 : s_ep + higher[u];
           if (t == 0) A.corner_cnt[ring * 6 + j] = min(total, 20);
         }
 #pragma unroll
-        for (int u = 0; u < 2; u++) {
+        for (int u = 0; u < UP; u++) {
           const int li = my_li[u];
           if (li < 0 || l_stat[li] != ST_PICKED) continue;
           if (pass == 0) {
@@ -391,7 +396,7 @@ __global__ __launch_bounds__(256) void extract_kernel(FeatArgs A) {
       }
       // leave the rank / state cells of this sector neutral for the next one
 #pragma unroll
-      for (int u = 0; u < 2; u++) if (my_li[u] >= 0) { l_rank[my_li[u]] = INT_MAX; l_stat[my_li[u]] = ST_OUT; }
+      for (int u = 0; u < UP; u++) if (my_li[u] >= 0) { l_rank[my_li[u]] = INT_MAX; l_stat[my_li[u]] = ST_OUT; }
     } else if (t == 0) {
       // sector at a cloud end (stale {0, 0} smoothness entries): the reference's serial walk as written
       // smooth[ep] is outside the sorted range but inside both loops
@@ -458,7 +463,7 @@ __global__ __launch_bounds__(256) void extract_kernel(FeatArgs A) {
     }
     __syncthreads();
     // every k in [sp, ep] with label <= 0 joins the ring's surface scan, in k order (:240-252): ballot compaction
-    for (int base = sp; base <= ep; base += 256) {
+    for (int base = sp; base <= ep; base += XT) {
       const int k = base + t;
       const bool v = k <= ep && l_label[k - w0] <= 0;
       const unsigned long long bal = __ballot(v);
@@ -466,14 +471,14 @@ __global__ __launch_bounds__(256) void extract_kernel(FeatArgs A) {
       __syncthreads();
       int woff = 0, tot = 0;
 #pragma unroll
-      for (int w = 0; w < 4; w++) { const int c = s_cw[par][w]; tot += c; if (w < wv) woff += c; }
+      for (int w = 0; w < XW; w++) { const int c = s_cw[par][w]; tot += c; if (w < wv) woff += c; }
       if (v) list[scan_cnt + woff + __popcll(bal & ((1ull << lane) - 1ull))] = k;
       scan_cnt += tot;
       par ^= 1;
     }
   }
   // write the ring's picked / label window back (the oracle's arrays after extraction)
-  for (int i = t; i < wlen; i += 256) {
+  for (int i = t; i < wlen; i += XT) {
     const int gi = w0 + i;
     if (gi >= s - 10 && gi <= e + 10 && gi >= -FRONT_GUARD && gi < n + FRONT_GUARD) {
       if (l_picked[i]) A.picked[gi] = 1;
@@ -487,7 +492,7 @@ __global__ __launch_bounds__(256) void extract_kernel(FeatArgs A) {
   const int m = scan_cnt;
   if (m == 0) { if (t == 0) A.surf_cnt[ring] = 0; return; }
   float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-  for (int i = t; i < m; i += 256) {
+  for (int i = t; i < m; i += XT) {
     const float4 p = A.extracted[list[i]];
     mn[0] = fminf(mn[0], p.x); mn[1] = fminf(mn[1], p.y); mn[2] = fminf(mn[2], p.z);
     mx[0] = fmaxf(mx[0], p.x); mx[1] = fmaxf(mx[1], p.y); mx[2] = fmaxf(mx[2], p.z);
@@ -501,21 +506,23 @@ __global__ __launch_bounds__(256) void extract_kernel(FeatArgs A) {
   __syncthreads();
 #pragma unroll
   for (int d = 0; d < 3; d++) {
-    mn[d] = fminf(fminf(s_red[0][d][0], s_red[0][d][1]), fminf(s_red[0][d][2], s_red[0][d][3]));
-    mx[d] = fmaxf(fmaxf(s_red[1][d][0], s_red[1][d][1]), fmaxf(s_red[1][d][2], s_red[1][d][3]));
+    float lo = s_red[0][d][0], hi = s_red[1][d][0];
+#pragma unroll
+    for (int w = 1; w < XW; w++) { lo = fminf(lo, s_red[0][d][w]); hi = fmaxf(hi, s_red[1][d][w]); }
+    mn[d] = lo; mx[d] = hi;
   }
   const float inv = 1.0f / A.leaf;
   const long long dx = (long long)((mx[0] - mn[0]) * inv) + 1, dy = (long long)((mx[1] - mn[1]) * inv) + 1, dz = (long long)((mx[2] - mn[2]) * inv) + 1;
   float4* out = A.surf_stage + (size_t)ring * FRONT_MAX_H;
   if (dx * dy * dz > (long long)INT_MAX) {  // PCL: warn and copy the input through
-    for (int i = t; i < m; i += 256) out[i] = A.extracted[list[i]];
+    for (int i = t; i < m; i += XT) out[i] = A.extracted[list[i]];
     if (t == 0) A.surf_cnt[ring] = m;
     return;
   }
   const int min_b0 = (int)floorf(mn[0] * inv), min_b1 = (int)floorf(mn[1] * inv), min_b2 = (int)floorf(mn[2] * inv);
   const int div_b0 = (int)floorf(mx[0] * inv) - min_b0 + 1, div_b1 = (int)floorf(mx[1] * inv) - min_b1 + 1;
   int np2 = 2; while (np2 < m) np2 <<= 1;
-  for (int i = t; i < np2; i += 256) {
+  for (int i = t; i < np2; i += XT) {
     unsigned long long kv = ~0ull;
     if (i < m) {
       const float4 p = A.extracted[list[i]];
@@ -526,11 +533,11 @@ __global__ __launch_bounds__(256) void extract_kernel(FeatArgs A) {
     keys[i] = kv;
   }
   __syncthreads();
-  bitonic_sort_lds(keys, np2);  // std::sort by cell index, ties by point order
+  bitonic_sort_lds<XT>(keys, np2);  // std::sort by cell index, ties by point order
   // run heads -> output slot; each head accumulates its run in order with float accumulators (pcl::CentroidPoint)
   if (t == 0) s_heads = 0;
   __syncthreads();
-  for (int base = 0; base < m; base += 256) {
+  for (int base = 0; base < m; base += XT) {
     const int i = base + t;
     const bool head = i < m && (i == 0 || (keys[i] >> 32) != (keys[i - 1] >> 32));
     int inc = head ? 1 : 0;
@@ -553,7 +560,7 @@ __global__ __launch_bounds__(256) void extract_kernel(FeatArgs A) {
       out[c + woff + inc - 1] = make_float4(sx / fc, sy / fc, sz / fc, si / fc);
     }
     __syncthreads();
-    if (t == 255) s_heads = c + woff + inc;
+    if (t == XT - 1) s_heads = c + woff + inc;
     __syncthreads();
   }
   if (t == 0) A.surf_cnt[ring] = s_heads;
@@ -703,7 +710,7 @@ int front_extract_enqueue(Front* f, const rolo_front_params* P, hipStream_t s) {
   const size_t lds = sizeof(unsigned long long) * SORT_CAP + sizeof(int) * WIN * 7 + sizeof(int) * (FRONT_MAX_H + 16);
   static bool attr_set = false;
   if (!attr_set) { FCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(extract_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set = true; }
-  extract_kernel<<<NS, 256, lds, s>>>(A);
+  extract_kernel<<<NS, XT, lds, s>>>(A);
   concat_kernel<<<NS * 6, 256, 0, s>>>(f->corner_stage, f->corner_cnt, NS * 6, 20, f->corner_out, f->counters + 1);
   concat_kernel<<<NS, 256, 0, s>>>(f->surf_stage, f->surf_cnt, NS, FRONT_MAX_H, f->surf_out, f->counters + 2);
   FCHK(hipGetLastError());
