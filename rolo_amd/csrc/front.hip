@@ -569,11 +569,17 @@ __global__ __launch_bounds__(XT) void extract_kernel(FeatArgs A) {
 // concatenate per-ring / per-sector staging areas in order
 __global__ __launch_bounds__(256) void concat_kernel(const float4* __restrict__ stage, const int* __restrict__ cnt, int n_groups, int group_cap,
                                                     float4* __restrict__ out, int* __restrict__ total) {
-  __shared__ int s_off;
+  __shared__ int s_off, s_part[4];
   const int g = blockIdx.x, t = threadIdx.x;
+  // offset of this group = sum of the counts before it: all 256 threads share the (up to n_scan * 6) loads
+  int part = 0;
+  for (int r = t; r < g; r += 256) part += cnt[r];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+  if ((t & 63) == 0) s_part[t >> 6] = part;
+  __syncthreads();
   if (t == 0) {
-    int off = 0;
-    for (int r = 0; r < g; r++) off += cnt[r];
+    const int off = s_part[0] + s_part[1] + s_part[2] + s_part[3];
     s_off = off;
     if (g == n_groups - 1) *total = off + cnt[g];
   }
