@@ -349,8 +349,26 @@ def extract_features(fp: FrontParams, proj):
 def voxelgrid(pts, leaf):
     pts = np.ascontiguousarray(pts, np.float32)
     out = np.zeros_like(pts)
-    m = lib().orc_voxelgrid(_f(pts), pts.shape[0], leaf, _f(out))
+    f = lib().orc_voxelgrid
+    f.argtypes = [C.POINTER(C.c_float), C.c_int, C.c_float, C.POINTER(C.c_float)]; f.restype = C.c_int
+    m = f(_f(pts), pts.shape[0], leaf, _f(out))
     return out[:m].copy()
+
+
+def get_transformation(x, y, z, roll, pitch, yaw):
+    T = np.zeros(16, np.float32)
+    f = lib().orc_get_transformation
+    f.argtypes = [C.c_float] * 6 + [C.POINTER(C.c_float)]; f.restype = None
+    f(x, y, z, roll, pitch, yaw, _f(T))
+    return T
+
+
+def get_translation_and_euler(T16):
+    T = np.ascontiguousarray(T16, np.float32).reshape(16); o = np.zeros(6, np.float32)
+    f = lib().orc_get_translation_and_euler
+    f.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_float)]; f.restype = None
+    f(_f(T), _f(o))
+    return o
 
 
 class Odom:

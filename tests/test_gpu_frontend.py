@@ -144,3 +144,25 @@ def test_nan_points_are_dropped_like_on_the_reference_cpu():
     assert pg["n"] == po["n"] and np.array_equal(pg["extracted"], po["extracted"]) and np.array_equal(pg["point_col_ind"], po["point_col_ind"])
     assert not np.isnan(pg["extracted"]).any()
     assert np.array_equal(eg["corner"], eo["corner"]) and np.array_equal(eg["surface"], eo["surface"])
+
+
+@pytest.mark.parametrize("name", ["front_vlp16", "front_os64"])
+def test_front_end_against_committed_golden(name):
+    """K1-K4 through the C ABI against tests/golden/front_*.npz (outputs of the independent numpy twin, oracle/twin_front.py):
+    thinned frames with duplicates, out-of-range points, an unknown ring and NaNs. Bit-exact."""
+    import os
+    from rolo_amd.rotvgicp import RotVGICP
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz"))
+    fg = front_params(n_scan=int(z["n_scan"]), horizon_scan=int(z["horizon_scan"]))
+    g = RotVGICP(); fe = FrontEnd(g, fg)
+    pg = fe.project(z["xyz"], z["ring"])
+    owner = z["owner"]
+    ext = np.zeros((owner.size, 4), np.float32)
+    ext[:, :3] = z["xyz"][owner]; ext[:, 3] = z["ring"][owner].astype(np.float32) * z["xyz"][owner, 2]
+    assert pg["n"] == owner.size and np.array_equal(pg["extracted"], ext)
+    for k in ("point_col_ind", "point_range", "start_ring", "end_ring"):
+        assert np.array_equal(pg[k], z[k]), k
+    eg = fe.extract(pg["n"], debug=True)
+    assert np.array_equal(eg["curvature"], z["curvature"])
+    assert np.array_equal(eg["picked"], z["picked"].astype(np.int32)) and np.array_equal(eg["label"], z["label"].astype(np.int32))
+    assert np.array_equal(eg["corner"], z["corner"]) and np.array_equal(eg["surface"], z["surface"])

@@ -1,0 +1,68 @@
+"""CPU: the C++ oracle's front end (projection, feature extraction, VoxelGrid, float pose algebra) against
+  * tests/golden/front_*.npz — outputs of the independent numpy twin (oracle/twin_front.py), committed by
+    tests/golden/make_golden_front.py;
+  * the twin itself, live, on whole seeded frames (the twin is pure numpy: nothing here needs a GPU).
+Everything is bit-exact: indices and float32 values."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import pyorc, twin_front as tw
+from rolo_amd import synth
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def golden_expected(z):
+    xyz, ring = z["xyz"], z["ring"]
+    owner = z["owner"]
+    ext = np.zeros((owner.size, 4), np.float32)
+    ext[:, :3] = xyz[owner]; ext[:, 3] = ring[owner].astype(np.float32) * xyz[owner, 2]
+    return ext
+
+
+@pytest.mark.parametrize("name", ["front_vlp16", "front_os64"])
+def test_front_end_against_committed_golden(name):
+    z = np.load(os.path.join(GOLD, name + ".npz"))
+    fo = pyorc.front_params(n_scan=int(z["n_scan"]), horizon_scan=int(z["horizon_scan"]))
+    po = pyorc.project(fo, z["xyz"], z["ring"])
+    assert po["n"] == z["owner"].size
+    assert np.array_equal(po["extracted"], golden_expected(z))
+    for k in ("point_col_ind", "point_range", "start_ring", "end_ring"):
+        assert np.array_equal(po[k], z[k]), k
+    eo = pyorc.extract_features(fo, po)
+    assert np.array_equal(eo["curvature"], z["curvature"])
+    assert np.array_equal(eo["picked"], z["picked"].astype(np.int32)) and np.array_equal(eo["label"], z["label"].astype(np.int32))
+    assert np.array_equal(eo["corner"], z["corner"]) and np.array_equal(eo["surface"], z["surface"])
+
+
+@pytest.mark.parametrize("sensor,cfg", [("vlp16", dict(n_scan=16, horizon_scan=1800)), ("os1-64", dict(n_scan=64, horizon_scan=1024))])
+def test_front_end_against_live_twin(sensor, cfg):
+    fr = synth.make_frame(sensor, synth.rpy_to_R(-0.02, 0.01, 1.1), np.array([-0.3, 0.5, 0.1]), synth.SEED + 3)
+    rs = np.random.RandomState(5)
+    perm = rs.permutation(fr.xyz.shape[0])          # any firing order: "first point wins" must follow it
+    xyz, ring = np.array(fr.xyz, np.float32)[perm], np.array(fr.ring, np.uint16)[perm]
+    for thresholds in ((0.8, 0.1, 0.4), (0.3, 0.3, 0.2)):
+        fo = pyorc.front_params(edge_threshold=thresholds[0], surf_threshold=thresholds[1], odometry_surf_leaf_size=thresholds[2], **cfg)
+        po = pyorc.project(fo, xyz, ring); eo = pyorc.extract_features(fo, po)
+        pt = tw.project(xyz, ring, cfg["n_scan"], cfg["horizon_scan"])
+        et = tw.extract_features(pt, cfg["n_scan"], *thresholds)
+        assert po["n"] == pt["n"]
+        for k in ("extracted", "point_col_ind", "point_range", "start_ring", "end_ring"):
+            assert np.array_equal(po[k], pt[k]), k
+        for k in ("curvature", "picked", "label", "corner", "surface"):
+            assert np.array_equal(eo[k], et[k]), k
+
+
+def test_voxelgrid_and_pose_algebra_against_twin():
+    rs = np.random.RandomState(11)
+    pts = (rs.normal(size=(4000, 4)) * np.array([6, 6, 1.5, 10])).astype(np.float32)
+    for leaf in (0.4, 1.0):
+        assert np.array_equal(pyorc.voxelgrid(pts, leaf), tw.voxel_grid(pts, leaf))
+    for pose in ([0.3, -0.1, 0.05, 0.01, -0.02, 0.5], [12.0, 3.0, -1.0, -0.4, 0.3, -2.9]):
+        T = pyorc.get_transformation(*pose)
+        # numpy's float32 sin / cos are its own SIMD kernels, glibc's sinf / cosf the oracle's: equal up to an ulp
+        assert np.abs(np.asarray(T, np.float32).reshape(4, 4) - tw.get_transformation(*pose)).max() <= 2e-6
+        assert np.abs(pyorc.get_translation_and_euler(T) - tw.get_translation_and_euler(np.asarray(T).reshape(4, 4))).max() <= 2e-6
+        assert np.abs(pyorc.get_translation_and_euler(T) - np.asarray(pose, np.float32)).max() <= 2e-6   # round trip
