@@ -66,3 +66,29 @@ def test_voxelgrid_and_pose_algebra_against_twin():
         assert np.abs(np.asarray(T, np.float32).reshape(4, 4) - tw.get_transformation(*pose)).max() <= 2e-6
         assert np.abs(pyorc.get_translation_and_euler(T) - tw.get_translation_and_euler(np.asarray(T).reshape(4, 4))).max() <= 2e-6
         assert np.abs(pyorc.get_translation_and_euler(T) - np.asarray(pose, np.float32)).max() <= 2e-6   # round trip
+
+
+def test_odometry_driver_against_twin():
+    """orc_odom_* (the C++ oracle's LidarOdometry) against oracle/twin_odom.py — the driver restated independently on the
+    registration twin — over a raw-frame sequence: same states, same poses up to float ulps of the pose chain."""
+    from oracle.twin_odom import TwinOdom
+    cfg = dict(n_scan=16, horizon_scan=1800)
+    fo = pyorc.front_params(**cfg)
+    oo = pyorc.Odom(pyorc.default_params(polar_resolution=(0.175, 0.175, 2.0)), 0.3)
+    to = TwinOdom(0.3)
+    R = np.eye(3); t = np.zeros(3)
+    statuses = []
+    for k in range(4):
+        fr = synth.make_frame("vlp16", R, t, synth.SEED + k)
+        eo = pyorc.extract_features(fo, pyorc.project(fo, fr.xyz, fr.ring))
+        stamp = 100.0 + 0.1 * k
+        if k == 2:
+            oo.backend_odometry(stamp - 0.05); to.backend_odometry(stamp - 0.05)
+        rco, pose_o, R_o, t_o = oo.cloud(stamp, eo["corner"], eo["surface"])
+        rct = to.cloud(stamp, eo["corner"], eo["surface"])
+        statuses.append(rct)
+        assert rct == rco
+        assert np.abs(to.LaserOdomPose - pose_o).max() <= 2e-5
+        assert np.abs(to.Rotation - R_o).max() <= 1e-6 and np.abs(to.Translation - t_o).max() <= 1e-6
+        t = t + R @ np.array([0.3, 0.02 * k, 0.0]); R = R @ synth.rpy_to_R(np.deg2rad(0.3), np.deg2rad(-0.2), np.deg2rad(2.0))
+    assert statuses == [0, 1, 2, 2]
