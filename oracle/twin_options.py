@@ -68,3 +68,55 @@ def so3_linearize_multi(tw: Twin, T, n_off):
     H = np.einsum("n,nki,nkl,nlj->ij", w, J, M, J)
     b = np.einsum("n,nki,nkl,nl->i", w, J, M, e)
     return err, H, b, src_i, tw.vox_keys[vox]
+
+
+def _se3_exp(d):
+    """so3.hpp:80-103 as a matrix exponential (scipy expm of the 4x4 twist)."""
+    from scipy.linalg import expm
+    X = np.zeros((4, 4)); X[:3, :3] = Twin._skew(np.asarray(d[:3], float)); X[:3, 3] = d[3:]
+    return expm(X)
+
+
+def align6(tw: Twin, optimizer, guess=None):
+    """computeTransformation :152-179 with step_lm :225-270 ("lm") or step_gn :208-222 ("gn"); is_converged :182-191.
+    Returns the final transformation (float-rounded like final_transformation_), the outer iterations and the converged flag."""
+    x0 = np.eye(4) if guess is None else np.asarray(guess, np.float32).astype(np.float64)
+    lam = -1.0
+    conv = False; it = 0
+
+    def converged(delta):
+        r = np.abs(delta[:3, :3] - np.eye(3)).max() / tw.rot_eps
+        t = np.abs(delta[:3, 3]).max() / tw.trans_eps
+        return max(r, t) < 1
+
+    for i in range(tw.max_iterations):
+        if conv:
+            break
+        it = i + 1
+        y0, H, b = tw.linearize6(x0)
+        if optimizer == "gn":
+            delta = _se3_exp(np.linalg.solve(H, -b))
+            x0 = delta @ x0
+        else:
+            if lam < 0:
+                lam = tw.lm_init * np.abs(np.diag(H)).max()
+            nu = 2.0; ok = False
+            for _ in range(tw.lm_max):
+                d = np.linalg.solve(H + lam * np.eye(6), -b)
+                delta = _se3_exp(d)
+                xi = delta @ x0
+                yi = tw.compute_error(xi)
+                rho = (y0 - yi) / (d @ (lam * d - b))
+                if rho < 0:
+                    if converged(delta):
+                        ok = True; break
+                    lam *= nu; nu *= 2
+                    continue
+                x0 = xi
+                lam *= max(1.0 / 3.0, 1 - (2 * rho - 1) ** 3)
+                ok = True
+                break
+            if not ok:
+                break
+        conv = converged(delta)
+    return x0, it, conv

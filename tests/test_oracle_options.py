@@ -46,3 +46,16 @@ def test_multi_offset_correspondences_and_linearisation(pair, neighbor, n_off):
         return a[np.lexsort(a.T[::-1])]
     assert np.array_equal(canon(s, keys_o[v]), canon(src_i, vox_keys))
     assert abs(e - et) <= 1e-9 * abs(et) and np.abs(H - Ht).max() <= 1e-9 * np.abs(Ht).max() and np.abs(b - bt).max() <= 1e-9 * np.abs(bt).max()
+
+
+@pytest.mark.parametrize("optimizer,name", [(1, "lm"), (0, "gn")])
+def test_six_dof_drivers(pair, optimizer, name):
+    """computeTransformation with step_lm / step_gn (lsq_registration_impl.hpp:152-270) against the twin's restatement."""
+    src, tgt = pair
+    o = pyorc.Reg(pyorc.default_params(polar_resolution=(0.175, 0.175, 2.0), optimizer=optimizer))
+    o.set_target(tgt); o.set_source(src)
+    rc, Tf, Td, iters, conv = o.align()
+    tw = Twin(src, tgt, voxel_type="polar", polar_res=(0.175, 0.175, 2.0))
+    x0, it, cv = topt.align6(tw, name)
+    assert rc == 0 and iters == it and bool(conv) == bool(cv)
+    assert np.abs(Td - x0).max() <= 1e-8
