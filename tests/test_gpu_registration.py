@@ -503,3 +503,25 @@ def test_batch_equals_individual():
     err, H, bvec = b.members[1].so3_linearize(single[1][-1][0])
     assert np.isfinite(err) and np.isfinite(H).all()
     b.close()
+
+
+def test_rccl_path_on_one_rank():
+    """The point-sharded schedule — partial rows reduced on the device, ncclAllReduce of the 32 fp64 sums on the context's
+    stream, controller on the reduced sums — driven on real hardware with a one-rank RCCL communicator (the pool has
+    single-GPU boxes): same poses as the plain path. The multi-rank arithmetic is covered by the shard-linearity test above
+    and the 2-rank gloo test."""
+    src, tgt, cfg = make_pair("os64_uniform")
+    ref = RotVGICP(); ref.setResolution(cfg["leaf"]); ref.setInputTarget(tgt); ref.setInputSource(src)
+    ref.register_async(None, np.zeros(3), G, L0); Tf0, Td0, t0 = ref.register_wait()
+    g = RotVGICP(); g.setResolution(cfg["leaf"])
+    g.comm_init(RotVGICP.comm_unique_id(), 0, 1)
+    for _ in range(3):   # eager frames: a context with a communicator does not capture graphs
+        g.setInputTarget(tgt); g.setInputSource(src)
+        g.register_async(None, np.zeros(3), G, L0)
+        Tf, Td, t = g.register_wait()
+        assert np.abs(Td - Td0).max() < 1e-11 and np.abs(t - t0).max() < 1e-11
+        assert g.last_stats.n_outer == ref.last_stats.n_outer and g.last_translation_stats.n_outer == ref.last_translation_stats.n_outer
+    # stage-level calls go through the collective as well
+    T = np.eye(4); T[:3, :3] = synth.rpy_to_R(0.003, -0.002, 0.01)
+    e1, H1, b1 = g.so3_linearize(T); e0, H0, b0 = ref.so3_linearize(T)
+    assert abs(e1 - e0) <= 1e-11 * abs(e0) and np.abs(H1 - H0).max() <= 1e-11 * np.abs(H0).max()
