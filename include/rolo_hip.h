@@ -211,7 +211,8 @@ int rolo_project_frame(rolo_ctx* ctx, const rolo_front_params* P, const float* p
  * shipped config). Arms the NEXT rolo_project_frame / rolo_odom_submit on this context: rel_time[i] = fabs(point.time) of
  * raw point i (what :358-359 stores; for clouds without a time field pass the azimuth-interpolated scanPeriod * relTime of
  * :303-326), odom_incre_rpy = odomIncreRoll/Pitch/Yaw, odom_time_diff = odomTimeDiff (:349-351; rolo_odom_increment does
- * the pose algebra). Range, pixel and every index still come from the raw point, as in the reference (:412-454). */
+ * the pose algebra). rel_time == NULL: the times come with the next message (rolo_odom_submit_msg). Range, pixel and every
+ * index still come from the raw point, as in the reference (:412-454). */
 typedef struct rolo_deskew { int enabled; float odom_incre_rpy[3]; float scan_period; double odom_time_diff; } rolo_deskew;
 int rolo_front_set_deskew(rolo_ctx* ctx, const rolo_deskew* d, const float* rel_time, int n_raw, int rel_time_on_device);
 /* lidarOdomAffineFront.inverse() * lidarOdomAffineBack -> pcl::getTranslationAndEulerAngles (:345-351); poses and increment as
@@ -253,6 +254,15 @@ int rolo_odom_frame(rolo_odom* o, const rolo_front_params* P, double stamp, cons
 int rolo_odom_submit(rolo_odom* o, const rolo_front_params* P, double stamp, const float* pts, int stride, const uint16_t* ring,
                      int n_raw, int pts_on_device);
 int rolo_odom_collect(rolo_odom* o, float* pose6, double* rot9, double* trans3, int* counts3);
+/* The same from the message itself: `data` is the payload of the sensor_msgs/PointCloud2 that ImageProjection::cloudHandler
+ * receives (n_points records of layout->point_step bytes), `layout` the byte offsets of the fields the node reads — what
+ * pcl::moveFromROSMsg and the Ouster conversion loop of cachePointCloud (imageProjection.cpp:188-212) do on the host runs as a
+ * kernel: x, y, z (FLOAT32), ring (UINT16 for Velodyne, UINT8 for Ouster), time (time_kind 1: Velodyne "time", FLOAT32 seconds;
+ * 2: Ouster "t", UINT32 nanoseconds, * 1e-9f; 0: none). A de-skew armed without times (rolo_odom_set_deskew with rel_time =
+ * NULL) takes fabs(time) of this message. */
+typedef struct rolo_cloud_layout { int point_step, off_x, off_y, off_z, off_ring, ring_bytes, off_time, time_kind; } rolo_cloud_layout;
+int rolo_odom_submit_msg(rolo_odom* o, const rolo_front_params* P, double stamp, const uint8_t* data, const rolo_cloud_layout* layout,
+                         int n_points, int data_on_device);
 /* options of the fused path: ROLO_ODOM_REUSE_COVARIANCES (default 0) = rolo_adopt_target_covariances between frames */
 #define ROLO_ODOM_REUSE_COVARIANCES 1
 int rolo_odom_set_option(rolo_odom* o, int option, int value);

@@ -131,6 +131,10 @@ public:
   void submit(const FrontParams& p, double stamp, const float* pts, int stride, const uint16_t* ring, int n, bool on_device = false) {
     check(rolo_odom_submit(odom_, &p, stamp, pts, stride, ring, n, on_device ? 1 : 0), "rolo_odom_submit");
   }
+  // submit() from the payload of the sensor_msgs/PointCloud2 itself (field offsets from msg.fields): no host-side extraction
+  void submitMsg(const FrontParams& p, double stamp, const uint8_t* data, const rolo_cloud_layout& layout, int n_points, bool on_device = false) {
+    check(rolo_odom_submit_msg(odom_, &p, stamp, data, &layout, n_points, on_device ? 1 : 0), "rolo_odom_submit_msg");
+  }
   Status collect() { return (Status)check(rolo_odom_collect(odom_, LaserOdomPose.data(), Rotation.data(), Translation.data(), counts.data()), "rolo_odom_collect"); }
   // de-skew of the next submit() / frame() (see ImageProjection::setDeskew)
   void setDeskew(const float odomIncreRPY[3], float scanPeriod, double odomTimeDiff, const float* rel_time, int n, bool deskewEnabled = true) {

@@ -36,6 +36,11 @@ class Deskew(C.Structure):
     _fields_ = [("enabled", C.c_int), ("odom_incre_rpy", C.c_float * 3), ("scan_period", C.c_float), ("odom_time_diff", C.c_double)]
 
 
+class CloudLayout(C.Structure):
+    _fields_ = [("point_step", C.c_int), ("off_x", C.c_int), ("off_y", C.c_int), ("off_z", C.c_int), ("off_ring", C.c_int),
+                ("ring_bytes", C.c_int), ("off_time", C.c_int), ("time_kind", C.c_int)]
+
+
 class FrontParams(C.Structure):
     _fields_ = [("n_scan", C.c_int), ("horizon_scan", C.c_int), ("downsample_rate", C.c_int),
                 ("lidar_min_range", C.c_float), ("lidar_max_range", C.c_float), ("edge_threshold", C.c_float),
@@ -104,6 +109,7 @@ SYMBOLS = {
     "rolo_odom_frame": (C.c_int, [vp, C.POINTER(FrontParams), C.c_double, vp, C.c_int, vp, C.c_int, C.c_int, fp, dp, dp, C.POINTER(C.c_int)]),
     "rolo_odom_submit": (C.c_int, [vp, C.POINTER(FrontParams), C.c_double, vp, C.c_int, vp, C.c_int, C.c_int]),
     "rolo_odom_collect": (C.c_int, [vp, fp, dp, dp, C.POINTER(C.c_int)]),
+    "rolo_odom_submit_msg": (C.c_int, [vp, C.POINTER(FrontParams), C.c_double, vp, C.POINTER(CloudLayout), C.c_int, C.c_int]),
     "rolo_odom_set_option": (C.c_int, [vp, C.c_int, C.c_int]),
     "rolo_odom_set_deskew": (C.c_int, [vp, C.POINTER(Deskew), vp, C.c_int, C.c_int]),
     "rolo_odom_increment": (None, [fp, fp, fp]),

@@ -36,6 +36,28 @@ constexpr int ST_OUT = 0, ST_UNDECIDED = 1, ST_PICKED = 2;
 
 namespace {
 
+// ---- sensor_msgs/PointCloud2 payload -> x, y, z / ring / per-point time -----------------------------------------------
+// What pcl::moveFromROSMsg + the Ouster conversion loop do on the host in ImageProjection::cachePointCloud
+// (imageProjection.cpp:188-212): fields are found by their byte offsets in the message, Velodyne "time" is a float in
+// seconds, Ouster "t" a uint32 in nanoseconds (dst.time = src.t * 1e-9f), ring is uint16 (Velodyne) or uint8 (Ouster).
+// Byte-wise loads: a point_step of 22 (the velodyne driver's packed layout) has no alignment to offer.
+ROLO_DEV unsigned load_u32_bytes(const unsigned char* p) { return (unsigned)p[0] | ((unsigned)p[1] << 8) | ((unsigned)p[2] << 16) | ((unsigned)p[3] << 24); }
+
+__global__ __launch_bounds__(256) void unpack_cloud_kernel(const unsigned char* __restrict__ data, rolo_cloud_layout L, int n, float* __restrict__ xyz,
+                                                          unsigned short* __restrict__ ring, float* __restrict__ rel_time) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const unsigned char* p = data + (size_t)i * L.point_step;
+  xyz[3 * (size_t)i] = __uint_as_float(load_u32_bytes(p + L.off_x));
+  xyz[3 * (size_t)i + 1] = __uint_as_float(load_u32_bytes(p + L.off_y));
+  xyz[3 * (size_t)i + 2] = __uint_as_float(load_u32_bytes(p + L.off_z));
+  ring[i] = L.ring_bytes == 1 ? (unsigned short)p[L.off_ring] : (unsigned short)(p[L.off_ring] | (p[L.off_ring + 1] << 8));
+  float t = 0.f;
+  if (L.time_kind == 1) t = __uint_as_float(load_u32_bytes(p + L.off_time));
+  else if (L.time_kind == 2) t = (float)load_u32_bytes(p + L.off_time) * 1e-9f;   // :209
+  rel_time[i] = fabsf(t);                                                          // deskewCloudInfo :358-359
+}
+
 // ---- K1 ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void project_kernel(const float* __restrict__ pts, int stride, const unsigned short* __restrict__ ring,
                                                      int n_raw, rolo_front_params P, int* __restrict__ owner) {
@@ -614,6 +636,10 @@ struct Front {
   bool deskew_armed = false;
   DeskewArgs deskew{};
   float* rel_time = nullptr; size_t cap_time = 0;   // staging when the times come from the host
+  bool deskew_from_msg = false;                      // armed without times: the next message brings them
+  // message-level entry: raw payload and what the unpack kernel makes of it
+  unsigned char* msg_raw = nullptr; size_t cap_msg = 0;
+  float* msg_xyz = nullptr; unsigned short* msg_ring = nullptr; float* msg_time = nullptr; size_t cap_msg_pts = 0;
 };
 
 thread_local std::string g_ferr;
@@ -626,7 +652,7 @@ bool dev_alloc(T*& p, size_t count) {
 
 void front_free(Front* f) {
   void* bufs[] = {f->raw, f->ring, f->owner, f->local_idx, f->ring_count, f->start_ring, f->end_ring, f->counters, f->extracted, f->col, f->range,
-                  f->range_mat, f->curv, f->picked, f->label, f->corner_stage, f->surf_stage, f->corner_out, f->surf_out, f->corner_cnt, f->surf_cnt, f->rel_time};
+                  f->range_mat, f->curv, f->picked, f->label, f->corner_stage, f->surf_stage, f->corner_out, f->surf_out, f->corner_cnt, f->surf_cnt, f->rel_time, f->msg_raw, f->msg_xyz, f->msg_ring, f->msg_time};
   for (void* b : bufs) if (b) (void)hipFree(b);
 }
 
@@ -753,6 +779,40 @@ int front_frame_features_enqueue(rolo_ctx* c, const rolo_front_params* P, const 
   return ROLO_OK;
 }
 
+// Message-level entry of the fused path: the PointCloud2 payload goes to the device as it is (one copy), the field
+// extraction the node does on the host runs as a kernel, and the frame continues device-resident.
+int front_frame_features_from_msg(rolo_ctx* c, const rolo_front_params* P, const unsigned char* data, const rolo_cloud_layout* L, int n_raw,
+                                  bool on_device, float4* d_feat, int* h_counts3, hipEvent_t done) {
+  if (L->point_step <= 0 || (L->ring_bytes != 1 && L->ring_bytes != 2) || L->time_kind < 0 || L->time_kind > 2) { ctx_set_error("bad cloud layout"); return ROLO_EINVAL; }
+  const int need = std::max(std::max(L->off_x, L->off_y), L->off_z) + 4;
+  if (L->off_x < 0 || L->off_y < 0 || L->off_z < 0 || L->off_ring < 0 || need > L->point_step || L->off_ring + L->ring_bytes > L->point_step ||
+      (L->time_kind && (L->off_time < 0 || L->off_time + 4 > L->point_step))) { ctx_set_error("cloud layout: field outside the point record"); return ROLO_EINVAL; }
+  Front* f = nullptr;
+  int rc = front_prepare(c, P, n_raw, 3, false, &f);
+  if (rc) return rc;
+  hipStream_t s = ctx_stream(c);
+  const size_t bytes = (size_t)n_raw * L->point_step;
+  if ((size_t)n_raw > f->cap_msg_pts || !f->msg_xyz) {
+    if (!dev_alloc(f->msg_xyz, 3 * (size_t)n_raw) || !dev_alloc(f->msg_ring, (size_t)n_raw) || !dev_alloc(f->msg_time, (size_t)n_raw)) { ctx_set_error("hipMalloc failed (message buffers)"); return ROLO_EHIP; }
+    f->cap_msg_pts = (size_t)n_raw;
+  }
+  const unsigned char* d_data = data;
+  if (!on_device) {
+    if (bytes > f->cap_msg || !f->msg_raw) { if (!dev_alloc(f->msg_raw, bytes)) { ctx_set_error("hipMalloc failed (message payload)"); return ROLO_EHIP; } f->cap_msg = bytes; }
+    FCHK(hipMemcpyAsync(f->msg_raw, data, bytes, hipMemcpyHostToDevice, s));
+    d_data = f->msg_raw;
+  }
+  if (n_raw > 0) unpack_cloud_kernel<<<(n_raw + 255) / 256, 256, 0, s>>>(d_data, *L, n_raw, f->msg_xyz, f->msg_ring, f->msg_time);
+  FCHK(hipGetLastError());
+  if (f->deskew_from_msg) {
+    f->deskew_from_msg = false;
+    if (L->time_kind == 0) { ctx_set_error("de-skew armed but the message has no time field"); return ROLO_EINVAL; }
+    f->deskew.rel_time = f->msg_time;
+    f->deskew_armed = true;
+  }
+  return front_frame_features_enqueue(c, P, f->msg_xyz, 3, f->msg_ring, n_raw, true, d_feat, h_counts3, done);
+}
+
 }  // namespace rolo
 
 using namespace rolo;
@@ -770,10 +830,15 @@ int rolo_front_set_deskew(rolo_ctx* c, const rolo_deskew* d, const float* rel_ti
   void** slot = ctx_front_slot(c);
   if (!*slot) *slot = new Front();
   Front* f = static_cast<Front*>(*slot);
-  f->deskew_armed = false;
+  f->deskew_armed = false; f->deskew_from_msg = false;
   if (!d->enabled) return ROLO_OK;   // deskewPoint returns the point as is (:371-372)
-  if (!rel_time || n_raw < 0) { ctx_set_error("de-skew needs the per-point times"); return ROLO_EINVAL; }
   if (!(d->odom_time_diff != 0.0) || !(d->scan_period != 0.f)) { ctx_set_error("de-skew: zero scan period / odometry time difference"); return ROLO_EINVAL; }
+  if (!rel_time) {   // the times come with the next message (rolo_odom_submit_msg)
+    f->deskew = DeskewArgs{nullptr, d->odom_incre_rpy[0], d->odom_incre_rpy[1], d->odom_incre_rpy[2], d->scan_period, d->odom_time_diff};
+    f->deskew_from_msg = true;
+    return ROLO_OK;
+  }
+  if (n_raw < 0) { ctx_set_error("de-skew needs the per-point times"); return ROLO_EINVAL; }
   const float* dt = rel_time;
   if (!on_device) {
     if ((size_t)n_raw > f->cap_time || !f->rel_time) {

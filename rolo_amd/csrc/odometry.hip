@@ -210,9 +210,8 @@ int rolo_odom_cloud(rolo_odom* o, double stamp, const float* corner, int n_corne
   return ret;
 }
 
-int rolo_odom_submit(rolo_odom* o, const rolo_front_params* P, double stamp, const float* pts, int stride, const uint16_t* ring, int n_raw,
-                     int pts_on_device) {
-  if (!o || !P || !pts || !ring || stride < 3 || n_raw < 0) return ROLO_EINVAL;
+static int submit_common(rolo_odom* o, const rolo_front_params* P, double stamp, const void* pts, int stride, const uint16_t* ring,
+                         const rolo_cloud_layout* layout, int n_raw, int on_device) {
   if (o->q_len == 2) { rolo::ctx_set_error("two frames are already in flight: collect one first"); return ROLO_ESTATE; }
   if (hipSetDevice(rolo::ctx_device(o->ctx)) != hipSuccess) { rolo::ctx_set_error("hipSetDevice failed"); return ROLO_EHIP; }
   int rc;
@@ -229,10 +228,24 @@ int rolo_odom_submit(rolo_odom* o, const rolo_front_params* P, double stamp, con
   }
   const int buf = (o->old_buf + 1 + o->q_len) % 3;
   rolo_odom::Slot& sl = o->q[(o->q_head + o->q_len) % 2];
-  if ((rc = rolo::front_frame_features_enqueue(o->fctx, P, pts, stride, ring, n_raw, pts_on_device != 0, o->d_feat[buf], sl.h_counts, sl.done))) return rc;
+  if (layout) rc = rolo::front_frame_features_from_msg(o->fctx, P, static_cast<const unsigned char*>(pts), layout, n_raw, on_device != 0, o->d_feat[buf], sl.h_counts, sl.done);
+  else rc = rolo::front_frame_features_enqueue(o->fctx, P, static_cast<const float*>(pts), stride, ring, n_raw, on_device != 0, o->d_feat[buf], sl.h_counts, sl.done);
+  if (rc) return rc;
   sl.stamp = stamp;
   o->q_len++;
   return ROLO_OK;
+}
+
+int rolo_odom_submit(rolo_odom* o, const rolo_front_params* P, double stamp, const float* pts, int stride, const uint16_t* ring, int n_raw,
+                     int pts_on_device) {
+  if (!o || !P || !pts || !ring || stride < 3 || n_raw < 0) return ROLO_EINVAL;
+  return submit_common(o, P, stamp, pts, stride, ring, nullptr, n_raw, pts_on_device);
+}
+
+int rolo_odom_submit_msg(rolo_odom* o, const rolo_front_params* P, double stamp, const uint8_t* data, const rolo_cloud_layout* layout, int n_points,
+                         int data_on_device) {
+  if (!o || !P || !data || !layout || n_points < 0) return ROLO_EINVAL;
+  return submit_common(o, P, stamp, data, 0, nullptr, layout, n_points, data_on_device);
 }
 
 int rolo_odom_collect(rolo_odom* o, float* pose6, double* rot9, double* trans3, int* counts3) {

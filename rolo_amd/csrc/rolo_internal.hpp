@@ -133,6 +133,8 @@ hipError_t launch_cov_pack(const double* m16, int n, double* soa, hipStream_t s)
 // front.hip: fused K1-K4 for the device-resident pipeline — raw frame -> corner ++ surface in d_feat; counts3 = N, n_corner, n_surface;
 // asynchronous on the context's stream (event `done` behind the read-back of the counts)
 size_t front_feature_capacity(const rolo_front_params* P);
+int front_frame_features_from_msg(rolo_ctx* c, const rolo_front_params* P, const unsigned char* data, const rolo_cloud_layout* L, int n_raw,
+                                  bool on_device, float4* d_feat, int* h_counts3_pinned, hipEvent_t done);
 int front_frame_features_enqueue(rolo_ctx* c, const rolo_front_params* P, const float* pts, int stride, const uint16_t* ring, int n_raw,
                                  bool on_device, float4* d_feat, int* h_counts3_pinned, hipEvent_t done);
 

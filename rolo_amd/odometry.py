@@ -68,6 +68,19 @@ class LidarOdometry:
             self._keep = getattr(self, "_keep", []) + [(xyz, ring)]
         check(lib().rolo_odom_submit(self._h, C.byref(front_params), stamp, pp, stride, rp, n_raw, on_dev), "rolo_odom_submit")
 
+    def submit_msg(self, front_params, stamp: float, payload: np.ndarray, layout):
+        """submit() from the bytes of a sensor_msgs/PointCloud2: `payload` a uint8 array (n * point_step), `layout` a
+        _lib.CloudLayout with the field offsets of the message."""
+        payload = np.ascontiguousarray(payload, np.uint8)
+        n = payload.size // layout.point_step
+        self._keep = getattr(self, "_keep", []) + [(payload,)]
+        check(lib().rolo_odom_submit_msg(self._h, C.byref(front_params), stamp, C.c_void_p(payload.ctypes.data), C.byref(layout), n, 0),
+              "rolo_odom_submit_msg")
+
+    def setDeskewFromMessage(self, dsk):
+        """De-skew the next submit_msg() with the per-point times of the message itself."""
+        check(lib().rolo_odom_set_deskew(self._h, C.byref(dsk), None, 0, 0), "rolo_odom_set_deskew")
+
     def collect(self):
         """Second half: finish the oldest submitted frame. Returns what frame() returns."""
         pose = np.zeros(6, np.float32); R = np.zeros((3, 3)); t = np.zeros(3); counts = (C.c_int * 3)()

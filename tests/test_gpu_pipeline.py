@@ -190,3 +190,56 @@ def test_fused_path_with_deskew_equals_staged():
         rcf, pose_f, R_f, t_f, cnt = fused.frame(fg, stamp, fr.xyz, fr.ring)
         assert rcf == rcs and cnt == (pg["n"], eg["corner"].shape[0], eg["surface"].shape[0])
         assert np.abs(pose_f - pose_s).max() < 1e-6 and np.abs(R_f - R_s).max() < 1e-9 and np.abs(t_f - t_s).max() < 1e-9
+
+
+def _pack_msg(fr, kind):
+    """Payload of a sensor_msgs/PointCloud2 as the drivers lay it out: Velodyne packed (point_step 22: x y z intensity
+    float32 @0..12, ring uint16 @16, time float32 @18) or Ouster (point_step 48: x y z @0..8, intensity @16, t uint32 ns @20,
+    reflectivity uint16 @24, ring uint8 @26, noise uint16 @28, range uint32 @32)."""
+    from rolo_amd._lib import CloudLayout
+    n = fr.xyz.shape[0]
+    t = (np.arange(n, dtype=np.float64) / n * 0.1)
+    if kind == "velodyne":
+        dt = np.dtype({"names": ["x", "y", "z", "intensity", "ring", "time"], "formats": ["<f4", "<f4", "<f4", "<f4", "<u2", "<f4"],
+                       "offsets": [0, 4, 8, 12, 16, 18], "itemsize": 22})
+        a = np.zeros(n, dt); a["time"] = t.astype(np.float32)
+        L = CloudLayout(22, 0, 4, 8, 16, 2, 18, 1)
+        rel = np.abs(a["time"])
+    else:
+        dt = np.dtype({"names": ["x", "y", "z", "intensity", "t", "reflectivity", "ring", "noise", "range"],
+                       "formats": ["<f4", "<f4", "<f4", "<f4", "<u4", "<u2", "u1", "<u2", "<u4"], "offsets": [0, 4, 8, 16, 20, 24, 26, 28, 32], "itemsize": 48})
+        a = np.zeros(n, dt); a["t"] = (t * 1e9).astype(np.uint32)
+        L = CloudLayout(48, 0, 4, 8, 26, 1, 20, 2)
+        rel = np.abs(a["t"].astype(np.float32) * np.float32(1e-9))          # dst.time = src.t * 1e-9f, imageProjection.cpp:209
+    a["x"], a["y"], a["z"] = fr.xyz[:, 0], fr.xyz[:, 1], fr.xyz[:, 2]
+    a["intensity"] = 7.0; a["ring"] = fr.ring
+    return a.view(np.uint8).reshape(-1), L, rel.astype(np.float32)
+
+
+@pytest.mark.parametrize("kind", ["velodyne", "ouster"])
+def test_submit_from_pointcloud2_payload(kind):
+    """rolo_odom_submit_msg: the field extraction of cachePointCloud (pcl::moveFromROSMsg, the Ouster conversion loop) as a
+    kernel on the raw message bytes — same frames, same poses as handing over x y z / ring arrays, with and without de-skew
+    from the message's own times."""
+    from rolo_amd.frontend import deskew_params
+    cfg = dict(n_scan=16, horizon_scan=1800)
+    fg = front_params(**cfg)
+    arrays = LidarOdometry(0, 0.3); msgs = LidarOdometry(0, 0.3)
+    for k, (R, t) in enumerate(trajectory(4)):
+        fr = synth.make_frame("vlp16", R, t, synth.SEED + k)
+        payload, L, rel = _pack_msg(fr, kind)
+        stamp = 100.0 + 0.1 * k
+        if k == 2:
+            arrays.odometryHandler(stamp - 0.05); msgs.odometryHandler(stamp - 0.05)
+        if k >= 2:   # de-skew the registered frames
+            dsk = deskew_params([0.002, -0.001, 0.025], 0.1, 0.1)
+            arrays.setDeskew(dsk, rel); msgs.setDeskewFromMessage(dsk)
+        arrays.submit(fg, stamp, fr.xyz, fr.ring); msgs.submit_msg(fg, stamp, payload, L)
+        ra, pa, Ra, ta, ca = arrays.collect(); rm, pm, Rm, tm, cm = msgs.collect()
+        assert ra == rm and ca == cm
+        assert np.abs(pm - pa).max() < 1e-6 and np.abs(Rm - Ra).max() < 1e-9 and np.abs(tm - ta).max() < 1e-9
+    # a layout that points outside the record is refused
+    from rolo_amd._lib import CloudLayout, RoloError
+    with pytest.raises(RoloError) as ei:
+        msgs.submit_msg(fg, 101.0, payload, CloudLayout(L.point_step, 0, 4, L.point_step - 2, L.off_ring, L.ring_bytes, L.off_time, L.time_kind))
+    assert ei.value.code == -1
