@@ -263,6 +263,9 @@ int rolo_odom_collect(rolo_odom* o, float* pose6, double* rot9, double* trans3, 
 typedef struct rolo_cloud_layout { int point_step, off_x, off_y, off_z, off_ring, ring_bytes, off_time, time_kind; } rolo_cloud_layout;
 int rolo_odom_submit_msg(rolo_odom* o, const rolo_front_params* P, double stamp, const uint8_t* data, const rolo_cloud_layout* layout,
                          int n_points, int data_on_device);
+/* The feature clouds of the last collected frame of the fused path, for the outgoing rolo/CloudInfoStamp (extracted_corner ++
+ * extracted_surface as n x 4 floats: x, y, z, intensity; corners first). features may be NULL to query the counts. */
+int rolo_odom_get_features(rolo_odom* o, float* features, int cap_points, int* n_corner, int* n_surface);
 /* options of the fused path: ROLO_ODOM_REUSE_COVARIANCES (default 0) = rolo_adopt_target_covariances between frames */
 #define ROLO_ODOM_REUSE_COVARIANCES 1
 int rolo_odom_set_option(rolo_odom* o, int option, int value);

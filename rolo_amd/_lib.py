@@ -110,6 +110,7 @@ SYMBOLS = {
     "rolo_odom_submit": (C.c_int, [vp, C.POINTER(FrontParams), C.c_double, vp, C.c_int, vp, C.c_int, C.c_int]),
     "rolo_odom_collect": (C.c_int, [vp, fp, dp, dp, C.POINTER(C.c_int)]),
     "rolo_odom_submit_msg": (C.c_int, [vp, C.POINTER(FrontParams), C.c_double, vp, C.POINTER(CloudLayout), C.c_int, C.c_int]),
+    "rolo_odom_get_features": (C.c_int, [vp, fp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "rolo_odom_set_option": (C.c_int, [vp, C.c_int, C.c_int]),
     "rolo_odom_set_deskew": (C.c_int, [vp, C.POINTER(Deskew), vp, C.c_int, C.c_int]),
     "rolo_odom_increment": (None, [fp, fp, fp]),

@@ -81,6 +81,7 @@ struct rolo_odom {
   float4* d_prop = nullptr;
   size_t d_cap = 0;
   int old_buf = 0, nOld = 0;
+  int nCornerOld = 0;   // corners lead the feature cloud of the last collected frame
   struct Slot { double stamp = 0; int* h_counts = nullptr; hipEvent_t done = nullptr; } q[2];
   int q_head = 0, q_len = 0;
   bool reuse_cov = false, cov_chain = false;  // cov_chain: the context's target covariances belong to d_feat[old_buf]
@@ -305,10 +306,22 @@ int rolo_odom_collect(rolo_odom* o, float* pose6, double* rot9, double* trans3, 
   }
   o->old_buf = buf;
   o->nOld = nNew;
+  o->nCornerOld = counts[1];
   if (pose6) memcpy(pose6, o->LaserOdomPose, sizeof(float) * 6);
   if (rot9) memcpy(rot9, o->Rotation, sizeof(double) * 9);
   if (trans3) memcpy(trans3, o->Translation, sizeof(double) * 3);
   return ret;
+}
+
+int rolo_odom_get_features(rolo_odom* o, float* features, int cap_points, int* n_corner, int* n_surface) {
+  if (!o || !n_corner || !n_surface) return ROLO_EINVAL;
+  *n_corner = o->nCornerOld; *n_surface = o->nOld - o->nCornerOld;
+  if (!features || o->nOld == 0) return ROLO_OK;
+  if (cap_points < o->nOld) { rolo::ctx_set_error("feature buffer too small"); return ROLO_EINVAL; }
+  if (hipSetDevice(rolo::ctx_device(o->ctx)) != hipSuccess) { rolo::ctx_set_error("hipSetDevice failed"); return ROLO_EHIP; }
+  // the last collected frame's features sit in d_feat[old_buf]; the front-end stream finished writing them before collect returned
+  if (hipMemcpy(features, o->d_feat[o->old_buf], sizeof(float4) * (size_t)o->nOld, hipMemcpyDeviceToHost) != hipSuccess) { rolo::ctx_set_error("feature read-back failed"); return ROLO_EHIP; }
+  return ROLO_OK;
 }
 
 int rolo_odom_frame(rolo_odom* o, const rolo_front_params* P, double stamp, const float* pts, int stride, const uint16_t* ring, int n_raw,

@@ -81,6 +81,14 @@ class LidarOdometry:
         """De-skew the next submit_msg() with the per-point times of the message itself."""
         check(lib().rolo_odom_set_deskew(self._h, C.byref(dsk), None, 0, 0), "rolo_odom_set_deskew")
 
+    def features(self):
+        """(corner, surface) clouds of the last collected frame of the fused path (n x 4: x, y, z, intensity)."""
+        nc, ns = C.c_int(0), C.c_int(0)
+        check(lib().rolo_odom_get_features(self._h, None, 0, C.byref(nc), C.byref(ns)), "rolo_odom_get_features")
+        buf = np.zeros((max(nc.value + ns.value, 1), 4), np.float32)
+        check(lib().rolo_odom_get_features(self._h, buf.ctypes.data_as(C.POINTER(C.c_float)), buf.shape[0], C.byref(nc), C.byref(ns)), "rolo_odom_get_features")
+        return buf[:nc.value].copy(), buf[nc.value:nc.value + ns.value].copy()
+
     def collect(self):
         """Second half: finish the oldest submitted frame. Returns what frame() returns."""
         pose = np.zeros(6, np.float32); R = np.zeros((3, 3)); t = np.zeros(3); counts = (C.c_int * 3)()

@@ -86,6 +86,8 @@ def test_fused_frame_equals_staged_nodes(sensor, cfg):
         rcs, pose_s, R_s, t_s = staged.cloudHandler(stamp, eg["corner"], eg["surface"])
         rch, pose_h, R_h, t_h, cnt = fused_h.frame(fg, stamp, fr.xyz, fr.ring)
         assert cnt == (pg["n"], eg["corner"].shape[0], eg["surface"].shape[0])
+        fc, fs = fused_h.features()   # what the outgoing CloudInfoStamp carries
+        assert np.array_equal(fc, eg["corner"]) and np.array_equal(fs, eg["surface"])
         d_xyz = torch.from_numpy(np.ascontiguousarray(fr.xyz, np.float32)).cuda()
         d_ring = torch.from_numpy(np.ascontiguousarray(fr.ring, np.uint16).view(np.int16)).cuda()
         torch.cuda.synchronize()
