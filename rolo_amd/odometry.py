@@ -68,14 +68,16 @@ class LidarOdometry:
             self._keep = getattr(self, "_keep", []) + [(xyz, ring)]
         check(lib().rolo_odom_submit(self._h, C.byref(front_params), stamp, pp, stride, rp, n_raw, on_dev), "rolo_odom_submit")
 
-    def submit_msg(self, front_params, stamp: float, payload: np.ndarray, layout):
-        """submit() from the bytes of a sensor_msgs/PointCloud2: `payload` a uint8 array (n * point_step), `layout` a
-        _lib.CloudLayout with the field offsets of the message."""
-        payload = np.ascontiguousarray(payload, np.uint8)
-        n = payload.size // layout.point_step
-        self._keep = getattr(self, "_keep", []) + [(payload,)]
-        check(lib().rolo_odom_submit_msg(self._h, C.byref(front_params), stamp, C.c_void_p(payload.ctypes.data), C.byref(layout), n, 0),
-              "rolo_odom_submit_msg")
+    def submit_msg(self, front_params, stamp: float, payload, layout, n_points=None):
+        """submit() from the bytes of a sensor_msgs/PointCloud2: `payload` a uint8 array (n * point_step) or an integer device
+        pointer (then pass n_points), `layout` a _lib.CloudLayout with the field offsets of the message."""
+        if isinstance(payload, int):
+            ptr, n, on_dev = C.c_void_p(payload), n_points, 1
+        else:
+            payload = np.ascontiguousarray(payload, np.uint8)
+            ptr, n, on_dev = C.c_void_p(payload.ctypes.data), payload.size // layout.point_step, 0
+            self._keep = getattr(self, "_keep", []) + [(payload,)]
+        check(lib().rolo_odom_submit_msg(self._h, C.byref(front_params), stamp, ptr, C.byref(layout), n, on_dev), "rolo_odom_submit_msg")
 
     def setDeskewFromMessage(self, dsk):
         """De-skew the next submit_msg() with the per-point times of the message itself."""
@@ -94,7 +96,7 @@ class LidarOdometry:
         pose = np.zeros(6, np.float32); R = np.zeros((3, 3)); t = np.zeros(3); counts = (C.c_int * 3)()
         fp, dp = C.POINTER(C.c_float), C.POINTER(C.c_double)
         rc = check(lib().rolo_odom_collect(self._h, pose.ctypes.data_as(fp), R.ctypes.data_as(dp), t.ctypes.data_as(dp), counts), "rolo_odom_collect")
-        if getattr(self, "_keep", None):
+        if getattr(self, "_keep", None):   # host inputs of the collected frame may go (device-pointer submits keep nothing)
             self._keep.pop(0)
         return rc, pose, R, t, tuple(counts)
 

@@ -226,7 +226,7 @@ def test_submit_from_pointcloud2_payload(kind):
     from rolo_amd.frontend import deskew_params
     cfg = dict(n_scan=16, horizon_scan=1800)
     fg = front_params(**cfg)
-    arrays = LidarOdometry(0, 0.3); msgs = LidarOdometry(0, 0.3)
+    arrays = LidarOdometry(0, 0.3); msgs = LidarOdometry(0, 0.3); dev = LidarOdometry(0, 0.3)
     for k, (R, t) in enumerate(trajectory(4)):
         fr = synth.make_frame("vlp16", R, t, synth.SEED + k)
         payload, L, rel = _pack_msg(fr, kind)
@@ -240,6 +240,16 @@ def test_submit_from_pointcloud2_payload(kind):
         ra, pa, Ra, ta, ca = arrays.collect(); rm, pm, Rm, tm, cm = msgs.collect()
         assert ra == rm and ca == cm
         assert np.abs(pm - pa).max() < 1e-6 and np.abs(Rm - Ra).max() < 1e-9 and np.abs(tm - ta).max() < 1e-9
+        # the payload may already be in HBM (e.g. written by a driver with GPU-direct): same again from a device pointer
+        import torch
+        d_payload = torch.from_numpy(payload.copy()).cuda(); torch.cuda.synchronize()
+        if k >= 2:
+            dev.setDeskewFromMessage(dsk)
+        if k == 2:
+            dev.odometryHandler(stamp - 0.05)
+        dev.submit_msg(fg, stamp, d_payload.data_ptr(), L, n_points=fr.xyz.shape[0])
+        rd, pd, Rd, td, cd = dev.collect()
+        assert rd == rm and cd == cm and np.abs(pd - pm).max() < 1e-6 and np.abs(td - tm).max() < 1e-9
     # a layout that points outside the record is refused
     from rolo_amd._lib import CloudLayout, RoloError
     with pytest.raises(RoloError) as ei:
