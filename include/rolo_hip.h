@@ -209,9 +209,9 @@ int rolo_project_frame(rolo_ctx* ctx, const rolo_front_params* P, const float* p
 /* ImageProjection::deskewPoint (src/imageProjection.cpp:368-396; deskewCloudInfo :266-366 prepares its inputs): rotation-only
  * de-skew of every stored point by the front-end odometry increment over the scan, `rolo/deskewEnabled` (off in every
  * shipped config). Arms the NEXT rolo_project_frame / rolo_odom_submit on this context: rel_time[i] = fabs(point.time) of
- * raw point i (what :358-359 stores; for clouds without a time field pass the azimuth-interpolated scanPeriod * relTime of
- * :303-326), odom_incre_rpy = odomIncreRoll/Pitch/Yaw, odom_time_diff = odomTimeDiff (:349-351; rolo_odom_increment does
- * the pose algebra). rel_time == NULL: the times come with the next message (rolo_odom_submit_msg). Range, pixel and every
+ * raw point i (what :358-359 stores), odom_incre_rpy = odomIncreRoll/Pitch/Yaw, odom_time_diff = odomTimeDiff (:349-351; rolo_odom_increment does
+ * the pose algebra). rel_time == NULL: the times come from the time field of the next message (rolo_odom_submit_msg) or, for
+ * points without one (timeFlag == -1), are interpolated from the azimuth as deskewCloudInfo does (:270-327). Range, pixel and every
  * index still come from the raw point, as in the reference (:412-454). */
 typedef struct rolo_deskew { int enabled; float odom_incre_rpy[3]; float scan_period; double odom_time_diff; } rolo_deskew;
 int rolo_front_set_deskew(rolo_ctx* ctx, const rolo_deskew* d, const float* rel_time, int n_raw, int rel_time_on_device);
@@ -259,7 +259,7 @@ int rolo_odom_collect(rolo_odom* o, float* pose6, double* rot9, double* trans3, 
  * pcl::moveFromROSMsg and the Ouster conversion loop of cachePointCloud (imageProjection.cpp:188-212) do on the host runs as a
  * kernel: x, y, z (FLOAT32), ring (UINT16 for Velodyne, UINT8 for Ouster), time (time_kind 1: Velodyne "time", FLOAT32 seconds;
  * 2: Ouster "t", UINT32 nanoseconds, * 1e-9f; 0: none). A de-skew armed without times (rolo_odom_set_deskew with rel_time =
- * NULL) takes fabs(time) of this message. */
+ * NULL) takes fabs(time) of this message, or the azimuth-interpolated times when the message has no time field. */
 typedef struct rolo_cloud_layout { int point_step, off_x, off_y, off_z, off_ring, ring_bytes, off_time, time_kind; } rolo_cloud_layout;
 int rolo_odom_submit_msg(rolo_odom* o, const rolo_front_params* P, double stamp, const uint8_t* data, const rolo_cloud_layout* layout,
                          int n_points, int data_on_device);

@@ -309,6 +309,14 @@ def deskew(incre_rpy, scan_period=0.1, odom_time_diff=0.1, enabled=1):
     return d
 
 
+def azimuth_times(xyz, scan_period=0.1):
+    a = np.ascontiguousarray(xyz, np.float32); out = np.zeros(a.shape[0], np.float32)
+    f = lib().orc_azimuth_times
+    f.argtypes = [C.POINTER(C.c_float), C.c_int, C.c_int, C.c_float, C.POINTER(C.c_float)]; f.restype = None
+    f(_f(a), a.shape[1], a.shape[0], scan_period, _f(out))
+    return out
+
+
 def odom_increment(front6, back6):
     f = np.ascontiguousarray(front6, np.float32); b = np.ascontiguousarray(back6, np.float32); o = np.zeros(6, np.float32)
     lib().orc_odom_increment(_f(f), _f(b), _f(o))

@@ -36,6 +36,31 @@ static void deskew_point(const orc_deskew* d, float rel_time_f, float& x, float&
   x = nx; y = ny; z = nz;
 }
 
+void orc_azimuth_times(const float* pts, int stride, int n, float scan_period, float* rel_time) {  // imageProjection.cpp:270-327
+  if (n <= 0) return;
+  bool halfPassed = false;
+  float startOri = -atan2f(pts[1], pts[0]);                                                       // :272
+  float endOri = -atan2f(pts[(size_t)(n - 1) * stride + 1], pts[(size_t)(n - 1) * stride]) + 2 * M_PI;   // :273 (double sum, stored float)
+  if (endOri - startOri > 3 * M_PI) endOri -= 2 * M_PI;                                           // :274-277
+  else if (endOri - startOri < M_PI) endOri += 2 * M_PI;
+  const float orientationDiff = endOri - startOri;
+  for (int i = 0; i < n; i++) {
+    const float px = pts[(size_t)i * stride + 1], pz = pts[(size_t)i * stride];                   // point.x = in.y, point.z = in.x (:303-305)
+    float ori = -atan2f(px, pz);                                                                   // :307
+    if (!halfPassed) {
+      if (ori < startOri - M_PI / 2) ori += 2 * M_PI;
+      else if (ori > startOri + M_PI * 3 / 2) ori -= 2 * M_PI;
+      if (ori - startOri > M_PI) halfPassed = true;
+    } else {
+      ori += 2 * M_PI;
+      if (ori < endOri - M_PI * 3 / 2) ori += 2 * M_PI;
+      else if (ori > endOri + M_PI / 2) ori -= 2 * M_PI;
+    }
+    const float relTime = (ori - startOri) / orientationDiff;                                     // :324
+    rel_time[i] = scan_period * relTime;                                                           // :325
+  }
+}
+
 int orc_project(const orc_front_params* P, const float* pts, int stride, const uint16_t* ring, int n_raw,
                 float* range_mat, float* full_cloud, float* extracted, int32_t* point_col_ind,
                 float* point_range, int32_t* start_ring, int32_t* end_ring) {

@@ -42,6 +42,9 @@ int orc_project_deskew(const orc_front_params* P, const float* pts, int stride, 
                        const float* rel_time, const orc_deskew* d,
                        float* range_mat, float* full_cloud, float* extracted, int32_t* point_col_ind,
                        float* point_range, int32_t* start_ring, int32_t* end_ring);
+/* deskewCloudInfo for clouds WITHOUT a time field (timeFlag == -1, imageProjection.cpp:270-327): the per-point time
+ * interpolated from the azimuth, rel_time[i] = scanPeriod * relTime — what that branch stores in deskewCloud->points[i].intensity. */
+void orc_azimuth_times(const float* pts, int stride, int n, float scan_period, float* rel_time);
 /* lidarOdomAffineFront.inverse() * lidarOdomAffineBack -> getTranslationAndEulerAngles (:293-299, 345-351); poses as
  * x, y, z, roll, pitch, yaw (odom2affine :514-522 goes through tf's quaternion -> RPY, done by the caller) */
 void orc_odom_increment(const float* front6, const float* back6, float* incre6);

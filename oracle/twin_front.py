@@ -168,6 +168,29 @@ def extract_features(proj, n_scan, edge_threshold=0.8, surf_threshold=0.1, leaf=
     return dict(corner=corner, surface=surface, curvature=curv[G:G + n].copy(), picked=picked[G:G + n].copy(), label=label[G:G + n].copy())
 
 
+def azimuth_times(xyz, scan_period=0.1):
+    """deskewCloudInfo without a time field (imageProjection.cpp:270-327), vectorised: halfPassed flips at the first point whose
+    (first-half-adjusted) azimuth is more than pi past the start, so the serial flag is a prefix property."""
+    xyz = np.asarray(xyz, F)
+    two_pi = 2 * math.pi
+    start = F(-np.arctan2(xyz[0, 1], xyz[0, 0]))
+    end = F(np.float64(F(-np.arctan2(xyz[-1, 1], xyz[-1, 0]))) + two_pi)
+    if np.float64(F(end - start)) > 3 * math.pi:
+        end = F(np.float64(end) - two_pi)
+    elif np.float64(F(end - start)) < math.pi:
+        end = F(np.float64(end) + two_pi)
+    diff = F(end - start)
+    ori = (-np.arctan2(xyz[:, 1], xyz[:, 0])).astype(F)
+    o64 = ori.astype(np.float64)
+    a = np.where(o64 < np.float64(start) - math.pi / 2, (o64 + two_pi).astype(F), np.where(o64 > np.float64(start) + math.pi * 3 / 2, (o64 - two_pi).astype(F), ori)).astype(F)
+    passed = (a - start).astype(F).astype(np.float64) > math.pi
+    k = int(np.argmax(passed)) if passed.any() else xyz.shape[0]            # the point that sets halfPassed still uses the first rule
+    b = (o64 + two_pi).astype(F); b64 = b.astype(np.float64)
+    b = np.where(b64 < np.float64(end) - math.pi * 3 / 2, (b64 + two_pi).astype(F), np.where(b64 > np.float64(end) + math.pi / 2, (b64 - two_pi).astype(F), b)).astype(F)
+    final = np.where(np.arange(xyz.shape[0]) <= k, a, b).astype(F)
+    return (F(scan_period) * ((final - start).astype(F) / diff).astype(F)).astype(F)
+
+
 # ---- float pose algebra of the odometry node ---------------------------------------------------------------------------
 def get_transformation(x, y, z, roll, pitch, yaw):
     """pcl::getTransformation (float): R = Rz(yaw) Ry(pitch) Rx(roll)."""

@@ -2,8 +2,8 @@
 // Replaces ImageProjection::projectPointCloud / cloudExtraction (reference src/imageProjection.cpp:399-505) and
 // FeatureExtraction::calculateSmoothness / markOccludedPoints / extractFeatures incl. pcl::VoxelGrid
 // (reference src/featureExtraction.cpp:87-266). De-skew (deskewPoint :368-396, off in every shipped config) is applied when
-// armed with rolo_front_set_deskew, for clouds with a per-point time; the azimuth-interpolated times of clouds without one
-// (:270-327) are left to the caller (pass them as rel_time).
+// armed with rolo_front_set_deskew: per-point times from the caller, from the message, or interpolated from the azimuth
+// (deskewCloudInfo :270-327) when the cloud carries none.
 //
 // MI355X design. The reference's three serial loops become:
 //   K1  one thread per raw point; "first point to claim a pixel wins" (imageProjection.cpp:451) is an atomicMin of
@@ -56,6 +56,47 @@ __global__ __launch_bounds__(256) void unpack_cloud_kernel(const unsigned char* 
   if (L.time_kind == 1) t = __uint_as_float(load_u32_bytes(p + L.off_time));
   else if (L.time_kind == 2) t = (float)load_u32_bytes(p + L.off_time) * 1e-9f;   // :209
   rel_time[i] = fabsf(t);                                                          // deskewCloudInfo :358-359
+}
+
+// ---- per-point times of a cloud without a time field: deskewCloudInfo, timeFlag == -1 (imageProjection.cpp:270-327) ----
+// The reference interpolates the time from the azimuth in a serial loop with one flag, halfPassed, that flips at the first
+// point whose (first-half-adjusted) azimuth is more than pi past the start: a prefix property. Kernel 1 finds that point
+// (atomicMin), kernel 2 applies the first-half rule up to and including it and the second-half rule after it.
+struct AzimuthRef { float start, end, diff; };
+ROLO_DEV AzimuthRef azimuth_ref(const float* __restrict__ pts, int stride, int n) {
+  float start = -atan2f(pts[1], pts[0]);                                                           // :272
+  float end = (float)((double)(-atan2f(pts[(size_t)(n - 1) * stride + 1], pts[(size_t)(n - 1) * stride])) + 2 * M_PI);   // :273
+  if ((double)(end - start) > 3 * M_PI) end = (float)((double)end - 2 * M_PI);                     // :274-277
+  else if ((double)(end - start) < M_PI) end = (float)((double)end + 2 * M_PI);
+  return AzimuthRef{start, end, end - start};
+}
+ROLO_DEV float azimuth_first_half(float ori, float start) {
+  if ((double)ori < (double)start - M_PI / 2) ori = (float)((double)ori + 2 * M_PI);
+  else if ((double)ori > (double)start + M_PI * 3 / 2) ori = (float)((double)ori - 2 * M_PI);
+  return ori;
+}
+__global__ __launch_bounds__(256) void azimuth_flag_kernel(const float* __restrict__ pts, int stride, int n, int* __restrict__ first_passed) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const AzimuthRef r = azimuth_ref(pts, stride, n);
+  const float a = azimuth_first_half(-atan2f(pts[(size_t)i * stride + 1], pts[(size_t)i * stride]), r.start);   // point.x = in.y, point.z = in.x (:303-307)
+  if ((double)(a - r.start) > M_PI) atomicMin(first_passed, i);
+}
+__global__ __launch_bounds__(256) void azimuth_time_kernel(const float* __restrict__ pts, int stride, int n, float scan_period,
+                                                          const int* __restrict__ first_passed, float* __restrict__ rel_time) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const AzimuthRef r = azimuth_ref(pts, stride, n);
+  float ori = -atan2f(pts[(size_t)i * stride + 1], pts[(size_t)i * stride]);
+  if (i <= *first_passed) {
+    ori = azimuth_first_half(ori, r.start);
+  } else {                                                                                          // :316-322
+    ori = (float)((double)ori + 2 * M_PI);
+    if ((double)ori < (double)r.end - M_PI * 3 / 2) ori = (float)((double)ori + 2 * M_PI);
+    else if ((double)ori > (double)r.end + M_PI / 2) ori = (float)((double)ori - 2 * M_PI);
+  }
+  const float relTime = (ori - r.start) / r.diff;                                                   // :324
+  rel_time[i] = scan_period * relTime;                                                              // :325
 }
 
 // ---- K1 ------------------------------------------------------------------------------------------------
@@ -707,6 +748,20 @@ int front_project_enqueue(Front* f, const rolo_front_params* P, const float* d_p
                           hipStream_t s) {
   const int NS = f->n_scan, H = f->H;
   const size_t npix = (size_t)NS * H;
+  if (f->deskew_from_msg) {   // armed without times and no time field came with the points: interpolate them from the azimuth
+    f->deskew_from_msg = false;
+    if (n_raw > 0) {
+      if ((size_t)n_raw > f->cap_time || !f->rel_time) {
+        if (!dev_alloc(f->rel_time, (size_t)n_raw)) { ctx_set_error("hipMalloc failed (de-skew times)"); return ROLO_EHIP; }
+        f->cap_time = (size_t)n_raw;
+      }
+      fill_int_kernel<<<1, 64, 0, s>>>(f->counters + 4, 1, INT_MAX);
+      azimuth_flag_kernel<<<(n_raw + 255) / 256, 256, 0, s>>>(d_pts, stride, n_raw, f->counters + 4);
+      azimuth_time_kernel<<<(n_raw + 255) / 256, 256, 0, s>>>(d_pts, stride, n_raw, f->deskew.scan_period, f->counters + 4, f->rel_time);
+      f->deskew.rel_time = f->rel_time;
+      f->deskew_armed = true;
+    }
+  }
   fill_int_kernel<<<256, 256, 0, s>>>(f->owner, (int)npix, INT_MAX);
   // guard cells of the per-point arrays are zero
   FCHK(hipMemsetAsync(f->col, 0, sizeof(int) * (npix + 2 * FRONT_GUARD), s));
@@ -804,9 +859,8 @@ int front_frame_features_from_msg(rolo_ctx* c, const rolo_front_params* P, const
   }
   if (n_raw > 0) unpack_cloud_kernel<<<(n_raw + 255) / 256, 256, 0, s>>>(d_data, *L, n_raw, f->msg_xyz, f->msg_ring, f->msg_time);
   FCHK(hipGetLastError());
-  if (f->deskew_from_msg) {
+  if (f->deskew_from_msg && L->time_kind != 0) {   // without a time field the projection interpolates the times from the azimuth
     f->deskew_from_msg = false;
-    if (L->time_kind == 0) { ctx_set_error("de-skew armed but the message has no time field"); return ROLO_EINVAL; }
     f->deskew.rel_time = f->msg_time;
     f->deskew_armed = true;
   }

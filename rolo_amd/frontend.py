@@ -57,6 +57,10 @@ class FrontEnd:
         rt = np.ascontiguousarray(rel_time, np.float32)
         check(lib().rolo_front_set_deskew(self.ctx._h, C.byref(dsk), C.c_void_p(rt.ctypes.data), rt.shape[0], 0), "rolo_front_set_deskew")
 
+    def setDeskewFromCloud(self, dsk: Deskew):
+        """deskewPoint for the next project() with the azimuth-interpolated times of deskewCloudInfo's timeFlag == -1 branch."""
+        check(lib().rolo_front_set_deskew(self.ctx._h, C.byref(dsk), None, 0, 0), "rolo_front_set_deskew")
+
     def project(self, xyz, ring, want_range_mat=False):
         xyz = np.ascontiguousarray(xyz, np.float32)
         ring = np.ascontiguousarray(ring, np.uint16)

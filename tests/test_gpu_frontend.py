@@ -166,3 +166,25 @@ def test_front_end_against_committed_golden(name):
     assert np.array_equal(eg["curvature"], z["curvature"])
     assert np.array_equal(eg["picked"], z["picked"].astype(np.int32)) and np.array_equal(eg["label"], z["label"].astype(np.int32))
     assert np.array_equal(eg["corner"], z["corner"]) and np.array_equal(eg["surface"], z["surface"])
+
+
+def test_deskew_with_azimuth_times():
+    """rel_time == NULL: the per-point times are interpolated from the azimuth on the device as deskewCloudInfo does for clouds
+    without a time field (timeFlag == -1) — the oracle's serial loop gives the same times and the same de-skewed cloud."""
+    from rolo_amd.frontend import deskew_params
+    from rolo_amd.rotvgicp import RotVGICP
+    cfg = dict(n_scan=16, horizon_scan=1800)
+    fr = synth.make_frame("vlp16", synth.rpy_to_R(0, 0, 0.4), np.zeros(3), synth.SEED)
+    order = np.argsort(-np.arctan2(fr.xyz[:, 1], fr.xyz[:, 0]), kind="stable")      # one sweep, like a spinning sensor
+    xyz = np.asarray(fr.xyz, np.float32)[order]; ring = np.asarray(fr.ring, np.uint16)[order]
+    fo = pyorc.front_params(**cfg); fg = front_params(**cfg)
+    inc = [0.004, -0.006, 0.035]
+    times = pyorc.azimuth_times(xyz, 0.1)
+    po = pyorc.project(fo, xyz, ring, times, pyorc.deskew(inc, 0.1, 0.0987))
+    g = RotVGICP(); fe = FrontEnd(g, fg)
+    fe.setDeskewFromCloud(deskew_params(inc, 0.1, 0.0987))
+    pg = fe.project(xyz, ring)
+    raw = pyorc.project(fo, xyz, ring)
+    assert pg["n"] == po["n"] and np.array_equal(pg["point_col_ind"], po["point_col_ind"]) and np.array_equal(pg["point_range"], po["point_range"])
+    assert np.abs(po["extracted"][:, :3] - raw["extracted"][:, :3]).max() > 0.05
+    assert np.abs(pg["extracted"][:, :3] - po["extracted"][:, :3]).max() <= 6e-6

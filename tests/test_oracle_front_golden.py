@@ -92,3 +92,17 @@ def test_odometry_driver_against_twin():
         assert np.abs(to.Rotation - R_o).max() <= 1e-6 and np.abs(to.Translation - t_o).max() <= 1e-6
         t = t + R @ np.array([0.3, 0.02 * k, 0.0]); R = R @ synth.rpy_to_R(np.deg2rad(0.3), np.deg2rad(-0.2), np.deg2rad(2.0))
     assert statuses == [0, 1, 2, 2]
+
+
+def test_azimuth_times_against_twin():
+    """deskewCloudInfo's branch for clouds without a time field (imageProjection.cpp:270-327): serial C++ restatement vs the
+    vectorised twin (the halfPassed flag as a prefix property). Equal up to the ulp between numpy's and glibc's float atan2."""
+    for sensor, yaw in (("vlp16", 0.7), ("os1-64", -2.1), ("vlp16", 3.0)):
+        fr = synth.make_frame(sensor, synth.rpy_to_R(0.0, 0.0, yaw), np.zeros(3), synth.SEED)
+        # a spinning sensor's firing order: sort the synthetic frame by azimuth so that the scan sweeps once
+        order = np.argsort(-np.arctan2(fr.xyz[:, 1], fr.xyz[:, 0]), kind="stable")
+        for xyz in (np.asarray(fr.xyz, np.float32), np.asarray(fr.xyz, np.float32)[order]):
+            to = pyorc.azimuth_times(xyz, 0.1); tt = tw.azimuth_times(xyz, 0.1)
+            assert np.abs(to - tt).max() <= 1e-7
+        swept = pyorc.azimuth_times(np.asarray(fr.xyz, np.float32)[order], 0.1)
+        assert swept[0] == 0 and abs(swept[-1] - 0.1) < 1e-6 and np.all(np.diff(swept) >= -1e-6) and swept.min() >= 0 and swept.max() <= 0.1 + 1e-6
