@@ -2,24 +2,34 @@
 """bench.py — scans/sec of the MI355X-native ROLO scan-matching hot path (contract: see the task statement).
 
 One "step" = one complete registration of a synthetic OS1-128 frame pair (128 x 1024 = 131 072 points each,
-the "128k-pt frame" of BASELINE.json): per-point 20-NN covariances of both clouds, target voxel-hash build
-(UNIFORM leaf 0.5 m), SO(3) LM stage forced to exactly 20 outer iterations, continuous-time translation LM
-stage — all enqueued on one HIP stream with the two clouds already resident in HBM when the timed region starts.
+the "128k-pt frame" of BASELINE.json) on every registration context kept in flight (default 4 per GPU): per-point
+20-NN covariances of both clouds, target voxel-hash build (UNIFORM leaf 0.5 m), SO(3) LM stage forced to exactly 20
+outer iterations, continuous-time translation LM stage — all enqueued on the context's HIP stream with the two clouds
+already resident in HBM when the timed region starts.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--mode replicas|shard] [--no-cpu] [--sensor os1-128]
 
-N > 1 (launched by torch.distributed.run, one rank per GPU):
-  replicas (default) — the path partitions by frame: every rank registers its own frames, no data-path
-                       collective, "scaling": "weak"; value = total frames / max-over-ranks time.
-  shard              — one frame, source points sharded over the ranks, one RCCL all-reduce of <= 32 fp64 per LM
-                       pass; reported under "sharded" next to the replicas number.
+Timing: W untimed warm-up steps, then rounds of EXACTLY K steps each, every round bracketed by barrier +
+torch.cuda.synchronize() on both sides and reduced with MAX over the ranks; at least 5 rounds and at least 0.5 s of
+timed work; `value` / `ms_per_step` are the MEDIAN round (all rounds are listed under "rounds_ms_per_step").
+
+N > 1: `python bench.py --gpus N` re-executes itself under torch.distributed.run (one rank per GPU, RCCL); launched by
+torch.distributed.run directly it reads RANK / LOCAL_RANK / WORLD_SIZE. Rank 0 prints the single JSON line.
+  replicas (value)   — the path partitions by frame: every rank registers its own frames, no data-path collective,
+                       "scaling": "weak"; value = total frames / max-over-ranks time.
+  sharded (extra)    — BASELINE configs[3]: ONE OS1-128 2048-column frame (262 144 points), K5 sharded by query point
+                       with an all-gather of the covariances, source points of the LM passes sharded with one RCCL
+                       all-reduce of 32 fp64 per pass; reported under "sharded" at N > 1.
+  config5 (extra)    — BASELINE configs[4]: 512 distinct OS1-64 pairs resident in HBM streamed through the contexts
+                       (pairs dealt round-robin to the ranks), hipGraph replay; "config5" in the JSON line.
 """
 from __future__ import annotations
 
 import argparse
-import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -28,7 +38,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured achievable copy rate
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
 def parse():
@@ -41,9 +51,7 @@ def parse():
     ap.add_argument("--mode", default="replicas", choices=["replicas", "shard"])
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay (profiling runs)")
-    ap.add_argument("--shard-leg", action="store_true",
-                    help="N>1: also time ONE frame with its source points sharded over the ranks (RCCL all-reduce of 32 fp64 per LM pass); "
-                         "opt-in because this container has a single GPU and that collective path has only run in the 2-rank gloo test")
+    ap.add_argument("--no-shard-leg", action="store_true", help="N>1: skip the point-sharded 262k-point leg")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="length of the bounded cpu_baseline sample")
     ap.add_argument("--streams", type=int, default=4,
                     help="registration contexts (HIP streams) kept in flight per GPU; a step is then one frame pair per stream")
@@ -51,6 +59,9 @@ def parse():
                     help="search source and target of a frame in one chain of launches (rolo_params.overlap_knn, the library default)")
     ap.add_argument("--no-pipeline", action="store_true", help="skip the raw-frame -> pose pipeline leg")
     ap.add_argument("--pipeline-only", action="store_true", help="run only the pipeline leg and print its dict (profiling runs)")
+    ap.add_argument("--no-config5", action="store_true", help="skip the 512-pair OS1-64 leg (BASELINE configs[4])")
+    ap.add_argument("--config5-pairs", type=int, default=512)
+    ap.add_argument("--single-round", action="store_true", help="one timed round only (profiling runs)")
     ap.add_argument("--batch", type=int, default=int(os.environ.get("ROLO_BENCH_BATCH", "1")),
                     help="frame pairs per registration call (rolo_batch_*: shared LM launches); 1 = one operator per frame")
     return ap.parse_args()
@@ -67,6 +78,25 @@ def usable_cores() -> int:
     except Exception:
         pass
     return max(1, n)
+
+
+def _free_port() -> int:
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def maybe_spawn(args):
+    """`python bench.py --gpus N` without a launcher: re-execute under torch.distributed.run, one rank per GPU."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    import torch
+    avail = torch.cuda.device_count()
+    if avail < args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: only {avail} GPU(s) visible on this node")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def pipeline_leg(args, torch, device):
@@ -124,8 +154,126 @@ def pipeline_leg(args, torch, device):
     return res
 
 
+def _config5_pair(i):
+    """pair i of BASELINE configs[4]: seed 20260926 + i, motion drawn U(+-2 deg), U(+-0.4 m)"""
+    from rolo_amd import synth
+    g = np.random.default_rng(synth.SEED + i)
+    rpy = g.uniform(-2.0, 2.0, 3); t = g.uniform(-0.4, 0.4, 3)
+    src, tgt, _ = synth.dense_pair("os1-64", seed=synth.SEED + i, rpy_deg=tuple(rpy), t=tuple(t))
+    return src, tgt
+
+
+def config5_leg(args, torch, dist, rank, world, local_rank, new_ctx, barrier):
+    """BASELINE configs[4]: 512 DISTINCT OS1-64 pairs (leaf 1.0 m, 20 iterations) resident in HBM, dealt round-robin to the ranks,
+    streamed through the contexts of each rank (hipGraph replay after the second pair of a context)."""
+    import multiprocessing as mp
+    from rolo_amd import synth
+    npairs = args.config5_pairs
+    mine = list(range(rank, npairs, world))
+    tg = time.perf_counter()
+    with mp.get_context("spawn").Pool(min(usable_cores(), max(1, len(mine)))) as pool:
+        pairs = pool.map(_config5_pair, mine, chunksize=2)
+    gen_s = time.perf_counter() - tg
+    dev = [(torch.from_numpy(s).cuda(), torch.from_numpy(t).cuda(), s.shape[0], t.shape[0]) for s, t in pairs]
+    guess = -np.asarray(synth.PREV_STEP_T, np.float64); last = guess * 0.97; zero3 = np.zeros(3)
+    ctxs = [new_ctx(leaf=1.0) for _ in range(max(args.streams, 1))]
+    results = [None] * len(dev)
+
+    def enqueue(g, k):
+        s, t, ns, nt = dev[k]
+        g.setInputTargetDevice(t.data_ptr(), nt, 4); g.setInputSourceDevice(s.data_ptr(), ns, 4)
+        g.register_async(None, zero3, guess, last, 0.1, 0.1, 0.3)
+
+    def sweep(store):
+        nxt = 0; inflight = []
+        for g in ctxs:
+            if nxt < len(dev):
+                enqueue(g, nxt); inflight.append((g, nxt)); nxt += 1
+        while inflight:
+            g, k = inflight.pop(0)
+            Tf, Td, t = g.register_wait()
+            if store:
+                results[k] = (Td.copy(), t.copy())
+            if nxt < len(dev):
+                enqueue(g, nxt); inflight.append((g, nxt)); nxt += 1
+
+    sweep(False)  # warm-up sweep: allocations, graph capture
+    import gc
+    times = []
+    for rep in range(3):
+        gc.collect(); gc.disable()
+        barrier(); t0 = time.perf_counter()
+        sweep(rep == 0)
+        barrier(); dt = time.perf_counter() - t0
+        gc.enable()
+        if world > 1:
+            tt = torch.tensor([dt], dtype=torch.float64, device="cuda"); dist.all_reduce(tt, op=dist.ReduceOp.MAX); dt = float(tt.item())
+        times.append(dt)
+    dt = float(np.median(times))
+    out = {"workload": f"{npairs} distinct os1-64 pairs (65 536 rays each, seeds {synth.SEED}+i, motions U(+-2 deg), U(+-0.4 m)), UNIFORM leaf 1.0 m, "
+                       f"20 SO(3) LM iterations + CT translation, resident in HBM, {len(ctxs)} contexts per GPU, hipGraph replay",
+           "scans_per_s_batch512": npairs / dt, "sweep_ms": [1e3 * x for x in times], "pairs_per_rank": len(mine), "generation_s": gen_s}
+    if rank == 0 and not args.no_cpu:
+        from oracle import pyorc
+        p = pyorc.default_params(voxel_type=pyorc.VOXEL_UNIFORM, voxel_resolution=1.0, fixed_iterations=20, num_threads=usable_cores())
+        worst_r = worst_t = 0.0
+        sample = list(range(0, len(mine), max(1, len(mine) // 16)))[:16]
+        for k in sample:
+            o = pyorc.Reg(p); o.set_target(pairs[k][1]); o.set_source(pairs[k][0])
+            rc, _, Td, _, _ = o.align(); rc2, to, _ = o.compute_translation(np.zeros(3), guess, last)
+            Tg, tg_ = results[k]
+            dR = Tg[:3, :3] @ Td[:3, :3].T
+            worst_r = max(worst_r, float(np.arccos(np.clip((np.trace(dR) - 1) / 2, -1, 1)))); worst_t = max(worst_t, float(np.abs(tg_ - to).max()))
+        out["parity_sample"] = {"pairs": [mine[k] for k in sample], "max_rot_err_rad": worst_r, "max_trans_err_m": worst_t,
+                                "bar": "<= 1e-5 rad, <= 1e-4 m vs the oracle"}
+    for g in ctxs:
+        g.close()
+    return out
+
+
+def cpu_baseline_legs(args, src, tgt, guess, last):
+    """The oracle (CPU restatement of the reference, same OpenMP structure) on this box's host cores: the headline workload with all
+    usable cores (`cpu_baseline`), BASELINE configs[0] (VLP-16 pair, POLAR voxels, convergence-driven, ONE thread), per-stage ms."""
+    from oracle import pyorc
+    from rolo_amd import synth
+    cores = usable_cores()
+
+    def sample(p, s, t, seconds, cap):
+        stages = {"set_inputs": 0.0, "covariances_kdtree_knn_svd": 0.0, "voxelmap": 0.0, "rotation_lm": 0.0, "translation_lm": 0.0}
+        t0 = time.perf_counter(); frames = 0
+        while True:
+            ta = time.perf_counter(); o = pyorc.Reg(p); o.set_target(t); o.set_source(s)
+            tb = time.perf_counter(); o.compute_covariances()
+            tc = time.perf_counter(); o.build_voxelmap()
+            td = time.perf_counter(); o.align()
+            te = time.perf_counter(); o.compute_translation(np.zeros(3), guess, last)
+            tf = time.perf_counter()
+            for k, v in zip(stages, (tb - ta, tc - tb, td - tc, te - td, tf - te)):
+                stages[k] += v
+            frames += 1
+            cdt = time.perf_counter() - t0
+            if cdt >= seconds or frames >= cap:
+                break
+        return frames, cdt, {k: 1e3 * v / frames for k, v in stages.items()}
+
+    p = pyorc.default_params(voxel_type=pyorc.VOXEL_UNIFORM, voxel_resolution=args.leaf, fixed_iterations=20, num_threads=cores)
+    frames, cdt, st = sample(p, src, tgt, args.cpu_seconds, 200)
+    out = {"cpu_baseline": {"value": frames / cdt, "unit": "scans/s", "cores": cores, "kind": "port",
+                            "sample": f"{frames} frame pair(s) of the same workload (kd-tree build, 20-NN covariances, voxel map, 20 SO(3) LM iterations, "
+                                      f"CT translation) on oracle/librolo_oracle.so, OMP threads = {cores} (cgroup CPU quota of this box; os.cpu_count() = "
+                                      f"{os.cpu_count()}), {cdt:.1f} s", "stage_ms": st}}
+    s16, t16, _ = synth.dense_pair("vlp16")
+    p1 = pyorc.default_params(polar_resolution=(0.175, 0.175, 2.0), num_threads=1)
+    f1, c1, st1 = sample(p1, s16, t16, min(args.cpu_seconds, 6.0), 100)
+    out["cpu_baseline_1thread"] = {"value": f1 / c1, "unit": "scans/s", "cores": 1, "kind": "port",
+                                   "sample": f"BASELINE configs[0]: {f1} VLP-16 pair(s) ({s16.shape[0]} points), POLAR voxels 0.175/0.175/2.0, reference convergence "
+                                             f"rule, 1 OMP thread, {c1:.1f} s", "stage_ms": st1}
+    return out
+
+
 def main():
     args = parse()
+    maybe_spawn(args)
     import torch  # device memory, streams and torch.distributed only
     import torch.distributed as dist
 
@@ -156,9 +304,9 @@ def main():
     guess = -np.asarray(synth.PREV_STEP_T, np.float64)
     last = guess * 0.97
 
-    def new_ctx(alone=False, g=None):
+    def new_ctx(alone=False, g=None, leaf=None):
         g = g or RotVGICP(local_rank)
-        g.setResolution(args.leaf)
+        g.setResolution(args.leaf if leaf is None else leaf)
         g.setFixedIterations(int(os.environ.get("ROLO_BENCH_ITERS", "20")))
         g.setOverlapKnn(args.pair_search == "on")
         g.setUseGraph(not args.no_graph)
@@ -179,24 +327,25 @@ def main():
                 new_ctx(g=m)
             self.guess = np.tile(guess, (B, 1)); self.last = np.tile(last, (B, 1)); self.zero = np.zeros((B, 3))
 
-        def enqueue(self):
+        def enqueue(self, ds, dt_, npts):
             for m in self.b.members:
-                m.setInputTargetDevice(d_tgt.data_ptr(), n, 4)
-                m.setInputSourceDevice(d_src.data_ptr(), n, 4)
+                m.setInputTargetDevice(dt_.data_ptr(), npts, 4)
+                m.setInputSourceDevice(ds.data_ptr(), npts, 4)
             self.b.register_async(None, self.zero, self.guess, self.last, 0.1, 0.1, 0.3)
 
         def register_wait(self):
             self.b.register_wait()
             self.last_stats = self.b.members[0].last_stats; self.last_translation_stats = self.b.members[0].last_translation_stats
 
-    def enqueue(g):
+    def enqueue(g, data):
+        ds, dt_, npts = data
         if isinstance(g, Batch):
-            return g.enqueue()
-        g.setInputTargetDevice(d_tgt.data_ptr(), n, 4)
-        g.setInputSourceDevice(d_src.data_ptr(), n, 4)
+            return g.enqueue(ds, dt_, npts)
+        g.setInputTargetDevice(dt_.data_ptr(), npts, 4)
+        g.setInputSourceDevice(ds.data_ptr(), npts, 4)
         g.register_async(None, zero3, guess, last, 0.1, 0.1, 0.3)
 
-    def run_steps(gs, k):
+    def run_steps(gs, k, data):
         """k steps; one step = one frame pair on every context of `gs`. Contexts are serviced round-robin
         (wait for a context's frame, immediately enqueue its next one) so the GPU always has work queued."""
         if not isinstance(gs, (list, tuple)):
@@ -204,23 +353,22 @@ def main():
         if k <= 0:
             return
         for g in gs:
-            enqueue(g)
+            enqueue(g, data)
         for it in range(k):
             for g in gs:
                 g.register_wait()
                 if it + 1 < k:
-                    enqueue(g)
+                    enqueue(g, data)
 
-    def timed(g, steps, warmup):
+    def timed_round(g, steps, data):
         import gc
-        run_steps(g, warmup)
         # CPython's cyclic GC walks every tracked object (torch is imported: ~40 ms per full collection) and fired once
         # per ~140 frames in the middle of the timed loop; collect now, keep it off while timing
         gc.collect()
         gc.disable()
         barrier()
         t0 = time.perf_counter()
-        run_steps(g, steps)
+        run_steps(g, steps, data)
         barrier()
         dt = time.perf_counter() - t0
         gc.enable()
@@ -230,6 +378,18 @@ def main():
             dt = float(t.item())
         return dt
 
+    def timed(g, steps, warmup, data):
+        """rounds of exactly `steps` steps; >= 5 rounds and >= 0.5 s in total (the round times are max-over-ranks values, so every
+        rank takes the same decisions); returns (median round time, all round times)"""
+        run_steps(g, warmup, data)
+        rounds = []
+        while True:
+            rounds.append(timed_round(g, steps, data))
+            if args.single_round or (len(rounds) >= 5 and (sum(rounds) >= 0.5 or len(rounds) >= 40)):
+                break
+        return float(np.median(rounds)), rounds
+
+    data = (d_src, d_tgt, n)
     g = new_ctx()
     ctxs = [g] + [new_ctx() for _ in range(max(args.streams, 1) - 1)]
     B = max(args.batch, 1)
@@ -237,12 +397,14 @@ def main():
         ctxs = [Batch(B) for _ in range(max(args.streams, 1))]
     else:
         B = 1
+    rccl_ranks = None
     if args.mode == "shard" and world > 1:
         ctxs = [g]
         uid = [RotVGICP.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
         g.comm_init(uid[0], rank, world)
-    dt = timed(ctxs, args.steps, args.warmup)
+        rccl_ranks = g.comm_info()[1]
+    dt, rounds = timed(ctxs, args.steps, args.warmup, data)
     frames_total = args.steps * len(ctxs) * B * (world if args.mode == "replicas" else 1)
     value = frames_total / dt
     rs, ts = ctxs[0].last_stats, ctxs[0].last_translation_stats
@@ -256,7 +418,9 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps,
-        "frames_per_step": len(ctxs) * B,
+        "frames_per_step": len(ctxs) * B * (world if args.mode == "replicas" else 1),
+        "timed_rounds": len(rounds),
+        "rounds_ms_per_step": [round(1e3 * r / args.steps, 4) for r in rounds],
         "higher_is_better": True,
         "scaling": "weak" if args.mode == "replicas" else "strong",
         "vs_baseline": None,
@@ -264,31 +428,58 @@ def main():
         "data": "synthetic",
         "config": {"workload": f"{args.sensor} dense frame pair, {n} pts/cloud, k=20 PLANE covariances, UNIFORM voxel leaf "
                                f"{args.leaf} m, 20 SO(3) LM iterations + CT translation LM", "mode": args.mode,
-                   "parallelism": f"{args.mode}{world}", "streams_per_gpu": len(ctxs), "frames_per_call": B, "hip_graph": not args.no_graph, "rot_outer": rs.n_outer, "trans_outer": ts.n_outer,
+                   "parallelism": f"{args.mode}{world}" + (" (one frame pair per rank and context, no data-path collective)" if args.mode == "replicas" else
+                                                            " (K5 by query point + all-gather, passes by source point + all-reduce of 32 fp64)"),
+                   "streams_per_gpu": len(ctxs), "frames_per_call": B, "hip_graph": not args.no_graph, "rot_outer": rs.n_outer, "trans_outer": ts.n_outer,
                    "passes_per_frame": passes, "n_correspondences": rs.n_correspondences},
     }
+    if rccl_ranks is not None:
+        out["config"]["rccl_ranks"] = rccl_ranks
 
-    # ---- frame-level HBM figure of BASELINE.json's metric ("scans/sec ...; achieved HBM GB/s"): SURVEY.md 8d's ALGORITHMIC bytes of
-    # one frame (360 B/pt covariances for both clouds, 136 B/pt + 96 B/voxel map build, 104 B/pt per linearise and per error
-    # evaluation; a fused pass is one of each except the first of a stage) x scans/s. `roofline` below stays the dominant kernel.
+    # ---- frame-level HBM figures of BASELINE.json's metric ("scans/sec ...; achieved HBM GB/s") -------------------------------------
+    # algorithmic: SURVEY.md 8d's bytes of one frame — 360 B/pt covariances for both clouds, 136 B/pt + 96 B/voxel map build, and
+    # 104 B/pt per FUSED pass launch (a launch evaluates the trial cost and the next linearisation in one sweep over the same
+    # records, so it is priced once, as DESIGN.md §4 and `roofline` do) x scans/s.
+    # measured: the PMC-summed fabric traffic of one frame ((2 FETCH_SIZE + WRITE_SIZE) KB over every kernel of a single-context
+    # eager frame, profiles/pmc_traffic.json) x scans/s — "rocprof-reported achieved HBM GB/s".
     try:
         from rolo_amd._lib import lib as _rl
         V = max(int(_rl().rolo_num_voxels(g._h)), 0)
-        n_eval = sum(2 * st.n_passes - 1 for st in (rs, ts))
-        frame_bytes = 360.0 * 2 * n + 136.0 * n + 96.0 * V + 104.0 * n * n_eval
-        out["frame_hbm"] = {"algorithmic_bytes_per_frame": frame_bytes, "achieved": frame_bytes * value / 1e9, "peak": HBM_PEAK_GBS * world,
-                            "unit": "GB/s", "frac": frame_bytes * value / 1e9 / (HBM_PEAK_GBS * world), "voxels": V, "linearise_plus_error_evaluations": n_eval}
+        frame_bytes = 360.0 * 2 * n + 136.0 * n + 96.0 * V + 104.0 * n * passes
+        fh = {"algorithmic_bytes_per_frame": frame_bytes, "achieved": frame_bytes * value / 1e9, "peak": HBM_PEAK_GBS * world,
+              "unit": "GB/s", "frac": frame_bytes * value / 1e9 / (HBM_PEAK_GBS * world), "voxels": V, "fused_pass_launches": passes}
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc) and args.sensor == "os1-128":
+            tr = json.load(open(pmc))
+            nfr = max(tr.get("knn_walk_kernel", {}).get("launches", 0), 1)
+            fabric = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in tr.values() if isinstance(v, dict) and "launches" in v) / nfr
+            fh.update({"fabric_bytes_per_frame": fabric, "achieved_fabric_GBps": fabric * value / 1e9, "frac_fabric": fabric * value / 1e9 / (HBM_PEAK_GBS * world),
+                       "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of a single-context eager run, not this run)"})
+        out["frame_hbm"] = fh
     except Exception as e:  # pragma: no cover
         out["frame_hbm"] = {"error": repr(e)}
+
+    # ---- measured-achievable HBM rate next to the nominal peak: device-to-device copy of 1 GiB ----
+    try:
+        a = torch.empty(1 << 30, dtype=torch.uint8, device="cuda"); b = torch.empty_like(a)
+        b.copy_(a); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            b.copy_(a)
+        torch.cuda.synchronize()
+        out["hbm_measured_copy_GBps"] = 5 * 2 * (1 << 30) / (time.perf_counter() - t0) / 1e9
+        del a, b
+    except Exception as e:  # pragma: no cover
+        out["hbm_measured_copy_GBps"] = None
 
     # ---- single-frame latency: one context alone ----
     if (len(ctxs) > 1 or B > 1) and args.mode == "replicas":
         gl = new_ctx(alone=True)
         lsteps = max(5, min(args.steps, 20))
-        run_steps(gl, 3)
+        run_steps(gl, 3, data)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        run_steps(gl, lsteps)
+        run_steps(gl, lsteps, data)
         torch.cuda.synchronize()
         out["config"]["single_frame_latency_ms"] = 1e3 * (time.perf_counter() - t0) / lsteps
         gl.close()
@@ -296,25 +487,42 @@ def main():
     # ---- roofline of the dominant kernel + per-kernel timing, measured live with HIP events on the ctx stream ----
     try:
         from rolo_amd import profile
-        out["roofline"] = profile.roofline(g, lambda: run_steps(g, 1), n, n, passes, HBM_PEAK_GBS)
+        out["roofline"] = profile.roofline(g, lambda: run_steps(g, 1, data), n, n, passes, HBM_PEAK_GBS)
     except Exception as e:  # pragma: no cover
         out["roofline"] = {"error": repr(e)}
 
-    # ---- optional: point-sharded leg at N>1 (never allowed to take the main number down with it) ----
-    if world > 1 and args.mode == "replicas" and args.shard_leg:
+    # ---- N>1: BASELINE configs[3] — ONE 262 144-point frame sharded over the ranks (never allowed to take the main number down) ----
+    if world > 1 and args.mode == "replicas" and not args.no_shard_leg:
         try:
-            src0, tgt0, _ = synth.dense_pair(args.sensor, seed=synth.SEED)
-            d_src.copy_(torch.from_numpy(src0)); d_tgt.copy_(torch.from_numpy(tgt0))
+            s2, t2, _ = synth.dense_pair("os1-128x2048", seed=synth.SEED)
+            d2 = (torch.from_numpy(s2).cuda(), torch.from_numpy(t2).cuda(), s2.shape[0])
             gs = new_ctx(alone=True)
             uid = [RotVGICP.comm_unique_id() if rank == 0 else None]
             dist.broadcast_object_list(uid, src=0)
             gs.comm_init(uid[0], rank, world)
-            dts = timed(gs, args.steps, args.warmup)
-            out["sharded"] = {"value": args.steps / dts, "unit": "scans/s", "ms_per_step": 1e3 * dts / args.steps,
-                              "note": "one frame, source points sharded over the ranks, RCCL all-reduce of 32 fp64 per LM pass "
-                                      "(kNN / voxel map replicated on every rank)"}
+            dts, rds = timed(gs, max(5, args.steps // 2), 2, d2)
+            stp = max(5, args.steps // 2)
+            out["sharded"] = {"value": stp / dts, "unit": "scans/s", "ms_per_frame": 1e3 * dts / stp, "rccl_ranks": gs.comm_info()[1], "scaling": "strong",
+                              "workload": f"os1-128x2048 dense frame pair, {s2.shape[0]} pts/cloud, leaf {args.leaf} m, 20 SO(3) LM iterations + CT translation",
+                              "note": "one frame: Morton sort / BVH / voxel map replicated on every rank, K5 searched by 1/W of the queries + ncclAllGather of the 48 B/pt "
+                                      "covariances, LM passes over 1/W of the source points + ncclAllReduce of 32 fp64 per pass", "passes": gs.last_stats.n_passes + gs.last_translation_stats.n_passes}
+            # the same frame on ONE rank's GPU alone, for the strong-scaling ratio (rank 0 only runs it while the others wait)
+            barrier()
+            if rank == 0:
+                g1 = new_ctx(alone=True)
+                run_steps(g1, 2, d2); torch.cuda.synchronize(); t0 = time.perf_counter(); run_steps(g1, stp, d2); torch.cuda.synchronize()
+                out["sharded"]["one_gpu_same_frame_scans_per_s"] = stp / (time.perf_counter() - t0)
+                g1.close()
+            barrier()
         except Exception as e:  # pragma: no cover
             out["sharded"] = {"error": repr(e)}
+
+    # ---- BASELINE configs[4]: 512 distinct OS1-64 pairs streamed through the contexts ----
+    if args.mode == "replicas" and not args.no_config5:
+        try:
+            out["config5"] = config5_leg(args, torch, dist, rank, world, local_rank, new_ctx, barrier)
+        except Exception as e:  # pragma: no cover
+            out["config5"] = {"error": repr(e)}
 
     # ---- drop-in pipeline leg: raw frames -> pose through the fused node cores (rolo_odom_frame), production settings ----
     if world == 1 and not args.no_pipeline:
@@ -323,26 +531,9 @@ def main():
         except Exception as e:  # pragma: no cover
             out["pipeline"] = {"error": repr(e)}
 
-    # ---- CPU baseline: the oracle (CPU restatement of the reference, same OpenMP structure) on this box's host cores ----
+    # ---- CPU baselines: the oracle on this box's host cores (rank 0, N = 1 only) ----
     if rank == 0 and world == 1 and not args.no_cpu:
-        from oracle import pyorc
-        cores = usable_cores()
-        p = pyorc.default_params(voxel_type=pyorc.VOXEL_UNIFORM, voxel_resolution=args.leaf, fixed_iterations=20, num_threads=cores)
-        t0 = time.perf_counter()
-        frames = 0
-        while True:  # bounded sample: about 10 s of CPU work
-            o = pyorc.Reg(p)
-            o.set_target(tgt); o.set_source(src)
-            o.align()
-            o.compute_translation(np.zeros(3), guess, last)
-            frames += 1
-            cdt = time.perf_counter() - t0
-            if cdt >= args.cpu_seconds or frames >= 200:
-                break
-        out["cpu_baseline"] = {"value": frames / cdt, "unit": "scans/s", "cores": cores, "kind": "port",
-                               "sample": f"{frames} frame pair(s) of the same workload (kd-tree build, 20-NN covariances, voxel map, 20 SO(3) "
-                                         f"LM iterations, CT translation) on oracle/librolo_oracle.so, OMP threads = {cores} "
-                                         f"(cgroup CPU quota of this box; os.cpu_count() = {os.cpu_count()}), {cdt:.1f} s"}
+        out.update(cpu_baseline_legs(args, src, tgt, guess, last))
 
     if rank == 0:
         print(json.dumps(out))

@@ -136,8 +136,8 @@ int rolo_compute_t_error(rolo_ctx* ctx, const double* t3, const double* init_gue
 
 /* pcl::Registration::align(out, guess) -> RotVGICP::computeTransformation :146-160 -> LsqRegistration::
  * computeTransformation (lsq_registration_impl.hpp:152-179). guess16 NULL = Identity. T_out_f16 =
- * getFinalTransformation() (float); T_out_d16 (optional) the double pose it was cast from.
- * aligned_out (optional, host): n_src x stride floats, the transformed source (pcl::transformPointCloud). */
+ * getFinalTransformation() (float); T_out_d16 (optional) the double pose it was cast from. The transformed source the
+ * reference also writes (pcl::transformPointCloud into `output`) is rolo_transform_cloud with T_out_f16. */
 int rolo_align(rolo_ctx* ctx, const float* guess16, float* T_out_f16, double* T_out_d16, rolo_stats* stats);
 /* RotVGICP::computeTranslation :163-169 -> lsq :55-80. trans3_io: in = start value, out = result. */
 int rolo_compute_translation(rolo_ctx* ctx, double* trans3_io, const double* init_guess3, const double* last_t03,
@@ -173,15 +173,23 @@ int rolo_transform_cloud(rolo_ctx* ctx, const float* in, float* out, int n, int 
 
 /* Multi-GPU point sharding: every rank holds the full clouds; rank r evaluates source points
  * [r*n/W, (r+1)*n/W) in the passes and the per-pass sums are all-reduced (fp64, <= 32 values) with RCCL on the
- * context's stream. unique_id = the 128-byte ncclUniqueId created by rank 0 (rolo_comm_unique_id) and
- * distributed by the caller (e.g. torch.distributed broadcast). */
+ * context's stream. K5 shards by query point: each rank searches 1/W of the Morton-sorted queries and the 48-byte covariances are
+ * all-gathered once per cloud and frame (ncclAllGather). unique_id = the 128-byte ncclUniqueId created by rank 0
+ * (rolo_comm_unique_id) and distributed by the caller (e.g. torch.distributed broadcast). */
 /* the slice of n source points rank r of `world` evaluates: [n*r/world, n*(r+1)/world) */
 void rolo_shard_range(int n, int rank, int world, int* begin, int* end);
 /* test hook: shard the passes WITHOUT a communicator — sums returned by the stage-level calls are then partial */
 int rolo_set_shard(rolo_ctx* ctx, int rank, int world);
+/* test hook: with rolo_set_shard and no communicator, also shard K5 (calculate_covariances, rot_vgicp_impl.hpp:430-496) by query point
+ * as a communicator does — every rank sorts the whole cloud, searches only its slice of the Morton-sorted queries (whole 256-query
+ * workgroups, equal slices) — but WITHOUT the all-gather: only the covariances of the own slice are valid afterwards (the rest of
+ * rolo_get_*_covariances is stale / undefined); the union over the ranks must equal the unsharded result. */
+int rolo_set_shard_knn(rolo_ctx* ctx, int on);
 int rolo_comm_unique_id(void* unique_id128);
 int rolo_comm_init(rolo_ctx* ctx, const void* unique_id128, int rank, int world);
 int rolo_comm_destroy(rolo_ctx* ctx);
+/* rank and size read back from the RCCL communicator itself (ncclCommUserRank / ncclCommCount); world = 0 without one */
+int rolo_comm_info(rolo_ctx* ctx, int* rank, int* world);
 
 /* Per-kernel timing with HIP events on the context's stream (bench.py's "roofline" object). While enabled, every
  * launch of the listed kernels is bracketed by an event pair; rolo_prof_read synchronises the stream and returns

@@ -96,6 +96,8 @@ SYMBOLS = {
     "rolo_get_trace": (C.c_int, [vp, C.POINTER(TraceRec), C.c_int]),
     "rolo_transform_cloud": (C.c_int, [vp, fp, fp, C.c_int, C.c_int, fp]),
     "rolo_shard_range": (None, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "rolo_comm_info": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "rolo_set_shard_knn": (C.c_int, [vp, C.c_int]),
     "rolo_set_shard": (C.c_int, [vp, C.c_int, C.c_int]),
     "rolo_comm_unique_id": (C.c_int, [vp]),
     "rolo_comm_init": (C.c_int, [vp, vp, C.c_int, C.c_int]),

@@ -29,15 +29,19 @@ def _stale(out, deps):
     return (not os.path.exists(out)) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps if os.path.exists(d))
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
+def build(force: bool = False, verbose: bool = False, tag: str = "", extra_flags=()) -> str:
+    """tag / extra_flags: A/B experiment builds (librolo_hip_<tag>.so, objects under csrc/_obj_<tag>/); the product is tag ''."""
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
     objs, jobs = [], []
+    objdir = os.path.join(CSRC, "_obj_" + tag) if tag else CSRC
+    lib = os.path.join(HERE, f"librolo_hip_{tag}.so") if tag else LIB
+    os.makedirs(objdir, exist_ok=True)
     for s in SOURCES:
         src = os.path.join(CSRC, s)
-        obj = os.path.join(CSRC, s.replace(".hip", ".o"))
+        obj = os.path.join(objdir, s.replace(".hip", ".o"))
         objs.append(obj)
         if force or _stale(obj, [src] + hdrs):
-            jobs.append([HIPCC] + FLAGS + EXTRA.get(s, []) + ["-c", src, "-o", obj])
+            jobs.append([HIPCC] + FLAGS + list(extra_flags) + EXTRA.get(s, []) + ["-c", src, "-o", obj])
     if jobs:
         with cf.ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as ex:
             for cmd, res in zip(jobs, ex.map(lambda c: subprocess.run(c, capture_output=True, text=True), jobs)):
@@ -45,14 +49,16 @@ def build(force: bool = False, verbose: bool = False) -> str:
                     sys.stderr.write(" ".join(cmd) + "\n" + res.stdout + res.stderr)
                 if res.returncode != 0:
                     raise RuntimeError("hipcc failed for " + cmd[-3])
-    if force or jobs or _stale(LIB, objs):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
+    if force or jobs or _stale(lib, objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs + ["-ldl"]
         res = subprocess.run(cmd, capture_output=True, text=True)
         if res.returncode != 0:
             sys.stderr.write(" ".join(cmd) + "\n" + res.stdout + res.stderr)
             raise RuntimeError("link failed")
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    _tag = next((a.split("=", 1)[1] for a in sys.argv if a.startswith("--tag=")), "")
+    _xf = [a.split("=", 1)[1] for a in sys.argv if a.startswith("--flag=")]
+    print(build(force="--force" in sys.argv, verbose=True, tag=_tag, extra_flags=_xf))

@@ -11,6 +11,7 @@
 #include <string>
 #include <vector>
 #include <algorithm>
+#include <atomic>
 
 using namespace rolo;
 
@@ -24,7 +25,7 @@ int fail_hip(hipError_t e, const char* what) {
 }
 #define HIPCHK(x) do { hipError_t _e = (x); if (_e != hipSuccess) return fail_hip(_e, #x); } while (0)
 
-unsigned long long g_alloc_epoch = 0;  // bumped on every (re)allocation: captured graphs hold raw device pointers
+std::atomic<unsigned long long> g_alloc_epoch{0};  // bumped on every (re)allocation: captured graphs hold raw device pointers
 
 template <typename T>
 int ensure(T*& p, size_t& cap, size_t need) {
@@ -45,7 +46,10 @@ struct Rccl {
   int (*GetUniqueId)(void*) = nullptr;
   int (*CommInitRank)(void**, int, /* ncclUniqueId by value: 128 bytes */ Uid, int) = nullptr;
   int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
   int (*CommDestroy)(void*) = nullptr;
+  int (*CommCount)(void*, int*) = nullptr;
+  int (*CommUserRank)(void*, int*) = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
 };
 Rccl g_rccl;
@@ -60,9 +64,12 @@ int load_rccl() {
   g_rccl.GetUniqueId = (int (*)(void*))dlsym(h, "ncclGetUniqueId");
   g_rccl.CommInitRank = (int (*)(void**, int, Uid, int))dlsym(h, "ncclCommInitRank");
   g_rccl.AllReduce = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(h, "ncclAllReduce");
+  g_rccl.AllGather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(h, "ncclAllGather");
   g_rccl.CommDestroy = (int (*)(void*))dlsym(h, "ncclCommDestroy");
   g_rccl.GetErrorString = (const char* (*)(int))dlsym(h, "ncclGetErrorString");
-  if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.CommDestroy) { g_err = "librccl: missing symbols"; return ROLO_ECOMM; }
+  g_rccl.CommCount = (int (*)(void*, int*))dlsym(h, "ncclCommCount");
+  g_rccl.CommUserRank = (int (*)(void*, int*))dlsym(h, "ncclCommUserRank");
+  if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.AllGather || !g_rccl.CommDestroy) { g_err = "librccl: missing symbols"; return ROLO_ECOMM; }
   return ROLO_OK;
 }
 constexpr int NCCL_FLOAT64 = 8;  // ncclDouble
@@ -93,6 +100,7 @@ struct rolo_ctx {
     size_t keys0_cap = 0, keys1_cap = 0, vals0_cap = 0, vals1_cap = 0;
     int* bbox = nullptr; size_t bbox_cap = 0;
     int32_t* nbr = nullptr; size_t nbr_cap = 0;   // neighbour indices between the walk and the covariance kernel
+    double* stage = nullptr; size_t stage_cap = 0;  // multi-GPU: covariance exchange buffer (sorted order, one segment per rank)
   } ks[2];
   hipStream_t stream2 = nullptr;   // second stream for the eager (uncaptured) path of rolo_batch_*
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -123,12 +131,13 @@ struct rolo_ctx {
   // multi-GPU
   void* comm = nullptr;
   int rank = 0, world = 1;
+  bool shard_knn = false;   // rolo_set_shard_knn: K5 by query slice without a communicator (test hook)
   // async registration bookkeeping
   bool async_pending = false;
   // hipGraph of one whole frame (rolo_register_async): captured on the second frame with an unchanged key, replayed after
   FrameArgs* h_args = nullptr;   // pinned; a captured H2D copy refreshes d_args on every replay
   FrameArgs* d_args = nullptr; size_t d_args_cap = 0;
-  struct GraphKey { int n_src, n_tgt; const void *src_xyz, *tgt_xyz; rolo_params P; unsigned long long epoch; int nrot, ntrans; } gkey{}, gseen{};
+  struct GraphKey { int n_src, n_tgt; const void *src_xyz, *tgt_xyz; rolo_params P; unsigned long long epoch; int nrot, ntrans, rank, world; } gkey{}, gseen{};
   // passes the last frames needed per stage (+1): the next frame enqueues that many predicated pass/controller pairs up
   // front instead of a fixed worst-case chunk; rolo_register_wait tops up if a frame needs more
   int hint_rot = 0, hint_trans = 0;
@@ -200,6 +209,7 @@ int prepare_cloud(rolo_ctx* c, CloudDev& cl, size_t& cov_cap, size_t& sorted_cap
   out.xyz = cl.xyz; out.sorted = cl.sorted; out.boxes = cl.boxes; out.cov = cl.cov;
   out.knn_idx = c->want_knn_lists ? cl.knn_idx : nullptr; out.knn_d2 = c->want_knn_lists ? cl.knn_d2 : nullptr;
   out.n = n; out.n_leaves = cl.n_leaves; out.P = P; out.n_sorted = 8 * cl.n_leaves;
+  out.q_begin = 0; out.q_end = out.n_sorted; out.stage = nullptr; out.chunk = out.n_sorted; out.stage_off = 0; out.seg = 0;
   return ROLO_OK;
 }
 
@@ -223,9 +233,36 @@ int build_clouds(rolo_ctx* c, bool do_src, bool do_tgt, hipStream_t stream) {
   A.c[0].nbr = S.nbr; if (nc > 1) A.c[1].nbr = S.nbr + 32 * (size_t)A.c[0].n_sorted;
   const size_t tmp = knn_sort_temp_bytes((int)n_total);
   if ((rc = ensure(S.sort_tmp, S.sort_tmp_cap, tmp + 256))) return rc;
+  // Multi-GPU ("K5 shards by query point with the full cloud replicated"): every rank sorts and builds the BVH of the whole
+  // cloud (cheap, identical on all ranks), searches only its slice of the Morton-sorted queries — whole 256-query workgroups, equal
+  // slices — and the 48-byte covariances are all-gathered once per frame in sorted order, then scattered to cov[] by original index.
+  const bool sharded = c->comm != nullptr || (c->world > 1 && c->shard_knn);
+  if (sharded) {
+    size_t seg = 0;
+    for (int i = 0; i < nc; i++) {
+      KnnCloud& K = A.c[i];
+      const int nb = (K.n_sorted + 255) / 256;
+      K.chunk = ((nb + c->world - 1) / c->world) * 256;
+      K.q_begin = std::min(c->rank * K.chunk, K.n_sorted);
+      K.q_end = std::min((c->rank + 1) * K.chunk, K.n_sorted);
+      K.stage_off = (int)seg;
+      seg += (size_t)K.chunk * 6;
+    }
+    if ((rc = ensure(S.stage, S.stage_cap, seg * (size_t)c->world))) return rc;
+    for (int i = 0; i < nc; i++) { A.c[i].seg = seg; A.c[i].stage = S.stage; }
+  }
   { ProfScope ps(c, ROLO_PROF_KNN_BUILD, stream); HIPCHK(launch_knn_build(A, S.sort_tmp, tmp, S.keys0, S.keys1, S.vals0, S.vals1, S.bbox, stream)); }
   { ProfScope ps(c, ROLO_PROF_KNN_WALK, stream); HIPCHK(launch_knn_walk(A, c->P.k_correspondences, stream)); }
   { ProfScope ps(c, ROLO_PROF_KNN_TAIL, stream); HIPCHK(launch_knn_tail(A, c->P.k_correspondences, c->P.regularization, stream)); }
+  if (sharded) {
+    if (c->comm) {
+      const size_t seg = A.c[0].seg;
+      int e = g_rccl.AllGather(S.stage + (size_t)c->rank * seg, S.stage, seg, NCCL_FLOAT64, c->comm, stream);
+      if (e != 0) { g_err = std::string("ncclAllGather: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "?"); return ROLO_ECOMM; }
+    }
+    // without a communicator (rolo_set_shard test hook) only the own slice is valid afterwards
+    HIPCHK(launch_knn_unstage(A, c->comm == nullptr, stream));
+  }
   if (do_src) { c->src.have_cov = true; c->src.have_sorted = true; }
   if (do_tgt) { c->tgt.have_cov = true; c->tgt.have_sorted = true; }
   return ROLO_OK;
@@ -447,7 +484,7 @@ void rolo_ctx_destroy(rolo_ctx* c) {
   if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
   void* bufs[] = {c->src.xyz, c->src.cov, c->src.sorted, c->src.boxes, c->src.knn_idx, c->src.knn_d2, c->tgt.xyz, c->tgt.cov, c->tgt.sorted,
                   c->tgt.boxes, c->tgt.knn_idx, c->tgt.knn_d2, c->ks[0].sort_tmp, c->ks[0].keys0, c->ks[0].keys1, c->ks[0].vals0, c->ks[0].vals1, c->ks[0].bbox,
-                  c->ks[1].sort_tmp, c->ks[1].keys0, c->ks[1].keys1, c->ks[1].vals0, c->ks[1].vals1, c->ks[1].bbox, c->ks[0].nbr, c->ks[1].nbr, c->tab.keys,
+                  c->ks[1].sort_tmp, c->ks[1].keys0, c->ks[1].keys1, c->ks[1].vals0, c->ks[1].vals1, c->ks[1].bbox, c->ks[0].nbr, c->ks[1].nbr, c->ks[0].stage, c->ks[1].stage, c->tab.keys,
                   c->tab.ids, c->tab.rec, c->tab.id_keys, c->tgt_keys, c->tgt_slot, c->counters, c->corr[0], c->corr[1], c->partials, c->sums,
                   c->state, c->trace, c->stage_in, c->stage_out, c->stage_d, c->stage_i};
   for (void* b : bufs) if (b) (void)hipFree(b);
@@ -809,10 +846,11 @@ int rolo_register_async(rolo_ctx* c, const float* guess16, const double* trans_s
   if (graphable) {
     rolo_ctx::GraphKey key{};
     key.n_src = c->src.n; key.n_tgt = c->tgt.n; key.src_xyz = c->src.xyz; key.tgt_xyz = c->tgt.xyz; key.P = c->P; key.epoch = g_alloc_epoch;
+    key.rank = c->rank; key.world = c->world;   // the captured launches bake the shard range in
     frame_chunks(c, key.nrot, key.ntrans);
     auto same = [](const rolo_ctx::GraphKey& a, const rolo_ctx::GraphKey& b) {
       return a.n_src == b.n_src && a.n_tgt == b.n_tgt && a.src_xyz == b.src_xyz && a.tgt_xyz == b.tgt_xyz && a.epoch == b.epoch &&
-             a.nrot == b.nrot && a.ntrans == b.ntrans && memcmp(&a.P, &b.P, sizeof(rolo_params)) == 0;
+             a.nrot == b.nrot && a.ntrans == b.ntrans && a.rank == b.rank && a.world == b.world && memcmp(&a.P, &b.P, sizeof(rolo_params)) == 0;
     };
     if (c->graph_exec && same(key, c->gkey)) {
       HIPCHK(hipGraphLaunch(c->graph_exec, c->stream));
@@ -1154,6 +1192,16 @@ int rolo_batch_register_wait(rolo_batch* b, float* Tf, double* Td, double* trans
 int rolo_set_shard(rolo_ctx* c, int rank, int world) {
   if (!c || world < 1 || rank < 0 || rank >= world) return ROLO_EINVAL;
   c->rank = rank; c->world = world; c->have_corr = false;
+  if (c->shard_knn) { c->src.have_cov = false; c->tgt.have_cov = false; c->have_map = false; }
+  if (c->graph_exec) { (void)hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }   // the captured schedule bakes the shard range in
+  c->gseen_valid = false;
+  return ROLO_OK;
+}
+
+int rolo_set_shard_knn(rolo_ctx* c, int on) {
+  if (!c) return ROLO_EINVAL;
+  c->shard_knn = on != 0;
+  c->src.have_cov = false; c->tgt.have_cov = false; c->have_map = false; c->have_corr = false;
   return ROLO_OK;
 }
 
@@ -1174,7 +1222,17 @@ int rolo_comm_init(rolo_ctx* c, const void* uid128, int rank, int world) {
   int e = g_rccl.CommInitRank(&c->comm, world, id, rank);
   if (e != 0) { g_err = std::string("ncclCommInitRank: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "?"); return ROLO_ECOMM; }
   c->rank = rank; c->world = world;
-  c->have_corr = false;
+  c->have_corr = false; c->src.have_cov = false; c->tgt.have_cov = false; c->have_map = false;
+  return ROLO_OK;
+}
+
+int rolo_comm_info(rolo_ctx* c, int* rank, int* world) {
+  if (!c) return ROLO_EINVAL;
+  if (!c->comm) { if (rank) *rank = 0; if (world) *world = 0; return ROLO_OK; }   // world 0: no communicator
+  int r = -1, w = -1;
+  if (!g_rccl.CommCount || !g_rccl.CommUserRank || g_rccl.CommCount(c->comm, &w) != 0 || g_rccl.CommUserRank(c->comm, &r) != 0) { g_err = "ncclCommCount / ncclCommUserRank failed"; return ROLO_ECOMM; }
+  if (rank) *rank = r;
+  if (world) *world = w;
   return ROLO_OK;
 }
 
@@ -1182,6 +1240,7 @@ int rolo_comm_destroy(rolo_ctx* c) {
   if (!c) return ROLO_EINVAL;
   if (c->comm && g_rccl.CommDestroy) { (void)hipStreamSynchronize(c->stream); g_rccl.CommDestroy(c->comm); }
   c->comm = nullptr; c->rank = 0; c->world = 1;
+  c->have_corr = false; c->src.have_cov = false; c->tgt.have_cov = false; c->have_map = false;
   return ROLO_OK;
 }
 

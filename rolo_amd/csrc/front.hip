@@ -18,6 +18,7 @@
 //       pcl::VoxelGrid is a second bitonic sort of (cell << 32 | order) keys followed by per-run centroids.
 // fp32 arithmetic follows the reference expression by expression; this file is compiled with -ffp-contract=off.
 #include "rolo_internal.hpp"
+#include <atomic>
 #include "dev_math.hpp"
 #include <cfloat>
 #include <climits>
@@ -664,7 +665,7 @@ __global__ __launch_bounds__(256) void feature_concat_kernel(const float4* __res
 
 struct Front {
   int device = 0;
-  size_t cap_raw = 0, cap_pix = 0, cap_scan = 0;
+  size_t cap_raw = 0, cap_raw_pts = 0, cap_pix = 0, cap_scan = 0;
   float* raw = nullptr; unsigned short* ring = nullptr;
   int *owner = nullptr, *local_idx = nullptr, *ring_count = nullptr, *start_ring = nullptr, *end_ring = nullptr, *counters = nullptr;
   float4* extracted = nullptr; int* col = nullptr; float* range = nullptr; float* range_mat = nullptr;
@@ -675,6 +676,7 @@ struct Front {
   bool projected = false;
   // rolo_front_set_deskew: armed for the next projection only
   bool deskew_armed = false;
+  int deskew_n = 0;   // length of the armed per-point time array
   DeskewArgs deskew{};
   float* rel_time = nullptr; size_t cap_time = 0;   // staging when the times come from the host
   bool deskew_from_msg = false;                      // armed without times: the next message brings them
@@ -717,12 +719,19 @@ int front_prepare(rolo_ctx* c, const rolo_front_params* P, int n_raw, int stride
   void** slot = ctx_front_slot(c);
   if (!*slot) *slot = new Front();
   Front* f = static_cast<Front*>(*slot);
+  f->device = ctx_device(c);
   const int NS = P->n_scan, H = P->horizon_scan;
   const size_t npix = (size_t)NS * H;
   bool ok = true;
+  // two capacities: floats of the staged records (n_raw * stride) and points (ring) — a later frame with a smaller stride can hold
+  // more points inside the same float capacity
   if (stage_raw && ((size_t)n_raw * stride > f->cap_raw || !f->raw)) {
-    ok = ok && dev_alloc(f->raw, (size_t)n_raw * stride) && dev_alloc(f->ring, (size_t)n_raw);
-    f->cap_raw = (size_t)n_raw * stride;
+    ok = ok && dev_alloc(f->raw, (size_t)n_raw * stride);
+    f->cap_raw = ok ? (size_t)n_raw * stride : 0;
+  }
+  if (stage_raw && ((size_t)n_raw > f->cap_raw_pts || !f->ring)) {
+    ok = ok && dev_alloc(f->ring, (size_t)n_raw);
+    f->cap_raw_pts = ok ? (size_t)n_raw : 0;
   }
   if (npix > f->cap_pix || !f->owner) {
     const size_t np = npix + 2 * FRONT_GUARD;
@@ -759,8 +768,13 @@ int front_project_enqueue(Front* f, const rolo_front_params* P, const float* d_p
       azimuth_flag_kernel<<<(n_raw + 255) / 256, 256, 0, s>>>(d_pts, stride, n_raw, f->counters + 4);
       azimuth_time_kernel<<<(n_raw + 255) / 256, 256, 0, s>>>(d_pts, stride, n_raw, f->deskew.scan_period, f->counters + 4, f->rel_time);
       f->deskew.rel_time = f->rel_time;
-      f->deskew_armed = true;
+      f->deskew_armed = true; f->deskew_n = n_raw;
     }
+  }
+  if (f->deskew_armed && f->deskew_n < n_raw) {   // ring_scatter_kernel reads rel_time[o] for every raw point of this frame
+    f->deskew_armed = false;
+    ctx_set_error("de-skew armed with fewer per-point times than the frame has points");
+    return ROLO_EINVAL;
   }
   fill_int_kernel<<<256, 256, 0, s>>>(f->owner, (int)npix, INT_MAX);
   // guard cells of the per-point arrays are zero
@@ -795,8 +809,9 @@ int front_extract_enqueue(Front* f, const rolo_front_params* P, hipStream_t s) {
   A.corner_stage = f->corner_stage; A.corner_cnt = f->corner_cnt; A.surf_stage = f->surf_stage; A.surf_cnt = f->surf_cnt;
   const size_t WIN = FRONT_MAX_H + 32;
   const size_t lds = sizeof(unsigned long long) * SORT_CAP + sizeof(int) * WIN * 7 + sizeof(int) * (FRONT_MAX_H + 16);
-  static bool attr_set = false;
-  if (!attr_set) { FCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(extract_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set = true; }
+  static std::atomic<unsigned long long> attr_set{0};   // per device ordinal (bit d): the attribute belongs to the device's code object
+  const unsigned long long dev_bit = 1ull << (f->device & 63);
+  if (!(attr_set.load() & dev_bit)) { FCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(extract_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set.fetch_or(dev_bit); }
   extract_kernel<<<NS, XT, lds, s>>>(A);
   concat_kernel<<<NS * 6, 256, 0, s>>>(f->corner_stage, f->corner_cnt, NS * 6, 20, f->corner_out, f->counters + 1);
   concat_kernel<<<NS, 256, 0, s>>>(f->surf_stage, f->surf_cnt, NS, FRONT_MAX_H, f->surf_out, f->counters + 2);
@@ -862,7 +877,7 @@ int front_frame_features_from_msg(rolo_ctx* c, const rolo_front_params* P, const
   if (f->deskew_from_msg && L->time_kind != 0) {   // without a time field the projection interpolates the times from the azimuth
     f->deskew_from_msg = false;
     f->deskew.rel_time = f->msg_time;
-    f->deskew_armed = true;
+    f->deskew_armed = true; f->deskew_n = n_raw;
   }
   return front_frame_features_enqueue(c, P, f->msg_xyz, 3, f->msg_ring, n_raw, true, d_feat, h_counts3, done);
 }
@@ -903,7 +918,7 @@ int rolo_front_set_deskew(rolo_ctx* c, const rolo_deskew* d, const float* rel_ti
     dt = f->rel_time;
   }
   f->deskew = DeskewArgs{dt, d->odom_incre_rpy[0], d->odom_incre_rpy[1], d->odom_incre_rpy[2], d->scan_period, d->odom_time_diff};
-  f->deskew_armed = true;
+  f->deskew_armed = true; f->deskew_n = n_raw;
   return ROLO_OK;
 }
 

@@ -364,17 +364,33 @@ extern "C" int rolo_debug_counters(unsigned long long* out, int reset) {
   if (reset) { unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_knn_stats), z, sizeof(z)); }
   return 0;
 }
+extern "C" int rolo_debug_wave_records(unsigned* out /* 16384 x 4 */) {
+  (void)hipDeviceSynchronize();
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_knn_wave_rec), sizeof(unsigned) * 16384 * 4) == hipSuccess ? 0 : -1;
+}
 #endif
 
+static inline int slice_blocks(const KnnCloud& c) { return (c.q_end - c.q_begin + 255) / 256; }
+
 hipError_t launch_knn_walk(const KnnPair& A, int k, hipStream_t s) {
-  const int g0 = (A.c[0].n_sorted + 255) / 256, g1 = A.n_clouds > 1 ? (A.c[1].n_sorted + 255) / 256 : 0;
+  const int g0 = slice_blocks(A.c[0]), g1 = A.n_clouds > 1 ? slice_blocks(A.c[1]) : 0;
+  if (g0 + g1 == 0) return hipSuccess;
   if (k == 20) knn_walk_kernel<20><<<g0 + g1, 256, 0, s>>>(A, g0, k);
   else knn_walk_kernel<32><<<g0 + g1, 256, 0, s>>>(A, g0, k);
   return hipGetLastError();
 }
 
+hipError_t launch_knn_unstage(const KnnPair& A, bool own_slice_only, hipStream_t s) {
+  const int g0 = own_slice_only ? slice_blocks(A.c[0]) : (A.c[0].n_sorted + 255) / 256;
+  const int g1 = A.n_clouds > 1 ? (own_slice_only ? slice_blocks(A.c[1]) : (A.c[1].n_sorted + 255) / 256) : 0;
+  if (g0 + g1 == 0) return hipSuccess;
+  knn_unstage_kernel<<<g0 + g1, 256, 0, s>>>(A, g0, own_slice_only ? 1 : 0);
+  return hipGetLastError();
+}
+
 hipError_t launch_knn_tail(const KnnPair& A, int k, int regularization, hipStream_t s) {
-  const int g0 = (A.c[0].n_sorted + 255) / 256, g1 = A.n_clouds > 1 ? (A.c[1].n_sorted + 255) / 256 : 0;
+  const int g0 = slice_blocks(A.c[0]), g1 = A.n_clouds > 1 ? slice_blocks(A.c[1]) : 0;
+  if (g0 + g1 == 0) return hipSuccess;
   if (k == 20) knn_tail_kernel<20><<<g0 + g1, 256, 0, s>>>(A, g0, k, regularization);
   else knn_tail_kernel<32><<<g0 + g1, 256, 0, s>>>(A, g0, k, regularization);
   return hipGetLastError();

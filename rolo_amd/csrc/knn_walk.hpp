@@ -23,6 +23,7 @@ constexpr int WALK_STACK = 48;
 
 #ifdef ROLO_KNN_STATS
 __device__ unsigned long long g_knn_stats[8];  // nodes, leaves, insert executions, walk cycles, waves, tail cycles
+__device__ unsigned g_knn_wave_rec[16384][4];   // per wavefront: nodes, leaves, insert executions, walk cycles
 #define KNN_STAT(x) x
 #else
 #define KNN_STAT(x)
@@ -88,10 +89,10 @@ __global__ __launch_bounds__(256, 8) void knn_walk_kernel(KnnPair A, int split, 
   int32_t* knn_idx = A.c[which].knn_idx;
   float* knn_d2 = A.c[which].knn_d2;
   const int n_sorted = A.c[which].n_sorted, P = A.c[which].P;
-  const int j = ((int)blockIdx.x - (which ? split : 0)) * 256 + tid;
+  const int j = A.c[which].q_begin + ((int)blockIdx.x - (which ? split : 0)) * 256 + tid;
   float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
   int qi = INT_MAX;
-  if (j < n_sorted) { q = sorted[j]; qi = __float_as_int(q.w); }
+  if (j < A.c[which].q_end) { q = sorted[j]; qi = __float_as_int(q.w); }
   const bool active = qi != INT_MAX;  // not padding
   const int kk = (KMAX == 20) ? 20 : k;
   const int n_leaves = n_sorted >> 3;
@@ -149,6 +150,8 @@ __global__ __launch_bounds__(256, 8) void knn_walk_kernel(KnnPair A, int split, 
     atomicAdd(&g_knn_stats[2], (unsigned long long)st_ins); atomicAdd(&g_knn_stats[3], (unsigned long long)(t1 - t0));
     atomicAdd(&g_knn_stats[4], 1ull);
     atomicAdd(&g_knn_stats[6], (unsigned long long)st_rounds);
+    const unsigned wid = blockIdx.x * 4 + wv;
+    if (wid < 16384) { g_knn_wave_rec[wid][0] = st_nodes; g_knn_wave_rec[wid][1] = st_leaves; g_knn_wave_rec[wid][2] = st_ins; g_knn_wave_rec[wid][3] = (unsigned)(t1 - t0); }
   }
   {
     int m = (int)st_lane;
@@ -177,16 +180,36 @@ __global__ __launch_bounds__(256, 8) void knn_walk_kernel(KnnPair A, int split, 
 template <int KMAX>
 __global__ __launch_bounds__(256) void knn_tail_kernel(KnnPair A, int split, int k, int reg) {
   const int which = (int)blockIdx.x >= split ? 1 : 0;
-  const int n_sorted = A.c[which].n_sorted;
-  const int j = ((int)blockIdx.x - (which ? split : 0)) * 256 + threadIdx.x;
-  if (j >= n_sorted) return;
-  const int qi = __float_as_int(A.c[which].sorted[j].w);
+  const KnnCloud& cl = A.c[which];
+  const int n_sorted = cl.n_sorted;
+  const int j = cl.q_begin + ((int)blockIdx.x - (which ? split : 0)) * 256 + threadIdx.x;
+  if (j >= cl.q_end) return;
+  const int qi = __float_as_int(cl.sorted[j].w);
   if (qi == INT_MAX) return;
-  const int32_t* __restrict__ nbr = A.c[which].nbr;
+  const int32_t* __restrict__ nbr = cl.nbr;
   int ki[KMAX];
 #pragma unroll
   for (int u = 0; u < KMAX; u++) ki[u] = nbr[(size_t)u * n_sorted + j];
-  knn_covariance_tail<KMAX>(ki, (KMAX == 20) ? 20 : k, A.c[which].xyz, A.c[which].n, qi, reg, A.c[which].cov);
+  if (cl.stage) {   // multi-GPU: into the exchange buffer, sorted order
+    double* o = cl.stage + (size_t)(j / cl.chunk) * cl.seg + cl.stage_off + (size_t)(j % cl.chunk) * 6;
+    knn_covariance_tail<KMAX>(ki, (KMAX == 20) ? 20 : k, cl.xyz, 1, 0, reg, o);   // pitch 1, index 0: six consecutive doubles
+  } else {
+    knn_covariance_tail<KMAX>(ki, (KMAX == 20) ? 20 : k, cl.xyz, cl.n, qi, reg, cl.cov);
+  }
+}
+
+// exchange buffer -> cov[] (SoA by original index) for every sorted position (after the all-gather) or the own slice only
+__global__ __launch_bounds__(256) void knn_unstage_kernel(KnnPair A, int split, int own_only) {
+  const int which = (int)blockIdx.x >= split ? 1 : 0;
+  const KnnCloud& cl = A.c[which];
+  const int j = (own_only ? cl.q_begin : 0) + ((int)blockIdx.x - (which ? split : 0)) * 256 + threadIdx.x;
+  if (j >= (own_only ? cl.q_end : cl.n_sorted)) return;
+  const int qi = __float_as_int(cl.sorted[j].w);
+  if (qi == INT_MAX) return;
+  const double* __restrict__ o = cl.stage + (size_t)(j / cl.chunk) * cl.seg + cl.stage_off + (size_t)(j % cl.chunk) * 6;
+  const size_t pitch = (size_t)cl.n;
+#pragma unroll
+  for (int v = 0; v < 6; v++) cl.cov[v * pitch + qi] = o[v];
 }
 
 }  // namespace

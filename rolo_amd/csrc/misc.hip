@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void transform_cloud_kernel(const float* __res
     o[r] = __fadd_rn(__fmul_rn(T.m[r * 4], x), __fadd_rn(__fmul_rn(T.m[r * 4 + 1], y), __fadd_rn(__fmul_rn(T.m[r * 4 + 2], z), T.m[r * 4 + 3])));
   for (int k = 3; k < stride; k++) d[k] = s[k];
   d[0] = o[0]; d[1] = o[1]; d[2] = o[2];
-  if (stride > 3) d[3] = 1.0f;
+  if (stride >= 8) d[3] = 1.0f;   // pcl::PointXYZI (32-byte records): data[3] = 1; n x 4 clouds (x, y, z, intensity) keep slot 3
 }
 
 }  // namespace

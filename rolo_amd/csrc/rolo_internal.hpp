@@ -92,13 +92,19 @@ struct BatchSlot { PassArgs a; LmState* st; rolo_trace_rec* trace; int grid; int
 
 // ---- launchers (defined in the .hip files) --------------------------------------------------------------
 // the clouds one chain of search launches works on (knn_cov.hip): source and target of a registration, or one cloud
-struct KnnCloud { const float4* xyz; float4* sorted; float4* boxes; double* cov; int32_t* knn_idx; float* knn_d2; int32_t* nbr; int n, n_leaves, P, n_sorted; };
+// q_begin / q_end: the slice of Morton-sorted query positions this rank searches (multi-GPU: K5 shards by query point, SURVEY 8e;
+// whole cloud otherwise). stage != nullptr: the covariances of the slice go to an exchange buffer in sorted order (6 doubles per
+// position; position j lives in segment j / chunk at stage + (j / chunk) * seg + stage_off + (j % chunk) * 6) instead of cov[].
+struct KnnCloud { const float4* xyz; float4* sorted; float4* boxes; double* cov; int32_t* knn_idx; float* knn_d2; int32_t* nbr; int n, n_leaves, P, n_sorted;
+                  int q_begin, q_end; double* stage; int chunk, stage_off; size_t seg; };
 struct KnnPair { KnnCloud c[2]; int n_clouds; };
 hipError_t launch_knn_build(const KnnPair& A, void* sort_tmp, size_t sort_tmp_bytes, uint32_t* keys0, uint32_t* keys1,
                             uint32_t* vals0, uint32_t* vals1, int* bbox, hipStream_t s);
 size_t knn_sort_temp_bytes(int n_total);
 hipError_t launch_knn_walk(const KnnPair& A, int k, hipStream_t s);                       // neighbour indices -> A.c[].nbr
 hipError_t launch_knn_tail(const KnnPair& A, int k, int regularization, hipStream_t s);   // covariances from A.c[].nbr
+// multi-GPU: exchange buffer (sorted order, all ranks' slices after the all-gather, or [q_begin, q_end) only) -> cov[] by original index
+hipError_t launch_knn_unstage(const KnnPair& A, bool own_slice_only, hipStream_t s);
 
 hipError_t launch_voxel_build(const CloudDev& tgt, VoxelTable tab, unsigned long long* tgt_keys, int* tgt_slot, int* counters, bool morton_order,
                               hipStream_t s);

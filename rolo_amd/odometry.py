@@ -61,11 +61,13 @@ class LidarOdometry:
         up to two frames in flight). Host arrays are kept alive until the matching collect()."""
         if isinstance(xyz, int):
             pp, rp, on_dev = C.c_void_p(xyz), C.c_void_p(ring), 1
+            keep = None   # placeholder: _keep stays 1:1 with the frames in flight
         else:
             xyz = np.ascontiguousarray(xyz, np.float32); ring = np.ascontiguousarray(ring, np.uint16)
             n_raw, stride = xyz.shape[0], xyz.shape[1]
             pp, rp, on_dev = C.c_void_p(xyz.ctypes.data), C.c_void_p(ring.ctypes.data), 0
-            self._keep = getattr(self, "_keep", []) + [(xyz, ring)]
+            keep = (xyz, ring)
+        self._keep = getattr(self, "_keep", []) + [keep]
         check(lib().rolo_odom_submit(self._h, C.byref(front_params), stamp, pp, stride, rp, n_raw, on_dev), "rolo_odom_submit")
 
     def submit_msg(self, front_params, stamp: float, payload, layout, n_points=None):
@@ -73,10 +75,12 @@ class LidarOdometry:
         pointer (then pass n_points), `layout` a _lib.CloudLayout with the field offsets of the message."""
         if isinstance(payload, int):
             ptr, n, on_dev = C.c_void_p(payload), n_points, 1
+            keep = None
         else:
             payload = np.ascontiguousarray(payload, np.uint8)
             ptr, n, on_dev = C.c_void_p(payload.ctypes.data), payload.size // layout.point_step, 0
-            self._keep = getattr(self, "_keep", []) + [(payload,)]
+            keep = (payload,)
+        self._keep = getattr(self, "_keep", []) + [keep]
         check(lib().rolo_odom_submit_msg(self._h, C.byref(front_params), stamp, ptr, C.byref(layout), n, on_dev), "rolo_odom_submit_msg")
 
     def setDeskewFromMessage(self, dsk):
@@ -96,7 +100,7 @@ class LidarOdometry:
         pose = np.zeros(6, np.float32); R = np.zeros((3, 3)); t = np.zeros(3); counts = (C.c_int * 3)()
         fp, dp = C.POINTER(C.c_float), C.POINTER(C.c_double)
         rc = check(lib().rolo_odom_collect(self._h, pose.ctypes.data_as(fp), R.ctypes.data_as(dp), t.ctypes.data_as(dp), counts), "rolo_odom_collect")
-        if getattr(self, "_keep", None):   # host inputs of the collected frame may go (device-pointer submits keep nothing)
+        if getattr(self, "_keep", None):   # host inputs of the collected frame may go (one entry per frame in flight)
             self._keep.pop(0)
         return rc, pose, R, t, tuple(counts)
 

@@ -19,7 +19,10 @@ import numpy as np
 from ._lib import lib, check
 
 SLOTS = {"knn_build": 0, "knn_walk": 1, "voxel_build": 2, "rot_pass": 3, "trans_pass": 4, "ctrl": 5, "knn_tail": 6}
-BYTES_PER_POINT = {"knn_walk": 336.0, "rot_pass": 104.0, "trans_pass": 104.0}
+# per point of the cloud(s) a launch works on; knn_build (Morton sort + BVH, not in SURVEY 8d) is priced as one read and one write of
+# the points; the controller moves no algorithmic bytes at all (pure overhead)
+BYTES_PER_POINT = {"knn_walk": 336.0, "knn_tail": 24.0, "knn_build": 32.0, "voxel_build": 136.0, "rot_pass": 104.0, "trans_pass": 104.0,
+                   "lm_pass": 104.0, "ctrl": 0.0}
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -60,13 +63,19 @@ def roofline(g, run_one_step, n_src, n_tgt, passes_per_frame, hbm_peak_gbs, reps
         per_frame_ms[k] = float(np.mean([r.sum() for r in real])) if real else 0.0
         allv = np.concatenate(real) if real else np.zeros(0)
         avg_ms[k] = float(allv.mean()) if allv.size else 0.0
-    # dominant kernel = largest share of the frame among the HBM-streaming kernels
-    cands = {k: per_frame_ms[k] for k in BYTES_PER_POINT}
-    dom = max(cands, key=cands.get)
-    if dom == "knn_walk":
-        # one launch searches one cloud, or the source/target pair of a frame (overlap_knn)
-        launches = np.mean([len(r) for r in acc["knn_walk"]]) if acc["knn_walk"] else 2.0
+    # dominant kernel = largest share of the frame's GPU time among ALL timed slots (controller and tree build included)
+    total = sum(per_frame_ms.values()) or 1.0
+    rank = sorted(per_frame_ms, key=per_frame_ms.get, reverse=True)
+    top3 = [{"kernel": k + "_kernel", "per_frame_ms": per_frame_ms[k], "share_of_timed_slots": per_frame_ms[k] / total} for k in rank[:3]]
+    dom = rank[0]
+    if dom in ("knn_walk", "knn_tail", "knn_build"):
+        # one launch works on one cloud, or on the source/target pair of a frame (overlap_knn)
+        launches = np.mean([len(r) for r in acc[dom]]) if acc[dom] else 2.0
+        if dom == "knn_build":
+            launches = 1.0 if launches else 1.0   # one event pair brackets the whole chain of build launches
         npts = (n_src + n_tgt) / max(launches, 1.0)
+    elif dom == "voxel_build":
+        npts = n_tgt
     else:
         npts = n_src
     algo_bytes = BYTES_PER_POINT[dom] * npts
@@ -79,5 +88,6 @@ def roofline(g, run_one_step, n_src, n_tgt, passes_per_frame, hbm_peak_gbs, reps
         except Exception:
             traffic = None
     return {"bound": "hbm", "kernel": dom + "_kernel", "achieved": achieved, "peak": hbm_peak_gbs, "unit": "GB/s",
-            "frac": achieved / hbm_peak_gbs, "traffic": traffic, "algorithmic_bytes_per_launch": algo_bytes,
-            "avg_launch_ms": avg_ms[dom], "per_frame_ms": per_frame_ms, "avg_ms": avg_ms}
+            "frac": achieved / hbm_peak_gbs, "traffic": traffic,
+            "traffic_source": "profiles/pmc_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, (2 FETCH + WRITE) KB; not measured in this run)",
+            "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": avg_ms[dom], "top3": top3, "per_frame_ms": per_frame_ms, "avg_ms": avg_ms}

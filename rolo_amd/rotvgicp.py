@@ -334,6 +334,12 @@ class RotVGICP:
         buf = C.create_string_buffer(unique_id, 128)
         check(lib().rolo_comm_init(self._h, buf, rank, world), "rolo_comm_init")
 
+    def comm_info(self):
+        """(rank, world) read back from the RCCL communicator; world 0 = none"""
+        r, w = C.c_int(), C.c_int()
+        check(lib().rolo_comm_info(self._h, C.byref(r), C.byref(w)), "rolo_comm_info")
+        return r.value, w.value
+
 
 class RotVGICPBatch:
     """B independent scan pairs registered with one call (BASELINE config 5; the reference would loop

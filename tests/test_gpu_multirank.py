@@ -1,0 +1,124 @@
+"""GPU tests of the N > 1 path on a one-GPU box.
+
+* K5 sharded by query point (every rank sorts the whole cloud and searches 1/W of the Morton-sorted queries): the union of the
+  ranks' covariance slices equals the unsharded result, bit for bit (test hook rolo_set_shard_knn: no communicator, no all-gather);
+* the whole collective schedule — ncclAllGather of the covariances, ncclAllReduce of the 32 fp64 per pass — with TWO ranks in two
+  processes that share the one device. RCCL may refuse two ranks on one device ("Duplicate GPU"); the test then skips and says
+  so: the one-rank communicator test (test_gpu_registration.py::test_rccl_path_on_one_rank) still drives every collective call.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from rolo_amd import synth  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+G = -np.asarray(synth.PREV_STEP_T)
+L0 = G * 0.97
+
+
+def _pair():
+    src, tgt, _ = synth.dense_pair("os1-64", col_stride=4)
+    return src, tgt
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_knn_sharded_by_query_point_union_is_exact(world):
+    from rolo_amd.rotvgicp import RotVGICP
+    from rolo_amd._lib import lib, check
+    src, tgt = _pair()
+    ref = RotVGICP(); ref.setResolution(1.0); ref.setInputTarget(tgt); ref.setInputSource(src)
+    ref.computeCovariances()
+    cs, ct = ref.getSourceCovariances(), ref.getTargetCovariances()
+    seen_s = np.zeros(src.shape[0], bool); seen_t = np.zeros(tgt.shape[0], bool)
+    counts = []
+    for r in range(world):
+        g = RotVGICP(); g.setResolution(1.0)
+        check(lib().rolo_set_shard_knn(g._h, 1), "rolo_set_shard_knn")
+        check(lib().rolo_set_shard(g._h, r, world), "rolo_set_shard")
+        g.setInputTarget(tgt); g.setInputSource(src)
+        g.computeCovariances()
+        ok_s = np.all(g.getSourceCovariances() == cs, axis=(1, 2)); ok_t = np.all(g.getTargetCovariances() == ct, axis=(1, 2))
+        counts.append(int(ok_s.sum()))
+        seen_s |= ok_s; seen_t |= ok_t
+        g.close()
+    assert seen_s.all() and seen_t.all()
+    # equal slices of whole 256-query workgroups: every rank but the last holds ceil(blocks / W) * 256 sorted positions
+    blocks = (8 * ((src.shape[0] + 7) // 8) + 255) // 256
+    chunk = -(-blocks // world) * 256
+    assert max(counts) <= chunk and sum(counts) >= src.shape[0]
+
+
+def _rank_main(rank, world, uid_path, out_path):
+    import time
+    import numpy as np
+    from rolo_amd.rotvgicp import RotVGICP
+    src, tgt = _pair()
+    if rank == 0:
+        uid = RotVGICP.comm_unique_id()
+        with open(uid_path + ".tmp", "wb") as f:
+            f.write(uid)
+        os.replace(uid_path + ".tmp", uid_path)
+    else:
+        t0 = time.time()
+        while not os.path.exists(uid_path):
+            if time.time() - t0 > 60:
+                raise SystemExit(3)
+            time.sleep(0.05)
+        uid = open(uid_path, "rb").read()
+    g = RotVGICP(0); g.setResolution(1.0)
+    try:
+        g.comm_init(uid, rank, world)
+    except Exception as e:  # RCCL refuses duplicate devices on some builds
+        np.save(out_path, np.array([np.nan]))
+        open(out_path + ".err", "w").write(repr(e))
+        return
+    res = []
+    for _ in range(2):
+        g.setInputTarget(tgt); g.setInputSource(src)
+        g.register_async(None, np.zeros(3), G, L0)
+        Tf, Td, t = g.register_wait()
+        res.append(np.concatenate([Td.reshape(-1), t]))
+    cov = g.getSourceCovariances()
+    np.save(out_path, np.concatenate([np.concatenate(res), cov.reshape(-1)[:4096]]))
+
+
+def test_two_ranks_one_device_rccl_allgather_allreduce(tmp_path):
+    import subprocess
+    from rolo_amd.rotvgicp import RotVGICP
+    world = 2
+    uid_path = str(tmp_path / "uid.bin")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", NCCL_DEBUG="WARN")
+    code = "import sys; sys.path.insert(0, %r); from tests.test_gpu_multirank import _rank_main; _rank_main(int(sys.argv[1]), %d, %r, sys.argv[2])" % (ROOT, world, uid_path)
+    procs = [subprocess.Popen([sys.executable, "-c", code, str(r), str(tmp_path / f"out{r}.npy")], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for r in range(world)]
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=150)[0].decode(errors="replace"))
+    except subprocess.TimeoutExpired:
+        for p in procs:
+            p.kill()
+        pytest.skip("two RCCL ranks on one device did not rendezvous within 150 s on this box (needs two GPUs)")
+    if any(p.returncode != 0 for p in procs):
+        pytest.skip("two RCCL ranks on one device: rank process failed: " + " | ".join(o[-300:] for o in outs))
+    res = [np.load(tmp_path / f"out{r}.npy") for r in range(world)]
+    if any(np.isnan(r[0]) for r in res):
+        pytest.skip("RCCL refuses two ranks on one device here: " + open(str(tmp_path / "out0.npy") + ".err").read()[:300])
+    src, tgt = _pair()
+    ref = RotVGICP(); ref.setResolution(1.0); ref.setInputTarget(tgt); ref.setInputSource(src)
+    ref.register_async(None, np.zeros(3), G, L0); Tf0, Td0, t0 = ref.register_wait()
+    want = np.concatenate([Td0.reshape(-1), t0])
+    for r in res:
+        for k in range(2):
+            got = r[19 * k:19 * (k + 1)]
+            assert np.abs(got - want).max() < 1e-11
+        # the all-gathered covariances are the unsharded ones, bit for bit
+        assert np.array_equal(r[38:], ref.getSourceCovariances().reshape(-1)[:4096])
+    assert np.array_equal(res[0], res[1])  # identical LM decisions on both ranks
