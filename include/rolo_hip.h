@@ -56,6 +56,10 @@ typedef struct rolo_params {
                                     kernel works on the pair) instead of one chain per cloud — both searches start together */
   int use_graph;                 /* tuning knob (default 1): rolo_register_async captures the frame's fixed launch schedule in a
                                     hipGraph on the second frame with unchanged sizes / buffers / parameters and replays it */
+  int fused_lm;                  /* tuning knob (default 0): 1 = ONE launch per LM trial (the controller runs in the prologue of the next pass,
+                                    in every workgroup) instead of a pass launch + a controller launch. Shortest chain for one frame at a
+                                    time (the odometry driver turns it on: frame latency -9 %); with several contexts sharing the GPU the
+                                    redundant prologues hold every CU and throughput drops (-22 % with four), so the default is off */
 } rolo_params;
 
 typedef struct rolo_stats {
@@ -194,7 +198,7 @@ int rolo_comm_info(rolo_ctx* ctx, int* rank, int* world);
 /* Per-kernel timing with HIP events on the context's stream (bench.py's "roofline" object). While enabled, every
  * launch of the listed kernels is bracketed by an event pair; rolo_prof_read synchronises the stream and returns
  * the durations (ms) of one slot in launch order, then forgets them. Returns the number of launches recorded. */
-enum { ROLO_PROF_KNN_BUILD = 0, ROLO_PROF_KNN_WALK, ROLO_PROF_VOXEL_BUILD, ROLO_PROF_ROT_PASS, ROLO_PROF_TRANS_PASS, ROLO_PROF_CTRL, ROLO_PROF_KNN_TAIL, ROLO_PROF_N };
+enum { ROLO_PROF_KNN_BUILD = 0, ROLO_PROF_KNN_WALK, ROLO_PROF_VOXEL_BUILD, ROLO_PROF_ROT_PASS, ROLO_PROF_TRANS_PASS, ROLO_PROF_CTRL, ROLO_PROF_KNN_TAIL, ROLO_PROF_LM_PASS /* fused trial: controller prologue + pass */, ROLO_PROF_N };
 int rolo_prof_enable(rolo_ctx* ctx, int on);
 int rolo_prof_read(rolo_ctx* ctx, int slot, float* ms, int cap);
 

@@ -18,7 +18,7 @@ class Params(C.Structure):
                 ("optimizer", C.c_int), ("max_iterations", C.c_int), ("rotation_epsilon", C.c_double),
                 ("transformation_epsilon", C.c_double), ("lm_max_iterations", C.c_int),
                 ("lm_init_lambda_factor", C.c_double), ("fixed_iterations", C.c_int), ("q2_intended", C.c_int),
-                ("overlap_knn", C.c_int), ("use_graph", C.c_int)]
+                ("overlap_knn", C.c_int), ("use_graph", C.c_int), ("fused_lm", C.c_int)]
 
 
 class Stats(C.Structure):

@@ -115,6 +115,7 @@ struct rolo_ctx {
   // passes
   int* corr[2] = {nullptr, nullptr}; size_t corr_cap[2] = {0, 0};
   double* partials = nullptr; size_t partials_cap = 0;
+  int lm_rows = 1;   // workgroups (= partial rows) of one fused LM launch
   double* sums = nullptr; size_t sums_cap = 0;
   LmState* state = nullptr; size_t state_cap = 0;
   rolo_trace_rec* trace = nullptr; size_t trace_cap = 0;
@@ -320,6 +321,21 @@ int ensure_map(rolo_ctx* c) {
   return ROLO_OK;
 }
 
+// workgroup size of the fused LM launches (tuning: ROLO_LM_THREADS = 256 | 512 | 1024)
+int lm_threads() {
+  static const int t = [] { const char* e = getenv("ROLO_LM_THREADS"); const int v = e ? atoi(e) : 512; return (v == 256 || v == 512 || v == 1024) ? v : 512; }();
+  return t;
+}
+int lm_ppt() {
+  static const int t = [] { const char* e = getenv("ROLO_LM_PPT"); const int v = e ? atoi(e) : 1; return (v >= 1 && v <= 16) ? v : 1; }();
+  return t;
+}
+bool lm_fused(const rolo_ctx* c) {
+  static const int force = [] { const char* e = getenv("ROLO_LM_FUSED"); return e ? atoi(e) : -1; }();   // A/B runs: 0 / 1 overrides the parameter
+  // with a communicator the sums pass through the all-reduce between pass and controller
+  return !c->comm && (force >= 0 ? force != 0 : c->P.fused_lm != 0);
+}
+
 void shard(const rolo_ctx* c, int& begin, int& end) { rolo_shard_range(c->src.n, c->rank, c->world, &begin, &end); }
 
 int prepare_pass(rolo_ctx* c, PassArgs& a, int& grid) {
@@ -328,7 +344,8 @@ int prepare_pass(rolo_ctx* c, PassArgs& a, int& grid) {
   for (int b = 0; b < 2; b++) if ((rc = ensure(c->corr[b], c->corr_cap[b], (size_t)c->src.n * noff))) return rc;
   int begin, end; shard(c, begin, end);
   grid = std::max(1, (end - begin + PASS_THREADS - 1) / PASS_THREADS);
-  if ((rc = ensure(c->partials, c->partials_cap, (size_t)grid * NV_MAX))) return rc;
+  c->lm_rows = std::max(1, (end - begin + lm_threads() * lm_ppt() - 1) / (lm_threads() * lm_ppt()));
+  if ((rc = ensure(c->partials, c->partials_cap, std::max((size_t)grid, 2 * (size_t)c->lm_rows) * NV_MAX))) return rc;
   a.src = c->src.xyz; a.cov = c->src.cov; a.n_total = c->src.n; a.begin = begin; a.end = end; a.n_off = noff;
   a.corr[0] = c->corr[0]; a.corr[1] = c->corr[1]; a.partials = c->partials; a.tab = c->tab;
   return ROLO_OK;
@@ -350,6 +367,21 @@ int enqueue_pass(rolo_ctx* c, const PassArgs& a, int grid, int stage) {
   } else {
     HIPCHK(launch_ctrl(c->state, c->partials, grid, nullptr, c->trace, stage, c->stream));
   }
+  return ROLO_OK;
+}
+
+// k fused trials + the closing launch; the state starts and ends in c->state[0] (see passes.hip lm_kernel)
+int enqueue_lm_chunk(rolo_ctx* c, const PassArgs& a, int k) {
+  LmState* sb[2] = {c->state, c->state + 1};
+  const int nrows = c->lm_rows;
+  double* rb[2] = {c->partials, c->partials + (size_t)nrows * NV_MAX};
+  const int dof = c->P.optimizer == ROLO_OPT_SO3_LM ? 3 : 6, T = lm_threads();
+  for (int j = 0; j < k; j++) {
+    ProfScope ps(c, ROLO_PROF_LM_PASS);
+    HIPCHK(launch_lm(dof, T, lm_ppt(), a, sb[j & 1], sb[(j + 1) & 1], rb[(j + 1) & 1], rb[j & 1], nrows, c->trace, 1, c->stream));
+  }
+  ProfScope ps(c, ROLO_PROF_LM_PASS);
+  HIPCHK(launch_lm(dof, T, lm_ppt(), a, sb[k & 1], sb[0], rb[(k + 1) & 1], rb[k & 1], nrows, c->trace, 0, c->stream));
   return ROLO_OK;
 }
 
@@ -399,7 +431,8 @@ int run_stage(rolo_ctx* c, const PassArgs& a, int grid, int stage, int first_chu
   const int hard_cap = (c->P.max_iterations + 2) * (c->P.lm_max_iterations + 1) + 8;
   int issued = 0;
   while (true) {
-    for (int i = 0; i < chunk; i++) { int rc = enqueue_pass(c, a, grid, stage); if (rc) return rc; }
+    if (lm_fused(c)) { int rc = enqueue_lm_chunk(c, a, chunk); if (rc) return rc; }
+    else for (int i = 0; i < chunk; i++) { int rc = enqueue_pass(c, a, grid, stage); if (rc) return rc; }
     issued += chunk;
     int rc = fetch_state(c);
     if (rc) return rc;
@@ -418,6 +451,7 @@ void** ctx_front_slot(rolo_ctx* c) { return &c->front; }
 hipStream_t ctx_stream(rolo_ctx* c) { return c->stream; }
 int ctx_device(rolo_ctx* c) { return c->device; }
 void ctx_set_error(const char* msg) { g_err = msg ? msg : ""; }
+void ctx_set_fused_lm(rolo_ctx* c, int on) { c->P.fused_lm = on ? 1 : 0; }
 }  // namespace rolo
 
 extern "C" {
@@ -447,6 +481,7 @@ void rolo_default_params(rolo_params* p) {
   p->q2_intended = 0;
   p->overlap_knn = 1;
   p->use_graph = 1;
+  p->fused_lm = 0;
 }
 
 int rolo_ctx_create(int device, rolo_ctx** out) {
@@ -464,11 +499,11 @@ int rolo_ctx_create(int device, rolo_ctx** out) {
   if (hipHostMalloc((void**)&c->h_state, sizeof(LmState)) != hipSuccess || hipHostMalloc((void**)&c->h_sums, sizeof(double) * NV_MAX) != hipSuccess ||
       hipHostMalloc((void**)&c->h_counters, sizeof(int) * 4) != hipSuccess || hipHostMalloc((void**)&c->h_args, sizeof(FrameArgs)) != hipSuccess) { delete c; g_err = "hipHostMalloc failed"; return ROLO_EHIP; }
   memset(c->h_state, 0, sizeof(LmState));
-  int rc = ensure(c->state, c->state_cap, 1);
+  int rc = ensure(c->state, c->state_cap, 2);   // [0] the state every entry point sees; [1] the other half of the fused launches' double buffer
   if (!rc) rc = ensure(c->sums, c->sums_cap, NV_MAX);
   if (!rc) rc = ensure(c->trace, c->trace_cap, TRACE_CAP);
   if (!rc) rc = ensure(c->d_args, c->d_args_cap, 1);
-  if (!rc && hipMemsetAsync(c->state, 0, sizeof(LmState), c->stream) != hipSuccess) rc = ROLO_EHIP;
+  if (!rc && hipMemsetAsync(c->state, 0, 2 * sizeof(LmState), c->stream) != hipSuccess) rc = ROLO_EHIP;
   if (rc) { rolo_ctx_destroy(c); return rc; }
   *out = c;
   return ROLO_OK;
@@ -823,8 +858,13 @@ static int enqueue_frame(rolo_ctx* c) {
   HIPCHK(hipMemcpyAsync(c->d_args, c->h_args, sizeof(FrameArgs), hipMemcpyHostToDevice, c->stream));
   HIPCHK(launch_frame_begin(c->state, c->d_args, c->stream));
   int nrot, ntrans; frame_chunks(c, nrot, ntrans);
-  for (int i = 0; i < nrot; i++) if ((rc = enqueue_pass(c, a, grid, 1))) return rc;
-  for (int i = 0; i < ntrans; i++) if ((rc = enqueue_pass(c, a, grid, 2))) return rc;
+  if (lm_fused(c)) {
+    // both stages are the same launches (the device decides which pass a launch evaluates); each hint carries one spare
+    if ((rc = enqueue_lm_chunk(c, a, std::max(nrot + ntrans - 1, 2)))) return rc;
+  } else {
+    for (int i = 0; i < nrot; i++) if ((rc = enqueue_pass(c, a, grid, 1))) return rc;
+    for (int i = 0; i < ntrans; i++) if ((rc = enqueue_pass(c, a, grid, 2))) return rc;
+  }
   HIPCHK(hipMemcpyAsync(c->h_state, c->state, sizeof(LmState), hipMemcpyDeviceToHost, c->stream));
   return ROLO_OK;
 }

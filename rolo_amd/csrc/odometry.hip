@@ -13,6 +13,7 @@
 namespace rolo {
 void ctx_set_error(const char* msg);
 int ctx_device(rolo_ctx* c);
+void ctx_set_fused_lm(rolo_ctx* c, int on);
 }
 
 namespace {
@@ -107,6 +108,7 @@ int rolo_odom_create(rolo_ctx* ctx, float ct_lambda, rolo_odom** out) {
   if (!ctx || !out) return ROLO_EINVAL;
   rolo_odom* o = new rolo_odom();
   o->ctx = ctx; o->ct_lambda = ct_lambda;
+  rolo::ctx_set_fused_lm(ctx, 1);   // one frame at a time: the shortest LM chain (rolo_params.fused_lm)
   *out = o;
   return ROLO_OK;
 }

@@ -109,9 +109,9 @@ ROLO_DEV void wave_reduce_scatter(const double (&acc)[NV], double* __restrict__ 
   if ((lane & ((64 >> NSTEPS) - 1)) == 0 && idx < NV) red_row[idx] = v[0];
 }
 
-template <int NV>
+template <int NV, int THREADS = PASS_THREADS>
 ROLO_DEV void block_reduce_store(double (&acc)[NV], const int (&slot)[NV], double* __restrict__ out_row) {
-  __shared__ double red[PASS_THREADS / 64][NV_MAX];
+  __shared__ double red[THREADS / 64][NV_MAX];
   const int wv = threadIdx.x >> 6;
   if constexpr (NV > 16) {   // 30 values: reduce-scatter (9.6 us per translation pass; one DPP reduction per value: 10.7)
     wave_reduce_scatter<NV>(acc, red[wv]);
@@ -127,7 +127,7 @@ ROLO_DEV void block_reduce_store(double (&acc)[NV], const int (&slot)[NV], doubl
   if (threadIdx.x < NV) {
     double s = 0;
 #pragma unroll
-    for (int w = 0; w < PASS_THREADS / 64; w++) s += red[w][threadIdx.x];
+    for (int w = 0; w < THREADS / 64; w++) s += red[w][threadIdx.x];
     // slot[] is a compile-time table; pick by thread index
     int sl = 0;
 #pragma unroll
@@ -167,31 +167,39 @@ ROLO_DEV void accumulate_hb(const Sym3& M, const Vec3& a, double wh, double wb_u
   }
 }
 
+// wave-uniform values that come out of LDS (the fused launches keep the state there) belong in scalar registers
+ROLO_DEV double uni(double v) {
+  return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+ROLO_DEV int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// what a pass needs of one source point: loaded before anything that depends on the LM state
+struct PtIn { float4 pf; Sym3 CA; };
+ROLO_DEV PtIn load_pt(const PassArgs& a, int i) {
+  PtIn o;
+  o.pf = a.src[i];
+  const size_t pitch = (size_t)a.n_total;
+  o.CA = Sym3{a.cov[i], a.cov[pitch + i], a.cov[2 * pitch + i], a.cov[3 * pitch + i], a.cov[4 * pitch + i], a.cov[5 * pitch + i]};
+  return o;
+}
+
 template <int DOF>
-ROLO_DEV void rot_pass_body(const PassArgs& a, const LmState* __restrict__ st, const int block) {
-  if (st->stage != 1) return;
+ROLO_DEV void rot_pass_compute(const PassArgs& a, const LmState* __restrict__ st, const int i, const bool valid, const PtIn& in,
+                               double (&acc)[3 + DOF * (DOF + 1) / 2 + DOF]) {
   constexpr int NH = DOF * (DOF + 1) / 2;
-  constexpr int NV = 3 + NH + DOF;
-  const int phase = st->phase;
-  const int cur = st->cur;
+  const int phase = uni(st->phase);
+  const int cur = uni(st->cur);
   const int* __restrict__ corr_old = a.corr[cur];
   int* __restrict__ corr_new = a.corr[phase == 0 ? cur : (cur ^ 1)];
   double R0[9], R1[9], t1[3];
 #pragma unroll
-  for (int i = 0; i < 9; i++) { R0[i] = st->x0_R[i]; R1[i] = st->xt_R[i]; }
+  for (int k = 0; k < 9; k++) { R0[k] = uni(st->x0_R[k]); R1[k] = uni(st->xt_R[k]); }
 #pragma unroll
-  for (int i = 0; i < 3; i++) t1[i] = st->xt_t[i];
-
-  double acc[NV];
-#pragma unroll
-  for (int v = 0; v < NV; v++) acc[v] = 0.0;
-
-  const int i = a.begin + block * PASS_THREADS + threadIdx.x;
-  if (i < a.end) {
-    const float4 pf = a.src[i];
+  for (int k = 0; k < 3; k++) t1[k] = uni(st->xt_t[k]);
+  if (valid) {
+    const float4 pf = in.pf;
     const Vec3 p{(double)pf.x, (double)pf.y, (double)pf.z};
-    const size_t pitch = (size_t)a.n_total;
-    const Sym3 CA{a.cov[i], a.cov[pitch + i], a.cov[2 * pitch + i], a.cov[3 * pitch + i], a.cov[4 * pitch + i], a.cov[5 * pitch + i]};
+    const Sym3 CA = in.CA;
     Vec3 tp = mat3_mulv(R1, p);
     tp.x += t1[0]; tp.y += t1[1]; tp.z += t1[2];
     const int n_off = a.n_off;
@@ -228,6 +236,21 @@ ROLO_DEV void rot_pass_body(const PassArgs& a, const LmState* __restrict__ st, c
       }
     }
   }
+}
+
+template <int DOF>
+ROLO_DEV void rot_pass_body(const PassArgs& a, const LmState* __restrict__ st, const int block) {
+  if (st->stage != 1) return;
+  constexpr int NH = DOF * (DOF + 1) / 2;
+  constexpr int NV = 3 + NH + DOF;
+  double acc[NV];
+#pragma unroll
+  for (int v = 0; v < NV; v++) acc[v] = 0.0;
+  const int i = a.begin + block * PASS_THREADS + threadIdx.x;
+  const bool valid = i < a.end;
+  PtIn in{};
+  if (valid) in = load_pt(a, i);
+  rot_pass_compute<DOF>(a, st, i, valid, in, acc);
   int slot[NV];
   slot[0] = V_YI; slot[1] = V_Y; slot[2] = V_N;
 #pragma unroll
@@ -239,32 +262,24 @@ ROLO_DEV void rot_pass_body(const PassArgs& a, const LmState* __restrict__ st, c
 
 // translation stage: t3_linearize (B) + compute_t_error (A) on the correspondences of the last rotation
 // linearisation, Mahalanobis from st->tr_R.
-ROLO_DEV void trans_pass_body(const PassArgs& a, const LmState* __restrict__ st, const int block) {
-  if (st->stage != 2) return;
-  constexpr int NH = 21, NV = 3 + NH + 6;
-  const int phase = st->phase;
-  const int* __restrict__ corr = a.corr[st->tr_cur];
+ROLO_DEV void trans_pass_compute(const PassArgs& a, const LmState* __restrict__ st, const int i, const bool valid, const PtIn& in, double (&acc)[30]) {
+  constexpr int NH = 21;
+  const int phase = uni(st->phase);
+  const int* __restrict__ corr = a.corr[uni(st->tr_cur)];
   double R[9];
 #pragma unroll
-  for (int i = 0; i < 9; i++) R[i] = st->tr_R[i];
-  const Vec3 tt{st->tt[0], st->tt[1], st->tt[2]};
-  const Vec3 g{st->g[0], st->g[1], st->g[2]};
-  const double dtn = st->dtn, dtn1 = st->dtn1, lam_n = st->lam_over_n;
+  for (int k = 0; k < 9; k++) R[k] = uni(st->tr_R[k]);
+  const Vec3 tt{uni(st->tt[0]), uni(st->tt[1]), uni(st->tt[2])};
+  const Vec3 g{uni(st->g[0]), uni(st->g[1]), uni(st->g[2])};
+  const double dtn = uni(st->dtn), dtn1 = uni(st->dtn1), lam_n = uni(st->lam_over_n);
   // last_transform keeps its initial value — Zero in t3_linearize (:539), (1,0,0,0) in compute_t_error (:637)
   Vec3 lastA{1.0, 0.0, 0.0}, lastB{0.0, 0.0, 0.0};
-  if (st->q2_intended) { lastA = Vec3{st->l[0], st->l[1], st->l[2]}; lastB = lastA; }
+  if (uni(st->q2_intended)) { lastA = Vec3{uni(st->l[0]), uni(st->l[1]), uni(st->l[2])}; lastB = lastA; }
   const double inv_dtn = 1.0 / dtn;
-
-  double acc[NV];
-#pragma unroll
-  for (int v = 0; v < NV; v++) acc[v] = 0.0;
-
-  const int i = a.begin + block * PASS_THREADS + threadIdx.x;
-  if (i < a.end) {
-    const float4 pf = a.src[i];
+  if (valid) {
+    const float4 pf = in.pf;
     const Vec3 p{(double)pf.x, (double)pf.y, (double)pf.z};
-    const size_t pitch = (size_t)a.n_total;
-    const Sym3 CA{a.cov[i], a.cov[pitch + i], a.cov[2 * pitch + i], a.cov[3 * pitch + i], a.cov[4 * pitch + i], a.cov[5 * pitch + i]};
+    const Sym3 CA = in.CA;
     const Sym3 RCA = sym3_rotate(R, CA);
     const Vec3 tp{p.x + tt.x, p.y + tt.y, p.z + tt.z};
     const Vec3 ba{p.x - g.x, p.y - g.y, p.z - g.z};
@@ -289,6 +304,19 @@ ROLO_DEV void trans_pass_body(const PassArgs& a, const LmState* __restrict__ st,
       accumulate_hb<6>(M, tp, r.w * (1.0 + lam_n * inv_dtn * inv_dtn), 0.0, vb, &acc[3], &acc[3 + NH]);
     }
   }
+}
+
+ROLO_DEV void trans_pass_body(const PassArgs& a, const LmState* __restrict__ st, const int block) {
+  if (st->stage != 2) return;
+  constexpr int NH = 21, NV = 3 + NH + 6;
+  double acc[NV];
+#pragma unroll
+  for (int v = 0; v < NV; v++) acc[v] = 0.0;
+  const int i = a.begin + block * PASS_THREADS + threadIdx.x;
+  const bool valid = i < a.end;
+  PtIn in{};
+  if (valid) in = load_pt(a, i);
+  trans_pass_compute(a, st, i, valid, in, acc);
   int slot[NV];
   slot[0] = V_YI; slot[1] = V_Y; slot[2] = V_N;
 #pragma unroll
@@ -700,6 +728,127 @@ __global__ __launch_bounds__(256) void ctrl_batch_kernel(const BatchSlot* __rest
   ctrl_body(S.st, S.a.partials, S.grid, nullptr, S.trace, stage);
 }
 
+// ---- one launch per LM trial: controller in the prologue of the pass ---------------------------------------------------------------
+// Every workgroup of launch j first finishes trial j-1 — sums the partial rows launch j-1 wrote (fixed order: deterministic, and the
+// same bits in every workgroup) and runs the scalar LM step on a copy of the state in LDS — then evaluates the pass the new state asks
+// for (rotation / 6-dof or translation stage) over its points and writes ITS row. Workgroup 0 also writes the new state back (and the
+// LM trace). State and rows are double-buffered between consecutive launches (a workgroup of launch j may still be reading what a
+// faster one would overwrite). Versus pass + ctrl_kernel launches this halves the launches of a solve; versus the first attempt at
+// this fusion (every one of 512 workgroups re-reading 512 rows of 256 B) the rows are compact (12 or 30 doubles), there
+// are n / THREADS of them with fat workgroups, and the point / covariance loads of the pass are issued before the prologue so that
+// they overlap the row reads and the scalar step. do_body = 0: the closing launch of a schedule (one workgroup, no pass).
+template <int COLS, int THREADS>
+ROLO_DEV void reduce_rows_compact(const double* __restrict__ rows, int nrows, int nv, double* __restrict__ part /* THREADS */, double* __restrict__ sums /* NV_MAX */) {
+  constexpr int GROUPS = THREADS / COLS;
+  constexpr int INFLIGHT = 16;
+  const int v = threadIdx.x % COLS, q = threadIdx.x / COLS;
+  double s0 = 0;
+  for (int b0 = q; b0 < nrows; b0 += GROUPS * INFLIGHT) {
+    double r[INFLIGHT];
+#pragma unroll
+    for (int u = 0; u < INFLIGHT; u++) { const int b = b0 + GROUPS * u; r[u] = (b < nrows && v < nv) ? rows[(size_t)b * NV_MAX + v] : 0.0; }
+#pragma unroll
+    for (int u = 0; u < INFLIGHT; u++) s0 += r[u];
+  }
+  part[q * COLS + v] = s0;
+  __syncthreads();
+  if (threadIdx.x < COLS) {
+    double t = 0;
+#pragma unroll 8
+    for (int k = 0; k < GROUPS; k++) t += part[k * COLS + threadIdx.x];
+    sums[threadIdx.x] = t;
+  }
+  __syncthreads();
+}
+
+template <int DOF, int THREADS>
+__global__ __launch_bounds__(THREADS) void lm_kernel(PassArgs a, const LmState* __restrict__ st_in, LmState* __restrict__ st_out,
+                                                    const double* __restrict__ rows_in, double* __restrict__ rows_out, int nrows,
+                                                    rolo_trace_rec* trace, int do_body, int ppt) {
+  __shared__ LmState sst;
+  __shared__ double part[THREADS];
+  __shared__ double csum[NV_MAX];   // compact: yi, y, n, H (lower triangle), b
+  __shared__ double sums[NV_MAX];   // V_* layout of the scalar step
+  static_assert(sizeof(LmState) % sizeof(int) == 0, "LmState must be int-copyable");
+  constexpr int NW = sizeof(LmState) / sizeof(int);
+  constexpr int NWT = (NW + THREADS - 1) / THREADS;
+  constexpr int NHR = DOF * (DOF + 1) / 2, NVR = 3 + NHR + DOF;
+  int sreg[NWT];
+  {
+    const int* g = reinterpret_cast<const int*>(st_in);
+#pragma unroll
+    for (int k = 0; k < NWT; k++) { const int w = threadIdx.x + THREADS * k; sreg[k] = w < NW ? g[w] : 0; }
+  }
+  // this thread's first point: independent of the state, in flight while the prologue runs. A workgroup owns ppt consecutive
+  // slabs of THREADS points (fewer, fatter workgroups leave the rest of the chip to the other contexts' kernels).
+  const int i0 = a.begin + (int)blockIdx.x * ppt * THREADS + (int)threadIdx.x;
+  const bool valid0 = do_body && i0 < a.end;
+  PtIn in{};
+  if (valid0) in = load_pt(a, i0);
+  {
+    int* l = reinterpret_cast<int*>(&sst);
+#pragma unroll
+    for (int k = 0; k < NWT; k++) { const int w = threadIdx.x + THREADS * k; if (w < NW) l[w] = sreg[k]; }
+  }
+  __syncthreads();
+  if (sst.stage != 0 && sst.pending) {
+    const int stage = sst.stage;
+    const int nv = stage == 1 ? NVR : 30;
+    if (nv <= 16) reduce_rows_compact<16, THREADS>(rows_in, nrows, nv, part, csum);
+    else reduce_rows_compact<32, THREADS>(rows_in, nrows, nv, part, csum);
+    if (threadIdx.x < NV_MAX) {
+      // compact -> V_* slots
+      const int nh = stage == 1 ? NHR : 21;
+      const int t = threadIdx.x;
+      if (t < nv) { const int sl = t < 3 ? t : (t < 3 + nh ? V_H + (t - 3) : V_B + (t - 3 - nh)); sums[sl] = csum[t]; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      rolo_trace_rec* tr = blockIdx.x == 0 ? trace : nullptr;
+      if (stage == 1) rot_step(&sst, sums, tr); else trans_step(&sst, sums, tr);   // without a buffer trace_count still advances
+    }
+    __syncthreads();
+  }
+  const int stage = sst.stage;
+  const bool body = do_body && stage != 0;
+  if (threadIdx.x == 0) sst.pending = body ? 1 : 0;
+  __syncthreads();
+  if (blockIdx.x == 0) {
+    int* g = reinterpret_cast<int*>(st_out);
+    const int* l = reinterpret_cast<const int*>(&sst);
+    for (int w = threadIdx.x; w < NW; w += THREADS) g[w] = l[w];
+  }
+  if (!body) return;
+  double* out_row = rows_out + (size_t)blockIdx.x * NV_MAX;
+  if (stage == 1) {
+    double acc[NVR];
+    int slot[NVR];
+#pragma unroll
+    for (int v = 0; v < NVR; v++) { acc[v] = 0.0; slot[v] = v; }
+    rot_pass_compute<DOF>(a, &sst, i0, valid0, in, acc);
+    for (int p = 1; p < ppt; p++) {
+      const int i = i0 + p * THREADS;
+      const bool valid = i < a.end;
+      if (valid) in = load_pt(a, i);
+      rot_pass_compute<DOF>(a, &sst, i, valid, in, acc);
+    }
+    block_reduce_store<NVR, THREADS>(acc, slot, out_row);
+  } else {
+    double acc[30];
+    int slot[30];
+#pragma unroll
+    for (int v = 0; v < 30; v++) { acc[v] = 0.0; slot[v] = v; }
+    trans_pass_compute(a, &sst, i0, valid0, in, acc);
+    for (int p = 1; p < ppt; p++) {
+      const int i = i0 + p * THREADS;
+      const bool valid = i < a.end;
+      if (valid) in = load_pt(a, i);
+      trans_pass_compute(a, &sst, i, valid, in, acc);
+    }
+    block_reduce_store<30, THREADS>(acc, slot, out_row);
+  }
+}
+
 ROLO_DEV void rot_begin_dev(LmState* st, const RotBegin& a) {
   for (int i = 0; i < 9; i++) { st->xt_R[i] = a.R[i]; st->x0_R[i] = a.R[i]; st->tr_R[i] = a.R[i]; }
   for (int i = 0; i < 3; i++) { st->xt_t[i] = a.t[i]; st->x0_t[i] = a.t[i]; }
@@ -712,7 +861,7 @@ ROLO_DEV void rot_begin_dev(LmState* st, const RotBegin& a) {
   st->run_trans = a.run_trans;
   st->rot_done = 0; st->rot_converged = 0; st->rot_failed = 0; st->rot_outer = 0; st->rot_passes = 0; st->rot_ncorr = 0;
   st->trans_done = 0; st->trans_failed = 0; st->trans_outer = 0; st->trans_passes = 0;
-  st->trace_count = 0; st->error = 0;
+  st->trace_count = 0; st->error = 0; st->pending = 0;
   st->optimizer = a.optimizer; st->max_iterations = a.max_iterations; st->fixed_iterations = a.fixed_iterations;
   st->lm_max = a.lm_max; st->q2_intended = a.q2_intended; st->rot_eps = a.rot_eps; st->trans_eps = a.trans_eps; st->lm_init = a.lm_init;
 }
@@ -725,7 +874,7 @@ __global__ void rot_begin_kernel(LmState* st, RotBegin a) {
 __global__ void trans_begin_kernel(LmState* st, TransBegin a) {
   if (threadIdx.x != 0) return;
   for (int i = 0; i < 3; i++) { st->t0[i] = a.t0[i]; st->g[i] = a.g[i]; st->l[i] = a.l[i]; }
-  st->dtn = a.dtn; st->dtn1 = a.dtn1; st->ct_lambda = a.ct_lambda;
+  st->dtn = a.dtn; st->dtn1 = a.dtn1; st->ct_lambda = a.ct_lambda; st->pending = 0;
   if (a.direct) trans_start(st);
 }
 
@@ -806,6 +955,21 @@ hipError_t launch_batch_ctrl(int stage, const BatchSlot* slots, int n_slots, hip
 }
 hipError_t launch_batch_begin(const BatchSlot* slots, const FrameArgs* args, int n_slots, hipStream_t s) {
   frame_begin_batch_kernel<<<(n_slots + 63) / 64, 64, 0, s>>>(slots, args, n_slots);
+  return hipGetLastError();
+}
+hipError_t launch_lm(int dof, int threads, int ppt, const PassArgs& a, const LmState* st_in, LmState* st_out, const double* rows_in, double* rows_out, int nrows,
+                     rolo_trace_rec* trace, int do_body, hipStream_t s) {
+  const int grid = do_body ? nrows : 1;
+  if (threads == 1024) {
+    if (dof == 3) lm_kernel<3, 1024><<<grid, 1024, 0, s>>>(a, st_in, st_out, rows_in, rows_out, nrows, trace, do_body, ppt);
+    else lm_kernel<6, 1024><<<grid, 1024, 0, s>>>(a, st_in, st_out, rows_in, rows_out, nrows, trace, do_body, ppt);
+  } else if (threads == 512) {
+    if (dof == 3) lm_kernel<3, 512><<<grid, 512, 0, s>>>(a, st_in, st_out, rows_in, rows_out, nrows, trace, do_body, ppt);
+    else lm_kernel<6, 512><<<grid, 512, 0, s>>>(a, st_in, st_out, rows_in, rows_out, nrows, trace, do_body, ppt);
+  } else {
+    if (dof == 3) lm_kernel<3, 256><<<grid, 256, 0, s>>>(a, st_in, st_out, rows_in, rows_out, nrows, trace, do_body, ppt);
+    else lm_kernel<6, 256><<<grid, 256, 0, s>>>(a, st_in, st_out, rows_in, rows_out, nrows, trace, do_body, ppt);
+  }
   return hipGetLastError();
 }
 hipError_t launch_reduce(const double* partials, int nblocks, double* sums, const LmState* st, int stage, hipStream_t s) {

@@ -71,6 +71,7 @@ struct LmState {
   int trans_done, trans_failed, trans_outer, trans_passes;
   int trace_count;
   int error;  // ROLO_E* raised on the device (key range, no correspondences)
+  int pending;  // fused LM launches: the rows of the previous launch wait to be summed and stepped on
   // parameters
   int optimizer, max_iterations, fixed_iterations, lm_max, q2_intended;
   double rot_eps, trans_eps, lm_init;
@@ -112,6 +113,10 @@ hipError_t launch_voxel_keys(const float4* pts, int n, VoxelTable tab, int32_t* 
 
 hipError_t launch_rot_pass(int dof, const PassArgs& a, const LmState* st, int grid, hipStream_t s);
 hipError_t launch_trans_pass(const PassArgs& a, const LmState* st, int grid, hipStream_t s);
+// fused trial (passes.hip lm_kernel): finish the pending trial (rows_in, st_in), write the new state to st_out (!= st_in unless grid 1),
+// evaluate the next pass into rows_out; threads in {256, 512, 1024}; nrows = workgroups of a pass; do_body = 0: closing launch
+hipError_t launch_lm(int dof, int threads, int ppt /* slabs of `threads` points per workgroup */, const PassArgs& a, const LmState* st_in, LmState* st_out, const double* rows_in, double* rows_out, int nrows,
+                     rolo_trace_rec* trace, int do_body, hipStream_t s);
 hipError_t launch_reduce(const double* partials, int nblocks, double* sums, const LmState* st, int stage, hipStream_t s);
 // controller: sums the rows of `partials` itself (single GPU) or takes all-reduced `sums` (partials == nullptr)
 hipError_t launch_ctrl(LmState* st, const double* partials, int nblocks, const double* sums, rolo_trace_rec* trace, int stage, hipStream_t s);

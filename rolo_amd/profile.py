@@ -18,7 +18,7 @@ import numpy as np
 
 from ._lib import lib, check
 
-SLOTS = {"knn_build": 0, "knn_walk": 1, "voxel_build": 2, "rot_pass": 3, "trans_pass": 4, "ctrl": 5, "knn_tail": 6}
+SLOTS = {"knn_build": 0, "knn_walk": 1, "voxel_build": 2, "rot_pass": 3, "trans_pass": 4, "ctrl": 5, "knn_tail": 6, "lm_pass": 7}
 # per point of the cloud(s) a launch works on; knn_build (Morton sort + BVH, not in SURVEY 8d) is priced as one read and one write of
 # the points; the controller moves no algorithmic bytes at all (pure overhead)
 BYTES_PER_POINT = {"knn_walk": 336.0, "knn_tail": 24.0, "knn_build": 32.0, "voxel_build": 136.0, "rot_pass": 104.0, "trans_pass": 104.0,
@@ -59,6 +59,8 @@ def roofline(g, run_one_step, n_src, n_tgt, passes_per_frame, hbm_peak_gbs, reps
                 r = r[:rot_real]      # the tail of the fixed schedule are predicated no-op launches
             elif k == "trans_pass":
                 r = r[:trans_real]
+            elif k == "lm_pass":
+                r = r[:rot_real + trans_real + 1]   # + the launch that finishes the last trial
             real.append(r)
         per_frame_ms[k] = float(np.mean([r.sum() for r in real])) if real else 0.0
         allv = np.concatenate(real) if real else np.zeros(0)

@@ -137,6 +137,11 @@ class RotVGICP:
         self._p.use_graph = int(on)
         self._push()
 
+    def setFusedLm(self, on: bool):
+        """tuning knob: one launch per LM trial (controller in the prologue of the next pass); see rolo_hip.h"""
+        self._p.fused_lm = int(on)
+        self._push()
+
     def setQ2Intended(self, on: bool):
         self._p.q2_intended = int(on)
         self._push()

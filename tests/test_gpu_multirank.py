@@ -36,23 +36,29 @@ def test_knn_sharded_by_query_point_union_is_exact(world):
     ref = RotVGICP(); ref.setResolution(1.0); ref.setInputTarget(tgt); ref.setInputSource(src)
     ref.computeCovariances()
     cs, ct = ref.getSourceCovariances(), ref.getTargetCovariances()
-    seen_s = np.zeros(src.shape[0], bool); seen_t = np.zeros(tgt.shape[0], bool)
-    counts = []
+    seen_s = np.zeros(src.shape[0], int); seen_t = np.zeros(tgt.shape[0], int)
+    ns, nt = src.shape[0], tgt.shape[0]
+
+    def slice_size(n, r):   # equal slices of whole 256-query workgroups of the Morton-sorted positions (padding sorts last)
+        blocks = (8 * ((n + 7) // 8) + 255) // 256
+        chunk = -(-blocks // world) * 256
+        return max(0, min((r + 1) * chunk, n) - r * chunk)
+
     for r in range(world):
         g = RotVGICP(); g.setResolution(1.0)
+        g.setInputTarget(tgt); g.setInputSource(src)
+        # poison the covariance buffers, then let the rank compute its slice only
+        g.setSourceCovariances(np.full((ns, 4, 4), np.nan)); g.setTargetCovariances(np.full((nt, 4, 4), np.nan))
         check(lib().rolo_set_shard_knn(g._h, 1), "rolo_set_shard_knn")
         check(lib().rolo_set_shard(g._h, r, world), "rolo_set_shard")
-        g.setInputTarget(tgt); g.setInputSource(src)
         g.computeCovariances()
-        ok_s = np.all(g.getSourceCovariances() == cs, axis=(1, 2)); ok_t = np.all(g.getTargetCovariances() == ct, axis=(1, 2))
-        counts.append(int(ok_s.sum()))
-        seen_s |= ok_s; seen_t |= ok_t
+        gs, gt = g.getSourceCovariances(), g.getTargetCovariances()
+        own_s = ~np.isnan(gs[:, 0, 0]); own_t = ~np.isnan(gt[:, 0, 0])
+        assert int(own_s.sum()) == slice_size(ns, r) and int(own_t.sum()) == slice_size(nt, r)
+        assert np.array_equal(gs[own_s], cs[own_s]) and np.array_equal(gt[own_t], ct[own_t])   # bit for bit
+        seen_s += own_s; seen_t += own_t
         g.close()
-    assert seen_s.all() and seen_t.all()
-    # equal slices of whole 256-query workgroups: every rank but the last holds ceil(blocks / W) * 256 sorted positions
-    blocks = (8 * ((src.shape[0] + 7) // 8) + 255) // 256
-    chunk = -(-blocks // world) * 256
-    assert max(counts) <= chunk and sum(counts) >= src.shape[0]
+    assert (seen_s == 1).all() and (seen_t == 1).all()   # the slices tile the clouds exactly
 
 
 def _rank_main(rank, world, uid_path, out_path):
