@@ -230,6 +230,12 @@ int rolo_front_set_deskew(rolo_ctx* ctx, const rolo_deskew* d, const float* rel_
 /* lidarOdomAffineFront.inverse() * lidarOdomAffineBack -> pcl::getTranslationAndEulerAngles (:345-351); poses and increment as
  * x, y, z, roll, pitch, yaw (float) */
 void rolo_odom_increment(const float* front6, const float* back6, float* incre6);
+/* The input of FeatureExtraction::laserCloudInfoHandler (src/featureExtraction.cpp:71-85) when that node runs as its own process: the arrays
+ * of the received rolo/cloud_info — extracted[n_valid*4] = fromROSMsg(cloud_projected) as x, y, z, intensity; pointColInd, pointRange
+ * (first n_valid entries), startRingIndex / endRingIndex [n_scan] — go where rolo_project_frame would have left them on the device;
+ * rolo_extract_features then runs as usual. */
+int rolo_front_load_projection(rolo_ctx* ctx, const rolo_front_params* P, const float* extracted, const int32_t* point_col_ind,
+                               const float* point_range, const int32_t* start_ring, const int32_t* end_ring, int n_valid);
 /* FeatureExtraction::calculateSmoothness + markOccludedPoints + extractFeatures (src/featureExtraction.cpp:87-266)
  * on the arrays rolo_project_frame left on the device (call order: project, then extract).
  * out (host): corner[nc*4], surface[ns*4] (sized for N points each); optional curvature/picked/label [N]. */

@@ -120,6 +120,7 @@ SYMBOLS = {
     "rolo_front_default_params": (None, [C.POINTER(FrontParams)]),
     "rolo_project_frame": (C.c_int, [vp, C.POINTER(FrontParams), fp, C.c_int, C.POINTER(C.c_uint16), C.c_int, fp, ip, fp,
                                      ip, ip, fp, C.POINTER(C.c_int)]),
+    "rolo_front_load_projection": (C.c_int, [vp, C.POINTER(FrontParams), fp, ip, fp, ip, ip, C.c_int]),
     "rolo_extract_features": (C.c_int, [vp, C.POINTER(FrontParams), fp, C.POINTER(C.c_int), fp, C.POINTER(C.c_int), fp,
                                         ip, ip]),
 }

@@ -957,6 +957,36 @@ int rolo_project_frame(rolo_ctx* c, const rolo_front_params* P, const float* pts
   return ROLO_OK;
 }
 
+// FeatureExtraction::laserCloudInfoHandler's input when the node runs in its own process: the arrays of the received
+// rolo/cloud_info (fromROSMsg(cloud_projected) + pointColInd / pointRange / start- / endRingIndex) go to the device buffers
+// rolo_project_frame would have left there; rolo_extract_features then runs as usual.
+int rolo_front_load_projection(rolo_ctx* c, const rolo_front_params* P, const float* extracted, const int32_t* point_col_ind, const float* point_range,
+                               const int32_t* start_ring, const int32_t* end_ring, int n_valid) {
+  if (!c || !P || n_valid < 0 || !start_ring || !end_ring || (n_valid > 0 && (!extracted || !point_col_ind || !point_range))) return ROLO_EINVAL;
+  if ((size_t)n_valid > (size_t)P->n_scan * P->horizon_scan) { ctx_set_error("more valid points than range-image pixels"); return ROLO_EINVAL; }
+  Front* f = nullptr;
+  int rc = front_prepare(c, P, 0, 4, false, &f);
+  if (rc) return rc;
+  hipStream_t s = ctx_stream(c);
+  const int NS = P->n_scan;
+  const size_t np = (size_t)NS * P->horizon_scan + 2 * FRONT_GUARD;
+  // guard cells and everything behind N are zero, as after a projection
+  FCHK(hipMemsetAsync(f->col, 0, sizeof(int) * np, s));
+  FCHK(hipMemsetAsync(f->range, 0, sizeof(float) * np, s));
+  if (n_valid) {
+    FCHK(hipMemcpyAsync(f->extracted + FRONT_GUARD, extracted, sizeof(float4) * (size_t)n_valid, hipMemcpyHostToDevice, s));
+    FCHK(hipMemcpyAsync(f->col + FRONT_GUARD, point_col_ind, sizeof(int) * (size_t)n_valid, hipMemcpyHostToDevice, s));
+    FCHK(hipMemcpyAsync(f->range + FRONT_GUARD, point_range, sizeof(float) * (size_t)n_valid, hipMemcpyHostToDevice, s));
+  }
+  FCHK(hipMemcpyAsync(f->start_ring, start_ring, sizeof(int) * (size_t)NS, hipMemcpyHostToDevice, s));
+  FCHK(hipMemcpyAsync(f->end_ring, end_ring, sizeof(int) * (size_t)NS, hipMemcpyHostToDevice, s));
+  FCHK(hipMemcpyAsync(f->counters, &n_valid, sizeof(int), hipMemcpyHostToDevice, s));
+  FCHK(hipStreamSynchronize(s));   // n_valid is a stack variable; pageable copies are staged anyway
+  f->n_valid = n_valid;
+  f->projected = true;
+  return ROLO_OK;
+}
+
 int rolo_extract_features(rolo_ctx* c, const rolo_front_params* P, float* corner, int* n_corner, float* surface, int* n_surface,
                           float* curvature, int32_t* neighbor_picked, int32_t* label) {
   if (!c || !P || !n_corner || !n_surface) return ROLO_EINVAL;

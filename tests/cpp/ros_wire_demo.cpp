@@ -1,0 +1,123 @@
+// Byte-level check of the ROS face without ROS (include/rolo_ros_wire.hpp, include/rolo_ros_nodes.hpp), in a C++-only process.
+//
+//   ros_wire_demo roundtrip <pc2|cis|odom|pose> in.bin out.bin     deserialise + re-serialise one ROS1 wire message (no GPU)
+//   ros_wire_demo quat roll pitch yaw                               tf::createQuaternionFromRPY, then tf::Matrix3x3(q).getRPY of it (no GPU)
+//   ros_wire_demo chain <velodyne|ouster> N_SCAN Horizon_SCAN deskew(0|1) backend_at outdir msg0.bin msg1.bin ...
+//       serialized sensor_msgs/PointCloud2 messages through the three nodes, each on its own context, every hop as wire bytes (what
+//       TCPROS would carry): writes outdir/cloud_info_<k>.bin, feature_info_<k>.bin, odom_<k>.bin, odom_cloud_<k>.bin, pose_<k>.bin
+//       (k = index of the processed cloud) and prints one status line per input message. The back end's first odometry arrives
+//       before input message `backend_at`.
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <iterator>
+#include <string>
+#include <vector>
+
+#include "rolo_ros_nodes.hpp"
+
+using namespace rolo;
+
+static std::vector<uint8_t> slurp(const std::string& path) {
+  std::ifstream f(path, std::ios::binary);
+  return std::vector<uint8_t>((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+}
+static void spit(const std::string& path, const std::vector<uint8_t>& b) {
+  std::ofstream f(path, std::ios::binary);
+  f.write(reinterpret_cast<const char*>(b.data()), (std::streamsize)b.size());
+}
+template <typename M> static int roundtrip(const std::string& in, const std::string& out) {
+  const std::vector<uint8_t> b = slurp(in);
+  M m;
+  if (!wire::deserialize(b.data(), b.size(), m)) { std::printf("malformed\n"); return 3; }
+  spit(out, wire::serialize(m));
+  std::printf("ok %zu\n", b.size());
+  return 0;
+}
+
+int main(int argc, char** argv) {
+  if (argc < 2) return 1;
+  const std::string mode = argv[1];
+  if (mode == "roundtrip" && argc == 5) {
+    const std::string t = argv[2];
+    if (t == "pc2") return roundtrip<wire::PointCloud2>(argv[3], argv[4]);
+    if (t == "cis") return roundtrip<wire::CloudInfoStamp>(argv[3], argv[4]);
+    if (t == "odom") return roundtrip<wire::Odometry>(argv[3], argv[4]);
+    if (t == "pose") return roundtrip<wire::PoseStamped>(argv[3], argv[4]);
+    return 1;
+  }
+  if (mode == "quat" && argc == 5) {
+    double q[4], r, p, y;
+    wire::createQuaternionFromRPY(std::atof(argv[2]), std::atof(argv[3]), std::atof(argv[4]), q);
+    wire::getRPY(q, r, p, y);
+    std::printf("%.17g %.17g %.17g %.17g %.17g %.17g %.17g\n", q[0], q[1], q[2], q[3], r, p, y);
+    return 0;
+  }
+  if (mode == "chain" && argc >= 9) {
+    ros1::NodeParams P;
+    P.sensor = std::string(argv[2]) == "ouster" ? ros1::LidarType::OUSTER : ros1::LidarType::VELODYNE;
+    P.N_SCAN = std::atoi(argv[3]); P.Horizon_SCAN = std::atoi(argv[4]);
+    P.deskewEnabled = std::atoi(argv[5]) != 0;
+    const int backend_at = std::atoi(argv[6]);
+    const std::string outdir = argv[7];
+    // config/params.yaml values of the shipped configuration
+    P.lidarMinRange = 2.0f; P.edgeThreshold = 0.8f; P.surfThreshold = 0.1f; P.odometrySurfLeafSize = 0.4f; P.CT_lambda = 0.3f;
+    P.odomTopic = "odometry/lidar"; P.lidarFrame = "lidar_link"; P.baselinkFrame = "base_link"; P.odometryFrame = "odom";
+    try {
+      Context ctxA, ctxB, ctxC;   // three nodes = three processes in the reference: nothing is shared but the messages
+      ros1::ImageProjectionNode A(ctxA, P);
+      ros1::FeatureExtractionNode B(ctxB, P);
+      ros1::LidarOdometryNode C(ctxC, P);
+      int processed = 0;
+      for (int k = 8; k < argc; k++) {
+        const int idx = k - 8;
+        const std::vector<uint8_t> raw = slurp(argv[k]);
+        wire::PointCloud2 msg;
+        if (!wire::deserialize(raw.data(), raw.size(), msg)) { std::printf("msg %d malformed\n", idx); return 3; }
+        if (idx == backend_at) { wire::Odometry mapped; mapped.header.stamp = msg.header.stamp; C.odometryHandler(mapped); }
+        wire::CloudInfoStamp infoA;
+        const ros1::Status sa = A.cloudHandler(msg, infoA);
+        if (sa != ros1::Status::Published) { std::printf("msg %d imageProjection %d\n", idx, (int)sa); continue; }
+        const std::vector<uint8_t> hopAB = wire::serialize(infoA);
+        spit(outdir + "/cloud_info_" + std::to_string(processed) + ".bin", hopAB);
+        wire::CloudInfoStamp inB, infoB;
+        if (!wire::deserialize(hopAB.data(), hopAB.size(), inB)) return 3;
+        const ros1::Status sb = B.laserCloudInfoHandler(inB, infoB);
+        if (sb != ros1::Status::Published) { std::printf("msg %d featureExtraction %d\n", idx, (int)sb); continue; }
+        const std::vector<uint8_t> hopBC = wire::serialize(infoB);
+        spit(outdir + "/feature_info_" + std::to_string(processed) + ".bin", hopBC);
+        wire::CloudInfoStamp inC;
+        if (!wire::deserialize(hopBC.data(), hopBC.size(), inC)) return 3;
+        ros1::LidarOdometryNode::Outputs o;
+        const ros1::Status sc = C.cloudHandler(inC, inC.header.stamp /* replay: "now" = the stamp of the cloud */, o);
+        if (sc == ros1::Status::Published) {
+          spit(outdir + "/odom_" + std::to_string(processed) + ".bin", wire::serialize(o.laser_odom_incremental));
+          spit(outdir + "/pose_" + std::to_string(processed) + ".bin", wire::serialize(o.laser_pose));
+          spit(outdir + "/odom_cloud_" + std::to_string(processed) + ".bin", wire::serialize(o.odometry_cloud));
+        }
+        std::printf("msg %d cloud %d lidarOdometry %d frame %d\n", idx, processed, (int)sc, (int)o.frame);
+        processed++;
+      }
+      // error paths of cachePointCloud: a non-dense cloud and a cloud without a ring field
+      {
+        const std::vector<uint8_t> raw = slurp(argv[8]);
+        wire::PointCloud2 msg; wire::deserialize(raw.data(), raw.size(), msg);
+        wire::CloudInfoStamp tmp;
+        Context ctxD; ros1::ImageProjectionNode D(ctxD, P);
+        wire::PointCloud2 bad = msg; bad.is_dense = 0;
+        D.cloudHandler(bad, tmp); D.cloudHandler(bad, tmp);
+        std::printf("nondense %d\n", (int)D.cloudHandler(bad, tmp));
+        Context ctxE; ros1::ImageProjectionNode E(ctxE, P);
+        wire::PointCloud2 noring = msg;
+        for (auto& f : noring.fields) if (f.name == "ring") f.name = "rng";
+        E.cloudHandler(noring, tmp); E.cloudHandler(noring, tmp);
+        std::printf("noring %d\n", (int)E.cloudHandler(noring, tmp));
+      }
+    } catch (const rolo::Error& e) {
+      std::fprintf(stderr, "rolo::Error %d: %s\n", e.code, e.what());
+      return 4;
+    }
+    return 0;
+  }
+  return 1;
+}

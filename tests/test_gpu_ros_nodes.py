@@ -1,0 +1,93 @@
+"""GPU: the ROS face end to end without ROS. Serialized sensor_msgs/PointCloud2 bytes go through the three node cores of
+include/rolo_ros_nodes.hpp in a C++-only process — each node on its own context, every hop as ROS1 wire bytes — and the serialized
+rolo/CloudInfoStamp / nav_msgs/Odometry they emit are parsed by an independent Python reader (tests/ros1_wire.py) and compared with
+the oracle chain (projection -> features -> LidarOdometry on the CPU): indices and feature clouds bit-exact, poses inside 1e-4 m / 1e-5 rad."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+from scipy.spatial.transform import Rotation
+
+from oracle import pyorc
+from rolo_amd import synth
+from tests import ros1_wire as W
+from tests.test_gpu_pipeline import trajectory
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def demo(tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("rosnodes") / "ros_wire_demo")
+    cmd = ["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "ros_wire_demo.cpp"), "-o", exe,
+           "-L", os.path.join(ROOT, "rolo_amd"), "-lrolo_hip", "-Wl,-rpath," + os.path.join(ROOT, "rolo_amd"), "-Wl,-rpath,/opt/rocm/lib"]
+    subprocess.run(cmd, check=True)
+    return exe
+
+
+@pytest.mark.parametrize("sensor,kind,cfg,ring_stride", [("vlp16", "velodyne", dict(n_scan=16, horizon_scan=1800), 1),
+                                                         ("os1-64", "ouster", dict(n_scan=64, horizon_scan=1024), 2)])
+def test_serialized_cloud_in_serialized_odometry_out(demo, tmp_path, sensor, kind, cfg, ring_stride):
+    poses = trajectory(7)
+    frames = [synth.make_frame(sensor, R, t, synth.SEED + k, ring_stride=ring_stride) for k, (R, t) in enumerate(poses)]
+    stamps = [100.0 + 0.1 * k for k in range(len(frames))]
+    paths = []
+    for k, fr in enumerate(frames):
+        msg = W.velodyne_msg(fr, stamps[k], seq=k) if kind == "velodyne" else W.ouster_msg(fr, stamps[k], seq=k)
+        p = tmp_path / f"msg{k}.bin"; p.write_bytes(W.pack_pc2(msg)); paths.append(str(p))
+    out = tmp_path / "out"; out.mkdir()
+    r = subprocess.run([demo, "chain", kind, str(cfg["n_scan"]), str(cfg["horizon_scan"]), "0", "4", str(out)] + paths, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.strip().splitlines()
+    # cachePointCloud: nothing until the third message; then cloud k is processed when message k + 2 arrives
+    assert lines[0] == "msg 0 imageProjection 1" and lines[1] == "msg 1 imageProjection 1"
+    got_frames = [int(l.split()[-1]) for l in lines[2:7]]
+    assert got_frames == [0, 1, 2, 2, 2]   # first frame, gated (no back-end odometry yet), then registered
+    assert lines[7] == "nondense -1" and lines[8] == "noring -2"
+
+    fo = pyorc.front_params(**cfg)
+    oo = pyorc.Odom(pyorc.default_params(polar_resolution=(0.175, 0.175, 2.0)), 0.3)
+    npix = cfg["n_scan"] * cfg["horizon_scan"]
+    prev_col = np.zeros(npix, np.int32); prev_rng = np.zeros(npix, np.float32)
+    for k in range(5):
+        fr = frames[k]
+        po = pyorc.project(fo, fr.xyz, fr.ring); eo = pyorc.extract_features(fo, po)
+        n = po["n"]
+        ci = W.parse_cloud_info((out / f"cloud_info_{k}.bin").read_bytes())
+        assert ci["header"]["seq"] == k and ci["header"]["sec"] == int(stamps[k]) and abs(ci["header"]["nsec"] * 1e-9 - (stamps[k] - int(stamps[k]))) < 1e-9
+        assert np.array_equal(ci["startRingIndex"], po["start_ring"]) and np.array_equal(ci["endRingIndex"], po["end_ring"])
+        # the index arrays are N_SCAN * Horizon_SCAN long; what lies behind N is whatever earlier frames left there (imageProjection.cpp:117-118)
+        assert ci["pointColInd"].shape[0] == npix and ci["pointRange"].shape[0] == npix
+        prev_col[:n] = po["point_col_ind"]; prev_rng[:n] = po["point_range"]
+        assert np.array_equal(ci["pointColInd"], prev_col) and np.array_equal(ci["pointRange"], prev_rng)
+        cp = ci["cloud_projected"]
+        assert cp["point_step"] == 32 and cp["width"] == n and cp["header"]["frame_id"] == "lidar_link" and cp["is_dense"] == 1
+        assert [f[:2] for f in cp["fields"]] == [("x", 0), ("y", 4), ("z", 8), ("intensity", 16)]
+        assert np.array_equal(W.xyzi_of(cp), po["extracted"])
+        assert np.array_equal(cp["data"].reshape(n, 32)[:, 12:16].copy().view(np.float32)[:, 0], np.ones(n, np.float32))   # PointXYZI data[3] = 1
+
+        fi = W.parse_cloud_info((out / f"feature_info_{k}.bin").read_bytes())
+        assert all(fi[a].size == 0 for a in ("startRingIndex", "endRingIndex", "pointColInd", "pointRange"))   # freeCloudInfoMemory
+        assert np.array_equal(W.xyzi_of(fi["extracted_corner"]), eo["corner"]) and np.array_equal(W.xyzi_of(fi["extracted_surface"]), eo["surface"])
+        assert fi["extracted_normal"]["width"] == 0 and len(fi["extracted_normal"]["fields"]) == 4
+        assert np.array_equal(W.xyzi_of(fi["cloud_projected"]), po["extracted"])
+
+        if k == 2:
+            oo.backend_odometry(stamps[k])
+        rco, pose_o, R_o, t_o = oo.cloud(stamps[k], eo["corner"], eo["surface"])
+        assert rco == got_frames[k]
+        if k == 0:
+            assert not (out / "odom_0.bin").exists()   # first frame: nothing is published
+            continue
+        od = W.parse_odometry((out / f"odom_{k}.bin").read_bytes())
+        assert od["header"]["frame_id"] == "odom" and od["child_frame_id"] == "lidar_odometry" and od["header"]["sec"] == int(stamps[k])
+        assert not od["pose_covariance"].any() and not od["twist"].any() and not od["twist_covariance"].any()
+        assert np.abs(od["position"] - pose_o[:3].astype(np.float64)).max() <= 1e-4
+        q_o = Rotation.from_euler("xyz", pose_o[3:].astype(np.float64)).as_quat()
+        assert min(np.abs(od["orientation"] - q_o).max(), np.abs(od["orientation"] + q_o).max()) <= 1e-5
+        oc = W.parse_cloud_info((out / f"odom_cloud_{k}.bin").read_bytes())
+        assert oc["odomAvailable"] == 1 and np.abs(oc["initialGuess"] - pose_o).max() < 2e-6
+        assert np.array_equal(oc["initialGuess"][:3].astype(np.float64), od["position"])   # the same LaserOdomPose floats on both topics
+        assert np.array_equal(W.xyzi_of(oc["extracted_corner"]), eo["corner"])
