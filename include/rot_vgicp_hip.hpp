@@ -72,6 +72,10 @@ public:
   using PointCloudTargetConstPtr = typename PointCloudTarget::ConstPtr;
   using Matrix4 = Eigen::Matrix4f;
   using Vector3d = Eigen::Vector3d;
+  using Matrix4d = Eigen::Matrix4d;
+  using CovarianceList = std::vector<Eigen::Matrix4d, Eigen::aligned_allocator<Eigen::Matrix4d>>;
+  using Matrix6d = Eigen::Matrix<double, 6, 6>;
+  using Vector6d = Eigen::Matrix<double, 6, 1>;
 #else
   using PointCloudSource = rolo::Cloud;
   using PointCloudTarget = rolo::Cloud;
@@ -79,6 +83,10 @@ public:
   using PointCloudTargetConstPtr = rolo::Cloud::ConstPtr;
   using Matrix4 = std::array<float, 16>;   // row-major
   using Vector3d = std::array<double, 3>;
+  using Matrix4d = std::array<double, 16>;  // row-major
+  using CovarianceList = std::vector<Matrix4d>;
+  using Matrix6d = std::array<double, 36>;  // row-major
+  using Vector6d = std::array<double, 6>;
 #endif
   static_assert(sizeof(PointSource) % sizeof(float) == 0 && sizeof(PointTarget) % sizeof(float) == 0, "points must be float records");
 
@@ -157,6 +165,40 @@ public:
     transform_into(output, T);  // lsq_registration_impl.hpp:75-78
   }
 
+  // ---- rot_vgicp.hpp:89-97: covariances in, covariances out (Matrix4d per point, last row / column zero) ----
+  void setSourceCovariances(const CovarianceList& covs) {   // rot_vgicp_impl.hpp:122-125
+    if (!src_ || covs.size() != src_->points.size()) throw std::invalid_argument("RotVGICP: one covariance per source point");
+    std::vector<double> m; flatten(covs, m);
+    check(rolo_set_source_covariances(ctx_, m.data()));
+  }
+  void setTargetCovariances(const CovarianceList& covs) {   // :127-130
+    if (!tgt_ || covs.size() != tgt_->points.size()) throw std::invalid_argument("RotVGICP: one covariance per target point");
+    std::vector<double> m; flatten(covs, m);
+    check(rolo_set_target_covariances(ctx_, m.data()));
+  }
+  // the reference returns its member vector (empty before the first align); here the covariances live in HBM and are fetched,
+  // computed first if a cloud has none yet
+  const CovarianceList& getSourceCovariances() { fetch_covs(true); return source_covs_; }
+  const CovarianceList& getTargetCovariances() { fetch_covs(false); return target_covs_; }
+
+  // ---- lsq_registration.hpp:55-57 ----
+  const Matrix6d& getFinalHessian() {   // lsq_registration_impl.hpp:45-47: Identity until a 6-dof LM step accepts
+    double H[36];
+    check(rolo_get_final_hessian(ctx_, H));
+    for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) at6(final_hessian_, i, j) = H[i * 6 + j];
+    return final_hessian_;
+  }
+  // evaluateCost(relative_pose, H, b) = linearize(Isometry3f(relative_pose).cast<double>(), H, b)  (:50-52): the 6-dof linearisation
+  double evaluateCost(const Matrix4& relative_pose, Matrix6d* H = nullptr, Vector6d* b = nullptr) {
+    float g[16]; to_rowmajor(relative_pose, g);
+    double T[16], H36[36], b6[6], err = 0;
+    for (int i = 0; i < 16; i++) T[i] = (double)g[i];
+    check(rolo_linearize(ctx_, T, H36, b6, &err));
+    if (H) for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) at6(*H, i, j) = H36[i * 6 + j];
+    if (b) for (int i = 0; i < 6; i++) (*b)[i] = b6[i];
+    return err;
+  }
+
   rolo_ctx* handle() { return ctx_; }
 
 private:
@@ -167,6 +209,29 @@ private:
     check(rolo_transform_cloud(ctx_, reinterpret_cast<const float*>(src_->points.data()), reinterpret_cast<float*>(output.points.data()),
                                (int)src_->points.size(), (int)(sizeof(PointSource) / sizeof(float)), T));
   }
+  void fetch_covs(bool source) {
+    const size_t n = source ? (src_ ? src_->points.size() : 0) : (tgt_ ? tgt_->points.size() : 0);
+    CovarianceList& out = source ? source_covs_ : target_covs_;
+    out.resize(n);
+    if (!n) return;
+    check(rolo_compute_covariances(ctx_));   // no-op for clouds that hold covariances already
+    std::vector<double> m(16 * n);
+    check(source ? rolo_get_source_covariances(ctx_, m.data()) : rolo_get_target_covariances(ctx_, m.data()));
+    for (size_t k = 0; k < n; k++) for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) at4(out[k], i, j) = m[16 * k + 4 * i + j];
+  }
+  static void flatten(const CovarianceList& covs, std::vector<double>& m) {
+    m.resize(16 * covs.size());
+    for (size_t k = 0; k < covs.size(); k++) for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) m[16 * k + 4 * i + j] = at4c(covs[k], i, j);
+  }
+#ifdef ROLO_HIP_WITH_PCL
+  static double& at4(Matrix4d& m, int i, int j) { return m(i, j); }
+  static double at4c(const Matrix4d& m, int i, int j) { return m(i, j); }
+  static double& at6(Matrix6d& m, int i, int j) { return m(i, j); }
+#else
+  static double& at4(Matrix4d& m, int i, int j) { return m[i * 4 + j]; }
+  static double at4c(const Matrix4d& m, int i, int j) { return m[i * 4 + j]; }
+  static double& at6(Matrix6d& m, int i, int j) { return m[i * 6 + j]; }
+#endif
 #ifdef ROLO_HIP_WITH_PCL
   static Matrix4 identity() { return Matrix4::Identity(); }
   static void to_rowmajor(const Matrix4& m, float* o) { for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) o[i * 4 + j] = m(i, j); }
@@ -184,6 +249,8 @@ private:
   float final_[16];
   bool converged_ = false;
   int nr_iterations_ = 0;
+  CovarianceList source_covs_, target_covs_;
+  Matrix6d final_hessian_{};
 };
 
 }  // namespace fast_gicp

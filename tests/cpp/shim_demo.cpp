@@ -2,6 +2,7 @@
 // LidarOdometry::scanRegeistration does (reference src/lidarOdometry.cpp:460-500), with no Python / torch in the process.
 // Reads two clouds (n x 4 float32: x y z intensity) from binary files, prints the results as one line of numbers.
 #include <cstdio>
+#include <cmath>
 #include <cstdlib>
 #include <vector>
 #include "rot_vgicp_hip.hpp"
@@ -36,6 +37,25 @@ int main(int argc, char** argv) {
   rot_vgicp.computeTranslation(aligned, reg_t, guess, last, 0.1, 0.1, 0.3f);
   for (int i = 0; i < 16; i++) std::printf("%.9g ", T[i]);
   std::printf("%.17g %.17g %.17g %d %zu\n", reg_t[0], reg_t[1], reg_t[2], rot_vgicp.hasConverged() ? 1 : 0, aligned.size());
+  // covariance accessors, getFinalHessian, evaluateCost (rot_vgicp.hpp:89-97, lsq_registration.hpp:55-57): a second operator fed with the
+  // first one's covariances must reproduce its rotation; line 3 = max |dT|, cost at identity, trace(H), |b|, final Hessian (0,0), n_covs
+  {
+    const auto& cs = rot_vgicp.getSourceCovariances();
+    const auto& ct = rot_vgicp.getTargetCovariances();
+    fast_gicp::RotVGICP<> second;
+    second.setPolarResolution(0.175, 0.175, 2.0);
+    second.setInputTarget(target); second.setInputSource(source);
+    second.setSourceCovariances(cs); second.setTargetCovariances(ct);
+    rolo::Cloud aligned2;
+    second.align(aligned2);
+    auto T2 = second.getFinalTransformation();
+    double dmax = 0; for (int i = 0; i < 16; i++) { const double d = std::fabs((double)T2[i] - (double)T[i]); if (d > dmax) dmax = d; }
+    fast_gicp::RotVGICP<>::Matrix4 I{}; for (int i = 0; i < 16; i++) I[i] = (i % 5 == 0) ? 1.f : 0.f;
+    fast_gicp::RotVGICP<>::Matrix6d H; fast_gicp::RotVGICP<>::Vector6d b;
+    const double cost = second.evaluateCost(I, &H, &b);
+    double tr = 0, bn = 0; for (int i = 0; i < 6; i++) { tr += H[i * 6 + i]; bn += b[i] * b[i]; }
+    std::printf("%.3g %.17g %.17g %.17g %.17g %zu\n", dmax, cost, tr, std::sqrt(bn), second.getFinalHessian()[0], cs.size());
+  }
   // error behaviour of the reference: aliasing the output with an input throws std::invalid_argument
   try { rot_vgicp.align(const_cast<rolo::Cloud&>(*source)); std::printf("no-throw\n"); }
   catch (const std::invalid_argument&) { std::printf("invalid_argument\n"); }

@@ -424,7 +424,14 @@ def test_cpp_shim_end_to_end(tmp_path):
     rc2, t_o, _ = o.compute_translation(np.zeros(3), g3, g3)
     assert np.abs(T - Tf_o).max() < 1e-6 and np.abs(t - t_o).max() <= 1e-4
     assert int(vals[19]) == int(cv) and int(vals[20]) == src.shape[0]
-    assert lines[1] == "invalid_argument"
+    # setSource/TargetCovariances, getSource/TargetCovariances, evaluateCost, getFinalHessian (rot_vgicp.hpp:89-97, lsq_registration.hpp:55-57):
+    # an operator fed with the first one's covariances reproduces its rotation; evaluateCost is the oracle's 6-dof linearisation
+    v2 = [float(v) for v in lines[1].split()]
+    assert v2[0] < 1e-6 and int(v2[5]) == src.shape[0]
+    e_o, H_o, b_o = o.linearize(np.eye(4))
+    assert abs(v2[1] - e_o) <= 1e-9 * abs(e_o) and abs(v2[2] - np.trace(H_o)) <= 1e-9 * abs(np.trace(H_o)) and abs(v2[3] - np.linalg.norm(b_o)) <= 1e-9 * np.linalg.norm(b_o)
+    assert v2[4] == 1.0   # final_hessian_ stays Identity on the SO(3) optimiser (lsq_registration_impl.hpp:16-24)
+    assert lines[2] == "invalid_argument"
 
 
 def test_graph_replay_equals_eager():
