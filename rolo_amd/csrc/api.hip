@@ -196,12 +196,12 @@ int prepare_cloud(rolo_ctx* c, CloudDev& cl, size_t& cov_cap, size_t& sorted_cap
   const int n = cl.n, k = c->P.k_correspondences;
   if (k < 1 || k > 32) { g_err = "k_correspondences must be in [1,32]"; return ROLO_EUNSUPPORTED; }
   if (n < k) { g_err = "cloud has fewer points than k_correspondences"; return ROLO_ETOOFEW; }
-  cl.n_leaves = (n + 7) / 8;
+  cl.n_leaves = (n + KNN_LEAF - 1) / KNN_LEAF;
   int P = 2; while (P < cl.n_leaves) P <<= 1;
   cl.P = P;
   int rc;
   if ((rc = ensure(cl.cov, cov_cap, 6 * (size_t)n))) return rc;
-  if ((rc = ensure(cl.sorted, sorted_cap, 8 * (size_t)cl.n_leaves))) return rc;
+  if ((rc = ensure(cl.sorted, sorted_cap, KNN_LEAF * (size_t)cl.n_leaves))) return rc;
   if ((rc = ensure(cl.boxes, boxes_cap, 4 * (size_t)P))) return rc;
   if (c->want_knn_lists) {
     if ((rc = ensure(cl.knn_idx, knn_cap, (size_t)n * k))) return rc;
@@ -209,7 +209,7 @@ int prepare_cloud(rolo_ctx* c, CloudDev& cl, size_t& cov_cap, size_t& sorted_cap
   }
   out.xyz = cl.xyz; out.sorted = cl.sorted; out.boxes = cl.boxes; out.cov = cl.cov;
   out.knn_idx = c->want_knn_lists ? cl.knn_idx : nullptr; out.knn_d2 = c->want_knn_lists ? cl.knn_d2 : nullptr;
-  out.n = n; out.n_leaves = cl.n_leaves; out.P = P; out.n_sorted = 8 * cl.n_leaves;
+  out.n = n; out.n_leaves = cl.n_leaves; out.P = P; out.n_sorted = KNN_LEAF * cl.n_leaves;
   out.q_begin = 0; out.q_end = out.n_sorted; out.stage = nullptr; out.chunk = out.n_sorted; out.stage_off = 0; out.seg = 0;
   return ROLO_OK;
 }
@@ -307,7 +307,7 @@ int ensure_map(rolo_ctx* c) {
   if ((rc = ensure(c->tab.rec, c->tab_rec_cap, (size_t)n * REC_DOUBLES))) return rc;
   if ((rc = ensure(c->tab.id_keys, c->tab_idk_cap, (size_t)n))) return rc;
   if ((rc = ensure(c->tgt_keys, c->tgt_keys_cap, (size_t)n))) return rc;
-  if ((rc = ensure(c->tgt_slot, c->tgt_slot_cap, (size_t)n + 8))) return rc;
+  if ((rc = ensure(c->tgt_slot, c->tgt_slot_cap, (size_t)n + KNN_LEAF))) return rc;
   if ((rc = ensure(c->counters, c->counters_cap, 4))) return rc;
   c->tab.mask = (unsigned)(capslots - 1);
   fill_table_params(c);
@@ -846,7 +846,7 @@ static int enqueue_frame(rolo_ctx* c) {
     if ((rc = ensure(c->tab.rec, c->tab_rec_cap, (size_t)n * REC_DOUBLES))) return rc;
     if ((rc = ensure(c->tab.id_keys, c->tab_idk_cap, (size_t)n))) return rc;
     if ((rc = ensure(c->tgt_keys, c->tgt_keys_cap, (size_t)n))) return rc;
-    if ((rc = ensure(c->tgt_slot, c->tgt_slot_cap, (size_t)n + 8))) return rc;
+    if ((rc = ensure(c->tgt_slot, c->tgt_slot_cap, (size_t)n + KNN_LEAF))) return rc;
     if ((rc = ensure(c->counters, c->counters_cap, 4))) return rc;
     c->tab.mask = (unsigned)(capslots - 1);
     fill_table_params(c);
@@ -1115,7 +1115,7 @@ static int enqueue_batch(rolo_batch* b, bool fork) {
     if ((rc = ensure(c->tab.rec, c->tab_rec_cap, (size_t)n * REC_DOUBLES))) return rc;
     if ((rc = ensure(c->tab.id_keys, c->tab_idk_cap, (size_t)n))) return rc;
     if ((rc = ensure(c->tgt_keys, c->tgt_keys_cap, (size_t)n))) return rc;
-    if ((rc = ensure(c->tgt_slot, c->tgt_slot_cap, (size_t)n + 8))) return rc;
+    if ((rc = ensure(c->tgt_slot, c->tgt_slot_cap, (size_t)n + KNN_LEAF))) return rc;
     if ((rc = ensure(c->counters, c->counters_cap, 4))) return rc;
     c->tab.mask = (unsigned)(capslots - 1);
     fill_table_params(c);

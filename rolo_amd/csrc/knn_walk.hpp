@@ -45,12 +45,12 @@ ROLO_DEV void knn_score_leaf(const float4* __restrict__ sorted, int g, const flo
                              unsigned& n_ins, unsigned& lane_acc, unsigned& rounds) {
   // fetch the whole leaf first: the address is wave-uniform, so these are 8 scalar loads in flight behind ONE wait
   // (loading inside the loop serialised 8 scalar-cache round trips per leaf behind the insert branch)
-  float4 pts[8];
+  float4 pts[KNN_LEAF];
 #pragma unroll
-  for (int u = 0; u < 8; u++) pts[u] = sorted[8 * (size_t)g + u];
+  for (int u = 0; u < KNN_LEAF; u++) pts[u] = sorted[KNN_LEAF * (size_t)g + u];
   KNN_STAT(const double bkey0 = bkey; int acc_leaf = 0;)
 #pragma unroll
-  for (int u = 0; u < 8; u++) {
+  for (int u = 0; u < KNN_LEAF; u++) {
     const float4 c = pts[u];
     const float dx = q.x - c.x, dy = q.y - c.y, dz = q.z - c.z;
     const float cd = ((dx * dx) + (dy * dy)) + (dz * dz);  // file is compiled with -ffp-contract=off
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256, 8) void knn_walk_kernel(KnnPair A, int split, 
   if (j < A.c[which].q_end) { q = sorted[j]; qi = __float_as_int(q.w); }
   const bool active = qi != INT_MAX;  // not padding
   const int kk = (KMAX == 20) ? 20 : k;
-  const int n_leaves = n_sorted >> 3;
+  const int n_leaves = n_sorted / KNN_LEAF;
   unsigned st_nodes = 0, st_leaves = 0, st_ins = 0, st_lane = 0, st_rounds = 0;
   KNN_STAT(const long long t0 = clock64();)
 
@@ -109,8 +109,8 @@ __global__ __launch_bounds__(256, 8) void knn_walk_kernel(KnnPair A, int split, 
   double bkey = active ? sentinel : key_pack(0.f, 0);
 
   // ---- seed: the wavefront's own 8 leaves ----
-  const int g_own0 = __builtin_amdgcn_readfirstlane(j >> 3);  // lane 0 of the wave: j is a multiple of 64
-  const int g_own1 = min(g_own0 + 8, n_leaves);
+  const int g_own0 = __builtin_amdgcn_readfirstlane(j / KNN_LEAF);  // lane 0 of the wave: j is a multiple of 64
+  const int g_own1 = min(g_own0 + 64 / KNN_LEAF, n_leaves);
   for (int g = g_own0; g < g_own1; g++) { knn_score_leaf<KMAX>(sorted, g, q, K, kk, bkey, bd, st_ins, st_lane, st_rounds); st_leaves++; }
 
   // ---- packet walk ----

@@ -219,7 +219,7 @@ hipError_t launch_voxel_build(const CloudDev& tgt, VoxelTable tab, unsigned long
   if (e != hipSuccess) return e;
   const int grid = (tgt.n + 255) / 256;
   if (morton_order && tgt.have_sorted) {   // Morton order of the neighbour search: tgt_slot (>= 8 * n_leaves entries) is indexed by sorted position
-    const int n_sorted = 8 * tgt.n_leaves, gs = (n_sorted + 255) / 256;
+    const int n_sorted = KNN_LEAF * tgt.n_leaves, gs = (n_sorted + 255) / 256;
     voxel_insert_sorted_kernel<<<gs, 256, 0, s>>>(tgt.sorted, n_sorted, tab, tgt_slot, counters);
     voxel_accum_sorted_kernel<<<gs, 256, 0, s>>>(tgt.sorted, tgt.cov, tgt.n, n_sorted, tab, tgt_slot);
   } else {                                 // input order

@@ -40,7 +40,7 @@ def test_knn_sharded_by_query_point_union_is_exact(world):
     ns, nt = src.shape[0], tgt.shape[0]
 
     def slice_size(n, r):   # equal slices of whole 256-query workgroups of the Morton-sorted positions (padding sorts last)
-        blocks = (8 * ((n + 7) // 8) + 255) // 256
+        blocks = (16 * ((n + 15) // 16) + 255) // 256   # whole leaves of 16 points
         chunk = -(-blocks // world) * 256
         return max(0, min((r + 1) * chunk, n) - r * chunk)
 
