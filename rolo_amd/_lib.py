@@ -47,7 +47,46 @@ class FrontParams(C.Structure):
                 ("surf_threshold", C.c_float), ("odometry_surf_leaf_size", C.c_float)]
 
 
+class EskfOptions(C.Structure):   # include/rolo_fusion.h
+    _fields_ = [(k, C.c_double) for k in ("max_dt", "q_linear_jerk_std", "q_angular_jerk_std", "r_position_std", "r_rotation_std", "init_position_std",
+                                          "init_rotation_std", "init_velocity_std", "init_angular_velocity_std", "init_acceleration_std",
+                                          "init_angular_acceleration_std")] + [("maximum_iteration", C.c_int), ("convergence_limit", C.c_double)]
+
+
+class FusionOdometry(C.Structure):
+    _fields_ = [("position", C.c_double * 3), ("orientation", C.c_double * 4), ("velocity", C.c_double * 3), ("speed", C.c_double),
+                ("path_appended", C.c_int), ("path_length", C.c_int)]
+
+
+class FuturePoint(C.Structure):
+    _fields_ = [("position", C.c_double * 3), ("orientation", C.c_double * 4), ("longitudinal_velocity_mps", C.c_double),
+                ("lateral_velocity_mps", C.c_double), ("heading_rate_rps", C.c_double), ("is_final", C.c_int)]
+
+
 dp, fp, ip, vp = C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_int32), C.c_void_p
+
+# include/rolo_fusion.h
+FUSION_SYMBOLS = {
+    "rolo_eskf_default_options": (None, [C.POINTER(EskfOptions)]),
+    "rolo_eskf_create": (C.c_int, [C.POINTER(EskfOptions), C.POINTER(vp)]),
+    "rolo_eskf_destroy": (None, [vp]),
+    "rolo_eskf_copy": (C.c_int, [vp, vp]),
+    "rolo_eskf_reset": (None, [vp]),
+    "rolo_eskf_initialized": (C.c_int, [vp]),
+    "rolo_eskf_last_time": (C.c_double, [vp]),
+    "rolo_eskf_process_measurement": (C.c_int, [vp, C.c_double, dp, dp, dp]),
+    "rolo_eskf_state_predict": (C.c_int, [vp, C.c_double]),
+    "rolo_eskf_get_state": (None, [vp, dp, dp, dp, dp, dp, dp]),
+    "rolo_eskf_get_covariance": (None, [vp, dp]),
+    "rolo_eskf_state_propagate": (C.c_int, [vp, C.c_double, C.c_double, dp, C.c_int]),
+    "rolo_fusion_create": (C.c_int, [C.POINTER(EskfOptions), C.POINTER(vp)]),
+    "rolo_fusion_destroy": (None, [vp]),
+    "rolo_fusion_mapping_odometry": (C.c_int, [vp, C.c_double, dp, dp]),
+    "rolo_fusion_lidar_odometry": (C.c_int, [vp, C.c_double, dp, dp]),
+    "rolo_fusion_timer": (C.c_int, [vp, C.c_double, C.POINTER(FusionOdometry)]),
+    "rolo_fusion_predict_timer": (C.c_int, [vp, C.POINTER(FuturePoint), C.c_int]),
+    "rolo_fusion_filter": (vp, [vp]),
+}
 
 # every symbol include/rolo_hip.h declares: name -> (restype, argtypes)
 SYMBOLS = {
@@ -144,7 +183,7 @@ def lib() -> C.CDLL:
         except ImportError:
             pass
         L = C.CDLL(LIB_PATH)
-        for name, (res, args) in SYMBOLS.items():
+        for name, (res, args) in list(SYMBOLS.items()) + list(FUSION_SYMBOLS.items()):
             f = getattr(L, name)  # AttributeError if a declared symbol is not exported
             f.restype = res
             f.argtypes = args

@@ -10,8 +10,8 @@ from rolo_amd import _lib
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_functions():
-    text = open(os.path.join(ROOT, "include", "rolo_hip.h")).read()
+def declared_functions(header="rolo_hip.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(rolo_[a-z0-9_]+)\s*\(", text)))
 
@@ -20,13 +20,14 @@ def test_header_and_binding_agree():
     names = declared_functions()
     assert len(names) >= 40
     assert sorted(_lib.SYMBOLS) == names
+    assert sorted(_lib.FUSION_SYMBOLS) == declared_functions("rolo_fusion.h")
 
 
 def test_library_exports_every_declared_symbol():
     if not os.path.exists(_lib.LIB_PATH):
         pytest.fail("rolo_amd/librolo_hip.so not built: run `python -m rolo_amd.build`")
     L = ctypes.CDLL(_lib.LIB_PATH)
-    for name in declared_functions():
+    for name in declared_functions() + declared_functions("rolo_fusion.h"):
         assert hasattr(L, name), name
     _lib.lib()  # binds argtypes for all of them
 
