@@ -120,6 +120,11 @@ int rolo_get_knn(rolo_ctx* ctx, int which /*0 source, 1 target*/, int32_t* idx, 
 /* VmfVoxelMap::create_voxelmap (vmp_voxel.hpp:167-197) on the target. */
 int rolo_build_voxelmap(rolo_ctx* ctx);
 int rolo_num_voxels(rolo_ctx* ctx);
+/* target points of the last map build whose POLAR voxel coordinate lies within 1e-12 (in bins) of a bin edge — the only place where the
+ * device's atan2 / acos (ulps away from glibc's) could put a point into a different voxel than the reference's CPU does. The synthetic
+ * scans of the tests hold a few (the azimuth wrap, atan2(y, x) + pi ~ 1e-16); their keys are checked against the CPU path like all others.
+ * UNIFORM keys are correctly rounded on both sides: always 0. */
+int rolo_num_edge_points(rolo_ctx* ctx);
 /* keys V x 3, counts V, means V x 4, covs V x 16 — voxel order is unspecified (match on keys). */
 int rolo_get_voxels(rolo_ctx* ctx, int32_t* keys, int32_t* counts, double* means, double* covs);
 /* polar_coord / voxel_coord (vmp_voxel.hpp:199-211) of the target points (n x 3). */

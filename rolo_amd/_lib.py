@@ -113,6 +113,7 @@ SYMBOLS = {
     "rolo_get_knn": (C.c_int, [vp, C.c_int, ip, fp]),
     "rolo_build_voxelmap": (C.c_int, [vp]),
     "rolo_num_voxels": (C.c_int, [vp]),
+    "rolo_num_edge_points": (C.c_int, [vp]),
     "rolo_get_voxels": (C.c_int, [vp, ip, ip, dp, dp]),
     "rolo_get_target_voxel_keys": (C.c_int, [vp, ip]),
     "rolo_so3_linearize": (C.c_int, [vp, dp, dp, dp, dp]),

@@ -112,6 +112,7 @@ struct rolo_ctx {
   int* counters = nullptr; size_t counters_cap = 0;
   bool have_map = false;
   int n_voxels = 0;
+  int n_edge = 0;   // target points of the last map build within 1e-12 of a POLAR bin edge
   // passes
   int* corr[2] = {nullptr, nullptr}; size_t corr_cap[2] = {0, 0};
   double* partials = nullptr; size_t partials_cap = 0;
@@ -188,6 +189,7 @@ int upload_cloud(rolo_ctx* c, CloudDev& cl, size_t& xyz_cap, const float* pts, i
   cl.n = n;
   cl.have_cov = false;
   cl.have_sorted = false;
+  cl.bbox6 = nullptr;
   return ROLO_OK;
 }
 
@@ -252,6 +254,9 @@ int build_clouds(rolo_ctx* c, bool do_src, bool do_tgt, hipStream_t stream) {
     if ((rc = ensure(S.stage, S.stage_cap, seg * (size_t)c->world))) return rc;
     for (int i = 0; i < nc; i++) { A.c[i].seg = seg; A.c[i].stage = S.stage; }
   }
+  // the build overwrites this scratch set's bounding boxes: whoever still pointed at them (a cloud searched earlier) loses them
+  if (c->src.bbox6 >= S.bbox && c->src.bbox6 < S.bbox + 12) c->src.bbox6 = nullptr;
+  if (c->tgt.bbox6 >= S.bbox && c->tgt.bbox6 < S.bbox + 12) c->tgt.bbox6 = nullptr;
   { ProfScope ps(c, ROLO_PROF_KNN_BUILD, stream); HIPCHK(launch_knn_build(A, S.sort_tmp, tmp, S.keys0, S.keys1, S.vals0, S.vals1, S.bbox, stream)); }
   { ProfScope ps(c, ROLO_PROF_KNN_WALK, stream); HIPCHK(launch_knn_walk(A, c->P.k_correspondences, stream)); }
   { ProfScope ps(c, ROLO_PROF_KNN_TAIL, stream); HIPCHK(launch_knn_tail(A, c->P.k_correspondences, c->P.regularization, stream)); }
@@ -264,8 +269,8 @@ int build_clouds(rolo_ctx* c, bool do_src, bool do_tgt, hipStream_t stream) {
     // without a communicator (rolo_set_shard test hook) only the own slice is valid afterwards
     HIPCHK(launch_knn_unstage(A, c->comm == nullptr, stream));
   }
-  if (do_src) { c->src.have_cov = true; c->src.have_sorted = true; }
-  if (do_tgt) { c->tgt.have_cov = true; c->tgt.have_sorted = true; }
+  if (do_src) { c->src.have_cov = true; c->src.have_sorted = true; c->src.cov_user = false; c->src.bbox6 = S.bbox; }
+  if (do_tgt) { c->tgt.have_cov = true; c->tgt.have_sorted = true; c->tgt.cov_user = false; c->tgt.bbox6 = S.bbox + (do_src ? 6 : 0); }
   return ROLO_OK;
 }
 
@@ -290,6 +295,12 @@ bool voxel_morton_order(const rolo_ctx* c) {
   return c->P.voxel_type == ROLO_VOXEL_POLAR;
 }
 
+// covariance entries bounded by 1 (regularisations that fix the spectrum, computed here): their voxel sums can go through fixed point
+bool voxel_fixed_cov(const rolo_ctx* c) {
+  const int r = c->P.regularization;
+  return !c->tgt.cov_user && (r == ROLO_REG_PLANE || r == ROLO_REG_NORMALIZED_MIN_EIG || r == ROLO_REG_PLANE_S);
+}
+
 void fill_table_params(rolo_ctx* c) {
   c->tab.voxel_type = c->P.voxel_type;
   c->tab.voxel_resolution = c->P.voxel_resolution;
@@ -311,11 +322,12 @@ int ensure_map(rolo_ctx* c) {
   if ((rc = ensure(c->counters, c->counters_cap, 4))) return rc;
   c->tab.mask = (unsigned)(capslots - 1);
   fill_table_params(c);
-  { ProfScope ps(c, ROLO_PROF_VOXEL_BUILD); HIPCHK(launch_voxel_build(c->tgt, c->tab, c->tgt_keys, c->tgt_slot, c->counters, voxel_morton_order(c), c->stream)); }
-  HIPCHK(hipMemcpyAsync(c->h_counters, c->counters, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  { ProfScope ps(c, ROLO_PROF_VOXEL_BUILD); HIPCHK(launch_voxel_build(c->tgt, c->tab, c->tgt_keys, c->tgt_slot, c->counters, voxel_morton_order(c), voxel_fixed_cov(c), c->tgt.bbox6, c->stream)); }
+  HIPCHK(hipMemcpyAsync(c->h_counters, c->counters, 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   if (c->h_counters[1] != 0) { g_err = "voxel coordinate outside the packed key range"; return c->h_counters[1]; }
   c->n_voxels = c->h_counters[0];
+  c->n_edge = c->h_counters[2];
   c->have_map = true;
   c->have_corr = false;
   return ROLO_OK;
@@ -588,7 +600,7 @@ int rolo_swap_source_and_target(rolo_ctx* c) {
   std::swap(c->src_xyz_cap, c->tgt_xyz_cap); std::swap(c->src_cov_cap, c->tgt_cov_cap);
   std::swap(c->src_sorted_cap, c->tgt_sorted_cap); std::swap(c->src_boxes_cap, c->tgt_boxes_cap);
   std::swap(c->src_knn_cap, c->tgt_knn_cap); std::swap(c->src_knnd_cap, c->tgt_knnd_cap);
-  c->have_map = false; c->have_corr = false;
+  c->have_map = false; c->have_corr = false;   // (bbox6 travels with the CloudDev)
   return ROLO_OK;
 }
 int rolo_adopt_target_covariances(rolo_ctx* c) {
@@ -630,7 +642,7 @@ static int set_covs(rolo_ctx* c, CloudDev& cl, size_t& cov_cap, const double* co
   HIPCHK(hipMemcpyAsync(c->stage_d, covs, sizeof(double) * 16 * (size_t)cl.n, hipMemcpyHostToDevice, c->stream));
   HIPCHK(launch_cov_pack(c->stage_d, cl.n, cl.cov, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
-  cl.have_cov = true;
+  cl.have_cov = true; cl.cov_user = true;
   return ROLO_OK;
 }
 int rolo_set_source_covariances(rolo_ctx* c, const double* covs) { if (!c) return ROLO_EINVAL; int rc = set_device(c); if (rc) return rc; c->have_corr = false; return set_covs(c, c->src, c->src_cov_cap, covs); }
@@ -660,6 +672,7 @@ int rolo_build_voxelmap(rolo_ctx* c) {
   return ensure_map(c);
 }
 int rolo_num_voxels(rolo_ctx* c) { return (c && c->have_map) ? c->n_voxels : ROLO_ESTATE; }
+int rolo_num_edge_points(rolo_ctx* c) { return (c && c->have_map) ? c->n_edge : ROLO_ESTATE; }
 
 static void unpack_key_host(unsigned long long key, int32_t* k3) {
   k3[0] = (int)(key & 0x1fffffu) - KEY_BIAS; k3[1] = (int)((key >> 21) & 0x1fffffu) - KEY_BIAS; k3[2] = (int)((key >> 42) & 0x1fffffu) - KEY_BIAS;
@@ -850,8 +863,8 @@ static int enqueue_frame(rolo_ctx* c) {
     if ((rc = ensure(c->counters, c->counters_cap, 4))) return rc;
     c->tab.mask = (unsigned)(capslots - 1);
     fill_table_params(c);
-    { ProfScope ps(c, ROLO_PROF_VOXEL_BUILD); HIPCHK(launch_voxel_build(c->tgt, c->tab, c->tgt_keys, c->tgt_slot, c->counters, voxel_morton_order(c), c->stream)); }
-    HIPCHK(hipMemcpyAsync(c->h_counters, c->counters, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    { ProfScope ps(c, ROLO_PROF_VOXEL_BUILD); HIPCHK(launch_voxel_build(c->tgt, c->tab, c->tgt_keys, c->tgt_slot, c->counters, voxel_morton_order(c), voxel_fixed_cov(c), c->tgt.bbox6, c->stream)); }
+    HIPCHK(hipMemcpyAsync(c->h_counters, c->counters, 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
   }
   PassArgs a; int grid;
   if ((rc = prepare_pass(c, a, grid))) return rc;
@@ -935,6 +948,7 @@ int rolo_register_wait(rolo_ctx* c, float* Tf, double* Td, double* trans_out, ro
   HIPCHK(hipStreamSynchronize(c->stream));
   if (c->h_counters[1] != 0) { g_err = "voxel coordinate outside the packed key range"; return c->h_counters[1]; }
   c->n_voxels = c->h_counters[0];
+  c->n_edge = c->h_counters[2];
   c->have_map = true;
   PassArgs a; int grid;
   if ((rc = prepare_pass(c, a, grid))) return rc;
@@ -1119,8 +1133,8 @@ static int enqueue_batch(rolo_batch* b, bool fork) {
     if ((rc = ensure(c->counters, c->counters_cap, 4))) return rc;
     c->tab.mask = (unsigned)(capslots - 1);
     fill_table_params(c);
-    HIPCHK(launch_voxel_build(c->tgt, c->tab, c->tgt_keys, c->tgt_slot, c->counters, voxel_morton_order(c), s2));
-    HIPCHK(hipMemcpyAsync(c->h_counters, c->counters, 2 * sizeof(int), hipMemcpyDeviceToHost, s2));
+    HIPCHK(launch_voxel_build(c->tgt, c->tab, c->tgt_keys, c->tgt_slot, c->counters, voxel_morton_order(c), voxel_fixed_cov(c), c->tgt.bbox6, s2));
+    HIPCHK(hipMemcpyAsync(c->h_counters, c->counters, 4 * sizeof(int), hipMemcpyDeviceToHost, s2));
     if (fork) { HIPCHK(hipEventRecord(b->ev_join[2 * i], s1)); HIPCHK(hipEventRecord(b->ev_join[2 * i + 1], s2)); }
     PassArgs a; int grid;
     if ((rc = prepare_pass(c, a, grid))) return rc;
@@ -1211,6 +1225,7 @@ int rolo_batch_register_wait(rolo_batch* b, float* Tf, double* Td, double* trans
     rolo_ctx* c = b->m[i];
     if (c->h_counters[1] != 0) { g_err = "voxel coordinate outside the packed key range"; if (!first_err) first_err = c->h_counters[1]; continue; }
     c->n_voxels = c->h_counters[0];
+    c->n_edge = c->h_counters[2];
     c->have_map = true;
     // a member whose data needed more trials than the fixed schedule holds is finished on its own (rare)
     if (!c->h_state->error && (!c->h_state->rot_done || !c->h_state->trans_done)) {

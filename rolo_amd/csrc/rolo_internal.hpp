@@ -44,11 +44,13 @@ struct CloudDev {          // one point cloud resident in HBM
   int n = 0;
   int cap = 0;
   bool have_cov = false;
+  bool cov_user = false;   // covariances handed in by the caller (rolo_set_*_covariances): entries not bounded by the regularisation
   // kNN acceleration structure (Morton-ordered implicit BVH)
   float4* sorted = nullptr;     // 8 * n_leaves, (x,y,z, bits(original index)); padding = +inf, index INT_MAX
   float4* boxes = nullptr;      // 2 * 2P entries: node h -> boxes[2h] = lo, boxes[2h+1] = hi ; leaves h in [P, 2P)
   int n_leaves = 0, P = 0;
   bool have_sorted = false;     // sorted / boxes belong to the current xyz
+  const int* bbox6 = nullptr;   // bounding box of the current xyz left by the search (device, 6 order-preserving ints); nullptr: unknown
   int32_t* knn_idx = nullptr;   // debug: n x k
   float* knn_d2 = nullptr;
 };
@@ -114,8 +116,10 @@ hipError_t launch_knn_tail(const KnnPair& A, int k, int regularization, hipStrea
 // multi-GPU: exchange buffer (sorted order, all ranks' slices after the all-gather, or [q_begin, q_end) only) -> cov[] by original index
 hipError_t launch_knn_unstage(const KnnPair& A, bool own_slice_only, hipStream_t s);
 
-hipError_t launch_voxel_build(const CloudDev& tgt, VoxelTable tab, unsigned long long* tgt_keys, int* tgt_slot, int* counters, bool morton_order,
-                              hipStream_t s);
+// fixed_cov: the covariance sums go through 64-bit fixed point as the positions always do (entries bounded by 1); false: fp64 atomics
+// bbox6: the target's bounding box as the neighbour search leaves it on the device (6 order-preserving ints), or nullptr
+hipError_t launch_voxel_build(const CloudDev& tgt, VoxelTable tab, unsigned long long* tgt_keys, int* tgt_slot, int* counters, bool morton_order, bool fixed_cov,
+                              const int* bbox6, hipStream_t s);
 hipError_t launch_voxel_keys(const float4* pts, int n, VoxelTable tab, int32_t* keys3, hipStream_t s);
 
 hipError_t launch_rot_pass(int dof, const PassArgs& a, const LmState* st, int grid, hipStream_t s);

@@ -19,6 +19,25 @@ ROLO_DEV void voxel_coord_dev(const VoxelTable& tab, double x, double y, double 
   }
 }
 
+// The same, also telling whether a POLAR coordinate lies within 1e-12 (in bins) of a bin edge: device atan2 / acos differ from glibc's by
+// ulps, so only there could the integer key differ from the CPU path's (SURVEY §7 "hard parts"); counted by the map build, asserted 0 by
+// the tests. UNIFORM keys are a division and a floor — correctly rounded on both sides, no hazard, nothing counted.
+ROLO_DEV void voxel_coord_dev_edge(const VoxelTable& tab, double x, double y, double z, int& kx, int& ky, int& kz, bool& near_edge) {
+  near_edge = false;
+  if (tab.voxel_type == ROLO_VOXEL_POLAR) {
+    const double r = sqrt((x * x + y * y) + z * z);
+    const double a = (atan2(y, x) + 3.14159265358979323846) / tab.polar_res[0], b = acos(z / r) / tab.polar_res[1], c = r / tab.polar_res[2];
+    const double fa = floor(a), fb = floor(b), fc = floor(c);
+    kx = (int)fa; ky = (int)fb; kz = (int)fc;
+    const double lo = 1e-12, hi = 1.0 - 1e-12;
+    near_edge = (a - fa) < lo || (a - fa) > hi || (b - fb) < lo || (b - fb) > hi || (c - fc) < lo || (c - fc) > hi;
+  } else {
+    kx = (int)floor(x / tab.voxel_resolution - 0.5);
+    ky = (int)floor(y / tab.voxel_resolution - 0.5);
+    kz = (int)floor(z / tab.voxel_resolution - 0.5);
+  }
+}
+
 ROLO_DEV bool pack_key(int kx, int ky, int kz, unsigned long long& key) {
   const unsigned ux = (unsigned)(kx + KEY_BIAS), uy = (unsigned)(ky + KEY_BIAS), uz = (unsigned)(kz + KEY_BIAS);
   if ((ux | uy | uz) >> 21) return false;

@@ -7,8 +7,11 @@
 // coordinates packed 3 x 21 bits — so a single atomicCAS both claims a slot and publishes the whole key. The
 // winner of a slot takes a compact voxel id from a counter and zeroes that voxel's 96-byte record. A second
 // kernel accumulates points into the records: consecutive lanes that hit the same voxel (targets arrive in scan
-// order, so runs are long) are combined inside the wavefront first, so HBM sees one fp64 atomic add per run
-// instead of one per point. A third kernel finalises (mean /= n, cov /= n, w = sqrt(n)). Lookups in the pass
+// order, so runs are long) are combined inside the wavefront first, so HBM sees one atomic add per run
+// instead of one per point. The sums are 64-bit FIXED-POINT integers (scale = the power of two that keeps n * max|value| below
+// 2^62: float coordinates are then represented exactly, covariances to ~6e-14): integer addition is associative, so every
+// voxel's mean and covariance come out bit-identical run after run and in either point order (fp64 atomics summed in arrival
+// order). A third kernel finalises (mean /= n, cov /= n, w = sqrt(n)). Lookups in the pass
 // kernels are then: pack key -> hash -> probe 8-byte slots -> 96-byte record gather.
 // Voxel coordinates are evaluated in fp64 with true divisions, exactly the reference's expressions, so the
 // integer keys are bit-identical to the CPU path (up to libm ulps of atan2/acos at bin edges).
@@ -21,13 +24,112 @@ namespace rolo {
 
 namespace {
 
+// counters: [0] voxels, [1] error code, [2] points within 1e-12 of a bin edge, [3] float bits of max |coordinate| of the target
+ROLO_DEV void note_point(bool valid, bool near_edge, int* counters) {
+  const unsigned long long edge = __ballot(valid && near_edge);
+  if (edge && (threadIdx.x & 63) == 0) atomicAdd(&counters[2], __popcll(edge));
+}
+
+// max |coordinate| of the target -> counters[3]: from the bounding box the neighbour search left on the device (6 order-preserving
+// ints: min xyz, max xyz), or, for a target whose covariances were handed in (no search ran), from the points themselves
+__global__ void maxabs_from_bbox_kernel(const int* __restrict__ bbox6, int* counters) {
+  if (threadIdx.x != 0) return;
+  float m = 0.f;
+  for (int k = 0; k < 6; k++) { const int o = bbox6[k]; m = fmaxf(m, fabsf(__int_as_float(o >= 0 ? o : o ^ 0x7fffffff))); }
+  counters[3] = __float_as_int(m);
+}
+__global__ __launch_bounds__(256) void maxabs_kernel(const float4* __restrict__ pts, int n, int* counters) {
+  __shared__ int sm[4];
+  float m = 0.f;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) { const float4 p = pts[i]; m = fmaxf(m, fmaxf(fmaxf(fabsf(p.x), fabsf(p.y)), fabsf(p.z))); }
+  int mb = __float_as_int(m);   // non-negative floats order like their bit patterns
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) mb = max(mb, __shfl_xor(mb, off, 64));
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = mb;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicMax(&counters[3], max(max(sm[0], sm[1]), max(sm[2], sm[3])));
+}
+
+// fixed-point scales (powers of two) of the position / covariance sums: n * max|value| * scale < 2^62
+struct FixScale { double pos, cov; };
+ROLO_DEV FixScale fix_scales(int n, const int* counters) {
+  const int bits_n = 32 - __clz(max(n, 1));
+  const int e = ((counters[3] >> 23) & 0xff) - 127;      // max|coordinate| < 2^(e+1)
+  FixScale s;
+  s.pos = ldexp(1.0, 62 - bits_n - (max(e, -1) + 1));
+  s.cov = ldexp(1.0, 62 - bits_n - 1);                   // |entries| <= 1 for the spectrally bounded regularisations
+  return s;
+}
+ROLO_DEV long long shfl_up_ll(long long v, int off) {
+  return (long long)(((unsigned long long)(unsigned)__shfl_up((int)((unsigned long long)v >> 32), off, 64) << 32) | (unsigned)__shfl_up((int)((unsigned long long)v & 0xffffffffull), off, 64));
+}
+
+// one point -> (id, 10 values) -> wave-level fold of runs of equal id -> one atomic per run and value.
+// fixed_cov: covariances go through the integer sums too (bounded entries); otherwise they keep fp64 atomics (options the
+// reference never selects, or covariances handed in by the caller: unbounded entries).
+ROLO_DEV void accumulate_point(const VoxelTable& tab, int id, const float4& p, const double (&c)[6], const FixScale& S, bool fixed_cov) {
+  const int lane = threadIdx.x & 63;
+  long long q[10];
+  double cv[6];
+#pragma unroll
+  for (int d = 0; d < 10; d++) q[d] = 0;
+#pragma unroll
+  for (int d = 0; d < 6; d++) cv[d] = 0.0;
+  if (id >= 0) {
+    q[0] = __double2ll_rn((double)p.x * S.pos); q[1] = __double2ll_rn((double)p.y * S.pos); q[2] = __double2ll_rn((double)p.z * S.pos);
+    if (fixed_cov) {
+#pragma unroll
+      for (int d = 0; d < 6; d++) q[3 + d] = __double2ll_rn(c[d] * S.cov);
+    } else {
+#pragma unroll
+      for (int d = 0; d < 6; d++) cv[d] = c[d];
+    }
+    q[9] = 1;
+  }
+  const int prev_id = __shfl_up(id, 1, 64);
+  const bool head = (lane == 0) || (prev_id != id);
+  const unsigned long long head_mask = __ballot(head);
+  const unsigned long long below = head_mask & ((lane == 63) ? ~0ull : ((1ull << (lane + 1)) - 1ull));
+  const int head_lane = 63 - __clzll(below);
+  const int dist = lane - head_lane;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+#pragma unroll
+    for (int d = 0; d < 10; d++) {
+      const long long o = shfl_up_ll(q[d], off);
+      if (dist >= off) q[d] += o;
+    }
+    if (!fixed_cov) {
+#pragma unroll
+      for (int d = 0; d < 6; d++) { const double o = __shfl_up(cv[d], off, 64); if (dist >= off) cv[d] += o; }
+    }
+  }
+  const int next_id = __shfl_down(id, 1, 64);
+  const bool tail = (lane == 63) || (next_id != id);
+  if (tail && id >= 0) {
+    unsigned long long* r = reinterpret_cast<unsigned long long*>(tab.rec + (size_t)id * REC_DOUBLES);
+#pragma unroll
+    for (int d = 0; d < 3; d++) atomicAdd(&r[d], (unsigned long long)q[d]);
+    if (fixed_cov) {
+#pragma unroll
+      for (int d = 3; d < 9; d++) atomicAdd(&r[d], (unsigned long long)q[d]);
+    } else {
+      double* rd = tab.rec + (size_t)id * REC_DOUBLES;
+#pragma unroll
+      for (int d = 0; d < 6; d++) atomicAdd(&rd[3 + d], cv[d]);
+    }
+    atomicAdd(&r[10], (unsigned long long)q[9]);
+  }
+}
+
 __global__ __launch_bounds__(256) void voxel_insert_kernel(const float4* __restrict__ pts, int n, VoxelTable tab,
                                                           unsigned long long* tgt_keys, int* tgt_slot, int* counters) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const float4 p = i < n ? pts[i] : make_float4(1.f, 1.f, 1.f, 0.f);
+  int kx, ky, kz; bool near_edge;
+  voxel_coord_dev_edge(tab, (double)p.x, (double)p.y, (double)p.z, kx, ky, kz, near_edge);
+  note_point(i < n, near_edge, counters);
   if (i >= n) return;
-  const float4 p = pts[i];
-  int kx, ky, kz;
-  voxel_coord_dev(tab, (double)p.x, (double)p.y, (double)p.z, kx, ky, kz);
   unsigned long long key;
   if (!pack_key(kx, ky, kz, key)) { atomicExch(&counters[1], ROLO_EKEYRANGE); tgt_slot[i] = -1; tgt_keys[i] = KEY_EMPTY; return; }
   unsigned h = hash_key(key) & tab.mask;
@@ -51,50 +153,21 @@ __global__ __launch_bounds__(256) void voxel_insert_kernel(const float4* __restr
 
 // wave-level segmented combine: lanes holding the same voxel id as their predecessor fold into the run head
 __global__ __launch_bounds__(256) void voxel_accum_kernel(const float4* __restrict__ pts, const double* __restrict__ cov, int n,
-                                                         VoxelTable tab, const int* __restrict__ tgt_slot) {
+                                                         VoxelTable tab, const int* __restrict__ tgt_slot, const int* __restrict__ counters, int fixed_cov) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int lane = threadIdx.x & 63;
   int id = -1;
-  double v[10];
-#pragma unroll
-  for (int d = 0; d < 10; d++) v[d] = 0.0;
+  float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+  double c[6] = {0, 0, 0, 0, 0, 0};
   if (i < n) {
     const int slot = tgt_slot[i];
     if (slot >= 0) {
       id = tab.ids[slot];
-      const float4 p = pts[i];
-      v[0] = (double)p.x; v[1] = (double)p.y; v[2] = (double)p.z;
+      p = pts[i];
 #pragma unroll
-      for (int d = 0; d < 6; d++) v[3 + d] = cov[(size_t)d * n + i];
-      v[9] = 1.0;
+      for (int d = 0; d < 6; d++) c[d] = cov[(size_t)d * n + i];
     }
   }
-  // inclusive segmented scan (Hillis-Steele) over runs of equal id; the last lane of each run holds the run total
-  // after summing leftwards, so instead fold rightwards: each lane adds the value `off` lanes to its left when the
-  // whole span [lane-off, lane] belongs to one run.
-  const int prev_id = __shfl_up(id, 1, 64);
-  const bool head = (lane == 0) || (prev_id != id);
-  // distance to the run head
-  unsigned long long head_mask = __ballot(head);
-  const unsigned long long below = head_mask & ((lane == 63) ? ~0ull : ((1ull << (lane + 1)) - 1ull));
-  const int head_lane = 63 - __clzll(below);
-  const int dist = lane - head_lane;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-#pragma unroll
-    for (int d = 0; d < 10; d++) {
-      double o = __shfl_up(v[d], off, 64);
-      if (dist >= off) v[d] += o;
-    }
-  }
-  const int next_id = __shfl_down(id, 1, 64);
-  const bool tail = (lane == 63) || (next_id != id);
-  if (tail && id >= 0) {
-    double* r = tab.rec + (size_t)id * REC_DOUBLES;
-#pragma unroll
-    for (int d = 0; d < 9; d++) atomicAdd(&r[d], v[d]);
-    atomicAdd(&r[10], v[9]);
-  }
+  accumulate_point(tab, id, p, c, fix_scales(n, counters), fixed_cov != 0);
 }
 
 // ---- the same two kernels over the target in MORTON order (CloudDev::sorted of the neighbour search) -----------------
@@ -109,11 +182,14 @@ __global__ __launch_bounds__(256) void voxel_insert_sorted_kernel(const float4* 
   const int lane = threadIdx.x & 63;
   unsigned long long key = KEY_EMPTY;
   bool valid = false;
-  if (j < n_sorted) {
-    const float4 p = sorted[j];
-    if (__float_as_int(p.w) != INT_MAX) {
-      int kx, ky, kz;
-      voxel_coord_dev(tab, (double)p.x, (double)p.y, (double)p.z, kx, ky, kz);
+  {
+    float4 p = j < n_sorted ? sorted[j] : make_float4(1.f, 1.f, 1.f, __int_as_float(INT_MAX));
+    const bool real = __float_as_int(p.w) != INT_MAX;
+    if (!real) { p.x = 1.f; p.y = 1.f; p.z = 1.f; }   // padding holds +inf
+    int kx, ky, kz; bool near_edge;
+    voxel_coord_dev_edge(tab, (double)p.x, (double)p.y, (double)p.z, kx, ky, kz, near_edge);
+    note_point(real, near_edge, counters);
+    if (real) {
       if (pack_key(kx, ky, kz, key)) valid = true;
       else { atomicExch(&counters[1], ROLO_EKEYRANGE); key = KEY_EMPTY; }
     }
@@ -148,57 +224,40 @@ __global__ __launch_bounds__(256) void voxel_insert_sorted_kernel(const float4* 
 }
 
 __global__ __launch_bounds__(256) void voxel_accum_sorted_kernel(const float4* __restrict__ sorted, const double* __restrict__ cov, int n, int n_sorted,
-                                                                VoxelTable tab, const int* __restrict__ slot_sorted) {
+                                                                VoxelTable tab, const int* __restrict__ slot_sorted, const int* __restrict__ counters, int fixed_cov) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  const int lane = threadIdx.x & 63;
   int id = -1;
-  double v[10];
-#pragma unroll
-  for (int d = 0; d < 10; d++) v[d] = 0.0;
+  float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+  double c[6] = {0, 0, 0, 0, 0, 0};
   if (j < n_sorted) {
     const int slot = slot_sorted[j];
     if (slot >= 0) {
       id = tab.ids[slot];   // written by another lane / workgroup of the insert kernel: visible after the kernel boundary
-      const float4 p = sorted[j];
+      p = sorted[j];
       const int i = __float_as_int(p.w);
-      v[0] = (double)p.x; v[1] = (double)p.y; v[2] = (double)p.z;
 #pragma unroll
-      for (int d = 0; d < 6; d++) v[3 + d] = cov[(size_t)d * n + i];
-      v[9] = 1.0;
+      for (int d = 0; d < 6; d++) c[d] = cov[(size_t)d * n + i];
     }
   }
-  const int prev_id = __shfl_up(id, 1, 64);
-  const bool head = (lane == 0) || (prev_id != id);
-  const unsigned long long head_mask = __ballot(head);
-  const unsigned long long below = head_mask & ((lane == 63) ? ~0ull : ((1ull << (lane + 1)) - 1ull));
-  const int head_lane = 63 - __clzll(below);
-  const int dist = lane - head_lane;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-#pragma unroll
-    for (int d = 0; d < 10; d++) {
-      double o = __shfl_up(v[d], off, 64);
-      if (dist >= off) v[d] += o;
-    }
-  }
-  const int next_id = __shfl_down(id, 1, 64);
-  const bool tail = (lane == 63) || (next_id != id);
-  if (tail && id >= 0) {
-    double* r = tab.rec + (size_t)id * REC_DOUBLES;
-#pragma unroll
-    for (int d = 0; d < 9; d++) atomicAdd(&r[d], v[d]);
-    atomicAdd(&r[10], v[9]);
-  }
+  accumulate_point(tab, id, p, c, fix_scales(n, counters), fixed_cov != 0);
 }
 
-__global__ __launch_bounds__(256) void voxel_finalize_kernel(VoxelTable tab, const int* counters) {
+__global__ __launch_bounds__(256) void voxel_finalize_kernel(VoxelTable tab, const int* counters, int n_pts, int fixed_cov) {
   const int id = blockIdx.x * blockDim.x + threadIdx.x;
   if (id >= counters[0]) return;
   double* r = tab.rec + (size_t)id * REC_DOUBLES;
-  const double n = r[10];
+  const long long* q = reinterpret_cast<const long long*>(r);
+  const FixScale S = fix_scales(n_pts, counters);
+  const double n = (double)q[10];
+  double v[9];
 #pragma unroll
-  for (int d = 0; d < 9; d++) r[d] = r[d] / n;  // vmp_voxel.hpp:102,107 (mean_dir /= n ; cov /= n)
+  for (int d = 0; d < 3; d++) v[d] = ((double)q[d] / S.pos) / n;                                // vmp_voxel.hpp:102 (mean_dir /= n)
+#pragma unroll
+  for (int d = 3; d < 9; d++) v[d] = (fixed_cov ? (double)q[d] / S.cov : r[d]) / n;            // :107 (cov /= n)
+#pragma unroll
+  for (int d = 0; d < 9; d++) r[d] = v[d];
   r[9] = sqrt(n);                               // w = sqrt(num_points), rot_vgicp_impl.hpp:336
+  r[10] = n;
 }
 
 __global__ __launch_bounds__(256) void voxel_keys_kernel(const float4* __restrict__ pts, int n, VoxelTable tab, int32_t* keys3) {
@@ -212,21 +271,24 @@ __global__ __launch_bounds__(256) void voxel_keys_kernel(const float4* __restric
 
 }  // namespace
 
-hipError_t launch_voxel_build(const CloudDev& tgt, VoxelTable tab, unsigned long long* tgt_keys, int* tgt_slot, int* counters, bool morton_order, hipStream_t s) {
+hipError_t launch_voxel_build(const CloudDev& tgt, VoxelTable tab, unsigned long long* tgt_keys, int* tgt_slot, int* counters, bool morton_order, bool fixed_cov,
+                              const int* bbox6, hipStream_t s) {
   hipError_t e = hipMemsetAsync(tab.keys, 0xFF, sizeof(unsigned long long) * ((size_t)tab.mask + 1), s);
   if (e != hipSuccess) return e;
-  e = hipMemsetAsync(counters, 0, 2 * sizeof(int), s);
+  e = hipMemsetAsync(counters, 0, 4 * sizeof(int), s);
   if (e != hipSuccess) return e;
   const int grid = (tgt.n + 255) / 256;
+  if (bbox6) maxabs_from_bbox_kernel<<<1, 64, 0, s>>>(bbox6, counters);
+  else maxabs_kernel<<<64, 256, 0, s>>>(tgt.xyz, tgt.n, counters);
   if (morton_order && tgt.have_sorted) {   // Morton order of the neighbour search: tgt_slot (>= 8 * n_leaves entries) is indexed by sorted position
     const int n_sorted = KNN_LEAF * tgt.n_leaves, gs = (n_sorted + 255) / 256;
     voxel_insert_sorted_kernel<<<gs, 256, 0, s>>>(tgt.sorted, n_sorted, tab, tgt_slot, counters);
-    voxel_accum_sorted_kernel<<<gs, 256, 0, s>>>(tgt.sorted, tgt.cov, tgt.n, n_sorted, tab, tgt_slot);
+    voxel_accum_sorted_kernel<<<gs, 256, 0, s>>>(tgt.sorted, tgt.cov, tgt.n, n_sorted, tab, tgt_slot, counters, fixed_cov ? 1 : 0);
   } else {                                 // input order
     voxel_insert_kernel<<<grid, 256, 0, s>>>(tgt.xyz, tgt.n, tab, tgt_keys, tgt_slot, counters);
-    voxel_accum_kernel<<<grid, 256, 0, s>>>(tgt.xyz, tgt.cov, tgt.n, tab, tgt_slot);
+    voxel_accum_kernel<<<grid, 256, 0, s>>>(tgt.xyz, tgt.cov, tgt.n, tab, tgt_slot, counters, fixed_cov ? 1 : 0);
   }
-  voxel_finalize_kernel<<<grid, 256, 0, s>>>(tab, counters);
+  voxel_finalize_kernel<<<grid, 256, 0, s>>>(tab, counters, tgt.n, fixed_cov ? 1 : 0);
   return hipGetLastError();
 }
 

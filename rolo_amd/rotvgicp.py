@@ -220,6 +220,10 @@ class RotVGICP:
     def buildVoxelMap(self):
         check(lib().rolo_build_voxelmap(self._h), "rolo_build_voxelmap")
 
+    def numEdgePoints(self) -> int:
+        """target points of the last map build within 1e-12 of a POLAR bin edge (rolo_num_edge_points)"""
+        return check(lib().rolo_num_edge_points(self._h), "rolo_num_edge_points")
+
     def voxels(self):
         V = check(lib().rolo_num_voxels(self._h), "rolo_num_voxels")
         keys = np.zeros((V, 3), np.int32); counts = np.zeros(V, np.int32); means = np.zeros((V, 4)); covs = np.zeros((V, 4, 4))
