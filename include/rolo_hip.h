@@ -295,6 +295,21 @@ int rolo_odom_set_option(rolo_odom* o, int option, int value);
 /* rolo_front_set_deskew for the next rolo_odom_submit / rolo_odom_frame of the fused path */
 int rolo_odom_set_deskew(rolo_odom* o, const rolo_deskew* d, const float* rel_time, int n_raw, int rel_time_on_device);
 
+/* ---- back end: scan-to-submap optimisation ---------------------------------------------------------------------
+ * scan2MapOptimization (src/backMapping.cpp:681-711) with cornerOptimization :720-824, surfOptimization :827-901,
+ * combineOptimizationCoeffs :904-925 and LMOptimization :929-1058: the down-sampled corner / surface points of the current scan
+ * (laserCloudCornerLastDS / laserCloudSurfLastDS, n x 4 floats) against the corner / surface sub-maps (laserCloud*FromMapDS), starting
+ * from and updating transformTobeMapped = (roll, pitch, yaw, x, y, z). Up to 30 Gauss-Newton iterations, each one kernel over the points
+ * (exact 5-NN in the sub-map's BVH, line / plane fit, Jacobian row, J^T J reduction) and a 6 x 6 float solve on the host.
+ * edge_min / surf_min = edgeFeatureMinValidNum / surfFeatureMinValidNum (utility.h: 10 / 100): with fewer features the call does nothing
+ * (stats->skipped). The context's source / target clouds are used as scratch for the sub-map trees: use a context of its own.
+ * transformUpdate()'s clamps (:1060-1068; tolerances FLT_MAX in every shipped config) are left to the caller.
+ * selected_out[n_corner + n_surf] / coeff_out[(n_corner + n_surf) * 4] (optional): laserCloudOri*Flag and coeffSel of the LAST iteration. */
+typedef struct rolo_scan2map_stats { int skipped, iterations, converged, degenerate, n_selected; } rolo_scan2map_stats;
+int rolo_scan2map_optimize(rolo_ctx* ctx, const float* corner, int n_corner, const float* surf, int n_surf, const float* map_corner, int m_corner,
+                           const float* map_surf, int m_surf, float* transformTobeMapped6, int edge_min, int surf_min, rolo_scan2map_stats* stats,
+                           unsigned char* selected_out, float* coeff_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -47,6 +47,10 @@ class FrontParams(C.Structure):
                 ("surf_threshold", C.c_float), ("odometry_surf_leaf_size", C.c_float)]
 
 
+class Scan2MapStats(C.Structure):
+    _fields_ = [("skipped", C.c_int), ("iterations", C.c_int), ("converged", C.c_int), ("degenerate", C.c_int), ("n_selected", C.c_int)]
+
+
 class EskfOptions(C.Structure):   # include/rolo_fusion.h
     _fields_ = [(k, C.c_double) for k in ("max_dt", "q_linear_jerk_std", "q_angular_jerk_std", "r_position_std", "r_rotation_std", "init_position_std",
                                           "init_rotation_std", "init_velocity_std", "init_angular_velocity_std", "init_acceleration_std",
@@ -112,6 +116,8 @@ SYMBOLS = {
     "rolo_set_target_covariances": (C.c_int, [vp, dp]),
     "rolo_get_knn": (C.c_int, [vp, C.c_int, ip, fp]),
     "rolo_build_voxelmap": (C.c_int, [vp]),
+    "rolo_scan2map_optimize": (C.c_int, [vp, fp, C.c_int, fp, C.c_int, fp, C.c_int, fp, C.c_int, fp, C.c_int, C.c_int, C.POINTER(Scan2MapStats),
+                                          C.POINTER(C.c_ubyte), fp]),
     "rolo_num_voxels": (C.c_int, [vp]),
     "rolo_num_edge_points": (C.c_int, [vp]),
     "rolo_get_voxels": (C.c_int, [vp, ip, ip, dp, dp]),

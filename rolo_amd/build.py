@@ -12,7 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librolo_hip.so")
-SOURCES = ["api.hip", "knn_cov.hip", "voxelmap.hip", "passes.hip", "misc.hip", "front.hip", "odometry.hip", "fusion.hip"]
+SOURCES = ["api.hip", "knn_cov.hip", "voxelmap.hip", "passes.hip", "misc.hip", "front.hip", "odometry.hip", "fusion.hip", "scan2map.hip"]
 HEADERS = ["rolo_internal.hpp", "dev_math.hpp", "voxel_dev.hpp", "knn_walk.hpp", os.path.join("..", "..", "include", "rolo_hip.h"),
            os.path.join("..", "..", "include", "rolo_fusion.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -23,7 +23,7 @@ FLAGS = os.environ.get("ROLO_EXTRA_FLAGS", "").split() + ["--offload-arch=gfx950
 # float32 paths whose results must be bit-identical to the CPU statement (kNN distances and their pruning bounds,
 # pcl::transformPointCloud, range-image projection, curvature): no FMA contraction (HIP's __fmul_rn/__fadd_rn are
 # plain operators that the compiler is otherwise free to fuse)
-EXTRA = {"knn_cov.hip": ["-ffp-contract=off"], "misc.hip": ["-ffp-contract=off"], "front.hip": ["-ffp-contract=off", "-O2"]}  # -O2: hipcc 7.2 -O3 hits "Illegal instruction detected" in the backend on this file
+EXTRA = {"knn_cov.hip": ["-ffp-contract=off"], "scan2map.hip": ["-ffp-contract=off"], "misc.hip": ["-ffp-contract=off"], "front.hip": ["-ffp-contract=off", "-O2"]}  # -O2: hipcc 7.2 -O3 hits "Illegal instruction detected" in the backend on this file
 
 
 def _stale(out, deps):

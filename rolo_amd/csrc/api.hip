@@ -194,8 +194,8 @@ int upload_cloud(rolo_ctx* c, CloudDev& cl, size_t& xyz_cap, const float* pts, i
 }
 
 // search structures of one cloud: geometry + allocations
-int prepare_cloud(rolo_ctx* c, CloudDev& cl, size_t& cov_cap, size_t& sorted_cap, size_t& boxes_cap, size_t& knn_cap, size_t& knnd_cap, KnnCloud& out) {
-  const int n = cl.n, k = c->P.k_correspondences;
+int prepare_cloud(rolo_ctx* c, CloudDev& cl, size_t& cov_cap, size_t& sorted_cap, size_t& boxes_cap, size_t& knn_cap, size_t& knnd_cap, KnnCloud& out, bool tree_only = false) {
+  const int n = cl.n, k = tree_only ? 1 : c->P.k_correspondences;
   if (k < 1 || k > 32) { g_err = "k_correspondences must be in [1,32]"; return ROLO_EUNSUPPORTED; }
   if (n < k) { g_err = "cloud has fewer points than k_correspondences"; return ROLO_ETOOFEW; }
   cl.n_leaves = (n + KNN_LEAF - 1) / KNN_LEAF;
@@ -218,11 +218,11 @@ int prepare_cloud(rolo_ctx* c, CloudDev& cl, size_t& cov_cap, size_t& sorted_cap
 
 // Morton sort, BVH, neighbour search and covariances of the source and / or the target in ONE chain of launches.
 // A pair shares the scratch set 0; a lone target uses set 1 so that it can run next to a lone source on another stream.
-int build_clouds(rolo_ctx* c, bool do_src, bool do_tgt, hipStream_t stream) {
+int build_clouds(rolo_ctx* c, bool do_src, bool do_tgt, hipStream_t stream, bool tree_only = false, KnnPair* out_pair = nullptr) {
   KnnPair A{};
   int rc, nc = 0;
-  if (do_src) { if ((rc = prepare_cloud(c, c->src, c->src_cov_cap, c->src_sorted_cap, c->src_boxes_cap, c->src_knn_cap, c->src_knnd_cap, A.c[nc]))) return rc; nc++; }
-  if (do_tgt) { if ((rc = prepare_cloud(c, c->tgt, c->tgt_cov_cap, c->tgt_sorted_cap, c->tgt_boxes_cap, c->tgt_knn_cap, c->tgt_knnd_cap, A.c[nc]))) return rc; nc++; }
+  if (do_src) { if ((rc = prepare_cloud(c, c->src, c->src_cov_cap, c->src_sorted_cap, c->src_boxes_cap, c->src_knn_cap, c->src_knnd_cap, A.c[nc], tree_only))) return rc; nc++; }
+  if (do_tgt) { if ((rc = prepare_cloud(c, c->tgt, c->tgt_cov_cap, c->tgt_sorted_cap, c->tgt_boxes_cap, c->tgt_knn_cap, c->tgt_knnd_cap, A.c[nc], tree_only))) return rc; nc++; }
   if (nc == 0) return ROLO_OK;
   A.n_clouds = nc;
   const size_t n_total = (size_t)A.c[0].n + (nc > 1 ? (size_t)A.c[1].n : 0);
@@ -258,6 +258,12 @@ int build_clouds(rolo_ctx* c, bool do_src, bool do_tgt, hipStream_t stream) {
   if (c->src.bbox6 >= S.bbox && c->src.bbox6 < S.bbox + 12) c->src.bbox6 = nullptr;
   if (c->tgt.bbox6 >= S.bbox && c->tgt.bbox6 < S.bbox + 12) c->tgt.bbox6 = nullptr;
   { ProfScope ps(c, ROLO_PROF_KNN_BUILD, stream); HIPCHK(launch_knn_build(A, S.sort_tmp, tmp, S.keys0, S.keys1, S.vals0, S.vals1, S.bbox, stream)); }
+  if (out_pair) *out_pair = A;
+  if (tree_only) {   // Hilbert sort + BVH only (scan-to-submap association searches it with foreign queries); no covariances
+    if (do_src) { c->src.have_sorted = true; c->src.have_cov = false; c->src.bbox6 = S.bbox; }
+    if (do_tgt) { c->tgt.have_sorted = true; c->tgt.have_cov = false; c->tgt.bbox6 = S.bbox + (do_src ? 6 : 0); }
+    return ROLO_OK;
+  }
   { ProfScope ps(c, ROLO_PROF_KNN_WALK, stream); HIPCHK(launch_knn_walk(A, c->P.k_correspondences, stream)); }
   { ProfScope ps(c, ROLO_PROF_KNN_TAIL, stream); HIPCHK(launch_knn_tail(A, c->P.k_correspondences, c->P.regularization, stream)); }
   if (sharded) {
@@ -464,6 +470,14 @@ hipStream_t ctx_stream(rolo_ctx* c) { return c->stream; }
 int ctx_device(rolo_ctx* c) { return c->device; }
 void ctx_set_error(const char* msg) { g_err = msg ? msg : ""; }
 void ctx_set_fused_lm(rolo_ctx* c, int on) { c->P.fused_lm = on ? 1 : 0; }
+// scan2map.hip: the two sub-map clouds (corner, surface) as the context's source / target with their search trees built
+int ctx_build_map_trees(rolo_ctx* c, const float* corner, int nc, const float* surf, int ns, int stride, KnnPair* out) {
+  int rc = set_device(c); if (rc) return rc;
+  if ((rc = upload_cloud(c, c->src, c->src_xyz_cap, corner, nc, stride, false))) return rc;
+  if ((rc = upload_cloud(c, c->tgt, c->tgt_xyz_cap, surf, ns, stride, false))) return rc;
+  c->have_map = false; c->have_corr = false;
+  return build_clouds(c, true, true, c->stream, true, out);
+}
 }  // namespace rolo
 
 extern "C" {

@@ -19,7 +19,7 @@
 namespace rolo {
 namespace {
 
-constexpr int WALK_STACK = 64;   // one lane per slot
+constexpr int WALK_STACK = 48;
 
 // Workgroup b of a launch runs on XCD b % 8 (round-robin dispatch), each XCD with its own 4 MB L2. Neighbouring packets of the
 // Hilbert-sorted cloud read the same leaves and boxes, so give every XCD a CONTIGUOUS eighth of the packets: what one wavefront
@@ -101,6 +101,7 @@ ROLO_DEV void knn_score_leaf(const float4* __restrict__ sorted, int g, const flo
 // go to A.c[].nbr, slot-major so every store is coalesced; knn_tail_kernel turns them into covariances.
 template <int KMAX>
 __global__ __launch_bounds__(256, 8) void knn_walk_kernel(KnnPair A, int split, int k) {
+  __shared__ int stk[4][WALK_STACK];
   const int tid = threadIdx.x;
   const int wv = tid >> 6;
   // which cloud of the pair this workgroup searches (wave-uniform: everything below stays in scalar registers)
@@ -136,9 +137,8 @@ __global__ __launch_bounds__(256, 8) void knn_walk_kernel(KnnPair A, int split, 
   for (int g = g_own0; g < g_own1; g++) { knn_score_leaf<KMAX>(sorted, g, q, K, kk, bkey, bd, st_ins, st_lane, st_rounds); st_leaves++; }
 
   // ---- packet walk ----
-  // the per-wave stack lives in ONE vector register — slot i in lane i, v_writelane / v_readlane with the wave-uniform stack pointer —
-  // instead of LDS: no ds_write / ds_read round trips, and no lgkmcnt coupling between stack traffic and the scalar fetches
-  int stack_v = 0;
+  // (a stack in one vector register — slot i in lane i, v_writelane / v_readlane — measured the same as this LDS stack: 0.202 vs 0.200 ms;
+  // gfx950's v_writelane takes its lane select from M0 when the value is an SGPR, which inline asm may not clobber safely)
   int sp = 0;
   int h = 1;
   while (true) {
@@ -154,11 +154,7 @@ __global__ __launch_bounds__(256, 8) void knn_walk_kernel(KnnPair A, int split, 
         // radius decides" rule needed a 6-step cross-lane max per node and did not reduce the nodes visited)
         const unsigned long long pref = __ballot((okl || okr) && (bl <= br));
         const bool left_first = 2 * __popcll(pref) >= __popcll(ml | mr);
-        if (sp < WALK_STACK) {
-          const int far_child = __builtin_amdgcn_readfirstlane(left_first ? 2 * h + 1 : 2 * h);
-          asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(stack_v) : "s"(far_child), "s"(sp) : "m0");   // one SGPR + M0: constant-bus rule
-          sp++;
-        }
+        if (sp < WALK_STACK) { stk[wv][sp] = left_first ? 2 * h + 1 : 2 * h; sp++; }
         h = left_first ? 2 * h : 2 * h + 1;
         continue;
       }
@@ -170,7 +166,7 @@ __global__ __launch_bounds__(256, 8) void knn_walk_kernel(KnnPair A, int split, 
     }
     if (sp == 0) break;
     sp--;
-    h = __builtin_amdgcn_readlane(stack_v, sp);
+    h = stk[wv][sp];
   }
 #ifdef ROLO_KNN_STATS
   const long long t1 = clock64();

@@ -1,0 +1,64 @@
+"""GPU: SURVEY 8f.4 — the back end's scan-to-submap optimisation (rolo_scan2map_optimize) against the independent numpy twin
+(oracle/twin_backend.py) on feature clouds the oracle's front end extracts from synthetic frames: which points are selected, their
+point-to-line / point-to-plane coefficients, the number of Gauss-Newton iterations and the optimised pose (<= 1e-4 m, <= 1e-5 rad
+vs the twin), and the pose error against the ground truth of the synthetic trajectory."""
+import numpy as np
+import pytest
+from scipy.spatial.transform import Rotation
+
+from oracle import pyorc, twin_backend
+from rolo_amd import synth
+from rolo_amd.backend import Scan2Map
+
+pytestmark = pytest.mark.gpu
+
+
+def features(sensor, cfg, R, t, seed):
+    fo = pyorc.front_params(**cfg)
+    fr = synth.make_frame(sensor, R, t, seed)
+    e = pyorc.extract_features(fo, pyorc.project(fo, fr.xyz, fr.ring))
+    return e["corner"], e["surface"]
+
+
+def to_world(pts, R, t):
+    o = pts.copy(); o[:, :3] = (pts[:, :3].astype(np.float64) @ R.T + t).astype(np.float32)
+    return o
+
+
+@pytest.mark.parametrize("sensor,cfg", [("vlp16", dict(n_scan=16, horizon_scan=1800)), ("os1-64", dict(n_scan=64, horizon_scan=1024))])
+def test_scan2map_matches_twin_and_recovers_the_pose(sensor, cfg):
+    # sub-map: the features of two key frames in the map frame; scan: a third frame at a known pose
+    poses = [(np.eye(3), np.zeros(3)), (synth.rpy_to_R(0.002, -0.003, 0.03), np.array([0.4, 0.03, 0.0])),
+             (synth.rpy_to_R(0.004, -0.002, 0.06), np.array([0.8, 0.08, 0.01]))]
+    mc, ms = [], []
+    for k in range(2):
+        c, s = features(sensor, cfg, *poses[k], synth.SEED + k)
+        mc.append(to_world(c, *poses[k])); ms.append(to_world(s, *poses[k]))
+    mc = np.concatenate(mc); ms = np.concatenate(ms)
+    corner, surf = features(sensor, cfg, *poses[2], synth.SEED + 2)
+    R2, t2 = poses[2]
+    rpy = Rotation.from_matrix(R2).as_euler("xyz")
+    truth = np.concatenate([rpy, t2]).astype(np.float32)
+    guess = (truth + np.array([0.004, -0.003, 0.01, 0.06, -0.04, 0.02], np.float32)).astype(np.float32)
+
+    g = Scan2Map()
+    tf_g, sel_g, co_g = g.scan2MapOptimization(corner, surf, mc, ms, guess, want_debug=True)
+    tf_t, st_t, sel_t, co_t = twin_backend.scan2map(corner, surf, mc, ms, guess)
+    st = g.last_stats
+    assert st.skipped == 0 and st_t["skipped"] == 0
+    assert st.converged == st_t["converged"] == 1 and st.degenerate == st_t["degenerate"]
+    assert abs(st.iterations - st_t["iterations"]) <= 1
+    # the last iteration's association: the same points selected but for threshold-borderline cases (float fits on two different
+    # eigen / least-squares routines), the same coefficients on the common ones
+    both = sel_g & sel_t
+    assert (sel_g != sel_t).mean() < 5e-3 and both.sum() > 0.5 * len(sel_t)
+    assert np.abs(np.abs(co_g[both]) - np.abs(co_t[both])).max() < 2e-3 and np.median(np.abs(co_g[both] - co_t[both])) < 1e-5
+    assert np.abs(tf_g[3:] - tf_t[3:]).max() <= 1e-4 and np.abs(tf_g[:3] - tf_t[:3]).max() <= 1e-5
+    # and it is the right pose: the perturbation is removed to the level the synthetic noise allows
+    assert np.abs(tf_g[3:] - truth[3:]).max() < 0.03 and np.abs(tf_g[:3] - truth[:3]).max() < 3e-3
+    assert np.abs(guess[3:] - truth[3:]).max() > 0.05
+
+    # too few features: nothing happens (backMapping.cpp:689, 708)
+    tf_s = g.scan2MapOptimization(corner[:5], surf, mc, ms, guess)
+    assert g.last_stats.skipped == 1 and np.array_equal(tf_s, guess)
+    g.close()
