@@ -452,7 +452,9 @@ def main():
         if os.path.exists(pmc) and args.sensor == "os1-128":
             tr = json.load(open(pmc))
             nfr = max(tr.get("knn_walk_kernel", {}).get("launches", 0), 1)
-            fabric = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in tr.values() if isinstance(v, dict) and "launches" in v) / nfr
+            # (the 1 GiB device-to-device copies of this script's own HBM copy test show up as __amd_rocclr_copyBuffer: not part of a frame)
+            fabric = sum(v["hbm_bytes_per_launch"] * v["launches"] for k, v in tr.items()
+                         if isinstance(v, dict) and "launches" in v and not k.startswith("__amd_rocclr_copyBuffer")) / nfr
             fh.update({"fabric_bytes_per_frame": fabric, "achieved_fabric_GBps": fabric * value / 1e9, "frac_fabric": fabric * value / 1e9 / (HBM_PEAK_GBS * world),
                        "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of a single-context eager run, not this run)"})
         out["frame_hbm"] = fh
