@@ -439,8 +439,10 @@ ROLO_DEV void so3_exp_R(const double* w, double* R) {  // so3.hpp:59-77 + Quater
     real = 1.0 - 1.0 / 8.0 * theta_sq + 1.0 / 384.0 * q4;
   } else {
     const double theta = sqrt(theta_sq), half = 0.5 * theta;
-    imag = sin(half) / theta;
-    real = cos(half);
+    double sh, ch;
+    sincos(half, &sh, &ch);
+    imag = sh / theta;
+    real = ch;
   }
   const double qw = real, qx = imag * w[0], qy = imag * w[1], qz = imag * w[2];
   const double tx = 2 * qx, ty = 2 * qy, tz = 2 * qz;
@@ -468,35 +470,51 @@ ROLO_DEV void se3_exp_Rt(const double* a, double* R, double* t) {  // so3.hpp:80
   for (int i = 0; i < 3; i++) t[i] = V[i * 3] * a[3] + V[i * 3 + 1] * a[4] + V[i * 3 + 2] * a[5];
 }
 
-ROLO_DEV void unpack_hb(LmState* st, const double* S, int dof) {
+// (everything the controller runs is templated on the degrees of freedom: with a run-time count the loops below stay loops of dependent
+// LDS accesses on ONE lane, and that lane's latency is the controller's whole duration)
+template <int DOF>
+ROLO_DEV void unpack_hb(LmState* __restrict__ st, const double* __restrict__ S) {
   int t = 0;
-  for (int i = 0; i < dof; i++) for (int j = 0; j <= i; j++) { st->H[i * 6 + j] = S[V_H + t]; st->H[j * 6 + i] = S[V_H + t]; t++; }
-  for (int i = 0; i < dof; i++) st->b[i] = S[V_B + i];
+#pragma unroll
+  for (int i = 0; i < DOF; i++) {
+#pragma unroll
+    for (int j = 0; j <= i; j++) { const double v = S[V_H + t]; st->H[i * 6 + j] = v; st->H[j * 6 + i] = v; t++; }
+  }
+#pragma unroll
+  for (int i = 0; i < DOF; i++) st->b[i] = S[V_B + i];
   st->y0 = S[V_Y];
   st->n_corr = (int)(S[V_N] + 0.5);
 }
 
-ROLO_DEV void trace_push(LmState* st, rolo_trace_rec* trace, int stage, int accepted, double yi, double rho, int dof) {
+template <int DOF>
+ROLO_DEV void trace_push(LmState* __restrict__ st, rolo_trace_rec* __restrict__ trace, int stage, int accepted, double yi, double rho) {
   if (!trace || st->trace_count >= TRACE_CAP) { st->trace_count++; return; }
   rolo_trace_rec& r = trace[st->trace_count++];
   r.stage = stage; r.outer = st->outer; r.trial = st->trial; r.accepted = accepted;
   r.y0 = st->y0; r.yi = yi; r.rho = rho; r.lambda = st->lambda;
-  double dn = 0; for (int i = 0; i < dof; i++) dn += st->d[i] * st->d[i];
+  double dn = 0;
+#pragma unroll
+  for (int i = 0; i < DOF; i++) dn += st->d[i] * st->d[i];
   r.dnorm = sqrt(dn);
 }
 
 // ---- rotation / 6-dof stage -------------------------------------------------------------------------------
-ROLO_DEV bool delta_converged(const LmState* st, bool rot_only) {  // lsq_registration_impl.hpp:182-191 / :328-335
+ROLO_DEV bool delta_converged(const LmState* __restrict__ st, bool rot_only) {  // lsq_registration_impl.hpp:182-191 / :328-335
+  const double ir = 1.0 / st->rot_eps;   // (1.0 / eps) * |.| as the reference writes it; the quotient is formed once
   double rmax = 0;
-  for (int i = 0; i < 9; i++) rmax = fmax(rmax, 1.0 / st->rot_eps * fabs(st->delta_R[i] - ((i % 4 == 0) ? 1.0 : 0.0)));
+#pragma unroll
+  for (int i = 0; i < 9; i++) rmax = fmax(rmax, ir * fabs(st->delta_R[i] - ((i % 4 == 0) ? 1.0 : 0.0)));
   if (rot_only) return rmax < 1;
+  const double it = 1.0 / st->trans_eps;
   double tmax = 0;
-  for (int i = 0; i < 3; i++) tmax = fmax(tmax, 1.0 / st->trans_eps * fabs(st->delta_t[i]));
+#pragma unroll
+  for (int i = 0; i < 3; i++) tmax = fmax(tmax, it * fabs(st->delta_t[i]));
   return fmax(rmax, tmax) < 1;
 }
 
-ROLO_DEV void rot_compute_step(LmState* st, int dof) {
-  if (dof == 3) {
+template <int DOF>
+ROLO_DEV void rot_compute_step(LmState* __restrict__ st) {
+  if constexpr (DOF == 3) {
     ldlt_solve<3>(st->H, st->lambda, st->b, st->d);
     st->d[3] = st->d[4] = st->d[5] = 0;
     so3_exp_R(st->d, st->delta_R);
@@ -506,20 +524,25 @@ ROLO_DEV void rot_compute_step(LmState* st, int dof) {
     se3_exp_Rt(st->d, st->delta_R, st->delta_t);
   }
   // xi = delta * x0
+#pragma unroll
   for (int i = 0; i < 3; i++) {
+#pragma unroll
     for (int j = 0; j < 3; j++) st->xt_R[i * 3 + j] = st->delta_R[i * 3] * st->x0_R[j] + st->delta_R[i * 3 + 1] * st->x0_R[3 + j] + st->delta_R[i * 3 + 2] * st->x0_R[6 + j];
     st->xt_t[i] = st->delta_R[i * 3] * st->x0_t[0] + st->delta_R[i * 3 + 1] * st->x0_t[1] + st->delta_R[i * 3 + 2] * st->x0_t[2] + st->delta_t[i];
   }
 }
 
-ROLO_DEV void rot_begin_outer(LmState* st, int dof) {
+template <int DOF>
+ROLO_DEV void rot_begin_outer(LmState* __restrict__ st) {
   if (st->optimizer == ROLO_OPT_GN) st->lambda = 0.0;
   else if (st->lambda < 0.0) {
-    double m = 0; for (int i = 0; i < dof; i++) m = fmax(m, fabs(st->H[i * 7]));
+    double m = 0;
+#pragma unroll
+    for (int i = 0; i < DOF; i++) m = fmax(m, fabs(st->H[i * 7]));
     st->lambda = st->lm_init * m;
   }
   st->nu = 2.0; st->trial = 0;
-  rot_compute_step(st, dof);
+  rot_compute_step<DOF>(st);
 }
 
 ROLO_DEV void trans_compute_step(LmState* st) {
@@ -549,42 +572,44 @@ ROLO_DEV void rot_finish(LmState* st, bool converged, bool failed) {
   else st->stage = 0;
 }
 
-ROLO_DEV void rot_step(LmState* st, const double* S, rolo_trace_rec* trace) {
-  const int dof = (st->optimizer == ROLO_OPT_SO3_LM) ? 3 : 6;
+template <int DOF>
+ROLO_DEV void rot_step_t(LmState* __restrict__ st, const double* __restrict__ S, rolo_trace_rec* __restrict__ trace) {
+  constexpr int dof = DOF;
   st->rot_passes++;
   if (st->phase == 0) {
     for (int i = 0; i < 9; i++) st->x0_R[i] = st->xt_R[i];
     for (int i = 0; i < 3; i++) st->x0_t[i] = st->xt_t[i];
-    unpack_hb(st, S, dof);
+    unpack_hb<DOF>(st, S);
     st->tr_cur = st->cur; st->tr_n_corr = st->n_corr;
     for (int i = 0; i < 9; i++) st->tr_R[i] = st->x0_R[i];
     if (st->n_corr <= 0) { st->error = ROLO_ENOCORR; rot_finish(st, false, true); return; }
     st->phase = 1;
-    rot_begin_outer(st, dof);
+    rot_begin_outer<DOF>(st);
     return;
   }
   const double yi = S[V_YI];
   double den = 0;
+#pragma unroll
   for (int i = 0; i < dof; i++) den += st->d[i] * (st->lambda * st->d[i] - st->b[i]);
   const double rho = (st->y0 - yi) / den;
   const bool gn = st->optimizer == ROLO_OPT_GN;
   if (!gn && rho < 0) {
     if (delta_converged(st, dof == 3)) {  // returns true without moving x0
-      trace_push(st, trace, 0, 2, yi, rho, dof);
+      trace_push<DOF>(st, trace, 0, 2, yi, rho);
       st->outer++;
       const bool done = st->fixed_iterations > 0 ? (st->outer >= st->fixed_iterations) : true;
       if (done) { rot_finish(st, true, false); return; }
-      rot_begin_outer(st, dof);  // the reference re-linearises at the same x0: identical H, b, y0, correspondences
+      rot_begin_outer<DOF>(st);  // the reference re-linearises at the same x0: identical H, b, y0, correspondences
       return;
     }
-    trace_push(st, trace, 0, 0, yi, rho, dof);
+    trace_push<DOF>(st, trace, 0, 0, yi, rho);
     st->lambda = st->nu * st->lambda; st->nu = 2 * st->nu;
     st->trial++;
     if (st->trial >= st->lm_max) { rot_finish(st, false, true); return; }  // "lm not converged!!"
-    rot_compute_step(st, dof);
+    rot_compute_step<DOF>(st);
     return;
   }
-  trace_push(st, trace, 0, 1, gn ? NAN : yi, gn ? NAN : rho, dof);
+  trace_push<DOF>(st, trace, 0, 1, gn ? NAN : yi, gn ? NAN : rho);
   for (int i = 0; i < 9; i++) st->x0_R[i] = st->xt_R[i];
   for (int i = 0; i < 3; i++) st->x0_t[i] = st->xt_t[i];
   if (!gn) { const double q = 2 * rho - 1; st->lambda = st->lambda * fmax(1.0 / 3.0, 1 - q * q * q); }
@@ -594,28 +619,35 @@ ROLO_DEV void rot_step(LmState* st, const double* S, rolo_trace_rec* trace) {
   const bool done = st->fixed_iterations > 0 ? (st->outer >= st->fixed_iterations) : (conv || st->outer >= st->max_iterations);
   if (done) { rot_finish(st, conv, false); return; }
   // next outer iteration: the (B) half of this pass IS so3_linearize(x0_new)
-  unpack_hb(st, S, dof);
+  unpack_hb<DOF>(st, S);
   st->cur ^= 1;
   st->tr_cur = st->cur; st->tr_n_corr = st->n_corr;
   for (int i = 0; i < 9; i++) st->tr_R[i] = st->x0_R[i];
   if (st->n_corr <= 0) { st->error = ROLO_ENOCORR; rot_finish(st, false, true); return; }
-  rot_begin_outer(st, dof);
+  rot_begin_outer<DOF>(st);
 }
 
-ROLO_DEV bool t_converged(const LmState* st) {  // :142-148
+ROLO_DEV void rot_step(LmState* __restrict__ st, const double* __restrict__ S, rolo_trace_rec* __restrict__ trace) {
+  if (st->optimizer == ROLO_OPT_SO3_LM) rot_step_t<3>(st, S, trace);
+  else rot_step_t<6>(st, S, trace);
+}
+
+ROLO_DEV bool t_converged(const LmState* __restrict__ st) {  // :142-148
+  const double it = 1.0 / st->trans_eps;
   double m = 0;
-  for (int i = 0; i < 3; i++) m = fmax(m, 1.0 / st->trans_eps * fabs(st->delta_t[i]));
+#pragma unroll
+  for (int i = 0; i < 3; i++) m = fmax(m, it * fabs(st->delta_t[i]));
   return m < 1;
 }
 ROLO_DEV void trans_finish(LmState* st, bool failed) {
   st->trans_done = 1; st->trans_failed = failed ? 1 : 0; st->trans_outer = st->outer; st->stage = 0;
 }
 
-ROLO_DEV void trans_step(LmState* st, const double* S, rolo_trace_rec* trace) {
+ROLO_DEV void trans_step(LmState* __restrict__ st, const double* __restrict__ S, rolo_trace_rec* __restrict__ trace) {
   st->trans_passes++;
   if (st->phase == 0) {
     const int keep = st->n_corr;
-    unpack_hb(st, S, 6);
+    unpack_hb<6>(st, S);
     st->n_corr = keep;
     st->phase = 1;
     trans_begin_outer(st);
@@ -623,25 +655,26 @@ ROLO_DEV void trans_step(LmState* st, const double* S, rolo_trace_rec* trace) {
   }
   const double yi = S[V_YI];
   double den = 0;
+#pragma unroll
   for (int i = 0; i < 6; i++) den += st->d[i] * (st->lambda * st->d[i] - st->b[i]);
   const double rho = (st->y0 - yi) / den;
   if (rho < 0) {
-    if (t_converged(st)) { trace_push(st, trace, 1, 2, yi, rho, 6); st->outer++; trans_finish(st, false); return; }
-    trace_push(st, trace, 1, 0, yi, rho, 6);
+    if (t_converged(st)) { trace_push<6>(st, trace, 1, 2, yi, rho); st->outer++; trans_finish(st, false); return; }
+    trace_push<6>(st, trace, 1, 0, yi, rho);
     st->lambda = st->nu * st->lambda; st->nu = 2 * st->nu;
     st->trial++;
     if (st->trial >= st->lm_max) { trans_finish(st, true); return; }
     trans_compute_step(st);
     return;
   }
-  trace_push(st, trace, 1, 1, yi, rho, 6);
+  trace_push<6>(st, trace, 1, 1, yi, rho);
   for (int i = 0; i < 3; i++) st->t0[i] = st->tt[i];
   { const double q = 2 * rho - 1; st->lambda = st->lambda * fmax(1.0 / 3.0, 1 - q * q * q); }
   st->outer++;
   const bool conv = t_converged(st);
   if (conv || st->outer >= st->max_iterations) { trans_finish(st, false); return; }
   const int keep = st->n_corr;
-  unpack_hb(st, S, 6);
+  unpack_hb<6>(st, S);
   st->n_corr = keep;
   trans_begin_outer(st);
 }
