@@ -463,6 +463,8 @@ def main():
 
     # ---- measured-achievable HBM rate next to the nominal peak: device-to-device copy of 1 GiB ----
     try:
+        if args.single_round:
+            raise RuntimeError("skipped in profiling runs")   # keeps the 1 GiB copies out of the rocprofv3 summaries
         a = torch.empty(1 << 30, dtype=torch.uint8, device="cuda"); b = torch.empty_like(a)
         b.copy_(a); torch.cuda.synchronize()
         t0 = time.perf_counter()

@@ -52,6 +52,7 @@ def roofline(g, run_one_step, n_src, n_tgt, passes_per_frame, hbm_peak_gbs, reps
     trans_real = g.last_translation_stats.n_passes
     per_frame_ms = {}
     avg_ms = {}
+    real_runs = {}
     for k, runs in acc.items():
         real = []
         for r in runs:
@@ -62,14 +63,21 @@ def roofline(g, run_one_step, n_src, n_tgt, passes_per_frame, hbm_peak_gbs, reps
             elif k == "lm_pass":
                 r = r[:rot_real + trans_real + 1]   # + the launch that finishes the last trial
             real.append(r)
+        real_runs[k] = real
         per_frame_ms[k] = float(np.mean([r.sum() for r in real])) if real else 0.0
         allv = np.concatenate(real) if real else np.zeros(0)
         avg_ms[k] = float(allv.mean()) if allv.size else 0.0
-    # dominant kernel = largest share of the frame's GPU time among ALL timed slots (controller and tree build included)
+    # top-3 = largest shares of the frame's GPU time among ALL timed slots (controller and tree build included). The roofline object is
+    # for the top kernel that MOVES algorithmic bytes (the controller moves none: it is pure overhead and is listed, not put on a roofline).
+    # An event pair around a sub-10 us launch also times the launch gap (rot_pass: 6.9 us in rocprofv3, 9.7 us between events), so the
+    # ranking of the byte-moving kernels charges every launch 2.7 us less; the reported durations stay the raw event times.
     total = sum(per_frame_ms.values()) or 1.0
     rank = sorted(per_frame_ms, key=per_frame_ms.get, reverse=True)
-    top3 = [{"kernel": k + "_kernel", "per_frame_ms": per_frame_ms[k], "share_of_timed_slots": per_frame_ms[k] / total} for k in rank[:3]]
-    dom = rank[0]
+    top3 = [{"kernel": k + "_kernel", "per_frame_ms": per_frame_ms[k], "share_of_timed_slots": per_frame_ms[k] / total,
+             "algorithmic_bytes_per_point": BYTES_PER_POINT.get(k, 0.0)} for k in rank[:3]]
+    launches_per_frame = {k: float(np.mean([len(r) for r in real_runs[k]])) if real_runs.get(k) else 0.0 for k in per_frame_ms}
+    movers = [k for k in per_frame_ms if BYTES_PER_POINT.get(k, 0.0) > 0.0]
+    dom = max(movers, key=lambda k: per_frame_ms[k] - 0.0027 * launches_per_frame[k])
     if dom in ("knn_walk", "knn_tail", "knn_build"):
         # one launch works on one cloud, or on the source/target pair of a frame (overlap_knn)
         launches = np.mean([len(r) for r in acc[dom]]) if acc[dom] else 2.0
