@@ -12,10 +12,11 @@
 //       pass adds the ring offsets and scatters (x,y,z,intensity), column and range — coalesced on both sides;
 //   K3  a stencil kernel (11-tap float sum in the reference's written order) plus a mark kernel — the marks only
 //       ever store 1 and depend only on ranges / columns, so the serial loop is order-free;
-//   K4  one workgroup per ring, everything for the ring staged in LDS: per sector a bitonic sort of packed
-//       (curvature bits << 32 | index) keys, then the inherently serial greedy corner / surface picks run on one lane
-//       against LDS (they are a few hundred LDS-latency steps), the label<=0 collection is a block compaction, and
-//       pcl::VoxelGrid is a second bitonic sort of (cell << 32 | order) keys followed by per-run centroids.
+//   K4  one workgroup of 1024 threads per ring, everything for the ring staged in LDS: all six sectors in one segmented bitonic sort of
+//       packed (curvature bits << 32 | index) keys; the greedy corner / surface picks — a serial walk in the reference — as the equivalent
+//       fixed point "picked iff no better-ranked candidate that reaches it is picked", every lane owning a position, a few rounds per
+//       sector (only the two sectors touching the cloud ends keep the serial walk); the label<=0 collection is a ballot
+//       compaction, and pcl::VoxelGrid is a second bitonic sort of (cell << 32 | order) keys followed by per-run centroids.
 // fp32 arithmetic follows the reference expression by expression; this file is compiled with -ffp-contract=off.
 #include "rolo_internal.hpp"
 #include <atomic>

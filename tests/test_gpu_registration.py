@@ -569,3 +569,28 @@ def test_rccl_path_on_one_rank():
     T = np.eye(4); T[:3, :3] = synth.rpy_to_R(0.003, -0.002, 0.01)
     e1, H1, b1 = g.so3_linearize(T); e0, H0, b0 = ref.so3_linearize(T)
     assert abs(e1 - e0) <= 1e-11 * abs(e0) and np.abs(H1 - H0).max() <= 1e-11 * np.abs(H0).max()
+
+
+@pytest.mark.parametrize("optimizer", [1, 0])   # 6-dof LevenbergMarquardt, GaussNewton
+def test_ill_conditioned_normal_equations_match_the_pivoted_solve(optimizer):
+    """The device controller solves (H + lambda I) d = -b with an UNPIVOTED LDL^T in registers; the reference (and the oracle) use Eigen's
+    pivoted LDLT. A single noisy plane barely constrains the in-plane motion: the 6 x 6 H of the 6-dof optimisers has a condition number
+    above 1e5 (plane-normal against in-plane weights, metres against radians), the solve takes 22 outer iterations — and the two
+    factorisations must still walk the same path: same number of iterations, same accept / reject decisions, same pose to far below the bars."""
+    g0 = np.random.default_rng(7)
+    n = 6000
+    xy = g0.uniform(-20, 20, (n, 2))
+    tgt = np.c_[xy, 0.02 * g0.standard_normal(n), np.ones(n)].astype(np.float32)
+    R = synth.rpy_to_R(0.004, -0.006, 0.01)
+    src = tgt.copy(); src[:, :3] = (tgt[:, :3].astype(np.float64) @ R.T).astype(np.float32) + 0.01 * g0.standard_normal((n, 3)).astype(np.float32)
+    src[:, :3] += np.float32([0.02, -0.01, 0.03])
+    cfg = dict(voxel_type=1, polar=(0.175, 0.175, 2.0), leaf=2.0)
+    o, g = make_both(src, tgt, cfg, optimizer=optimizer)
+    rc, Tf_o, Td_o, it_o, cv_o = o.align()
+    g.align(); Td_g = g.final_transformation_d
+    e, H, b = o.linearize(np.eye(4))
+    assert np.linalg.cond(H) > 1e5
+    assert rc == 0 and g.last_stats.n_outer == it_o and it_o > 10
+    assert rot_angle(Td_g[:3, :3], Td_o[:3, :3]) < 1e-8 and np.abs(Td_g[:3, 3] - Td_o[:3, 3]).max() < 1e-7
+    tg, to = g.trace(), o.trace()
+    assert len(tg) == len(to) and [r["accepted"] for r in tg] == [r["accepted"] for r in to]
