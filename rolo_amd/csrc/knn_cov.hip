@@ -33,9 +33,10 @@ ROLO_DEV float ord2f(int k) { int i = k >= 0 ? k : k ^ 0x7fffffff; return __int_
 // with n_clouds = 1.
 constexpr int BBOX_BLOCKS = 64;
 
-__global__ void bbox_init_kernel(int* bbox) {  // 2 clouds x (min xyz, max xyz)
-  const int t = threadIdx.x;
+__global__ __launch_bounds__(1024) void bbox_init_kernel(int* bbox, int* sort_cnt, int n_cnt) {  // 2 clouds x (min xyz, max xyz); the sort's digit counters
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t < 12) bbox[t] = (t % 6) < 3 ? INT_MAX : INT_MIN;
+  for (int k = t; k < n_cnt; k += gridDim.x * blockDim.x) sort_cnt[k] = 0;
 }
 
 __global__ __launch_bounds__(256) void bbox_kernel(KnnPair A, int* bbox) {
@@ -105,7 +106,99 @@ ROLO_DEV uint32_t hilbert30(uint32_t x, uint32_t y, uint32_t z) {
 
 // keys: 30-bit Morton code + the cloud number in bit 30, so one sort of both clouds leaves each cloud sorted in its own
 // range [0, n0) / [n0, n0 + n1) of the arrays
-__global__ __launch_bounds__(256) void morton_kernel(KnnPair A, int split, const int* __restrict__ bbox, uint32_t* keys, uint32_t* vals) {
+// ---- key sort: a stable LSD radix sort in four 8-bit passes, written for this path (round 1 used rocPRIM's merge sort: 17 launches) --------
+// The keys are <= 31 bits and there are at most a few hundred thousand of them, so the array is cut into SORT_NB = 64 tiles, one 1024-thread
+// workgroup each. A pass is ONE launch: the workgroup of tile b reads the per-tile digit counts of this pass (64 x 256 counters: its scan is a
+// prologue, not a kernel), ranks its elements stably — waves own consecutive 64-element runs, equal digits inside a run are matched with 8
+// ballots, runs are ordered by a 16-step prefix per digit in LDS — and scatters keys and values. The digit counts of the NEXT pass are
+// collected by the scatter itself (one integer atomic per element on the counter of its destination tile; integer counts do not depend on
+// the order of arrival, so the result is deterministic), and those of the first pass by the key kernel: 1 + 4 launches in all, the
+// result identical to a stable sort by key (ties by original index) — what rocPRIM's radix_sort_pairs returned.
+constexpr int SORT_NB = 64, SORT_T = 1024;
+ROLO_DEV int sort_tile(int n_total) { return ((n_total + SORT_NB - 1) / SORT_NB + SORT_T - 1) / SORT_T * SORT_T; }
+
+constexpr int SORT_EPT = 4;   // elements per thread and round: a wave ranks 256 consecutive elements between two workgroup barriers
+__global__ __launch_bounds__(SORT_T) void sort_scatter_kernel(const uint32_t* __restrict__ kin, const uint32_t* __restrict__ vin, uint32_t* __restrict__ kout,
+                                                             uint32_t* __restrict__ vout, int n, int tile, int pass, int* __restrict__ cnt /* [4][SORT_NB][256] */) {
+  __shared__ int wcnt[SORT_T / 64][256];
+  __shared__ int base[256], run[256], wsum[4];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, blk = blockIdx.x;
+  const int* __restrict__ c = cnt + (size_t)pass * SORT_NB * 256;
+  for (int k = tid; k < (SORT_T / 64) * 256; k += SORT_T) (&wcnt[0][0])[k] = 0;
+  int t = 0;
+  if (tid < 256) {
+    int before = 0;
+    int v[SORT_NB];
+#pragma unroll
+    for (int b = 0; b < SORT_NB; b++) v[b] = c[b * 256 + tid];
+#pragma unroll
+    for (int b = 0; b < SORT_NB; b++) { t += v[b]; if (b < blk) before += v[b]; }
+    run[tid] = before;   // elements with this digit in earlier tiles (becomes the running offset inside the tile below)
+    // exclusive scan of the 256 digit totals: inside the wave by shuffles, across the four waves through LDS
+    int incl = t;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(incl, off, 64); if (lane >= off) incl += o; }
+    if (lane == 63) wsum[wv] = incl;
+    t = incl - t;   // exclusive inside the wave
+  }
+  __syncthreads();
+  if (tid < 256) { int add = 0; for (int w = 0; w < wv; w++) add += wsum[w]; base[tid] = t + add; }
+  __syncthreads();
+  const int shift = 8 * pass;
+  for (int r0 = 0; r0 < tile; r0 += SORT_T * SORT_EPT) {
+    // the wave's run of this round: 256 consecutive elements, lane-contiguous in SORT_EPT sub-rounds of 64
+    uint32_t key[SORT_EPT]; int off[SORT_EPT], e[SORT_EPT];
+#pragma unroll
+    for (int j = 0; j < SORT_EPT; j++) {
+      e[j] = blk * tile + r0 + (wv * SORT_EPT + j) * 64 + lane;
+      const bool valid = e[j] < n && (r0 + (wv * SORT_EPT + j) * 64 + lane) < tile;
+      key[j] = valid ? kin[e[j]] : 0u;
+      if (!valid) e[j] = -1;
+    }
+#pragma unroll
+    for (int j = 0; j < SORT_EPT; j++) {
+      const bool valid = e[j] >= 0;
+      const int d = (int)((key[j] >> shift) & 255u);
+      unsigned long long m = __ballot(valid);
+#pragma unroll
+      for (int bit = 0; bit < 8; bit++) {
+        const bool one = (d >> bit) & 1;
+        const unsigned long long bl = __ballot(one);
+        m &= one ? bl : ~bl;
+      }
+      const int rank = __popcll(m & ((1ull << lane) - 1ull));
+      int old = 0;
+      if (valid && rank == 0) { old = wcnt[wv][d]; wcnt[wv][d] = old + __popcll(m); }   // one leader per (wave, digit): no atomics needed
+      const int leader = valid ? __ffsll((long long)m) - 1 : lane;
+      old = __shfl(old, leader, 64);
+      off[j] = old + rank;   // position among this wave's elements of digit d so far
+    }
+    __syncthreads();
+    if (tid < 256) {
+      int acc = run[tid];
+#pragma unroll
+      for (int w = 0; w < SORT_T / 64; w++) { const int v = wcnt[w][tid]; wcnt[w][tid] = acc; acc += v; }
+      run[tid] = acc;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < SORT_EPT; j++) {
+      if (e[j] >= 0) {
+        const int d = (int)((key[j] >> shift) & 255u);
+        const int dest = base[d] + wcnt[wv][d] + off[j];
+        kout[dest] = key[j]; vout[dest] = vin[e[j]];
+        if (pass < 3) atomicAdd(&cnt[(size_t)(pass + 1) * SORT_NB * 256 + (dest / tile) * 256 + (int)((key[j] >> (shift + 8)) & 255u)], 1);
+      }
+    }
+    if (r0 + SORT_T * SORT_EPT < tile) {
+      __syncthreads();
+      for (int k = tid; k < (SORT_T / 64) * 256; k += SORT_T) (&wcnt[0][0])[k] = 0;
+      __syncthreads();
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void morton_kernel(KnnPair A, int split, const int* __restrict__ bbox, uint32_t* keys, uint32_t* vals, int* __restrict__ cnt, int tile) {
   const int which = (int)blockIdx.x >= split ? 1 : 0;
   const float4* __restrict__ p = A.c[which].xyz;
   const int n = A.c[which].n;
@@ -126,6 +219,7 @@ __global__ __launch_bounds__(256) void morton_kernel(KnnPair A, int split, const
   keys[i] = expand10(ix) | (expand10(iy) << 1) | (expand10(iz) << 2) | ((uint32_t)which << 30);
 #endif
   vals[i] = (uint32_t)i;
+  if (cnt) atomicAdd(&cnt[((off + i) / tile) * 256 + (int)(keys[i] & 255u)], 1);   // digit counts of the first sort pass
 }
 
 // one thread per leaf: gather its 8 points in Morton order, write them + the leaf box
@@ -350,10 +444,15 @@ ROLO_DEV void knn_covariance_tail(const int (&ki)[KMAX], int kk, const float4* _
 namespace rolo {
 
 size_t knn_sort_temp_bytes(int n) {  // for n points in total (one cloud or the sum of a pair), keys of up to 31 bits
+#ifdef ROLO_KNN_ROCPRIM_SORT
   size_t bytes = 0;
   (void)rocprim::radix_sort_pairs(nullptr, bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
                                   (size_t)n, 0, 31, (hipStream_t)0);
   return bytes;
+#else
+  (void)n;
+  return sizeof(int) * 4 * SORT_NB * 256;   // digit counters of the four passes
+#endif
 }
 
 // Morton sort + implicit BVHs of the pair's clouds. sorted / boxes must be allocated for n_leaves / P of each cloud;
@@ -362,14 +461,29 @@ hipError_t launch_knn_build(const KnnPair& A, void* sort_tmp, size_t sort_tmp_by
                             uint32_t* vals0, uint32_t* vals1, int* bbox, hipStream_t s) {
   const int nc = A.n_clouds;
   const int n_total = A.c[0].n + (nc > 1 ? A.c[1].n : 0);
-  bbox_init_kernel<<<1, 64, 0, s>>>(bbox);
-  bbox_kernel<<<BBOX_BLOCKS * nc, 256, 0, s>>>(A, bbox);
   const int g0 = (A.c[0].n + 255) / 256, g1 = nc > 1 ? (A.c[1].n + 255) / 256 : 0;
-  morton_kernel<<<g0 + g1, 256, 0, s>>>(A, g0, bbox, keys0, vals0);
+#ifdef ROLO_KNN_ROCPRIM_SORT
+  bbox_init_kernel<<<1, 64, 0, s>>>(bbox, nullptr, 0);
+  bbox_kernel<<<BBOX_BLOCKS * nc, 256, 0, s>>>(A, bbox);
+  morton_kernel<<<g0 + g1, 256, 0, s>>>(A, g0, bbox, keys0, vals0, nullptr, 1);
   hipError_t e = rocprim::radix_sort_pairs(sort_tmp, sort_tmp_bytes, keys0, keys1, vals0, vals1, (size_t)n_total, 0, nc > 1 ? 31 : 30, s);
   if (e != hipSuccess) return e;
+  const uint32_t* order = vals1;
+#else
+  (void)sort_tmp_bytes;
+  int* cnt = static_cast<int*>(sort_tmp);
+  const int tile = ((n_total + SORT_NB - 1) / SORT_NB + SORT_T - 1) / SORT_T * SORT_T;
+  bbox_init_kernel<<<16, 1024, 0, s>>>(bbox, cnt, 4 * SORT_NB * 256);
+  bbox_kernel<<<BBOX_BLOCKS * nc, 256, 0, s>>>(A, bbox);
+  morton_kernel<<<g0 + g1, 256, 0, s>>>(A, g0, bbox, keys0, vals0, cnt, tile);
+  sort_scatter_kernel<<<SORT_NB, SORT_T, 0, s>>>(keys0, vals0, keys1, vals1, n_total, tile, 0, cnt);
+  sort_scatter_kernel<<<SORT_NB, SORT_T, 0, s>>>(keys1, vals1, keys0, vals0, n_total, tile, 1, cnt);
+  sort_scatter_kernel<<<SORT_NB, SORT_T, 0, s>>>(keys0, vals0, keys1, vals1, n_total, tile, 2, cnt);
+  sort_scatter_kernel<<<SORT_NB, SORT_T, 0, s>>>(keys1, vals1, keys0, vals0, n_total, tile, 3, cnt);
+  const uint32_t* order = vals0;
+#endif
   const int l0 = (A.c[0].P + 255) / 256, l1 = nc > 1 ? (A.c[1].P + 255) / 256 : 0;
-  leaf_kernel<<<l0 + l1, 256, 0, s>>>(A, l0, vals1);
+  leaf_kernel<<<l0 + l1, 256, 0, s>>>(A, l0, order);
   int count0 = A.c[0].P, count1 = nc > 1 ? A.c[1].P : 1;
   while (count0 > 1 || count1 > 1) {
     const int chunk0 = count0 < 512 ? count0 : 512, chunk1 = count1 < 512 ? count1 : 512;
