@@ -33,10 +33,9 @@ ROLO_DEV float ord2f(int k) { int i = k >= 0 ? k : k ^ 0x7fffffff; return __int_
 // with n_clouds = 1.
 constexpr int BBOX_BLOCKS = 64;
 
-__global__ __launch_bounds__(1024) void bbox_init_kernel(int* bbox, int* sort_cnt, int n_cnt) {  // 2 clouds x (min xyz, max xyz); the sort's digit counters
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void bbox_init_kernel(int* bbox) {  // 2 clouds x (min xyz, max xyz)
+  const int t = threadIdx.x;
   if (t < 12) bbox[t] = (t % 6) < 3 ? INT_MAX : INT_MIN;
-  for (int k = t; k < n_cnt; k += gridDim.x * blockDim.x) sort_cnt[k] = 0;
 }
 
 __global__ __launch_bounds__(256) void bbox_kernel(KnnPair A, int* bbox) {
@@ -108,12 +107,13 @@ ROLO_DEV uint32_t hilbert30(uint32_t x, uint32_t y, uint32_t z) {
 // range [0, n0) / [n0, n0 + n1) of the arrays
 // ---- key sort: a stable LSD radix sort in four 8-bit passes, written for this path (round 1 used rocPRIM's merge sort: 17 launches) --------
 // The keys are <= 31 bits and there are at most a few hundred thousand of them, so the array is cut into SORT_NB = 64 tiles, one 1024-thread
-// workgroup each. A pass is ONE launch: the workgroup of tile b reads the per-tile digit counts of this pass (64 x 256 counters: its scan is a
-// prologue, not a kernel), ranks its elements stably — waves own consecutive 64-element runs, equal digits inside a run are matched with 8
-// ballots, runs are ordered by a 16-step prefix per digit in LDS — and scatters keys and values. The digit counts of the NEXT pass are
-// collected by the scatter itself (one integer atomic per element on the counter of its destination tile; integer counts do not depend on
-// the order of arrival, so the result is deterministic), and those of the first pass by the key kernel: 1 + 4 launches in all, the
-// result identical to a stable sort by key (ties by original index) — what rocPRIM's radix_sort_pairs returned.
+// workgroup each. A pass is a histogram launch (per tile: 256 digit counts by LDS atomics, plain stores; the first pass's are counted by the
+// key kernel, which uses the same tiling) and a scatter launch: the workgroup of tile b reads the 64 x 256 counts (their scan is a prologue,
+// not a kernel), ranks its elements stably — waves own consecutive 64-element runs, equal digits inside a run are matched with 8 ballots,
+// runs are ordered by a 16-step prefix per digit in LDS — and scatters keys and values. 1 + 7 launches, the result identical to a stable
+// sort by key (ties by original index) — what rocPRIM's radix_sort_pairs returned. (Counting the next pass's digits inside the scatter, one
+// global integer atomic per element on the counter of its destination tile, saved the three histogram launches and cost 18 us per pass:
+// 262 k device-scope atomics cross the fabric.)
 constexpr int SORT_NB = 64, SORT_T = 1024;
 ROLO_DEV int sort_tile(int n_total) { return ((n_total + SORT_NB - 1) / SORT_NB + SORT_T - 1) / SORT_T * SORT_T; }
 
@@ -187,7 +187,6 @@ __global__ __launch_bounds__(SORT_T) void sort_scatter_kernel(const uint32_t* __
         const int d = (int)((key[j] >> shift) & 255u);
         const int dest = base[d] + wcnt[wv][d] + off[j];
         kout[dest] = key[j]; vout[dest] = vin[e[j]];
-        if (pass < 3) atomicAdd(&cnt[(size_t)(pass + 1) * SORT_NB * 256 + (dest / tile) * 256 + (int)((key[j] >> (shift + 8)) & 255u)], 1);
       }
     }
     if (r0 + SORT_T * SORT_EPT < tile) {
@@ -198,28 +197,59 @@ __global__ __launch_bounds__(SORT_T) void sort_scatter_kernel(const uint32_t* __
   }
 }
 
-__global__ __launch_bounds__(256) void morton_kernel(KnnPair A, int split, const int* __restrict__ bbox, uint32_t* keys, uint32_t* vals, int* __restrict__ cnt, int tile) {
-  const int which = (int)blockIdx.x >= split ? 1 : 0;
-  const float4* __restrict__ p = A.c[which].xyz;
-  const int n = A.c[which].n;
-  const int off = which ? A.c[0].n : 0;
-  bbox += 6 * which; keys += off; vals += off;
-  int i = ((int)blockIdx.x - (which ? split : 0)) * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float mnx = ord2f(bbox[0]), mny = ord2f(bbox[1]), mnz = ord2f(bbox[2]);
-  float ext = fmaxf(fmaxf(ord2f(bbox[3]) - mnx, ord2f(bbox[4]) - mny), ord2f(bbox[5]) - mnz);
-  float sc = ext > 0.f ? 1024.0f / ext : 0.f;
-  float4 q = p[i];
-  int ix = min(1023, max(0, (int)((q.x - mnx) * sc)));
-  int iy = min(1023, max(0, (int)((q.y - mny) * sc)));
-  int iz = min(1023, max(0, (int)((q.z - mnz) * sc)));
+// keys of both clouds of the pair (cloud number = bit 30), one workgroup per sort tile; also the tile's digit counts of the first sort pass
+__global__ __launch_bounds__(SORT_T) void morton_kernel(KnnPair A, const int* __restrict__ bbox, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, int n_total, int tile,
+                                                       int* __restrict__ cnt) {
+  __shared__ int hist[256];
+  __shared__ float par[2][4];   // per cloud: min x, y, z and the scale
+  const int tid = threadIdx.x, blk = blockIdx.x;
+  if (tid < 256) hist[tid] = 0;
+  if (tid < 2) {
+    const int* bb = bbox + 6 * tid;
+    const float mnx = ord2f(bb[0]), mny = ord2f(bb[1]), mnz = ord2f(bb[2]);
+    const float ext = fmaxf(fmaxf(ord2f(bb[3]) - mnx, ord2f(bb[4]) - mny), ord2f(bb[5]) - mnz);
+    par[tid][0] = mnx; par[tid][1] = mny; par[tid][2] = mnz; par[tid][3] = ext > 0.f ? 1024.0f / ext : 0.f;
+  }
+  __syncthreads();
+  const int n0 = A.c[0].n;
+  for (int r = tid; r < tile; r += SORT_T) {
+    const int e = blk * tile + r;
+    if (e >= n_total) break;
+    const int which = e >= n0 ? 1 : 0;
+    const int i = e - (which ? n0 : 0);
+    const float4 q = A.c[which].xyz[i];
+    const float mnx = par[which][0], mny = par[which][1], mnz = par[which][2], sc = par[which][3];
+    const int ix = min(1023, max(0, (int)((q.x - mnx) * sc)));
+    const int iy = min(1023, max(0, (int)((q.y - mny) * sc)));
+    const int iz = min(1023, max(0, (int)((q.z - mnz) * sc)));
 #ifndef ROLO_KNN_MORTON   // A/B builds: the Z-order curve this replaced (walk 0.274 ms against 0.230 ms for the 2 x 131 072-point pair)
-  keys[i] = hilbert30((uint32_t)ix, (uint32_t)iy, (uint32_t)iz) | ((uint32_t)which << 30);
+    const uint32_t key = hilbert30((uint32_t)ix, (uint32_t)iy, (uint32_t)iz) | ((uint32_t)which << 30);
 #else
-  keys[i] = expand10(ix) | (expand10(iy) << 1) | (expand10(iz) << 2) | ((uint32_t)which << 30);
+    const uint32_t key = expand10(ix) | (expand10(iy) << 1) | (expand10(iz) << 2) | ((uint32_t)which << 30);
 #endif
-  vals[i] = (uint32_t)i;
-  if (cnt) atomicAdd(&cnt[((off + i) / tile) * 256 + (int)(keys[i] & 255u)], 1);   // digit counts of the first sort pass
+    keys[e] = key;
+    vals[e] = (uint32_t)i;
+    atomicAdd(&hist[key & 255u], 1);
+  }
+  __syncthreads();
+  if (cnt && tid < 256) cnt[blk * 256 + tid] = hist[tid];
+}
+
+// digit counts of sort pass `pass` for every tile of the (partially sorted) keys: LDS atomics, plain stores — counting the next pass's digits
+// with global atomics inside the scatter cost 18 us per pass (262 k device-scope atomics cross the fabric), this launch costs 4
+__global__ __launch_bounds__(SORT_T) void sort_hist_kernel(const uint32_t* __restrict__ keys, int n, int tile, int pass, int* __restrict__ cnt) {
+  __shared__ int hist[256];
+  const int tid = threadIdx.x, blk = blockIdx.x;
+  if (tid < 256) hist[tid] = 0;
+  __syncthreads();
+  const int shift = 8 * pass;
+  for (int r = tid; r < tile; r += SORT_T) {
+    const int e = blk * tile + r;
+    if (e >= n) break;
+    atomicAdd(&hist[(keys[e] >> shift) & 255u], 1);
+  }
+  __syncthreads();
+  if (tid < 256) cnt[(size_t)pass * SORT_NB * 256 + blk * 256 + tid] = hist[tid];
 }
 
 // one thread per leaf: gather its 8 points in Morton order, write them + the leaf box
@@ -461,11 +491,11 @@ hipError_t launch_knn_build(const KnnPair& A, void* sort_tmp, size_t sort_tmp_by
                             uint32_t* vals0, uint32_t* vals1, int* bbox, hipStream_t s) {
   const int nc = A.n_clouds;
   const int n_total = A.c[0].n + (nc > 1 ? A.c[1].n : 0);
-  const int g0 = (A.c[0].n + 255) / 256, g1 = nc > 1 ? (A.c[1].n + 255) / 256 : 0;
 #ifdef ROLO_KNN_ROCPRIM_SORT
-  bbox_init_kernel<<<1, 64, 0, s>>>(bbox, nullptr, 0);
+  const int tile_ = ((n_total + SORT_NB - 1) / SORT_NB + SORT_T - 1) / SORT_T * SORT_T;
+  bbox_init_kernel<<<1, 64, 0, s>>>(bbox);
   bbox_kernel<<<BBOX_BLOCKS * nc, 256, 0, s>>>(A, bbox);
-  morton_kernel<<<g0 + g1, 256, 0, s>>>(A, g0, bbox, keys0, vals0, nullptr, 1);
+  morton_kernel<<<SORT_NB, SORT_T, 0, s>>>(A, bbox, keys0, vals0, n_total, tile_, nullptr);
   hipError_t e = rocprim::radix_sort_pairs(sort_tmp, sort_tmp_bytes, keys0, keys1, vals0, vals1, (size_t)n_total, 0, nc > 1 ? 31 : 30, s);
   if (e != hipSuccess) return e;
   const uint32_t* order = vals1;
@@ -473,12 +503,15 @@ hipError_t launch_knn_build(const KnnPair& A, void* sort_tmp, size_t sort_tmp_by
   (void)sort_tmp_bytes;
   int* cnt = static_cast<int*>(sort_tmp);
   const int tile = ((n_total + SORT_NB - 1) / SORT_NB + SORT_T - 1) / SORT_T * SORT_T;
-  bbox_init_kernel<<<16, 1024, 0, s>>>(bbox, cnt, 4 * SORT_NB * 256);
+  bbox_init_kernel<<<1, 64, 0, s>>>(bbox);
   bbox_kernel<<<BBOX_BLOCKS * nc, 256, 0, s>>>(A, bbox);
-  morton_kernel<<<g0 + g1, 256, 0, s>>>(A, g0, bbox, keys0, vals0, cnt, tile);
+  morton_kernel<<<SORT_NB, SORT_T, 0, s>>>(A, bbox, keys0, vals0, n_total, tile, cnt);
   sort_scatter_kernel<<<SORT_NB, SORT_T, 0, s>>>(keys0, vals0, keys1, vals1, n_total, tile, 0, cnt);
+  sort_hist_kernel<<<SORT_NB, SORT_T, 0, s>>>(keys1, n_total, tile, 1, cnt);
   sort_scatter_kernel<<<SORT_NB, SORT_T, 0, s>>>(keys1, vals1, keys0, vals0, n_total, tile, 1, cnt);
+  sort_hist_kernel<<<SORT_NB, SORT_T, 0, s>>>(keys0, n_total, tile, 2, cnt);
   sort_scatter_kernel<<<SORT_NB, SORT_T, 0, s>>>(keys0, vals0, keys1, vals1, n_total, tile, 2, cnt);
+  sort_hist_kernel<<<SORT_NB, SORT_T, 0, s>>>(keys1, n_total, tile, 3, cnt);
   sort_scatter_kernel<<<SORT_NB, SORT_T, 0, s>>>(keys1, vals1, keys0, vals0, n_total, tile, 3, cnt);
   const uint32_t* order = vals0;
 #endif
@@ -496,25 +529,21 @@ hipError_t launch_knn_build(const KnnPair& A, void* sort_tmp, size_t sort_tmp_by
 }
 
 #ifdef ROLO_KNN_STATS
-extern "C" int rolo_debug_counters(unsigned long long* out, int reset) {
+extern "C" int rolo_debug_wave_records(unsigned* out /* 16384 x 6 */) {
   (void)hipDeviceSynchronize();
-  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_knn_stats), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
-  if (reset) { unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_knn_stats), z, sizeof(z)); }
-  return 0;
-}
-extern "C" int rolo_debug_wave_records(unsigned* out /* 16384 x 4 */) {
-  (void)hipDeviceSynchronize();
-  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_knn_wave_rec), sizeof(unsigned) * 16384 * 4) == hipSuccess ? 0 : -1;
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_knn_wave_rec), sizeof(unsigned) * 16384 * 6) == hipSuccess ? 0 : -1;
 }
 #endif
 
 static inline int slice_blocks(const KnnCloud& c) { return (c.q_end - c.q_begin + 255) / 256; }
 
 hipError_t launch_knn_walk(const KnnPair& A, int k, hipStream_t s) {
-  const int g0 = slice_blocks(A.c[0]), g1 = A.n_clouds > 1 ? slice_blocks(A.c[1]) : 0;
+  constexpr int QPB = 4 * ROLO_KNN_PACKET;   // queries per workgroup of the walk
+  const int g0 = (A.c[0].q_end - A.c[0].q_begin + QPB - 1) / QPB, g1 = A.n_clouds > 1 ? (A.c[1].q_end - A.c[1].q_begin + QPB - 1) / QPB : 0;
   if (g0 + g1 == 0) return hipSuccess;
-  if (k == 20) knn_walk_kernel<20><<<g0 + g1, 256, 0, s>>>(A, g0, k);
-  else knn_walk_kernel<32><<<g0 + g1, 256, 0, s>>>(A, g0, k);
+  static const int pad = [] { const char* e = getenv("ROLO_KNN_LDS_PAD"); return e ? atoi(e) : 0; }();   // experiment: occupancy limit through LDS
+  if (k == 20) knn_walk_kernel<20><<<g0 + g1, 256, pad, s>>>(A, g0, k);
+  else knn_walk_kernel<32><<<g0 + g1, 256, pad, s>>>(A, g0, k);
   return hipGetLastError();
 }
 

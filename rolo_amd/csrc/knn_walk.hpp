@@ -43,9 +43,12 @@ ROLO_DEV int xcd_contiguous_block(int b, int G) {
 #endif
 }
 
+// Instrumented build (-DROLO_KNN_STATS): one record per wavefront of the walk. Everything is counted in scalar registers and stored once at
+// the very end; the start time comes from a NON-volatile asm that also produces the root node index, so it cannot move. (A store, an atomic, a
+// clock builtin or a volatile asm before the loop is a potential memory clobber to the compiler: after it the wave-uniform box / leaf loads are
+// no longer provably unclobbered and turn into vector loads — 64 more VGPRs, spills, a 5-10x slower walk. That is what a first version measured.)
 #ifdef ROLO_KNN_STATS
-__device__ unsigned long long g_knn_stats[8];  // nodes, leaves, insert executions, walk cycles, waves, tail cycles
-__device__ unsigned g_knn_wave_rec[16384][4];   // per wavefront: nodes, leaves, insert executions, walk cycles
+__device__ unsigned g_knn_wave_rec[16384][6];   // nodes, leaves, insert executions, pushes, start, end (100 MHz wall clock)
 #define KNN_STAT(x) x
 #else
 #define KNN_STAT(x)
@@ -70,7 +73,6 @@ ROLO_DEV void knn_score_leaf(const float4* __restrict__ sorted, int g, const flo
   float4 pts[KNN_LEAF];
 #pragma unroll
   for (int u = 0; u < KNN_LEAF; u++) pts[u] = sorted[KNN_LEAF * (size_t)g + u];
-  KNN_STAT(const double bkey0 = bkey; int acc_leaf = 0;)
 #pragma unroll
   for (int u = 0; u < KNN_LEAF; u++) {
     const float4 c = pts[u];
@@ -78,29 +80,41 @@ ROLO_DEV void knn_score_leaf(const float4* __restrict__ sorted, int g, const flo
     const float cd = ((dx * dx) + (dy * dy)) + (dz * dz);  // file is compiled with -ffp-contract=off
     const double ck = key_pack(cd, __float_as_int(c.w));
     KNN_STAT(if (__any(ck < bkey)) n_ins++;)
-    KNN_STAT(if (ck < bkey0) acc_leaf++;)
     if (ck < bkey) {
-      // sorted insert, descending slot order so every step reads not-yet-overwritten neighbours
+      // sorted insert, descending slot order so every step reads not-yet-overwritten neighbours — in four tiers: a slot whose lower
+      // neighbour is already <= the candidate in EVERY lane keeps its value (min(ck, K[s]) = K[s] and K[s-1] <= K[s]), so the lower tiers
+      // run only if some lane's candidate sorts below them. Late in the walk candidates barely beat the k-th best: most executions stop
+      // after the first tier (fp64 min / max issue at half the fp32 rate — the insert is two thirds of the walk's VALU cycles).
+      constexpr int T = KMAX / 4;
 #pragma unroll
-      for (int s = KMAX - 1; s >= 1; s--) K[s] = vmax_f64(K[s - 1], vmin_f64(ck, K[s]));
-      K[0] = vmin_f64(ck, K[0]);
+      for (int s = KMAX - 1; s >= 3 * T; s--) K[s] = vmax_f64(K[s - 1], vmin_f64(ck, K[s]));
+      if (__any(ck < K[3 * T - 1])) {
+#pragma unroll
+        for (int s = 3 * T - 1; s >= 2 * T; s--) K[s] = vmax_f64(K[s - 1], vmin_f64(ck, K[s]));
+        if (__any(ck < K[2 * T - 1])) {
+#pragma unroll
+          for (int s = 2 * T - 1; s >= T; s--) K[s] = vmax_f64(K[s - 1], vmin_f64(ck, K[s]));
+          if (__any(ck < K[T - 1])) {
+#pragma unroll
+            for (int s = T - 1; s >= 1; s--) K[s] = vmax_f64(K[s - 1], vmin_f64(ck, K[s]));
+            K[0] = vmin_f64(ck, K[0]);
+          }
+        }
+      }
 #pragma unroll
       for (int s = 0; s < KMAX; s++) if (s == kk - 1) bkey = K[s];
       bd = key_d2(bkey);
     }
   }
-#ifdef ROLO_KNN_STATS
-  lane_acc += acc_leaf;
-  int m = acc_leaf;
-  for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o));
-  rounds += m;
-#endif
 }
 
 // The walk keeps only the 20 packed keys and the query live (58 VGPRs): cut for 8 wavefronts per SIMD. Neighbour indices
 // go to A.c[].nbr, slot-major so every store is coalesced; knn_tail_kernel turns them into covariances.
+#ifndef ROLO_KNN_WALK_OCC
+#define ROLO_KNN_WALK_OCC 8
+#endif
 template <int KMAX>
-__global__ __launch_bounds__(256, 8) void knn_walk_kernel(KnnPair A, int split, int k) {
+__global__ __launch_bounds__(256, ROLO_KNN_WALK_OCC) void knn_walk_kernel(KnnPair A, int split, int k) {
   __shared__ int stk[4][WALK_STACK];
   const int tid = threadIdx.x;
   const int wv = tid >> 6;
@@ -112,15 +126,18 @@ __global__ __launch_bounds__(256, 8) void knn_walk_kernel(KnnPair A, int split, 
   int32_t* knn_idx = A.c[which].knn_idx;
   float* knn_d2 = A.c[which].knn_d2;
   const int n_sorted = A.c[which].n_sorted, P = A.c[which].P;
-  const int j = A.c[which].q_begin + (blk - (which ? split : 0)) * 256 + tid;
+#ifndef ROLO_KNN_PACKET
+#define ROLO_KNN_PACKET 64   // queries per wavefront (experiment: 32 / 16 leave the upper lanes idle — shorter dependent chain per wave, more waves)
+#endif
+  const int lane_ = tid & 63;
+  const int j = A.c[which].q_begin + (blk - (which ? split : 0)) * (4 * ROLO_KNN_PACKET) + wv * ROLO_KNN_PACKET + lane_;
   float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
   int qi = INT_MAX;
-  if (j < A.c[which].q_end) { q = sorted[j]; qi = __float_as_int(q.w); }
+  if (lane_ < ROLO_KNN_PACKET && j < A.c[which].q_end) { q = sorted[j]; qi = __float_as_int(q.w); }
   const bool active = qi != INT_MAX;  // not padding
   const int kk = (KMAX == 20) ? 20 : k;
   const int n_leaves = n_sorted / KNN_LEAF;
   unsigned st_nodes = 0, st_leaves = 0, st_ins = 0, st_lane = 0, st_rounds = 0;
-  KNN_STAT(const long long t0 = clock64();)
 
   // K[0..KMAX) ascending; sentinel = (inf, INT_MAX)
   const double sentinel = key_pack(INFINITY, INT_MAX);
@@ -133,7 +150,7 @@ __global__ __launch_bounds__(256, 8) void knn_walk_kernel(KnnPair A, int split, 
 
   // ---- seed: the wavefront's own 8 leaves ----
   const int g_own0 = __builtin_amdgcn_readfirstlane(j / KNN_LEAF);  // lane 0 of the wave: j is a multiple of 64
-  const int g_own1 = min(g_own0 + 64 / KNN_LEAF, n_leaves);
+  const int g_own1 = min(g_own0 + ROLO_KNN_PACKET / KNN_LEAF, n_leaves);
   for (int g = g_own0; g < g_own1; g++) { knn_score_leaf<KMAX>(sorted, g, q, K, kk, bkey, bd, st_ins, st_lane, st_rounds); st_leaves++; }
 
   // ---- packet walk ----
@@ -141,8 +158,27 @@ __global__ __launch_bounds__(256, 8) void knn_walk_kernel(KnnPair A, int split, 
   // gfx950's v_writelane takes its lane select from M0 when the value is an SGPR, which inline asm may not clobber safely)
   int sp = 0;
   int h = 1;
+#ifdef ROLO_KNN_STATS
+  unsigned long long wt0;
+  asm("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)\n\ts_mov_b32 %1, 1" : "=s"(wt0), "=s"(h));
+  unsigned st_push = 0;
+#endif
+#if defined(ROLO_KNN_PRIO)
+  int it = 0;   // s_setprio below is a plain asm tied to this counter: the builtin (and any volatile asm) counts as a memory clobber, after which
+                // the wave-uniform leaf loads are no longer provably unclobbered and become vector loads (64 more VGPRs, spills)
+#endif
   while (true) {
     h = __builtin_amdgcn_readfirstlane(h);
+#if defined(ROLO_KNN_PRIO) && ROLO_KNN_PRIO == 1   // rotate the issue priority among the waves of a SIMD
+    it++;
+    if ((it & 7) == 0) { switch (((it >> 3) + (int)blockIdx.x) & 3) { case 0: asm("s_setprio 0" : "+s"(it)); break; case 1: asm("s_setprio 1" : "+s"(it)); break; case 2: asm("s_setprio 2" : "+s"(it)); break; default: asm("s_setprio 3" : "+s"(it)); } }
+#elif defined(ROLO_KNN_PRIO) && ROLO_KNN_PRIO == 2   // the further a wave has come, the higher its priority
+    it++;
+    if (it == 48) asm("s_setprio 1" : "+s"(it)); else if (it == 96) asm("s_setprio 2" : "+s"(it)); else if (it == 144) asm("s_setprio 3" : "+s"(it));
+#elif defined(ROLO_KNN_PRIO) && ROLO_KNN_PRIO == 3   // the less a wave has done, the higher its priority (fair share)
+    it++;
+    if (it == 1) asm("s_setprio 3" : "+s"(it)); else if (it == 32) asm("s_setprio 2" : "+s"(it)); else if (it == 64) asm("s_setprio 1" : "+s"(it)); else if (it == 96) asm("s_setprio 0" : "+s"(it));
+#endif
     if (h < P) {
       st_nodes++;
       const float4 llo = boxes[4 * (size_t)h], lhi = boxes[4 * (size_t)h + 1], rlo = boxes[4 * (size_t)h + 2], rhi = boxes[4 * (size_t)h + 3];
@@ -154,7 +190,7 @@ __global__ __launch_bounds__(256, 8) void knn_walk_kernel(KnnPair A, int split, 
         // radius decides" rule needed a 6-step cross-lane max per node and did not reduce the nodes visited)
         const unsigned long long pref = __ballot((okl || okr) && (bl <= br));
         const bool left_first = 2 * __popcll(pref) >= __popcll(ml | mr);
-        if (sp < WALK_STACK) { stk[wv][sp] = left_first ? 2 * h + 1 : 2 * h; sp++; }
+        if (sp < WALK_STACK) { stk[wv][sp] = left_first ? 2 * h + 1 : 2 * h; sp++; KNN_STAT(st_push++;) }
         h = left_first ? 2 * h : 2 * h + 1;
         continue;
       }
@@ -169,20 +205,12 @@ __global__ __launch_bounds__(256, 8) void knn_walk_kernel(KnnPair A, int split, 
     h = stk[wv][sp];
   }
 #ifdef ROLO_KNN_STATS
-  const long long t1 = clock64();
-  if ((tid & 63) == 0) {
-    atomicAdd(&g_knn_stats[0], (unsigned long long)st_nodes); atomicAdd(&g_knn_stats[1], (unsigned long long)st_leaves);
-    atomicAdd(&g_knn_stats[2], (unsigned long long)st_ins); atomicAdd(&g_knn_stats[3], (unsigned long long)(t1 - t0));
-    atomicAdd(&g_knn_stats[4], 1ull);
-    atomicAdd(&g_knn_stats[6], (unsigned long long)st_rounds);
-    const unsigned wid = blk * 4 + wv;
-    if (wid < 16384) { g_knn_wave_rec[wid][0] = st_nodes; g_knn_wave_rec[wid][1] = st_leaves; g_knn_wave_rec[wid][2] = st_ins; g_knn_wave_rec[wid][3] = (unsigned)(t1 - t0); }
-  }
-  {
-    int m = (int)st_lane;
-    for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o));
-    if ((tid & 63) == 0) atomicAdd(&g_knn_stats[7], (unsigned long long)m);
-  }
+  { unsigned long long wt1; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(wt1));
+    const unsigned wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if ((threadIdx.x & 63) == 0 && wid < 16384) {
+      g_knn_wave_rec[wid][0] = st_nodes; g_knn_wave_rec[wid][1] = st_leaves; g_knn_wave_rec[wid][2] = st_ins; g_knn_wave_rec[wid][3] = st_push;
+      g_knn_wave_rec[wid][4] = (unsigned)wt0; g_knn_wave_rec[wid][5] = (unsigned)wt1;
+    } }
 #endif
   (void)st_nodes; (void)st_leaves; (void)st_ins; (void)st_lane; (void)st_rounds;
 
@@ -198,9 +226,6 @@ __global__ __launch_bounds__(256, 8) void knn_walk_kernel(KnnPair A, int split, 
   int32_t* __restrict__ nbr = A.c[which].nbr;
 #pragma unroll
   for (int u = 0; u < KMAX; u++) nbr[(size_t)u * n_sorted + j] = ki[u];
-#ifdef ROLO_KNN_STATS
-  if ((tid & 63) == 0) atomicAdd(&g_knn_stats[5], (unsigned long long)(clock64() - t1));
-#endif
 }
 
 template <int KMAX>
