@@ -254,33 +254,36 @@ __global__ __launch_bounds__(SORT_T) void sort_hist_kernel(const uint32_t* __res
 
 // one thread per leaf: gather its 8 points in Morton order, write them + the leaf box
 __global__ __launch_bounds__(256) void leaf_kernel(KnnPair A, int split, const uint32_t* __restrict__ order) {
+  // one thread per slot of the sorted copy (a thread per leaf gathered its 16 points one after the other: 13 us); the leaf box is a min / max
+  // over the 16 lanes of the leaf — exact, so the order of the reduction does not matter
   const int which = (int)blockIdx.x >= split ? 1 : 0;
   const float4* __restrict__ p = A.c[which].xyz;
   const int n = A.c[which].n, n_leaves = A.c[which].n_leaves, P = A.c[which].P;
   float4* sorted = A.c[which].sorted; float4* boxes = A.c[which].boxes;
   order += which ? A.c[0].n : 0;
-  int g = ((int)blockIdx.x - (which ? split : 0)) * blockDim.x + threadIdx.x;
-  if (g >= P) return;
-  float4 lo = make_float4(INFINITY, INFINITY, INFINITY, 0.f), hi = make_float4(-INFINITY, -INFINITY, -INFINITY, 0.f);
+  const int s = ((int)blockIdx.x - (which ? split : 0)) * blockDim.x + threadIdx.x;
+  const int g = s / KNN_LEAF;
+  if (g >= P) return;   // whole leaves only: KNN_LEAF divides the block size
+  float lox = INFINITY, loy = INFINITY, loz = INFINITY, hix = -INFINITY, hiy = -INFINITY, hiz = -INFINITY;
   if (g < n_leaves) {
-#pragma unroll
-    for (int u = 0; u < KNN_LEAF; u++) {
-      int s = KNN_LEAF * g + u;
-      float4 o;
-      if (s < n) {
-        uint32_t idx = order[s];
-        float4 q = p[idx];
-        o = make_float4(q.x, q.y, q.z, __int_as_float((int)idx));
-        lo.x = fminf(lo.x, q.x); lo.y = fminf(lo.y, q.y); lo.z = fminf(lo.z, q.z);
-        hi.x = fmaxf(hi.x, q.x); hi.y = fmaxf(hi.y, q.y); hi.z = fmaxf(hi.z, q.z);
-      } else {
-        o = make_float4(INFINITY, INFINITY, INFINITY, __int_as_float(INT_MAX));
-      }
-      sorted[s] = o;
+    float4 o = make_float4(INFINITY, INFINITY, INFINITY, __int_as_float(INT_MAX));
+    if (s < n) {
+      const uint32_t idx = order[s];
+      const float4 q = p[idx];
+      o = make_float4(q.x, q.y, q.z, __int_as_float((int)idx));
+      lox = hix = q.x; loy = hiy = q.y; loz = hiz = q.z;
     }
+    sorted[s] = o;
   }
-  boxes[2 * (size_t)(P + g)] = lo;
-  boxes[2 * (size_t)(P + g) + 1] = hi;
+#pragma unroll
+  for (int m = 1; m < KNN_LEAF; m <<= 1) {
+    lox = fminf(lox, __shfl_xor(lox, m)); loy = fminf(loy, __shfl_xor(loy, m)); loz = fminf(loz, __shfl_xor(loz, m));
+    hix = fmaxf(hix, __shfl_xor(hix, m)); hiy = fmaxf(hiy, __shfl_xor(hiy, m)); hiz = fmaxf(hiz, __shfl_xor(hiz, m));
+  }
+  if ((s & (KNN_LEAF - 1)) == 0) {
+    boxes[2 * (size_t)(P + g)] = make_float4(lox, loy, loz, 0.f);
+    boxes[2 * (size_t)(P + g) + 1] = make_float4(hix, hiy, hiz, 0.f);
+  }
 }
 
 // Builds log2(chunk) levels of the implicit BVH in LDS: inputs are the `count_in` nodes at heap indices
@@ -515,7 +518,8 @@ hipError_t launch_knn_build(const KnnPair& A, void* sort_tmp, size_t sort_tmp_by
   sort_scatter_kernel<<<SORT_NB, SORT_T, 0, s>>>(keys1, vals1, keys0, vals0, n_total, tile, 3, cnt);
   const uint32_t* order = vals0;
 #endif
-  const int l0 = (A.c[0].P + 255) / 256, l1 = nc > 1 ? (A.c[1].P + 255) / 256 : 0;
+  static_assert(256 % KNN_LEAF == 0 && (KNN_LEAF & (KNN_LEAF - 1)) == 0, "leaf_kernel reduces a leaf inside a wavefront");
+  const int l0 = (A.c[0].P * KNN_LEAF + 255) / 256, l1 = nc > 1 ? (A.c[1].P * KNN_LEAF + 255) / 256 : 0;
   leaf_kernel<<<l0 + l1, 256, 0, s>>>(A, l0, order);
   int count0 = A.c[0].P, count1 = nc > 1 ? A.c[1].P : 1;
   while (count0 > 1 || count1 > 1) {
