@@ -106,18 +106,27 @@ ROLO_DEV uint32_t hilbert30(uint32_t x, uint32_t y, uint32_t z) {
 // keys: 30-bit Morton code + the cloud number in bit 30, so one sort of both clouds leaves each cloud sorted in its own
 // range [0, n0) / [n0, n0 + n1) of the arrays
 // ---- key sort: a stable LSD radix sort in four 8-bit passes, written for this path (round 1 used rocPRIM's merge sort: 17 launches) --------
-// The keys are <= 31 bits and there are at most a few hundred thousand of them, so the array is cut into SORT_NB = 64 tiles, one 1024-thread
+// The keys are <= 31 bits and there are at most a few hundred thousand of them, so the array is cut into SORT_NB = 128 tiles (64 tiles x 4 elements per thread: build 0.090 ms, 128 x 2: 0.076, 256 x 2 on 512 threads: 0.078), one 1024-thread
 // workgroup each. A pass is a histogram launch (per tile: 256 digit counts by LDS atomics, plain stores; the first pass's are counted by the
-// key kernel, which uses the same tiling) and a scatter launch: the workgroup of tile b reads the 64 x 256 counts (their scan is a prologue,
+// key kernel, which uses the same tiling) and a scatter launch: the workgroup of tile b reads the 128 x 256 counts (their scan is a prologue,
 // not a kernel), ranks its elements stably — waves own consecutive 64-element runs, equal digits inside a run are matched with 8 ballots,
 // runs are ordered by a 16-step prefix per digit in LDS — and scatters keys and values. 1 + 7 launches, the result identical to a stable
 // sort by key (ties by original index) — what rocPRIM's radix_sort_pairs returned. (Counting the next pass's digits inside the scatter, one
 // global integer atomic per element on the counter of its destination tile, saved the three histogram launches and cost 18 us per pass:
 // 262 k device-scope atomics cross the fabric.)
-constexpr int SORT_NB = 64, SORT_T = 1024;
+#ifndef ROLO_SORT_NB
+#define ROLO_SORT_NB 128
+#endif
+#ifndef ROLO_SORT_T
+#define ROLO_SORT_T 1024
+#endif
+#ifndef ROLO_SORT_EPT
+#define ROLO_SORT_EPT 2
+#endif
+constexpr int SORT_NB = ROLO_SORT_NB, SORT_T = ROLO_SORT_T;
 ROLO_DEV int sort_tile(int n_total) { return ((n_total + SORT_NB - 1) / SORT_NB + SORT_T - 1) / SORT_T * SORT_T; }
 
-constexpr int SORT_EPT = 4;   // elements per thread and round: a wave ranks 256 consecutive elements between two workgroup barriers
+constexpr int SORT_EPT = ROLO_SORT_EPT;   // elements per thread and round: a wave ranks 256 consecutive elements between two workgroup barriers
 __global__ __launch_bounds__(SORT_T) void sort_scatter_kernel(const uint32_t* __restrict__ kin, const uint32_t* __restrict__ vin, uint32_t* __restrict__ kout,
                                                              uint32_t* __restrict__ vout, int n, int tile, int pass, int* __restrict__ cnt /* [4][SORT_NB][256] */) {
   __shared__ int wcnt[SORT_T / 64][256];
@@ -125,14 +134,22 @@ __global__ __launch_bounds__(SORT_T) void sort_scatter_kernel(const uint32_t* __
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, blk = blockIdx.x;
   const int* __restrict__ c = cnt + (size_t)pass * SORT_NB * 256;
   for (int k = tid; k < (SORT_T / 64) * 256; k += SORT_T) (&wcnt[0][0])[k] = 0;
+  // digit totals over all tiles and over the tiles before this one: every thread sums a share of the tiles, the shares meet in LDS
+  constexpr int Q = SORT_T / 256;
+  __shared__ int part[2][Q][256];
+  {
+    const int d = tid & 255, q = tid >> 8;
+    int tot = 0, bef = 0;
+#pragma unroll 16
+    for (int b = q; b < SORT_NB; b += Q) { const int v = c[b * 256 + d]; tot += v; bef += b < blk ? v : 0; }
+    part[0][q][d] = tot; part[1][q][d] = bef;
+  }
+  __syncthreads();
   int t = 0;
   if (tid < 256) {
     int before = 0;
-    int v[SORT_NB];
 #pragma unroll
-    for (int b = 0; b < SORT_NB; b++) v[b] = c[b * 256 + tid];
-#pragma unroll
-    for (int b = 0; b < SORT_NB; b++) { t += v[b]; if (b < blk) before += v[b]; }
+    for (int q = 0; q < Q; q++) { t += part[0][q][tid]; before += part[1][q][tid]; }
     run[tid] = before;   // elements with this digit in earlier tiles (becomes the running offset inside the tile below)
     // exclusive scan of the 256 digit totals: inside the wave by shuffles, across the four waves through LDS
     int incl = t;
