@@ -32,11 +32,17 @@ ROLO_DEV void note_point(bool valid, bool near_edge, int* counters) {
 
 // max |coordinate| of the target -> counters[3]: from the bounding box the neighbour search left on the device (6 order-preserving
 // ints: min xyz, max xyz), or, for a target whose covariances were handed in (no search ran), from the points themselves
-__global__ void maxabs_from_bbox_kernel(const int* __restrict__ bbox6, int* counters) {
-  if (threadIdx.x != 0) return;
-  float m = 0.f;
-  for (int k = 0; k < 6; k++) { const int o = bbox6[k]; m = fmaxf(m, fabsf(__int_as_float(o >= 0 ? o : o ^ 0x7fffffff))); }
-  counters[3] = __float_as_int(m);
+// clears the hash table and the four counters in one launch (two memset launches and a one-thread kernel before); with the bounding box
+// at hand counters[3] gets max |coordinate| right here
+__global__ __launch_bounds__(256) void voxel_clear_kernel(unsigned long long* __restrict__ keys, size_t n_slots, const int* __restrict__ bbox6, int* counters) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (size_t k = t; k < n_slots; k += (size_t)gridDim.x * blockDim.x) keys[k] = KEY_EMPTY;
+  if (t < 3) counters[t] = 0;
+  if (t == 3) {
+    float m = 0.f;
+    if (bbox6) for (int k = 0; k < 6; k++) { const int o = bbox6[k]; m = fmaxf(m, fabsf(__int_as_float(o >= 0 ? o : o ^ 0x7fffffff))); }
+    counters[3] = __float_as_int(m);
+  }
 }
 __global__ __launch_bounds__(256) void maxabs_kernel(const float4* __restrict__ pts, int n, int* counters) {
   __shared__ int sm[4];
@@ -273,13 +279,10 @@ __global__ __launch_bounds__(256) void voxel_keys_kernel(const float4* __restric
 
 hipError_t launch_voxel_build(const CloudDev& tgt, VoxelTable tab, unsigned long long* tgt_keys, int* tgt_slot, int* counters, bool morton_order, bool fixed_cov,
                               const int* bbox6, hipStream_t s) {
-  hipError_t e = hipMemsetAsync(tab.keys, 0xFF, sizeof(unsigned long long) * ((size_t)tab.mask + 1), s);
-  if (e != hipSuccess) return e;
-  e = hipMemsetAsync(counters, 0, 4 * sizeof(int), s);
-  if (e != hipSuccess) return e;
+  static_assert(KEY_EMPTY == ~0ull, "voxel_clear_kernel and the 0xFF memsets elsewhere agree on the empty key");
   const int grid = (tgt.n + 255) / 256;
-  if (bbox6) maxabs_from_bbox_kernel<<<1, 64, 0, s>>>(bbox6, counters);
-  else maxabs_kernel<<<64, 256, 0, s>>>(tgt.xyz, tgt.n, counters);
+  voxel_clear_kernel<<<256, 256, 0, s>>>(tab.keys, (size_t)tab.mask + 1, bbox6, counters);
+  if (!bbox6) maxabs_kernel<<<64, 256, 0, s>>>(tgt.xyz, tgt.n, counters);
   if (morton_order && tgt.have_sorted) {   // Morton order of the neighbour search: tgt_slot (>= 8 * n_leaves entries) is indexed by sorted position
     const int n_sorted = KNN_LEAF * tgt.n_leaves, gs = (n_sorted + 255) / 256;
     voxel_insert_sorted_kernel<<<gs, 256, 0, s>>>(tgt.sorted, n_sorted, tab, tgt_slot, counters);
