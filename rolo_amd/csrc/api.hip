@@ -231,7 +231,7 @@ int build_clouds(rolo_ctx* c, bool do_src, bool do_tgt, hipStream_t stream, bool
   if ((rc = ensure(S.keys1, S.keys1_cap, n_total))) return rc;
   if ((rc = ensure(S.vals0, S.vals0_cap, n_total))) return rc;
   if ((rc = ensure(S.vals1, S.vals1_cap, n_total))) return rc;
-  if ((rc = ensure(S.bbox, S.bbox_cap, 16))) return rc;
+  if ((rc = ensure(S.bbox, S.bbox_cap, knn_bbox_ints()))) return rc;
   if ((rc = ensure(S.nbr, S.nbr_cap, 32 * ((size_t)A.c[0].n_sorted + (nc > 1 ? (size_t)A.c[1].n_sorted : 0))))) return rc;
   A.c[0].nbr = S.nbr; if (nc > 1) A.c[1].nbr = S.nbr + 32 * (size_t)A.c[0].n_sorted;
   const size_t tmp = knn_sort_temp_bytes((int)n_total);

@@ -31,19 +31,14 @@ ROLO_DEV float ord2f(int k) { int i = k >= 0 ? k : k ^ 0x7fffffff; return __int_
 // launches (workgroups [0, split) belong to cloud 0, the rest to cloud 1) — half the launches of two separate chains,
 // both searches start together and fill the chip that one search alone leaves half empty. A single cloud is a pair
 // with n_clouds = 1.
-constexpr int BBOX_BLOCKS = 64;
-
-__global__ void bbox_init_kernel(int* bbox) {  // 2 clouds x (min xyz, max xyz)
-  const int t = threadIdx.x;
-  if (t < 12) bbox[t] = (t % 6) < 3 ? INT_MAX : INT_MIN;
-}
+constexpr int BBOX_BLOCKS = 128;   // per cloud; each writes its partial box to bbox[BBOX_PART + ...] — no atomics, no init launch
+constexpr int BBOX_PART = 16;
 
 __global__ __launch_bounds__(256) void bbox_kernel(KnnPair A, int* bbox) {
   __shared__ float smn[4][3], smx[4][3];
   const int which = blockIdx.x / BBOX_BLOCKS, blk = blockIdx.x - which * BBOX_BLOCKS;
   const float4* __restrict__ p = A.c[which].xyz;
   const int n = A.c[which].n;
-  bbox += 6 * which;
   float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
   for (int i = blk * blockDim.x + threadIdx.x; i < n; i += BBOX_BLOCKS * blockDim.x) {
     float4 q = p[i];
@@ -64,13 +59,15 @@ __global__ __launch_bounds__(256) void bbox_kernel(KnnPair A, int* bbox) {
     for (int d = 0; d < 3; d++) { smn[wv][d] = mn[d]; smx[wv][d] = mx[d]; }
   }
   __syncthreads();
-  // one atomic per block and component (a per-wave atomic on 6 hot words serialised 2048 waves: 141 us)
+  // the block's partial box; the key kernel folds the BBOX_BLOCKS partials of a cloud in its prologue (a per-wave atomic on 6 hot words
+  // serialised 2048 waves: 141 us; one atomic per block: 7 us and an init launch)
   if (threadIdx.x < 3) {
     const int d = threadIdx.x;
     const float a = fminf(fminf(smn[0][d], smn[1][d]), fminf(smn[2][d], smn[3][d]));
     const float b = fmaxf(fmaxf(smx[0][d], smx[1][d]), fmaxf(smx[2][d], smx[3][d]));
-    atomicMin(&bbox[d], f2ord(a));
-    atomicMax(&bbox[3 + d], f2ord(b));
+    int* part = bbox + BBOX_PART + (which * BBOX_BLOCKS + blk) * 6;
+    part[d] = f2ord(a);
+    part[3 + d] = f2ord(b);
   }
 }
 
@@ -124,6 +121,7 @@ ROLO_DEV uint32_t hilbert30(uint32_t x, uint32_t y, uint32_t z) {
 #define ROLO_SORT_EPT 2
 #endif
 constexpr int SORT_NB = ROLO_SORT_NB, SORT_T = ROLO_SORT_T;
+static_assert(SORT_T >= 12 * 64, "the key kernel folds the 12 box components with one wavefront each");
 ROLO_DEV int sort_tile(int n_total) { return ((n_total + SORT_NB - 1) / SORT_NB + SORT_T - 1) / SORT_T * SORT_T; }
 
 constexpr int SORT_EPT = ROLO_SORT_EPT;   // elements per thread and round: a wave ranks 256 consecutive elements between two workgroup barriers
@@ -215,14 +213,27 @@ __global__ __launch_bounds__(SORT_T) void sort_scatter_kernel(const uint32_t* __
 }
 
 // keys of both clouds of the pair (cloud number = bit 30), one workgroup per sort tile; also the tile's digit counts of the first sort pass
-__global__ __launch_bounds__(SORT_T) void morton_kernel(KnnPair A, const int* __restrict__ bbox, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, int n_total, int tile,
+__global__ __launch_bounds__(SORT_T) void morton_kernel(KnnPair A, int* __restrict__ bbox, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, int n_total, int tile,
                                                        int* __restrict__ cnt) {
   __shared__ int hist[256];
   __shared__ float par[2][4];   // per cloud: min x, y, z and the scale
   const int tid = threadIdx.x, blk = blockIdx.x;
   if (tid < 256) hist[tid] = 0;
-  if (tid < 2) {
-    const int* bb = bbox + 6 * tid;
+  __shared__ int fin[12];
+  {  // fold the partial boxes: wave w < 12 owns component w % 6 of cloud w / 6
+    const int w = tid >> 6, lane = tid & 63;
+    if (w < 6 * A.n_clouds) {
+      const bool is_min = (w % 6) < 3;
+      int v = is_min ? INT_MAX : INT_MIN;
+      for (int b = lane; b < BBOX_BLOCKS; b += 64) { const int o = bbox[BBOX_PART + ((w / 6) * BBOX_BLOCKS + b) * 6 + (w % 6)]; v = is_min ? min(v, o) : max(v, o); }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(v, off, 64); v = is_min ? min(v, o) : max(v, o); }
+      if (lane == 0) { fin[w] = v; if (blk == 0) bbox[w] = v; }   // the final box, for the voxel map's scales
+    }
+  }
+  __syncthreads();
+  if (tid < A.n_clouds) {
+    const int* bb = fin + 6 * tid;
     const float mnx = ord2f(bb[0]), mny = ord2f(bb[1]), mnz = ord2f(bb[2]);
     const float ext = fmaxf(fmaxf(ord2f(bb[3]) - mnx, ord2f(bb[4]) - mny), ord2f(bb[5]) - mnz);
     par[tid][0] = mnx; par[tid][1] = mny; par[tid][2] = mnz; par[tid][3] = ext > 0.f ? 1024.0f / ext : 0.f;
@@ -493,6 +504,8 @@ ROLO_DEV void knn_covariance_tail(const int (&ki)[KMAX], int kk, const float4* _
 
 namespace rolo {
 
+size_t knn_bbox_ints() { return BBOX_PART + 2 * BBOX_BLOCKS * 6; }
+
 size_t knn_sort_temp_bytes(int n) {  // for n points in total (one cloud or the sum of a pair), keys of up to 31 bits
 #ifdef ROLO_KNN_ROCPRIM_SORT
   size_t bytes = 0;
@@ -513,7 +526,6 @@ hipError_t launch_knn_build(const KnnPair& A, void* sort_tmp, size_t sort_tmp_by
   const int n_total = A.c[0].n + (nc > 1 ? A.c[1].n : 0);
 #ifdef ROLO_KNN_ROCPRIM_SORT
   const int tile_ = ((n_total + SORT_NB - 1) / SORT_NB + SORT_T - 1) / SORT_T * SORT_T;
-  bbox_init_kernel<<<1, 64, 0, s>>>(bbox);
   bbox_kernel<<<BBOX_BLOCKS * nc, 256, 0, s>>>(A, bbox);
   morton_kernel<<<SORT_NB, SORT_T, 0, s>>>(A, bbox, keys0, vals0, n_total, tile_, nullptr);
   hipError_t e = rocprim::radix_sort_pairs(sort_tmp, sort_tmp_bytes, keys0, keys1, vals0, vals1, (size_t)n_total, 0, nc > 1 ? 31 : 30, s);
@@ -523,7 +535,6 @@ hipError_t launch_knn_build(const KnnPair& A, void* sort_tmp, size_t sort_tmp_by
   (void)sort_tmp_bytes;
   int* cnt = static_cast<int*>(sort_tmp);
   const int tile = ((n_total + SORT_NB - 1) / SORT_NB + SORT_T - 1) / SORT_T * SORT_T;
-  bbox_init_kernel<<<1, 64, 0, s>>>(bbox);
   bbox_kernel<<<BBOX_BLOCKS * nc, 256, 0, s>>>(A, bbox);
   morton_kernel<<<SORT_NB, SORT_T, 0, s>>>(A, bbox, keys0, vals0, n_total, tile, cnt);
   sort_scatter_kernel<<<SORT_NB, SORT_T, 0, s>>>(keys0, vals0, keys1, vals1, n_total, tile, 0, cnt);
