@@ -264,8 +264,10 @@ int build_clouds(rolo_ctx* c, bool do_src, bool do_tgt, hipStream_t stream, bool
     if (do_tgt) { c->tgt.have_sorted = true; c->tgt.have_cov = false; c->tgt.bbox6 = S.bbox + (do_src ? 6 : 0); }
     return ROLO_OK;
   }
-  { ProfScope ps(c, ROLO_PROF_KNN_WALK, stream); HIPCHK(launch_knn_walk(A, c->P.k_correspondences, stream)); }
-  { ProfScope ps(c, ROLO_PROF_KNN_TAIL, stream); HIPCHK(launch_knn_tail(A, c->P.k_correspondences, c->P.regularization, stream)); }
+  // ROLO_KNN_FUSE_TAIL=1: the covariance tail inside the walk kernel instead of its own launch (an A/B: slower, see knn_walk.hpp)
+  static const bool split_tail = [] { const char* e = getenv("ROLO_KNN_FUSE_TAIL"); return !(e && atoi(e) != 0); }();
+  { ProfScope ps(c, ROLO_PROF_KNN_WALK, stream); HIPCHK(launch_knn_walk(A, c->P.k_correspondences, split_tail ? -1 : c->P.regularization, stream)); }
+  if (split_tail) { ProfScope ps(c, ROLO_PROF_KNN_TAIL, stream); HIPCHK(launch_knn_tail(A, c->P.k_correspondences, c->P.regularization, stream)); }
   if (sharded) {
     if (c->comm) {
       const size_t seg = A.c[0].seg;

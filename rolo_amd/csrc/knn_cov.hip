@@ -569,13 +569,19 @@ extern "C" int rolo_debug_wave_records(unsigned* out /* 16384 x 6 */) {
 
 static inline int slice_blocks(const KnnCloud& c) { return (c.q_end - c.q_begin + 255) / 256; }
 
-hipError_t launch_knn_walk(const KnnPair& A, int k, hipStream_t s) {
+hipError_t launch_knn_walk(const KnnPair& A, int k, int regularization_or_minus1, hipStream_t s) {
   constexpr int QPB = 4 * ROLO_KNN_PACKET;   // queries per workgroup of the walk
   const int g0 = (A.c[0].q_end - A.c[0].q_begin + QPB - 1) / QPB, g1 = A.n_clouds > 1 ? (A.c[1].q_end - A.c[1].q_begin + QPB - 1) / QPB : 0;
   if (g0 + g1 == 0) return hipSuccess;
   static const int pad = [] { const char* e = getenv("ROLO_KNN_LDS_PAD"); return e ? atoi(e) : 0; }();   // experiment: occupancy limit through LDS
-  if (k == 20) knn_walk_kernel<20><<<g0 + g1, 256, pad, s>>>(A, g0, k);
-  else knn_walk_kernel<32><<<g0 + g1, 256, pad, s>>>(A, g0, k);
+  if (k == 20) {
+    if (regularization_or_minus1 >= 0) knn_walk_kernel<20, true><<<g0 + g1, 256, pad, s>>>(A, g0, k, regularization_or_minus1);
+    else knn_walk_kernel<20, false><<<g0 + g1, 256, pad, s>>>(A, g0, k, -1);
+  }
+  else {
+    if (regularization_or_minus1 >= 0) knn_walk_kernel<32, true><<<g0 + g1, 256, pad, s>>>(A, g0, k, regularization_or_minus1);
+    else knn_walk_kernel<32, false><<<g0 + g1, 256, pad, s>>>(A, g0, k, -1);
+  }
   return hipGetLastError();
 }
 

@@ -111,10 +111,10 @@ ROLO_DEV void knn_score_leaf(const float4* __restrict__ sorted, int g, const flo
 // The walk keeps only the 20 packed keys and the query live (58 VGPRs): cut for 8 wavefronts per SIMD. Neighbour indices
 // go to A.c[].nbr, slot-major so every store is coalesced; knn_tail_kernel turns them into covariances.
 #ifndef ROLO_KNN_WALK_OCC
-#define ROLO_KNN_WALK_OCC 8
+#define ROLO_KNN_WALK_OCC 4   // 128 VGPRs allowed: the loop needs 61, the slack buys the compiler ~3 % (0.196 -> 0.188 ms); a 2 x 131 072-point pair fills 4 waves per SIMD
 #endif
-template <int KMAX>
-__global__ __launch_bounds__(256, ROLO_KNN_WALK_OCC) void knn_walk_kernel(KnnPair A, int split, int k) {
+template <int KMAX, bool FUSE_TAIL>
+__global__ __launch_bounds__(256, ROLO_KNN_WALK_OCC) void knn_walk_kernel(KnnPair A, int split, int k, int reg) {
   __shared__ int stk[4][WALK_STACK];
   const int tid = threadIdx.x;
   const int wv = tid >> 6;
@@ -223,9 +223,22 @@ __global__ __launch_bounds__(256, ROLO_KNN_WALK_OCC) void knn_walk_kernel(KnnPai
 #pragma unroll
     for (int u = 0; u < KMAX; u++) if (u < kk) { knn_idx[(size_t)qi * kk + u] = ki[u]; knn_d2[(size_t)qi * kk + u] = key_d2(K[u]); }
   }
-  int32_t* __restrict__ nbr = A.c[which].nbr;
+  if (!FUSE_TAIL) {   // neighbour indices only (slot-major, coalesced): knn_tail_kernel turns them into covariances
+    int32_t* __restrict__ nbr = A.c[which].nbr;
 #pragma unroll
-  for (int u = 0; u < KMAX; u++) nbr[(size_t)u * n_sorted + j] = ki[u];
+    for (int u = 0; u < KMAX; u++) nbr[(size_t)u * n_sorted + j] = ki[u];
+    return;
+  }
+  // FUSE_TAIL (ROLO_KNN_FUSE_TAIL=1, an A/B): covariance + regularisation right here, so that the light wavefronts do theirs while the heavy
+  // ones are still walking and the 42 MB of index traffic disappear. Measured: 0.2335 ms against 0.1884 + 0.0394 ms for walk + tail launch,
+  // and the 4-context throughput falls from 2750 to 2490 scans/s — the tails' fp64 work competes with the walking wavefronts for issue slots.
+  const KnnCloud& cl = A.c[which];
+  if (cl.stage) {   // multi-GPU: into the exchange buffer, sorted order
+    double* o = cl.stage + (size_t)(j / cl.chunk) * cl.seg + cl.stage_off + (size_t)(j % cl.chunk) * 6;
+    knn_covariance_tail<KMAX>(ki, kk, cl.xyz, 1, 0, reg, o);
+  } else {
+    knn_covariance_tail<KMAX>(ki, kk, cl.xyz, cl.n, qi, reg, cl.cov);
+  }
 }
 
 template <int KMAX>

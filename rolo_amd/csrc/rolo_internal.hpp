@@ -112,7 +112,8 @@ hipError_t launch_knn_build(const KnnPair& A, void* sort_tmp, size_t sort_tmp_by
                             uint32_t* vals0, uint32_t* vals1, int* bbox, hipStream_t s);
 size_t knn_sort_temp_bytes(int n_total);
 size_t knn_bbox_ints();   // ints of the bounding-box buffer: 12 for the final boxes of a pair + the partial boxes behind them
-hipError_t launch_knn_walk(const KnnPair& A, int k, hipStream_t s);                       // neighbour indices -> A.c[].nbr
+// regularization >= 0: the walk ends in the covariance tail (A.c[].cov / the exchange buffer); -1: neighbour indices -> A.c[].nbr only
+hipError_t launch_knn_walk(const KnnPair& A, int k, int regularization_or_minus1, hipStream_t s);
 hipError_t launch_knn_tail(const KnnPair& A, int k, int regularization, hipStream_t s);   // covariances from A.c[].nbr
 // multi-GPU: exchange buffer (sorted order, all ranks' slices after the all-gather, or [q_begin, q_end) only) -> cov[] by original index
 hipError_t launch_knn_unstage(const KnnPair& A, bool own_slice_only, hipStream_t s);
