@@ -341,9 +341,9 @@ int ensure_map(rolo_ctx* c) {
   return ROLO_OK;
 }
 
-// workgroup size of the fused LM launches (tuning: ROLO_LM_THREADS = 256 | 512 | 1024)
+// workgroup size of the fused LM launches (tuning: ROLO_LM_THREADS = 512 | 1024)
 int lm_threads() {
-  static const int t = [] { const char* e = getenv("ROLO_LM_THREADS"); const int v = e ? atoi(e) : 512; return (v == 256 || v == 512 || v == 1024) ? v : 512; }();
+  static const int t = [] { const char* e = getenv("ROLO_LM_THREADS"); const int v = e ? atoi(e) : 512; return (v == 512 || v == 1024) ? v : 512; }();
   return t;
 }
 int lm_ppt() {

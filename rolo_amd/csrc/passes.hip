@@ -996,12 +996,9 @@ hipError_t launch_lm(int dof, int threads, int ppt, const PassArgs& a, const LmS
   if (threads == 1024) {
     if (dof == 3) lm_kernel<3, 1024><<<grid, 1024, 0, s>>>(a, st_in, st_out, rows_in, rows_out, nrows, trace, do_body, ppt);
     else lm_kernel<6, 1024><<<grid, 1024, 0, s>>>(a, st_in, st_out, rows_in, rows_out, nrows, trace, do_body, ppt);
-  } else if (threads == 512) {
+  } else {
     if (dof == 3) lm_kernel<3, 512><<<grid, 512, 0, s>>>(a, st_in, st_out, rows_in, rows_out, nrows, trace, do_body, ppt);
     else lm_kernel<6, 512><<<grid, 512, 0, s>>>(a, st_in, st_out, rows_in, rows_out, nrows, trace, do_body, ppt);
-  } else {
-    if (dof == 3) lm_kernel<3, 256><<<grid, 256, 0, s>>>(a, st_in, st_out, rows_in, rows_out, nrows, trace, do_body, ppt);
-    else lm_kernel<6, 256><<<grid, 256, 0, s>>>(a, st_in, st_out, rows_in, rows_out, nrows, trace, do_body, ppt);
   }
   return hipGetLastError();
 }

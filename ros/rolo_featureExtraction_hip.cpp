@@ -1,5 +1,5 @@
 // rolo_featureExtraction on MI355X — replaces src/featureExtraction.cpp of sdwyc/ROLO: same topics and queue sizes (:42-49, :290-301);
-// the work is rolo::ros1::FeatureExtractionNode. Built only inside a catkin workspace; not compiled in this repository.
+// the work is rolo::ros1::FeatureExtractionNode. Built only inside a catkin workspace; here it is type-checked against mock ROS headers (tests/test_ros_sources_compile.py).
 #include "rolo_ros_convert.hpp"
 
 class FeatureExtractionRos {

@@ -1,6 +1,6 @@
 // rolo_imageProjection on MI355X — replaces src/imageProjection.cpp of sdwyc/ROLO: same node name, topics, queue sizes and transport
 // hints (:86-93, :515-528); everything between "message arrived" and "publish" is rolo::ros1::ImageProjectionNode
-// (include/rolo_ros_nodes.hpp -> librolo_hip.so). Built only inside a catkin workspace (see ros/README.md); not compiled in this repository.
+// (include/rolo_ros_nodes.hpp -> librolo_hip.so). Built only inside a catkin workspace (see ros/README.md); here it is type-checked against mock ROS headers (tests/test_ros_sources_compile.py).
 #include <mutex>
 
 #include "rolo_ros_convert.hpp"

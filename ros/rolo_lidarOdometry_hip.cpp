@@ -1,7 +1,7 @@
 // rolo_lidarOdometry on MI355X — replaces the LidarOdometry half of src/lidarOdometry.cpp of sdwyc/ROLO: same topics, queue sizes,
 // frames and TF (:394-405, :645-697, :715-729); the work is rolo::ros1::LidarOdometryNode. The TransformFusion half of the reference
 // node (20 Hz ESKF-smoothed odomTopic, :47-323) runs on rolo_fusion_* (include/rolo_fusion.h) in the same process.
-// Built only inside a catkin workspace; not compiled in this repository.
+// Built only inside a catkin workspace; here it is type-checked against mock ROS headers (tests/test_ros_sources_compile.py).
 #include <algorithm>
 #include <mutex>
 

@@ -1,7 +1,7 @@
 // Field-by-field copies between the ROS message classes and the wire structs of include/rolo_ros_wire.hpp. Only the catkin node
 // sources in this directory include this file (it needs roscpp, sensor_msgs, nav_msgs, geometry_msgs and the generated
-// rolo/CloudInfoStamp.h); nothing else in the repository does. NOT compiled in this repository's CI image (no ROS there) — the logic
-// the nodes run lives in include/rolo_ros_nodes.hpp, which is.
+// rolo/CloudInfoStamp.h); nothing else in the repository does. Type-checked in this repository against declaration-only stand-ins of the ROS
+// API (tests/test_ros_sources_compile.py; no ROS in the image) — the logic the nodes run lives in include/rolo_ros_nodes.hpp.
 #pragma once
 #include <geometry_msgs/PoseStamped.h>
 #include <nav_msgs/Odometry.h>
