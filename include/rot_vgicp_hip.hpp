@@ -13,7 +13,8 @@
 //
 // Two build modes:
 //   * with PCL + Eigen on the include path (the ROLO catkin workspace): define ROLO_HIP_WITH_PCL before including;
-//     the class then takes pcl::PointCloud<PointT>::ConstPtr / Eigen types exactly like the reference;
+//     the class then takes pcl::PointCloud<PointT>::ConstPtr / Eigen types exactly like the reference (type-checked here against
+//     declaration-level stand-ins of those types: tests/cpp/shim_pcl_check.cpp, tests/cpp/mock_pcl);
 //   * without them (this repository's CI image has neither): a POD cloud `rolo::Cloud` (n x 8 floats, the
 //     pcl::PointXYZI memory layout) and plain arrays stand in, same methods.
 // The class owns one rolo_ctx (one HIP stream); like the reference object it is not thread-safe.

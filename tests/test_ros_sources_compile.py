@@ -21,3 +21,15 @@ def test_node_source_compiles_and_links(node, tmp_path):
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-4000:]
     assert os.path.exists(exe)
+
+
+def test_pcl_branch_of_the_drop_in_class_type_checks(tmp_path):
+    """include/rot_vgicp_hip.hpp with ROLO_HIP_WITH_PCL against tests/cpp/mock_pcl: every member function instantiated"""
+    import rolo_amd.build as B
+    B.build()
+    exe = str(tmp_path / "shim_pcl_check")
+    cmd = ["g++", "-std=c++17", "-O0", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "tests", "cpp", "mock_pcl"), "-I", os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "tests", "cpp", "shim_pcl_check.cpp"), "-o", exe,
+           "-L", os.path.join(ROOT, "rolo_amd"), "-lrolo_hip", "-Wl,-rpath," + os.path.join(ROOT, "rolo_amd"), "-Wl,-rpath,/opt/rocm/lib"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-4000:]
