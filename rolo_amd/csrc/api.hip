@@ -112,6 +112,8 @@ struct rolo_ctx {
   int* counters = nullptr; size_t counters_cap = 0;
   bool have_map = false;
   int n_voxels = 0;
+  VoxelFuse vf{};           // enqueue_frame arms it before the search when the map can be built inside the search's launches
+  bool vf_done = false;     // the search just enqueued did carry the map build
   int n_edge = 0;   // target points of the last map build within 1e-12 of a POLAR bin edge
   // passes
   int* corr[2] = {nullptr, nullptr}; size_t corr_cap[2] = {0, 0};
@@ -218,6 +220,17 @@ int prepare_cloud(rolo_ctx* c, CloudDev& cl, size_t& cov_cap, size_t& sorted_cap
 
 // Morton sort, BVH, neighbour search and covariances of the source and / or the target in ONE chain of launches.
 // A pair shares the scratch set 0; a lone target uses set 1 so that it can run next to a lone source on another stream.
+// ROLO_KNN_FUSE_TAIL=1: the covariance tail inside the walk kernel instead of its own launch (an A/B: slower, see knn_walk.hpp)
+static bool fused_tail_env() {
+  static const bool v = [] { const char* e = getenv("ROLO_KNN_FUSE_TAIL"); return e && atoi(e) != 0; }();
+  return v;
+}
+// ROLO_VOXEL_FUSE=0: the voxel map as its own launches after the search (the A/B of VoxelFuse)
+static bool voxel_fuse_env() {
+  static const bool v = [] { const char* e = getenv("ROLO_VOXEL_FUSE"); return !(e && atoi(e) == 0); }();
+  return v;
+}
+
 int build_clouds(rolo_ctx* c, bool do_src, bool do_tgt, hipStream_t stream, bool tree_only = false, KnnPair* out_pair = nullptr) {
   KnnPair A{};
   int rc, nc = 0;
@@ -257,17 +270,20 @@ int build_clouds(rolo_ctx* c, bool do_src, bool do_tgt, hipStream_t stream, bool
   // the build overwrites this scratch set's bounding boxes: whoever still pointed at them (a cloud searched earlier) loses them
   if (c->src.bbox6 >= S.bbox && c->src.bbox6 < S.bbox + 12) c->src.bbox6 = nullptr;
   if (c->tgt.bbox6 >= S.bbox && c->tgt.bbox6 < S.bbox + 12) c->tgt.bbox6 = nullptr;
-  { ProfScope ps(c, ROLO_PROF_KNN_BUILD, stream); HIPCHK(launch_knn_build(A, S.sort_tmp, tmp, S.keys0, S.keys1, S.vals0, S.vals1, S.bbox, stream)); }
+  VoxelFuse vf = c->vf;
+  vf.enabled = vf.enabled && do_tgt && !sharded && !tree_only && !fused_tail_env();
+  if (vf.enabled) { vf.which = do_src ? 1 : 0; vf.bbox6 = S.bbox + 6 * vf.which; vf.tgt_xyz = c->tgt.xyz; vf.n_tgt = c->tgt.n; }
+  c->vf_done = vf.enabled != 0;
+  { ProfScope ps(c, ROLO_PROF_KNN_BUILD, stream); HIPCHK(launch_knn_build(A, S.sort_tmp, tmp, S.keys0, S.keys1, S.vals0, S.vals1, S.bbox, vf, stream)); }
   if (out_pair) *out_pair = A;
   if (tree_only) {   // Hilbert sort + BVH only (scan-to-submap association searches it with foreign queries); no covariances
     if (do_src) { c->src.have_sorted = true; c->src.have_cov = false; c->src.bbox6 = S.bbox; }
     if (do_tgt) { c->tgt.have_sorted = true; c->tgt.have_cov = false; c->tgt.bbox6 = S.bbox + (do_src ? 6 : 0); }
     return ROLO_OK;
   }
-  // ROLO_KNN_FUSE_TAIL=1: the covariance tail inside the walk kernel instead of its own launch (an A/B: slower, see knn_walk.hpp)
-  static const bool split_tail = [] { const char* e = getenv("ROLO_KNN_FUSE_TAIL"); return !(e && atoi(e) != 0); }();
-  { ProfScope ps(c, ROLO_PROF_KNN_WALK, stream); HIPCHK(launch_knn_walk(A, c->P.k_correspondences, split_tail ? -1 : c->P.regularization, stream)); }
-  if (split_tail) { ProfScope ps(c, ROLO_PROF_KNN_TAIL, stream); HIPCHK(launch_knn_tail(A, c->P.k_correspondences, c->P.regularization, stream)); }
+  const bool split_tail = !fused_tail_env();
+  { ProfScope ps(c, ROLO_PROF_KNN_WALK, stream); HIPCHK(launch_knn_walk(A, c->P.k_correspondences, split_tail ? -1 : c->P.regularization, vf, stream)); }
+  if (split_tail) { ProfScope ps(c, ROLO_PROF_KNN_TAIL, stream); HIPCHK(launch_knn_tail(A, c->P.k_correspondences, c->P.regularization, vf, stream)); }
   if (sharded) {
     if (c->comm) {
       const size_t seg = A.c[0].seg;
@@ -330,7 +346,7 @@ int ensure_map(rolo_ctx* c) {
   if ((rc = ensure(c->counters, c->counters_cap, 4))) return rc;
   c->tab.mask = (unsigned)(capslots - 1);
   fill_table_params(c);
-  { ProfScope ps(c, ROLO_PROF_VOXEL_BUILD); HIPCHK(launch_voxel_build(c->tgt, c->tab, c->tgt_keys, c->tgt_slot, c->counters, voxel_morton_order(c), voxel_fixed_cov(c), c->tgt.bbox6, c->stream)); }
+  { ProfScope ps(c, ROLO_PROF_VOXEL_BUILD); HIPCHK(launch_voxel_build(c->tgt, c->tab, c->tgt_keys, c->tgt_slot, c->counters, voxel_morton_order(c), voxel_fixed_cov(c), c->tgt.bbox6, false, c->stream)); }
   HIPCHK(hipMemcpyAsync(c->h_counters, c->counters, 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   if (c->h_counters[1] != 0) { g_err = "voxel coordinate outside the packed key range"; return c->h_counters[1]; }
@@ -865,8 +881,9 @@ int rolo_compute_translation(rolo_ctx* c, double* trans, const double* g3, const
 // everything of one frame after the clouds are on the device; per-frame arguments come from c->h_args (pinned)
 static int enqueue_frame(rolo_ctx* c) {
   int rc;
-  if ((rc = ensure_covs(c))) return rc;
-  // voxel map without the host round trip of ensure_map(): errors are picked up in rolo_register_wait
+  if (c->src.n <= 0 || c->tgt.n <= 0) { g_err = "source/target not set"; return ROLO_ESTATE; }
+  // voxel map without the host round trip of ensure_map(): errors are picked up in rolo_register_wait. The table is sized first: when
+  // the target's covariances are about to be computed (and are bounded), the search's own launches build the map (VoxelFuse).
   {
     const int n = c->tgt.n;
     size_t capslots = 1024; while (capslots < 2 * (size_t)n) capslots <<= 1;
@@ -879,7 +896,17 @@ static int enqueue_frame(rolo_ctx* c) {
     if ((rc = ensure(c->counters, c->counters_cap, 4))) return rc;
     c->tab.mask = (unsigned)(capslots - 1);
     fill_table_params(c);
-    { ProfScope ps(c, ROLO_PROF_VOXEL_BUILD); HIPCHK(launch_voxel_build(c->tgt, c->tab, c->tgt_keys, c->tgt_slot, c->counters, voxel_morton_order(c), voxel_fixed_cov(c), c->tgt.bbox6, c->stream)); }
+    c->vf_done = false;
+    c->vf = VoxelFuse{};
+    if (!c->tgt.have_cov && voxel_fuse_env() && knn_voxel_fuse_supported()) {
+      c->tgt.cov_user = false;   // about to be computed here
+      if (voxel_fixed_cov(c)) { c->vf.enabled = 1; c->vf.tab = c->tab; c->vf.tgt_keys = c->tgt_keys; c->vf.tgt_slot = c->tgt_slot; c->vf.counters = c->counters; }
+    }
+    rc = ensure_covs(c);
+    c->vf.enabled = 0;
+    if (rc) return rc;
+    { ProfScope ps(c, ROLO_PROF_VOXEL_BUILD); HIPCHK(launch_voxel_build(c->tgt, c->tab, c->tgt_keys, c->tgt_slot, c->counters, voxel_morton_order(c), voxel_fixed_cov(c), c->tgt.bbox6, c->vf_done, c->stream)); }
+    c->vf_done = false;
     HIPCHK(hipMemcpyAsync(c->h_counters, c->counters, 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
   }
   PassArgs a; int grid;
@@ -1149,7 +1176,7 @@ static int enqueue_batch(rolo_batch* b, bool fork) {
     if ((rc = ensure(c->counters, c->counters_cap, 4))) return rc;
     c->tab.mask = (unsigned)(capslots - 1);
     fill_table_params(c);
-    HIPCHK(launch_voxel_build(c->tgt, c->tab, c->tgt_keys, c->tgt_slot, c->counters, voxel_morton_order(c), voxel_fixed_cov(c), c->tgt.bbox6, s2));
+    HIPCHK(launch_voxel_build(c->tgt, c->tab, c->tgt_keys, c->tgt_slot, c->counters, voxel_morton_order(c), voxel_fixed_cov(c), c->tgt.bbox6, false, s2));
     HIPCHK(hipMemcpyAsync(c->h_counters, c->counters, 4 * sizeof(int), hipMemcpyDeviceToHost, s2));
     if (fork) { HIPCHK(hipEventRecord(b->ev_join[2 * i], s1)); HIPCHK(hipEventRecord(b->ev_join[2 * i + 1], s2)); }
     PassArgs a; int grid;

@@ -16,6 +16,7 @@
 #include <string.h>
 #include "rolo_internal.hpp"
 #include "dev_math.hpp"
+#include "voxel_dev.hpp"
 #include <rocprim/rocprim.hpp>
 #include <cfloat>
 #include <climits>
@@ -126,7 +127,14 @@ ROLO_DEV int sort_tile(int n_total) { return ((n_total + SORT_NB - 1) / SORT_NB 
 
 constexpr int SORT_EPT = ROLO_SORT_EPT;   // elements per thread and round: a wave ranks 256 consecutive elements between two workgroup barriers
 __global__ __launch_bounds__(SORT_T) void sort_scatter_kernel(const uint32_t* __restrict__ kin, const uint32_t* __restrict__ vin, uint32_t* __restrict__ kout,
-                                                             uint32_t* __restrict__ vout, int n, int tile, int pass, int* __restrict__ cnt /* [4][SORT_NB][256] */) {
+                                                             uint32_t* __restrict__ vout, int n, int tile, int pass, int* __restrict__ cnt /* [4][SORT_NB][256] */,
+                                                             VoxelFuse vf) {
+  if ((int)blockIdx.x >= SORT_NB) {   // VoxelFuse: this pass's quarter of the target points goes into the voxel hash table on the CUs the sort leaves idle
+    const int nt = vf.n_tgt, quarter = (nt + 3) / 4;
+    const int i = pass * quarter + ((int)blockIdx.x - SORT_NB) * SORT_T + (int)threadIdx.x;
+    voxel_insert_point(vf.tab, vf.tgt_xyz, i < (pass + 1) * quarter ? nt : 0, i, vf.tgt_keys, vf.tgt_slot, vf.counters);
+    return;
+  }
   __shared__ int wcnt[SORT_T / 64][256];
   __shared__ int base[256], run[256], wsum[4];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, blk = blockIdx.x;
@@ -213,8 +221,15 @@ __global__ __launch_bounds__(SORT_T) void sort_scatter_kernel(const uint32_t* __
 }
 
 // keys of both clouds of the pair (cloud number = bit 30), one workgroup per sort tile; also the tile's digit counts of the first sort pass
+constexpr int VF_CLEAR_BLOCKS = 64;   // VoxelFuse: workgroups behind the key kernel's that clear the target's voxel table
 __global__ __launch_bounds__(SORT_T) void morton_kernel(KnnPair A, int* __restrict__ bbox, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, int n_total, int tile,
-                                                       int* __restrict__ cnt) {
+                                                       int* __restrict__ cnt, VoxelFuse vf) {
+  if ((int)blockIdx.x >= SORT_NB) {
+    const size_t n_slots = (size_t)vf.tab.mask + 1;
+    for (size_t k = (size_t)((int)blockIdx.x - SORT_NB) * SORT_T + threadIdx.x; k < n_slots; k += (size_t)VF_CLEAR_BLOCKS * SORT_T) vf.tab.keys[k] = KEY_EMPTY;
+    if (blockIdx.x == SORT_NB && threadIdx.x < 3) vf.counters[threadIdx.x] = 0;   // counters[3] (max |coordinate|) is block 0's
+    return;
+  }
   __shared__ int hist[256];
   __shared__ float par[2][4];   // per cloud: min x, y, z and the scale
   const int tid = threadIdx.x, blk = blockIdx.x;
@@ -228,10 +243,15 @@ __global__ __launch_bounds__(SORT_T) void morton_kernel(KnnPair A, int* __restri
       for (int b = lane; b < BBOX_BLOCKS; b += 64) { const int o = bbox[BBOX_PART + ((w / 6) * BBOX_BLOCKS + b) * 6 + (w % 6)]; v = is_min ? min(v, o) : max(v, o); }
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(v, off, 64); v = is_min ? min(v, o) : max(v, o); }
-      if (lane == 0) { fin[w] = v; if (blk == 0) bbox[w] = v; }   // the final box, for the voxel map's scales
+      if (lane == 0) { fin[w] = v; if (blk == 0) bbox[w] = v; }   // the final box, for the voxel map's scales (separate map build)
     }
   }
   __syncthreads();
+  if (vf.enabled && blk == 0 && tid == 0) {   // VoxelFuse: max |coordinate| of the target for the fixed-point scales (voxel_clear_body's job otherwise)
+    float m = 0.f;
+    for (int k = 0; k < 6; k++) { const int o = fin[6 * vf.which + k]; m = fmaxf(m, fabsf(__int_as_float(o >= 0 ? o : o ^ 0x7fffffff))); }
+    vf.counters[3] = __float_as_int(m);
+  }
   if (tid < A.n_clouds) {
     const int* bb = fin + 6 * tid;
     const float mnx = ord2f(bb[0]), mny = ord2f(bb[1]), mnz = ord2f(bb[2]);
@@ -441,7 +461,7 @@ ROLO_DEV void inv3(const double (&A)[9], double (&o)[9]) {
 // covariance of the neighbourhood + regularisation, one lane per query
 template <int KMAX>
 ROLO_DEV void knn_covariance_tail(const int (&ki)[KMAX], int kk, const float4* __restrict__ orig, int n, int qi, int reg,
-                                  double* __restrict__ cov) {
+                                  double* __restrict__ cov, double (&c6)[6]) {
   // ---- covariance of the neighbourhood (rot_vgicp_impl.hpp:438-455), fp64, centred two-pass ----
   // the K neighbours are gathered once and stay in registers for both passes (this kernel is not occupancy-critical)
   float px[KMAX], py[KMAX], pz[KMAX];
@@ -489,12 +509,9 @@ ROLO_DEV void knn_covariance_tail(const int (&ki)[KMAX], int kk, const float4* _
       for (int b = 0; b < 3; b++) out[a * 3 + b] = (U[a * 3 + 0] * v0) * V[b * 3 + 0] + (U[a * 3 + 1] * v1) * V[b * 3 + 1] + (U[a * 3 + 2] * v2) * V[b * 3 + 2];
   }
   const size_t pitch = (size_t)n;
-  cov[0 * pitch + qi] = out[0];
-  cov[1 * pitch + qi] = 0.5 * (out[1] + out[3]);
-  cov[2 * pitch + qi] = 0.5 * (out[2] + out[6]);
-  cov[3 * pitch + qi] = out[4];
-  cov[4 * pitch + qi] = 0.5 * (out[5] + out[7]);
-  cov[5 * pitch + qi] = out[8];
+  c6[0] = out[0]; c6[1] = 0.5 * (out[1] + out[3]); c6[2] = 0.5 * (out[2] + out[6]); c6[3] = out[4]; c6[4] = 0.5 * (out[5] + out[7]); c6[5] = out[8];
+#pragma unroll
+  for (int d = 0; d < 6; d++) cov[d * pitch + qi] = c6[d];
 }
 
 }  // namespace
@@ -503,6 +520,14 @@ ROLO_DEV void knn_covariance_tail(const int (&ki)[KMAX], int kk, const float4* _
 #include "knn_walk.hpp"
 
 namespace rolo {
+
+bool knn_voxel_fuse_supported() {
+#ifdef ROLO_KNN_ROCPRIM_SORT
+  return false;   // the insert rides on the hand-written sort's scatter launches
+#else
+  return true;
+#endif
+}
 
 size_t knn_bbox_ints() { return BBOX_PART + 2 * BBOX_BLOCKS * 6; }
 
@@ -521,29 +546,30 @@ size_t knn_sort_temp_bytes(int n) {  // for n points in total (one cloud or the 
 // Morton sort + implicit BVHs of the pair's clouds. sorted / boxes must be allocated for n_leaves / P of each cloud;
 // keys / vals hold n0 + n1 entries, bbox 12 ints.
 hipError_t launch_knn_build(const KnnPair& A, void* sort_tmp, size_t sort_tmp_bytes, uint32_t* keys0, uint32_t* keys1,
-                            uint32_t* vals0, uint32_t* vals1, int* bbox, hipStream_t s) {
+                            uint32_t* vals0, uint32_t* vals1, int* bbox, const VoxelFuse& vf, hipStream_t s) {
   const int nc = A.n_clouds;
   const int n_total = A.c[0].n + (nc > 1 ? A.c[1].n : 0);
 #ifdef ROLO_KNN_ROCPRIM_SORT
   const int tile_ = ((n_total + SORT_NB - 1) / SORT_NB + SORT_T - 1) / SORT_T * SORT_T;
   bbox_kernel<<<BBOX_BLOCKS * nc, 256, 0, s>>>(A, bbox);
-  morton_kernel<<<SORT_NB, SORT_T, 0, s>>>(A, bbox, keys0, vals0, n_total, tile_, nullptr);
+  morton_kernel<<<SORT_NB + (vf.enabled ? VF_CLEAR_BLOCKS : 0), SORT_T, 0, s>>>(A, bbox, keys0, vals0, n_total, tile_, nullptr, vf);
   hipError_t e = rocprim::radix_sort_pairs(sort_tmp, sort_tmp_bytes, keys0, keys1, vals0, vals1, (size_t)n_total, 0, nc > 1 ? 31 : 30, s);
   if (e != hipSuccess) return e;
   const uint32_t* order = vals1;
 #else
   (void)sort_tmp_bytes;
   int* cnt = static_cast<int*>(sort_tmp);
+  const int gvf = vf.enabled ? ((vf.n_tgt + 3) / 4 + SORT_T - 1) / SORT_T : 0;   // insert workgroups per scatter launch
   const int tile = ((n_total + SORT_NB - 1) / SORT_NB + SORT_T - 1) / SORT_T * SORT_T;
   bbox_kernel<<<BBOX_BLOCKS * nc, 256, 0, s>>>(A, bbox);
-  morton_kernel<<<SORT_NB, SORT_T, 0, s>>>(A, bbox, keys0, vals0, n_total, tile, cnt);
-  sort_scatter_kernel<<<SORT_NB, SORT_T, 0, s>>>(keys0, vals0, keys1, vals1, n_total, tile, 0, cnt);
+  morton_kernel<<<SORT_NB + (vf.enabled ? VF_CLEAR_BLOCKS : 0), SORT_T, 0, s>>>(A, bbox, keys0, vals0, n_total, tile, cnt, vf);
+  sort_scatter_kernel<<<SORT_NB + gvf, SORT_T, 0, s>>>(keys0, vals0, keys1, vals1, n_total, tile, 0, cnt, vf);
   sort_hist_kernel<<<SORT_NB, SORT_T, 0, s>>>(keys1, n_total, tile, 1, cnt);
-  sort_scatter_kernel<<<SORT_NB, SORT_T, 0, s>>>(keys1, vals1, keys0, vals0, n_total, tile, 1, cnt);
+  sort_scatter_kernel<<<SORT_NB + gvf, SORT_T, 0, s>>>(keys1, vals1, keys0, vals0, n_total, tile, 1, cnt, vf);
   sort_hist_kernel<<<SORT_NB, SORT_T, 0, s>>>(keys0, n_total, tile, 2, cnt);
-  sort_scatter_kernel<<<SORT_NB, SORT_T, 0, s>>>(keys0, vals0, keys1, vals1, n_total, tile, 2, cnt);
+  sort_scatter_kernel<<<SORT_NB + gvf, SORT_T, 0, s>>>(keys0, vals0, keys1, vals1, n_total, tile, 2, cnt, vf);
   sort_hist_kernel<<<SORT_NB, SORT_T, 0, s>>>(keys1, n_total, tile, 3, cnt);
-  sort_scatter_kernel<<<SORT_NB, SORT_T, 0, s>>>(keys1, vals1, keys0, vals0, n_total, tile, 3, cnt);
+  sort_scatter_kernel<<<SORT_NB + gvf, SORT_T, 0, s>>>(keys1, vals1, keys0, vals0, n_total, tile, 3, cnt, vf);
   const uint32_t* order = vals0;
 #endif
   static_assert(256 % KNN_LEAF == 0 && (KNN_LEAF & (KNN_LEAF - 1)) == 0, "leaf_kernel reduces a leaf inside a wavefront");
@@ -569,10 +595,11 @@ extern "C" int rolo_debug_wave_records(unsigned* out /* 16384 x 6 */) {
 
 static inline int slice_blocks(const KnnCloud& c) { return (c.q_end - c.q_begin + 255) / 256; }
 
-hipError_t launch_knn_walk(const KnnPair& A, int k, int regularization_or_minus1, hipStream_t s) {
+hipError_t launch_knn_walk(const KnnPair& A, int k, int regularization_or_minus1, const VoxelFuse& vf, hipStream_t s) {
   constexpr int QPB = 4 * ROLO_KNN_PACKET;   // queries per workgroup of the walk
   const int g0 = (A.c[0].q_end - A.c[0].q_begin + QPB - 1) / QPB, g1 = A.n_clouds > 1 ? (A.c[1].q_end - A.c[1].q_begin + QPB - 1) / QPB : 0;
   if (g0 + g1 == 0) return hipSuccess;
+  (void)vf;   // (insert workgroups appended to THIS launch made its wave-uniform leaf loads vector loads: a store anywhere in the kernel is a potential clobber)
   static const int pad = [] { const char* e = getenv("ROLO_KNN_LDS_PAD"); return e ? atoi(e) : 0; }();   // experiment: occupancy limit through LDS
   if (k == 20) {
     if (regularization_or_minus1 >= 0) knn_walk_kernel<20, true><<<g0 + g1, 256, pad, s>>>(A, g0, k, regularization_or_minus1);
@@ -593,11 +620,11 @@ hipError_t launch_knn_unstage(const KnnPair& A, bool own_slice_only, hipStream_t
   return hipGetLastError();
 }
 
-hipError_t launch_knn_tail(const KnnPair& A, int k, int regularization, hipStream_t s) {
+hipError_t launch_knn_tail(const KnnPair& A, int k, int regularization, const VoxelFuse& vf, hipStream_t s) {
   const int g0 = slice_blocks(A.c[0]), g1 = A.n_clouds > 1 ? slice_blocks(A.c[1]) : 0;
   if (g0 + g1 == 0) return hipSuccess;
-  if (k == 20) knn_tail_kernel<20><<<g0 + g1, 256, 0, s>>>(A, g0, k, regularization);
-  else knn_tail_kernel<32><<<g0 + g1, 256, 0, s>>>(A, g0, k, regularization);
+  if (k == 20) knn_tail_kernel<20><<<g0 + g1, 256, 0, s>>>(A, g0, k, regularization, vf);
+  else knn_tail_kernel<32><<<g0 + g1, 256, 0, s>>>(A, g0, k, regularization, vf);
   return hipGetLastError();
 }
 

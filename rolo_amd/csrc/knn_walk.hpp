@@ -235,31 +235,42 @@ __global__ __launch_bounds__(256, ROLO_KNN_WALK_OCC) void knn_walk_kernel(KnnPai
   const KnnCloud& cl = A.c[which];
   if (cl.stage) {   // multi-GPU: into the exchange buffer, sorted order
     double* o = cl.stage + (size_t)(j / cl.chunk) * cl.seg + cl.stage_off + (size_t)(j % cl.chunk) * 6;
-    knn_covariance_tail<KMAX>(ki, kk, cl.xyz, 1, 0, reg, o);
+    double c6[6]; knn_covariance_tail<KMAX>(ki, kk, cl.xyz, 1, 0, reg, o, c6);
   } else {
-    knn_covariance_tail<KMAX>(ki, kk, cl.xyz, cl.n, qi, reg, cl.cov);
+    double c6[6]; knn_covariance_tail<KMAX>(ki, kk, cl.xyz, cl.n, qi, reg, cl.cov, c6);
   }
 }
 
 template <int KMAX>
-__global__ __launch_bounds__(256) void knn_tail_kernel(KnnPair A, int split, int k, int reg) {
+__global__ __launch_bounds__(256) void knn_tail_kernel(KnnPair A, int split, int k, int reg, VoxelFuse vf) {
   const int blk = xcd_contiguous_block((int)blockIdx.x, (int)gridDim.x);
   const int which = blk >= split ? 1 : 0;
   const KnnCloud& cl = A.c[which];
   const int n_sorted = cl.n_sorted;
   const int j = cl.q_begin + (blk - (which ? split : 0)) * 256 + threadIdx.x;
-  if (j >= cl.q_end) return;
-  const int qi = __float_as_int(cl.sorted[j].w);
-  if (qi == INT_MAX) return;
-  const int32_t* __restrict__ nbr = cl.nbr;
-  int ki[KMAX];
+  const bool fuse = vf.enabled && which == vf.which;   // workgroup-uniform: this workgroup's points also go into the voxel map
+  float4 sp = make_float4(0.f, 0.f, 0.f, 0.f);
+  int qi = INT_MAX;
+  if (j < cl.q_end) { sp = cl.sorted[j]; qi = __float_as_int(sp.w); }
+  const bool act = qi != INT_MAX;
+  if (!act && !fuse) return;
+  double c6[6] = {0, 0, 0, 0, 0, 0};
+  if (act) {
+    const int32_t* __restrict__ nbr = cl.nbr;
+    int ki[KMAX];
 #pragma unroll
-  for (int u = 0; u < KMAX; u++) ki[u] = nbr[(size_t)u * n_sorted + j];
-  if (cl.stage) {   // multi-GPU: into the exchange buffer, sorted order
-    double* o = cl.stage + (size_t)(j / cl.chunk) * cl.seg + cl.stage_off + (size_t)(j % cl.chunk) * 6;
-    knn_covariance_tail<KMAX>(ki, (KMAX == 20) ? 20 : k, cl.xyz, 1, 0, reg, o);   // pitch 1, index 0: six consecutive doubles
-  } else {
-    knn_covariance_tail<KMAX>(ki, (KMAX == 20) ? 20 : k, cl.xyz, cl.n, qi, reg, cl.cov);
+    for (int u = 0; u < KMAX; u++) ki[u] = nbr[(size_t)u * n_sorted + j];
+    if (cl.stage) {   // multi-GPU: into the exchange buffer, sorted order
+      double* o = cl.stage + (size_t)(j / cl.chunk) * cl.seg + cl.stage_off + (size_t)(j % cl.chunk) * 6;
+      knn_covariance_tail<KMAX>(ki, (KMAX == 20) ? 20 : k, cl.xyz, 1, 0, reg, o, c6);   // pitch 1, index 0: six consecutive doubles
+    } else {
+      knn_covariance_tail<KMAX>(ki, (KMAX == 20) ? 20 : k, cl.xyz, cl.n, qi, reg, cl.cov, c6);
+    }
+  }
+  if (fuse) {   // every lane of the wavefront takes part in the segmented fold
+    int id = -1;
+    if (act) { const int slot = vf.tgt_slot[qi]; if (slot >= 0) id = vf.tab.ids[slot]; }
+    accumulate_point(vf.tab, id, sp, c6, fix_scales(cl.n, vf.counters), true);
   }
 }
 

@@ -108,20 +108,34 @@ struct BatchSlot { PassArgs a; LmState* st; rolo_trace_rec* trace; int grid; int
 struct KnnCloud { const float4* xyz; float4* sorted; float4* boxes; double* cov; int32_t* knn_idx; float* knn_d2; int32_t* nbr; int n, n_leaves, P, n_sorted;
                   int q_begin, q_end; double* stage; int chunk, stage_off; size_t seg; };
 struct KnnPair { KnnCloud c[2]; int n_clouds; };
+// The target's voxel map built inside the search's launches (single GPU, covariances computed here and bounded): the table is cleared by
+// extra workgroups of the key kernel, the points are inserted by extra workgroups of the four sort-scatter launches (a quarter each, on
+// the CUs the 128 sort tiles leave idle: nothing on the critical path), and the tail accumulates each target point's covariance straight
+// from registers, in curve order. Only voxel_finalize_kernel is left of the map build.
+struct VoxelFuse {
+  int enabled;        // 0: the map is built by launch_voxel_build alone
+  int which;          // index of the target cloud in the pair
+  VoxelTable tab;
+  unsigned long long* tgt_keys; int* tgt_slot; int* counters;
+  const int* bbox6;   // the target's final bounding box (written by the key kernel)
+  const float4* tgt_xyz; int n_tgt;   // the target in input order (what the insert workgroups read)
+};
 hipError_t launch_knn_build(const KnnPair& A, void* sort_tmp, size_t sort_tmp_bytes, uint32_t* keys0, uint32_t* keys1,
-                            uint32_t* vals0, uint32_t* vals1, int* bbox, hipStream_t s);
+                            uint32_t* vals0, uint32_t* vals1, int* bbox, const VoxelFuse& vf, hipStream_t s);
 size_t knn_sort_temp_bytes(int n_total);
+bool knn_voxel_fuse_supported();
 size_t knn_bbox_ints();   // ints of the bounding-box buffer: 12 for the final boxes of a pair + the partial boxes behind them
 // regularization >= 0: the walk ends in the covariance tail (A.c[].cov / the exchange buffer); -1: neighbour indices -> A.c[].nbr only
-hipError_t launch_knn_walk(const KnnPair& A, int k, int regularization_or_minus1, hipStream_t s);
-hipError_t launch_knn_tail(const KnnPair& A, int k, int regularization, hipStream_t s);   // covariances from A.c[].nbr
+hipError_t launch_knn_walk(const KnnPair& A, int k, int regularization_or_minus1, const VoxelFuse& vf, hipStream_t s);
+hipError_t launch_knn_tail(const KnnPair& A, int k, int regularization, const VoxelFuse& vf, hipStream_t s);   // covariances from A.c[].nbr
 // multi-GPU: exchange buffer (sorted order, all ranks' slices after the all-gather, or [q_begin, q_end) only) -> cov[] by original index
 hipError_t launch_knn_unstage(const KnnPair& A, bool own_slice_only, hipStream_t s);
 
 // fixed_cov: the covariance sums go through 64-bit fixed point as the positions always do (entries bounded by 1); false: fp64 atomics
 // bbox6: the target's bounding box as the neighbour search leaves it on the device (6 order-preserving ints), or nullptr
+// prefused: clear / insert / accumulate already ran inside the search's launches (VoxelFuse): finalize only
 hipError_t launch_voxel_build(const CloudDev& tgt, VoxelTable tab, unsigned long long* tgt_keys, int* tgt_slot, int* counters, bool morton_order, bool fixed_cov,
-                              const int* bbox6, hipStream_t s);
+                              const int* bbox6, bool prefused, hipStream_t s);
 hipError_t launch_voxel_keys(const float4* pts, int n, VoxelTable tab, int32_t* keys3, hipStream_t s);
 
 hipError_t launch_rot_pass(int dof, const PassArgs& a, const LmState* st, int grid, hipStream_t s);

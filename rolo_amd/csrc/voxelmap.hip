@@ -24,25 +24,10 @@ namespace rolo {
 
 namespace {
 
-// counters: [0] voxels, [1] error code, [2] points within 1e-12 of a bin edge, [3] float bits of max |coordinate| of the target
-ROLO_DEV void note_point(bool valid, bool near_edge, int* counters) {
-  const unsigned long long edge = __ballot(valid && near_edge);
-  if (edge && (threadIdx.x & 63) == 0) atomicAdd(&counters[2], __popcll(edge));
-}
-
-// max |coordinate| of the target -> counters[3]: from the bounding box the neighbour search left on the device (6 order-preserving
-// ints: min xyz, max xyz), or, for a target whose covariances were handed in (no search ran), from the points themselves
 // clears the hash table and the four counters in one launch (two memset launches and a one-thread kernel before); with the bounding box
 // at hand counters[3] gets max |coordinate| right here
 __global__ __launch_bounds__(256) void voxel_clear_kernel(unsigned long long* __restrict__ keys, size_t n_slots, const int* __restrict__ bbox6, int* counters) {
-  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  for (size_t k = t; k < n_slots; k += (size_t)gridDim.x * blockDim.x) keys[k] = KEY_EMPTY;
-  if (t < 3) counters[t] = 0;
-  if (t == 3) {
-    float m = 0.f;
-    if (bbox6) for (int k = 0; k < 6; k++) { const int o = bbox6[k]; m = fmaxf(m, fabsf(__int_as_float(o >= 0 ? o : o ^ 0x7fffffff))); }
-    counters[3] = __float_as_int(m);
-  }
+  voxel_clear_body(keys, n_slots, bbox6, counters, (size_t)blockIdx.x * blockDim.x + threadIdx.x, (size_t)gridDim.x * blockDim.x);
 }
 __global__ __launch_bounds__(256) void maxabs_kernel(const float4* __restrict__ pts, int n, int* counters) {
   __shared__ int sm[4];
@@ -56,105 +41,9 @@ __global__ __launch_bounds__(256) void maxabs_kernel(const float4* __restrict__ 
   if (threadIdx.x == 0) atomicMax(&counters[3], max(max(sm[0], sm[1]), max(sm[2], sm[3])));
 }
 
-// fixed-point scales (powers of two) of the position / covariance sums: n * max|value| * scale < 2^62
-struct FixScale { double pos, cov; };
-ROLO_DEV FixScale fix_scales(int n, const int* counters) {
-  const int bits_n = 32 - __clz(max(n, 1));
-  const int e = ((counters[3] >> 23) & 0xff) - 127;      // max|coordinate| < 2^(e+1)
-  FixScale s;
-  s.pos = ldexp(1.0, 62 - bits_n - (max(e, -1) + 1));
-  s.cov = ldexp(1.0, 62 - bits_n - 1);                   // |entries| <= 1 for the spectrally bounded regularisations
-  return s;
-}
-ROLO_DEV long long shfl_up_ll(long long v, int off) {
-  return (long long)(((unsigned long long)(unsigned)__shfl_up((int)((unsigned long long)v >> 32), off, 64) << 32) | (unsigned)__shfl_up((int)((unsigned long long)v & 0xffffffffull), off, 64));
-}
-
-// one point -> (id, 10 values) -> wave-level fold of runs of equal id -> one atomic per run and value.
-// fixed_cov: covariances go through the integer sums too (bounded entries); otherwise they keep fp64 atomics (options the
-// reference never selects, or covariances handed in by the caller: unbounded entries).
-ROLO_DEV void accumulate_point(const VoxelTable& tab, int id, const float4& p, const double (&c)[6], const FixScale& S, bool fixed_cov) {
-  const int lane = threadIdx.x & 63;
-  long long q[10];
-  double cv[6];
-#pragma unroll
-  for (int d = 0; d < 10; d++) q[d] = 0;
-#pragma unroll
-  for (int d = 0; d < 6; d++) cv[d] = 0.0;
-  if (id >= 0) {
-    q[0] = __double2ll_rn((double)p.x * S.pos); q[1] = __double2ll_rn((double)p.y * S.pos); q[2] = __double2ll_rn((double)p.z * S.pos);
-    if (fixed_cov) {
-#pragma unroll
-      for (int d = 0; d < 6; d++) q[3 + d] = __double2ll_rn(c[d] * S.cov);
-    } else {
-#pragma unroll
-      for (int d = 0; d < 6; d++) cv[d] = c[d];
-    }
-    q[9] = 1;
-  }
-  const int prev_id = __shfl_up(id, 1, 64);
-  const bool head = (lane == 0) || (prev_id != id);
-  const unsigned long long head_mask = __ballot(head);
-  const unsigned long long below = head_mask & ((lane == 63) ? ~0ull : ((1ull << (lane + 1)) - 1ull));
-  const int head_lane = 63 - __clzll(below);
-  const int dist = lane - head_lane;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-#pragma unroll
-    for (int d = 0; d < 10; d++) {
-      const long long o = shfl_up_ll(q[d], off);
-      if (dist >= off) q[d] += o;
-    }
-    if (!fixed_cov) {
-#pragma unroll
-      for (int d = 0; d < 6; d++) { const double o = __shfl_up(cv[d], off, 64); if (dist >= off) cv[d] += o; }
-    }
-  }
-  const int next_id = __shfl_down(id, 1, 64);
-  const bool tail = (lane == 63) || (next_id != id);
-  if (tail && id >= 0) {
-    unsigned long long* r = reinterpret_cast<unsigned long long*>(tab.rec + (size_t)id * REC_DOUBLES);
-#pragma unroll
-    for (int d = 0; d < 3; d++) atomicAdd(&r[d], (unsigned long long)q[d]);
-    if (fixed_cov) {
-#pragma unroll
-      for (int d = 3; d < 9; d++) atomicAdd(&r[d], (unsigned long long)q[d]);
-    } else {
-      double* rd = tab.rec + (size_t)id * REC_DOUBLES;
-#pragma unroll
-      for (int d = 0; d < 6; d++) atomicAdd(&rd[3 + d], cv[d]);
-    }
-    atomicAdd(&r[10], (unsigned long long)q[9]);
-  }
-}
-
 __global__ __launch_bounds__(256) void voxel_insert_kernel(const float4* __restrict__ pts, int n, VoxelTable tab,
                                                           unsigned long long* tgt_keys, int* tgt_slot, int* counters) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const float4 p = i < n ? pts[i] : make_float4(1.f, 1.f, 1.f, 0.f);
-  int kx, ky, kz; bool near_edge;
-  voxel_coord_dev_edge(tab, (double)p.x, (double)p.y, (double)p.z, kx, ky, kz, near_edge);
-  note_point(i < n, near_edge, counters);
-  if (i >= n) return;
-  unsigned long long key;
-  if (!pack_key(kx, ky, kz, key)) { atomicExch(&counters[1], ROLO_EKEYRANGE); tgt_slot[i] = -1; tgt_keys[i] = KEY_EMPTY; return; }
-  unsigned h = hash_key(key) & tab.mask;
-  while (true) {
-    unsigned long long prev = atomicCAS(&tab.keys[h], KEY_EMPTY, key);
-    if (prev == KEY_EMPTY) {
-      int id = atomicAdd(&counters[0], 1);
-      tab.ids[h] = id;
-      tab.id_keys[id] = key;
-      double* r = tab.rec + (size_t)id * REC_DOUBLES;
-#pragma unroll
-      for (int d = 0; d < REC_DOUBLES; d++) r[d] = 0.0;
-      break;
-    }
-    if (prev == key) break;
-    h = (h + 1) & tab.mask;
-  }
-  tgt_slot[i] = (int)h;
-  tgt_keys[i] = key;
+  voxel_insert_point(tab, pts, n, blockIdx.x * blockDim.x + threadIdx.x, tgt_keys, tgt_slot, counters);
 }
 
 // wave-level segmented combine: lanes holding the same voxel id as their predecessor fold into the run head
@@ -278,9 +167,13 @@ __global__ __launch_bounds__(256) void voxel_keys_kernel(const float4* __restric
 }  // namespace
 
 hipError_t launch_voxel_build(const CloudDev& tgt, VoxelTable tab, unsigned long long* tgt_keys, int* tgt_slot, int* counters, bool morton_order, bool fixed_cov,
-                              const int* bbox6, hipStream_t s) {
+                              const int* bbox6, bool prefused, hipStream_t s) {
   static_assert(KEY_EMPTY == ~0ull, "voxel_clear_kernel and the 0xFF memsets elsewhere agree on the empty key");
   const int grid = (tgt.n + 255) / 256;
+  if (prefused) {
+    voxel_finalize_kernel<<<grid, 256, 0, s>>>(tab, counters, tgt.n, 1);
+    return hipGetLastError();
+  }
   voxel_clear_kernel<<<256, 256, 0, s>>>(tab.keys, (size_t)tab.mask + 1, bbox6, counters);
   if (!bbox6) maxabs_kernel<<<64, 256, 0, s>>>(tgt.xyz, tgt.n, counters);
   if (morton_order && tgt.have_sorted) {   // Morton order of the neighbour search: tgt_slot (>= 8 * n_leaves entries) is indexed by sorted position
