@@ -102,7 +102,11 @@ struct rolo_ctx {
     int32_t* nbr = nullptr; size_t nbr_cap = 0;   // neighbour indices between the walk and the covariance kernel
     double* stage = nullptr; size_t stage_cap = 0;  // multi-GPU: covariance exchange buffer (sorted order, one segment per rank)
   } ks[2];
-  hipStream_t stream2 = nullptr;   // second stream for the eager (uncaptured) path of rolo_batch_*
+  hipEvent_t ev_done = nullptr;    // end of the frame rolo_register_async enqueued (the stream may carry other contexts' frames behind it)
+  hipStream_t stream2 = nullptr;   // second stream for the eager (uncaptured) path of rolo_batch_*. Created WITH the context on purpose: HIP deals streams
+                                   // to its 4 hardware queues in creation order, so the main streams of four contexts land on two queues, two streams each
+                                   // — measured the best layout for frames of several contexts in flight on MI355X (2930 scans/s; one
+                                   // queue per context 2140, three contexts on three queues 2620, GPU_MAX_HW_QUEUES=8 1310)
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   // voxel map
   VoxelTable tab{};
@@ -112,6 +116,7 @@ struct rolo_ctx {
   int* counters = nullptr; size_t counters_cap = 0;
   bool have_map = false;
   int n_voxels = 0;
+  unsigned long long* stamps = nullptr; size_t stamps_cap = 0; unsigned long long* h_stamps = nullptr;   // ROLO_STAMP=1 debug timeline (pinned)
   VoxelFuse vf{};           // enqueue_frame arms it before the search when the map can be built inside the search's launches
   bool vf_done = false;     // the search just enqueued did carry the map build
   int n_edge = 0;   // target points of the last map build within 1e-12 of a POLAR bin edge
@@ -539,7 +544,7 @@ int rolo_ctx_create(int device, rolo_ctx** out) {
   rolo_default_params(&c->P);
   if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
       hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) { delete c; g_err = "hipStreamCreate failed"; return ROLO_EHIP; }
+      hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming) != hipSuccess) { delete c; g_err = "hipStreamCreate failed"; return ROLO_EHIP; }
   if (hipHostMalloc((void**)&c->h_state, sizeof(LmState)) != hipSuccess || hipHostMalloc((void**)&c->h_sums, sizeof(double) * NV_MAX) != hipSuccess ||
       hipHostMalloc((void**)&c->h_counters, sizeof(int) * 4) != hipSuccess || hipHostMalloc((void**)&c->h_args, sizeof(FrameArgs)) != hipSuccess) { delete c; g_err = "hipHostMalloc failed"; return ROLO_EHIP; }
   memset(c->h_state, 0, sizeof(LmState));
@@ -577,6 +582,7 @@ void rolo_ctx_destroy(rolo_ctx* c) {
   if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+  if (c->ev_done) (void)hipEventDestroy(c->ev_done);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -879,9 +885,17 @@ int rolo_compute_translation(rolo_ctx* c, double* trans, const double* g3, const
 }
 
 // everything of one frame after the clouds are on the device; per-frame arguments come from c->h_args (pinned)
+static bool stamp_env() { static const bool v = [] { const char* e = getenv("ROLO_STAMP"); return e && atoi(e) != 0; }(); return v; }
+#define STAMP(slot) do { if (stamp_env()) HIPCHK(launch_stamp(c->stamps, slot, c->stream)); } while (0)
+
 static int enqueue_frame(rolo_ctx* c) {
   int rc;
   if (c->src.n <= 0 || c->tgt.n <= 0) { g_err = "source/target not set"; return ROLO_ESTATE; }
+  if (stamp_env()) {
+    if ((rc = ensure(c->stamps, c->stamps_cap, 8))) return rc;
+    if (!c->h_stamps) HIPCHK(hipHostMalloc((void**)&c->h_stamps, sizeof(unsigned long long) * 8));
+  }
+  STAMP(0);
   // voxel map without the host round trip of ensure_map(): errors are picked up in rolo_register_wait. The table is sized first: when
   // the target's covariances are about to be computed (and are bounded), the search's own launches build the map (VoxelFuse).
   {
@@ -905,6 +919,7 @@ static int enqueue_frame(rolo_ctx* c) {
     rc = ensure_covs(c);
     c->vf.enabled = 0;
     if (rc) return rc;
+    STAMP(1);
     { ProfScope ps(c, ROLO_PROF_VOXEL_BUILD); HIPCHK(launch_voxel_build(c->tgt, c->tab, c->tgt_keys, c->tgt_slot, c->counters, voxel_morton_order(c), voxel_fixed_cov(c), c->tgt.bbox6, c->vf_done, c->stream)); }
     c->vf_done = false;
     HIPCHK(hipMemcpyAsync(c->h_counters, c->counters, 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -913,19 +928,29 @@ static int enqueue_frame(rolo_ctx* c) {
   if ((rc = prepare_pass(c, a, grid))) return rc;
   HIPCHK(hipMemcpyAsync(c->d_args, c->h_args, sizeof(FrameArgs), hipMemcpyHostToDevice, c->stream));
   HIPCHK(launch_frame_begin(c->state, c->d_args, c->stream));
+  STAMP(2);
   int nrot, ntrans; frame_chunks(c, nrot, ntrans);
   if (lm_fused(c)) {
     // both stages are the same launches (the device decides which pass a launch evaluates); each hint carries one spare
     if ((rc = enqueue_lm_chunk(c, a, std::max(nrot + ntrans - 1, 2)))) return rc;
   } else {
     for (int i = 0; i < nrot; i++) if ((rc = enqueue_pass(c, a, grid, 1))) return rc;
+    STAMP(3);
     for (int i = 0; i < ntrans; i++) if ((rc = enqueue_pass(c, a, grid, 2))) return rc;
   }
+  STAMP(4);
+  if (stamp_env()) HIPCHK(hipMemcpyAsync(c->h_stamps, c->stamps, sizeof(unsigned long long) * 8, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipMemcpyAsync(c->h_state, c->state, sizeof(LmState), hipMemcpyDeviceToHost, c->stream));
   return ROLO_OK;
 }
 
-int rolo_register_async(rolo_ctx* c, const float* guess16, const double* trans_start, const double* g3, const double* l3, double dtn, double dtn1, float lam) {
+extern "C" int rolo_debug_stamps(rolo_ctx* c, unsigned long long* out8) {   // after rolo_register_wait; zeros unless ROLO_STAMP=1
+  if (!c || !out8) return ROLO_EINVAL;
+  if (c->h_stamps) memcpy(out8, c->h_stamps, sizeof(unsigned long long) * 8); else memset(out8, 0, sizeof(unsigned long long) * 8);
+  return ROLO_OK;
+}
+
+static int register_async_impl(rolo_ctx* c, const float* guess16, const double* trans_start, const double* g3, const double* l3, double dtn, double dtn1, float lam) {
   if (!c || !g3 || !l3) return ROLO_EINVAL;
   if (c->async_pending) { g_err = "a registration is already in flight on this context"; return ROLO_ESTATE; }
   int rc = set_device(c); if (rc) return rc;
@@ -983,12 +1008,18 @@ int rolo_register_async(rolo_ctx* c, const float* guess16, const double* trans_s
   return ROLO_OK;
 }
 
+int rolo_register_async(rolo_ctx* c, const float* guess16, const double* trans_start, const double* g3, const double* l3, double dtn, double dtn1, float lam) {
+  const int rc = register_async_impl(c, guess16, trans_start, g3, l3, dtn, dtn1, lam);
+  if (rc == ROLO_OK && c->async_pending) HIPCHK(hipEventRecord(c->ev_done, c->stream));
+  return rc;
+}
+
 int rolo_register_wait(rolo_ctx* c, float* Tf, double* Td, double* trans_out, rolo_stats* rs, rolo_stats* ts) {
   if (!c) return ROLO_EINVAL;
   if (!c->async_pending) { g_err = "no registration in flight"; return ROLO_ESTATE; }
   int rc = set_device(c); if (rc) return rc;
   c->async_pending = false;
-  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipEventSynchronize(c->ev_done));
   if (c->h_counters[1] != 0) { g_err = "voxel coordinate outside the packed key range"; return c->h_counters[1]; }
   c->n_voxels = c->h_counters[0];
   c->n_edge = c->h_counters[2];

@@ -54,6 +54,13 @@ __global__ __launch_bounds__(256) void transform_cloud_kernel(const float* __res
 
 }  // namespace
 
+// debug timeline (ROLO_STAMP=1): one thread leaves the 100 MHz wall clock in buf[slot]; enqueue_frame places five of them per frame
+__global__ void stamp_kernel(unsigned long long* buf, int slot) { buf[slot] = wall_clock64(); }
+hipError_t launch_stamp(unsigned long long* buf, int slot, hipStream_t s) {
+  stamp_kernel<<<1, 1, 0, s>>>(buf, slot);
+  return hipGetLastError();
+}
+
 hipError_t launch_pack_xyz(const float* in, int stride, float4* out, int n, hipStream_t s) {
   if (n > 0) pack_xyz_kernel<<<(n + 255) / 256, 256, 0, s>>>(in, stride, out, n);
   return hipGetLastError();

@@ -136,6 +136,7 @@ hipError_t launch_knn_unstage(const KnnPair& A, bool own_slice_only, hipStream_t
 // prefused: clear / insert / accumulate already ran inside the search's launches (VoxelFuse): finalize only
 hipError_t launch_voxel_build(const CloudDev& tgt, VoxelTable tab, unsigned long long* tgt_keys, int* tgt_slot, int* counters, bool morton_order, bool fixed_cov,
                               const int* bbox6, bool prefused, hipStream_t s);
+hipError_t launch_stamp(unsigned long long* buf, int slot, hipStream_t s);   // debug timeline
 hipError_t launch_voxel_keys(const float4* pts, int n, VoxelTable tab, int32_t* keys3, hipStream_t s);
 
 hipError_t launch_rot_pass(int dof, const PassArgs& a, const LmState* st, int grid, hipStream_t s);
