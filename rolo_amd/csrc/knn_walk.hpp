@@ -241,8 +241,11 @@ __global__ __launch_bounds__(256, ROLO_KNN_WALK_OCC) void knn_walk_kernel(KnnPai
   }
 }
 
+#ifndef ROLO_KNN_TAIL_OCC
+#define ROLO_KNN_TAIL_OCC 2
+#endif
 template <int KMAX>
-__global__ __launch_bounds__(256) void knn_tail_kernel(KnnPair A, int split, int k, int reg, VoxelFuse vf) {
+__global__ __launch_bounds__(256, ROLO_KNN_TAIL_OCC) void knn_tail_kernel(KnnPair A, int split, int k, int reg, VoxelFuse vf) {
   const int blk = xcd_contiguous_block((int)blockIdx.x, (int)gridDim.x);
   const int which = blk >= split ? 1 : 0;
   const KnnCloud& cl = A.c[which];

@@ -139,6 +139,41 @@ def test_voxel_map_is_bit_reproducible(pair):
     assert np.array_equal(k[o], recs[0][0]) and np.array_equal(c[o], recs[0][1]) and np.array_equal(m[o], recs[0][2]) and np.array_equal(v[o], recs[0][3])
 
 
+def _register_once(kind):
+    src, tgt, cfg = make_pair(kind)
+    _, g = make_both(src, tgt, cfg)
+    z = np.zeros(3)
+    g.register_async(None, z, z, z, 0.1, 0.1, 0.3)
+    Tf, Td, t = g.register_wait()
+    k, c, m, v = g.voxels(); o = np.lexsort(k.T[::-1])
+    g.close()
+    return np.asarray(Td, np.float64), np.asarray(t, np.float64), (k[o], c[o], m[o], v[o])
+
+
+def test_voxel_map_built_inside_the_search_is_the_same_map(pair):
+    """rolo_register_async builds the target's voxel map inside the search's launches (VoxelFuse: cleared beside the key kernel, filled beside
+    the sort scatters, accumulated by the covariance tail in curve order); rolo_build_voxelmap builds it with its own launches in input
+    order. Integer sums: the two maps are the same bits, and so is a registration with the fusion switched off (a fresh process: the
+    switch is read once)."""
+    kind, src, tgt, cfg = pair
+    _, g = make_both(src, tgt, cfg)
+    g.buildVoxelMap()
+    k, c, m, v = g.voxels(); o = np.lexsort(k.T[::-1])
+    ref = (k[o], c[o], m[o], v[o])
+    g.close()
+    Td, t, fused = _register_once(kind)
+    for a, b in zip(ref, fused):
+        assert np.array_equal(a, b)
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, json; sys.path.insert(0, %r); from tests.test_gpu_registration import _register_once;"
+            "Td, t, _ = _register_once(%r); print(json.dumps([Td.ravel().tolist(), t.tolist()]))" % (root, kind))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, ROLO_VOXEL_FUSE="0"), cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    Td0, t0 = json.loads(r.stdout.strip().splitlines()[-1])
+    assert np.array_equal(Td.ravel(), np.asarray(Td0)) and np.array_equal(t, np.asarray(t0))
+
+
 def test_linearize_stages(pair):
     _, src, tgt, cfg = pair
     o, g = make_both(src, tgt, cfg)
