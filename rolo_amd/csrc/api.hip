@@ -393,7 +393,7 @@ int prepare_pass(rolo_ctx* c, PassArgs& a, int& grid) {
 }
 
 // one LM trial: fused pass + controller launch, both predicated on the device state
-int enqueue_pass(rolo_ctx* c, const PassArgs& a, int grid, int stage) {
+int enqueue_pass(rolo_ctx* c, const PassArgs& a, int grid, int stage, bool publish = false) {
   {
     ProfScope ps(c, stage == 1 ? ROLO_PROF_ROT_PASS : ROLO_PROF_TRANS_PASS);
     if (stage == 1) HIPCHK(launch_rot_pass(c->P.optimizer == ROLO_OPT_SO3_LM ? 3 : 6, a, c->state, grid, c->stream));
@@ -404,9 +404,9 @@ int enqueue_pass(rolo_ctx* c, const PassArgs& a, int grid, int stage) {
     HIPCHK(launch_reduce(c->partials, grid, c->sums, c->state, stage, c->stream));
     int e = g_rccl.AllReduce(c->sums, c->sums, NV_MAX, NCCL_FLOAT64, NCCL_SUM, c->comm, c->stream);
     if (e != 0) { g_err = std::string("ncclAllReduce: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "?"); return ROLO_ECOMM; }
-    HIPCHK(launch_ctrl(c->state, nullptr, 0, c->sums, c->trace, stage, c->stream));
+    HIPCHK(launch_ctrl(c->state, nullptr, 0, c->sums, c->trace, stage, c->stream, publish ? c->h_state : nullptr));
   } else {
-    HIPCHK(launch_ctrl(c->state, c->partials, grid, nullptr, c->trace, stage, c->stream));
+    HIPCHK(launch_ctrl(c->state, c->partials, grid, nullptr, c->trace, stage, c->stream, publish ? c->h_state : nullptr));
   }
   return ROLO_OK;
 }
@@ -920,14 +920,12 @@ static int enqueue_frame(rolo_ctx* c) {
     c->vf.enabled = 0;
     if (rc) return rc;
     STAMP(1);
-    { ProfScope ps(c, ROLO_PROF_VOXEL_BUILD); HIPCHK(launch_voxel_build(c->tgt, c->tab, c->tgt_keys, c->tgt_slot, c->counters, voxel_morton_order(c), voxel_fixed_cov(c), c->tgt.bbox6, c->vf_done, c->stream)); }
+    { ProfScope ps(c, ROLO_PROF_VOXEL_BUILD); HIPCHK(launch_voxel_build(c->tgt, c->tab, c->tgt_keys, c->tgt_slot, c->counters, voxel_morton_order(c), voxel_fixed_cov(c), c->tgt.bbox6, c->vf_done, c->stream, c->h_counters)); }   // the finalize kernel leaves the counters in pinned memory
     c->vf_done = false;
-    HIPCHK(hipMemcpyAsync(c->h_counters, c->counters, 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
   }
   PassArgs a; int grid;
   if ((rc = prepare_pass(c, a, grid))) return rc;
-  HIPCHK(hipMemcpyAsync(c->d_args, c->h_args, sizeof(FrameArgs), hipMemcpyHostToDevice, c->stream));
-  HIPCHK(launch_frame_begin(c->state, c->d_args, c->stream));
+  HIPCHK(launch_frame_begin(c->state, c->h_args, c->stream));   // read straight from pinned host memory (one 64-thread kernel; a copy launch before)
   STAMP(2);
   int nrot, ntrans; frame_chunks(c, nrot, ntrans);
   if (lm_fused(c)) {
@@ -936,11 +934,11 @@ static int enqueue_frame(rolo_ctx* c) {
   } else {
     for (int i = 0; i < nrot; i++) if ((rc = enqueue_pass(c, a, grid, 1))) return rc;
     STAMP(3);
-    for (int i = 0; i < ntrans; i++) if ((rc = enqueue_pass(c, a, grid, 2))) return rc;
+    for (int i = 0; i < ntrans; i++) if ((rc = enqueue_pass(c, a, grid, 2, i + 1 == ntrans && !c->comm))) return rc;   // the last controller publishes the state
   }
   STAMP(4);
   if (stamp_env()) HIPCHK(hipMemcpyAsync(c->h_stamps, c->stamps, sizeof(unsigned long long) * 8, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipMemcpyAsync(c->h_state, c->state, sizeof(LmState), hipMemcpyDeviceToHost, c->stream));
+  if (lm_fused(c) || c->comm || ntrans == 0) HIPCHK(hipMemcpyAsync(c->h_state, c->state, sizeof(LmState), hipMemcpyDeviceToHost, c->stream));
   return ROLO_OK;
 }
 

@@ -684,8 +684,10 @@ ROLO_DEV void trans_step(LmState* __restrict__ st, const double* __restrict__ S,
 // this in the last workgroup of the pass (arrival ticket + agent-scope release: 26.2 us per trial vs 11.7 + 9.9), and
 // running it redundantly in the prologue of the next pass (every workgroup re-reduces the rows: faster alone,
 // slower when four contexts share the GPU).
+// pub: pinned host copy of the state, written by the LAST controller launch of a frame's schedule whether or not it has a step to take
+// (replaces a device-to-host copy launch per frame)
 ROLO_DEV void ctrl_body(LmState* st, const double* __restrict__ partials, int nblocks, const double* __restrict__ sums_in,
-                        rolo_trace_rec* trace, int stage) {
+                        rolo_trace_rec* trace, int stage, LmState* pub = nullptr) {
   __shared__ double sums[NV_MAX];
   __shared__ double part[8][NV_MAX];
   // the scalar LM step touches ~150 fields: stage the whole state through LDS (one coalesced read, one write)
@@ -716,7 +718,10 @@ ROLO_DEV void ctrl_body(LmState* st, const double* __restrict__ partials, int nb
     for (int k = 0; k < NWT; k++) { const int i = threadIdx.x + 256 * k; if (i < NW) l[i] = sreg[k]; }
   }
   __syncthreads();
-  if (sst.stage != stage) return;  // predicated launch: nothing to do (uniform)
+  if (sst.stage != stage) {  // predicated launch: nothing to do (uniform)
+    if (pub) { int* h = reinterpret_cast<int*>(pub); const int* l = reinterpret_cast<const int*>(&sst); for (int i = threadIdx.x; i < NW; i += 256) h[i] = l[i]; }
+    return;
+  }
   if (partials) {
     // fixed combination order => deterministic for a given grid
     double s0 = 0;
@@ -749,12 +754,13 @@ ROLO_DEV void ctrl_body(LmState* st, const double* __restrict__ partials, int nb
     int* g = reinterpret_cast<int*>(st);
     const int* l = reinterpret_cast<const int*>(&sst);
     for (int i = threadIdx.x; i < NW; i += 256) g[i] = l[i];
+    if (pub) { int* h = reinterpret_cast<int*>(pub); for (int i = threadIdx.x; i < NW; i += 256) h[i] = l[i]; }
   }
 }
 
 __global__ __launch_bounds__(256) void ctrl_kernel(LmState* st, const double* __restrict__ partials, int nblocks,
-                                                  const double* __restrict__ sums_in, rolo_trace_rec* trace, int stage) {
-  ctrl_body(st, partials, nblocks, sums_in, trace, stage);
+                                                  const double* __restrict__ sums_in, rolo_trace_rec* trace, int stage, LmState* pub) {
+  ctrl_body(st, partials, nblocks, sums_in, trace, stage, pub);
 }
 __global__ __launch_bounds__(256) void ctrl_batch_kernel(const BatchSlot* __restrict__ slots, int stage) {
   const BatchSlot& S = slots[blockIdx.x];
@@ -1006,8 +1012,8 @@ hipError_t launch_reduce(const double* partials, int nblocks, double* sums, cons
   reduce_kernel<<<1, 256, 0, s>>>(partials, nblocks, sums, st, stage);
   return hipGetLastError();
 }
-hipError_t launch_ctrl(LmState* st, const double* partials, int nblocks, const double* sums, rolo_trace_rec* trace, int stage, hipStream_t s) {
-  ctrl_kernel<<<1, 256, 0, s>>>(st, partials, nblocks, sums, trace, stage);
+hipError_t launch_ctrl(LmState* st, const double* partials, int nblocks, const double* sums, rolo_trace_rec* trace, int stage, hipStream_t s, LmState* pub) {
+  ctrl_kernel<<<1, 256, 0, s>>>(st, partials, nblocks, sums, trace, stage, pub);
   return hipGetLastError();
 }
 hipError_t launch_rot_begin(LmState* st, const RotBegin& a, hipStream_t s) {

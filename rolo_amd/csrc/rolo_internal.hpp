@@ -135,7 +135,7 @@ hipError_t launch_knn_unstage(const KnnPair& A, bool own_slice_only, hipStream_t
 // bbox6: the target's bounding box as the neighbour search leaves it on the device (6 order-preserving ints), or nullptr
 // prefused: clear / insert / accumulate already ran inside the search's launches (VoxelFuse): finalize only
 hipError_t launch_voxel_build(const CloudDev& tgt, VoxelTable tab, unsigned long long* tgt_keys, int* tgt_slot, int* counters, bool morton_order, bool fixed_cov,
-                              const int* bbox6, bool prefused, hipStream_t s);
+                              const int* bbox6, bool prefused, hipStream_t s, int* pub_counters = nullptr /* pinned host copy of the 4 counters, written by the finalize kernel */);
 hipError_t launch_stamp(unsigned long long* buf, int slot, hipStream_t s);   // debug timeline
 hipError_t launch_voxel_keys(const float4* pts, int n, VoxelTable tab, int32_t* keys3, hipStream_t s);
 
@@ -147,7 +147,8 @@ hipError_t launch_lm(int dof, int threads, int ppt /* slabs of `threads` points 
                      rolo_trace_rec* trace, int do_body, hipStream_t s);
 hipError_t launch_reduce(const double* partials, int nblocks, double* sums, const LmState* st, int stage, hipStream_t s);
 // controller: sums the rows of `partials` itself (single GPU) or takes all-reduced `sums` (partials == nullptr)
-hipError_t launch_ctrl(LmState* st, const double* partials, int nblocks, const double* sums, rolo_trace_rec* trace, int stage, hipStream_t s);
+// pub != nullptr: also leave the state in that (pinned host) copy, step or no step
+hipError_t launch_ctrl(LmState* st, const double* partials, int nblocks, const double* sums, rolo_trace_rec* trace, int stage, hipStream_t s, LmState* pub = nullptr);
 
 struct RotBegin { double R[9], t[3]; int optimizer, max_iterations, fixed_iterations, lm_max, q2_intended; double rot_eps, trans_eps, lm_init; int run_trans; };
 struct TransBegin { double t0[3], g[3], l[3], dtn, dtn1; float ct_lambda; int direct; /* 1: start now (rotation already done) */ };

@@ -137,8 +137,9 @@ __global__ __launch_bounds__(256) void voxel_accum_sorted_kernel(const float4* _
   accumulate_point(tab, id, p, c, fix_scales(n, counters), fixed_cov != 0);
 }
 
-__global__ __launch_bounds__(256) void voxel_finalize_kernel(VoxelTable tab, const int* counters, int n_pts, int fixed_cov) {
+__global__ __launch_bounds__(256) void voxel_finalize_kernel(VoxelTable tab, const int* counters, int n_pts, int fixed_cov, int* pub_counters) {
   const int id = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pub_counters && id < 4) pub_counters[id] = counters[id];   // the counters are final before this launch
   if (id >= counters[0]) return;
   double* r = tab.rec + (size_t)id * REC_DOUBLES;
   const long long* q = reinterpret_cast<const long long*>(r);
@@ -167,11 +168,11 @@ __global__ __launch_bounds__(256) void voxel_keys_kernel(const float4* __restric
 }  // namespace
 
 hipError_t launch_voxel_build(const CloudDev& tgt, VoxelTable tab, unsigned long long* tgt_keys, int* tgt_slot, int* counters, bool morton_order, bool fixed_cov,
-                              const int* bbox6, bool prefused, hipStream_t s) {
+                              const int* bbox6, bool prefused, hipStream_t s, int* pub_counters) {
   static_assert(KEY_EMPTY == ~0ull, "voxel_clear_kernel and the 0xFF memsets elsewhere agree on the empty key");
   const int grid = (tgt.n + 255) / 256;
   if (prefused) {
-    voxel_finalize_kernel<<<grid, 256, 0, s>>>(tab, counters, tgt.n, 1);
+    voxel_finalize_kernel<<<grid, 256, 0, s>>>(tab, counters, tgt.n, 1, pub_counters);
     return hipGetLastError();
   }
   voxel_clear_kernel<<<256, 256, 0, s>>>(tab.keys, (size_t)tab.mask + 1, bbox6, counters);
@@ -184,7 +185,7 @@ hipError_t launch_voxel_build(const CloudDev& tgt, VoxelTable tab, unsigned long
     voxel_insert_kernel<<<grid, 256, 0, s>>>(tgt.xyz, tgt.n, tab, tgt_keys, tgt_slot, counters);
     voxel_accum_kernel<<<grid, 256, 0, s>>>(tgt.xyz, tgt.cov, tgt.n, tab, tgt_slot, counters, fixed_cov ? 1 : 0);
   }
-  voxel_finalize_kernel<<<grid, 256, 0, s>>>(tab, counters, tgt.n, fixed_cov ? 1 : 0);
+  voxel_finalize_kernel<<<grid, 256, 0, s>>>(tab, counters, tgt.n, fixed_cov ? 1 : 0, pub_counters);
   return hipGetLastError();
 }
 
