@@ -13,7 +13,10 @@ constexpr int V_Y = 1;    // cost of the new linearisation
 constexpr int V_N = 2;    // number of correspondences of the new linearisation
 constexpr int V_H = 3;    // lower triangle of H, row-major: (0,0) (1,0) (1,1) (2,0) ... 6 or 21 values
 constexpr int V_B = 24;   // b, 3 or 6 values
-constexpr int PASS_THREADS = 256;
+#ifndef ROLO_PASS_THREADS
+#define ROLO_PASS_THREADS 256
+#endif
+constexpr int PASS_THREADS = ROLO_PASS_THREADS;
 
 constexpr unsigned long long KEY_EMPTY = ~0ull;
 constexpr int KEY_BIAS = 1 << 20;
