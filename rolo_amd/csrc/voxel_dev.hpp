@@ -64,8 +64,7 @@ ROLO_DEV int voxel_lookup(const VoxelTable& tab, int kx, int ky, int kz) {
   unsigned h = hash_key(key) & tab.mask;
   while (true) {
     const unsigned long long cur = tab.keys[h];
-    const int id = tab.ids[h];   // fetched WITH the key, not after the compare: one dependent round trip less in the passes (the slot of a free key is garbage, unused)
-    if (cur == key) return id;
+    if (cur == key) return tab.ids[h];
     if (cur == KEY_EMPTY) return -1;
     h = (h + 1) & tab.mask;
   }
