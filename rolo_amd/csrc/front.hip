@@ -291,10 +291,23 @@ struct FeatArgs {
 
 // One workgroup of XT = 1024 threads per ring: 128 rings are only 128 workgroups, so the parallelism has to come from inside —
 // 16 wavefronts (4 per SIMD) hide the LDS / cross-lane latency of the sorts that 4 wavefronts (1 per SIMD) exposed.
-constexpr int XT = 1024, XW = XT / 64, UP = (512 + XT - 1) / XT;   // threads, wavefronts, sector positions per thread
+#ifndef ROLO_XT
+#define ROLO_XT 1024
+#endif
+constexpr int XT = ROLO_XT, XW = XT / 64, UP = (512 + XT - 1) / XT;   // threads, wavefronts, sector positions per thread
+#ifdef ROLO_XT_STATS
+__device__ unsigned long long g_xt[128][8];   // per ring: phase time stamps of extract_kernel (shader clock)
+#define XT_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 128) g_xt[blockIdx.x][k] = clock64(); } while (0)
+extern "C" int rolo_debug_extract_times(unsigned long long* out /* 128 x 8 */) {
+  (void)hipDeviceSynchronize();
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_xt), sizeof(unsigned long long) * 128 * 8) == hipSuccess ? 0 : -1;
+}
+#else
+#define XT_STAMP(k)
+#endif
 __global__ __launch_bounds__(XT) void extract_kernel(FeatArgs A) {
   extern __shared__ unsigned char smem_raw[];
-  // layout: keys[SORT_CAP] u64 | l_picked | l_col | l_label | l_curv (ring window) | list[FRONT_MAX_H+16] | l_brk | l_rank | l_stat (window)
+  // layout: keys[SORT_CAP] u64 | l_picked | l_col | l_label | l_curv (ring window) | list[FRONT_MAX_H+16] | l_brk | l_rank | l_stat | l_reach (window)
   unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem_raw);
   const int WIN = FRONT_MAX_H + 2 * 16;
   int* l_picked = reinterpret_cast<int*>(keys + SORT_CAP);
@@ -305,12 +318,14 @@ __global__ __launch_bounds__(XT) void extract_kernel(FeatArgs A) {
   int* l_brk = list + (FRONT_MAX_H + 16);
   int* l_rank = l_brk + WIN;
   int* l_stat = l_rank + WIN;
+  int* l_reach = l_stat + WIN;   // how far a pick's suppression marks go from this cell: forward | backward << 4 (0..5 each)
   __shared__ int s_heads, s_ep;
   __shared__ int s_pk[UP][XW], s_cw[2][XW];
   __shared__ float s_red[2][3][XW];
   __shared__ int s_wsum[XW];
 
   const int ring = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  XT_STAMP(0);
   const int s = A.start_ring[ring], e = A.end_ring[ring];
   const int n = *A.n_ptr;
   // ring window in LDS: global indices [w0, w0 + wlen)
@@ -331,6 +346,15 @@ __global__ __launch_bounds__(XT) void extract_kernel(FeatArgs A) {
   for (int i = t; i < wlen; i += XT) { l_rank[i] = INT_MAX; l_stat[i] = ST_OUT; }
   __syncthreads();
   for (int i = t; i + 1 < wlen; i += XT) l_brk[i] = abs(l_col[i + 1] - l_col[i]) > 10 ? 1 : 0;
+  __syncthreads();
+  for (int i = t; i < wlen; i += XT) {   // once per ring: the rounds below then read their neighbours without a dependent chain of break tests
+    int fr = 0, br = 0;
+    if (i >= 5 && i + 5 < wlen) {
+      for (int d = 1; d <= 5; d++) { if (l_brk[i + d - 1]) break; fr = d; }
+      for (int d = 1; d <= 5; d++) { if (l_brk[i - d]) break; br = d; }
+    }
+    l_reach[i] = fr | (br << 4);
+  }
 
   // ---- all six sector sorts at once (they depend on the curvatures only): a segmented bitonic sort, 6 x seg keys ----
   int seg = 2;
@@ -357,7 +381,9 @@ __global__ __launch_bounds__(XT) void extract_kernel(FeatArgs A) {
     keys[i] = kv;
   }
   __syncthreads();
+  XT_STAMP(1);
   bitonic_sort_lds_seg<XT>(keys, 6 * seg, seg);   // std::sort(begin+sp, begin+ep) with the (value, ind) tie order
+  XT_STAMP(2);
 
   for (int j = 0; j < 6; j++) {
     const int sp = (s * (6 - j) + e * j) / 6;
@@ -365,8 +391,18 @@ __global__ __launch_bounds__(XT) void extract_kernel(FeatArgs A) {
     if (sp >= ep) { if (t == 0) A.corner_cnt[ring * 6 + j] = 0; continue; }  // uniform
     const unsigned long long* skeys = keys + j * seg;
     const int len = ep - sp;  // sorted range [sp, ep); positions sp..ep take part in the picks
-    if (sp >= 5 && ep < n - 5 && len < 512) {
-      // ---- parallel greedy picks (every position is a live point of this ring, all distinct) ----
+    // Sectors at the two ends of the cloud hold the reference's stale {0, 0} smoothness entries: entries that all name POINT 0,
+    // with curvature 0. With sane thresholds (0 is a surface candidate, not a corner) they amount to "point 0 is the best-ranked surface
+    // candidate": in the sector that holds point 0 the parallel picks below handle that as it stands (the duplicates fold onto one window
+    // cell); in the last sector of the cloud point 0 was picked long ago — the ring that holds it ran first in the reference — so the
+    // entries do nothing and are skipped. Anything odder (tiny clouds, both ends in one sector, thresholds that flip the argument) takes the
+    // serial walk as written. (Both end sectors on the serial walk: 155 us of this kernel's 170 on the OS1-128 frame.)
+    const bool head_sp = sp < 5, tail_sp = ep >= n - 5;
+    const bool thr_ok = A.surf_threshold > 0.f && A.edge_threshold >= 0.f;
+    const bool head_ok = !head_sp || (thr_ok && !tail_sp && ep >= 5 && w0 <= 0 && -w0 < wlen);
+    const bool tail_ok = !tail_sp || (thr_ok && !head_sp && n >= 64 && A.start_ring[0] == 0 && A.end_ring[0] >= 30);
+    if (head_ok && tail_ok && len < 512) {
+      // ---- parallel greedy picks ----
       // The reference walks the sector in curvature order and a pick marks its +-5 neighbours (up to a column break) as
       // taken. Equivalent fixed point: a candidate is picked iff no better-ranked candidate that reaches it is picked.
       // Every round decides the candidates whose better-ranked reaching candidates are all decided; the chains are a
@@ -381,17 +417,35 @@ __global__ __launch_bounds__(XT) void extract_kernel(FeatArgs A) {
           my_li[u] = -1; my_rank[u] = INT_MAX;
           if (p <= len) {
             const int k = sp + p;
-            const int ind = (k == ep) ? ep : (int)(unsigned)(skeys[p] & 0xffffffffull);
+            const int ind = (k == ep) ? ((ep >= 5 && ep < n - 5) ? ep : 0) : (int)(unsigned)(skeys[p] & 0xffffffffull);   // smooth[ep] is outside the sorted range
             const int li = ind - w0;
-            const int rank = pass == 0 ? ((k == ep) ? 0 : ep - k) : p;   // corners walk k = ep .. sp, surfaces k = sp .. ep
-            const float cv = l_curv[li];
-            const bool cand = l_picked[li] == 0 && (pass == 0 ? cv > thr : cv < thr);
-            my_li[u] = li; my_rank[u] = rank;
-            l_rank[li] = rank;
-            l_stat[li] = cand ? ST_UNDECIDED : ST_OUT;
+            if (li >= 0 && li < wlen) {   // a stale entry of the cloud's last sector names point 0, far outside this ring's window: a no-op (above)
+              const bool stale = ind == 0;   // (head sector) curvature 0 whatever l_curv holds
+              const int rank = pass == 0 ? ((k == ep) ? 0 : ep - k) : p;   // corners walk k = ep .. sp, surfaces k = sp .. ep
+              const float cv = stale ? 0.f : l_curv[li];
+              const bool cand = l_picked[li] == 0 && (pass == 0 ? cv > thr : cv < thr);
+              my_li[u] = li; my_rank[u] = rank;
+              l_rank[li] = rank;
+              l_stat[li] = cand ? ST_UNDECIDED : ST_OUT;
+            }
           }
         }
         __syncthreads();
+        // which of the ten neighbours can suppress this candidate: within reach and better ranked — fixed for the stage
+        unsigned my_nb[UP];
+#pragma unroll
+        for (int u = 0; u < UP; u++) {
+          my_nb[u] = 0u;
+          const int li = my_li[u];
+          if (li < 0) continue;
+          const int rc = l_reach[li], fr = rc & 15, br = rc >> 4;
+#pragma unroll
+          for (int d = 1; d <= 5; d++) {
+            const int rf = l_rank[li + d], rb = l_rank[li - d];
+            if (d <= fr && rf < my_rank[u]) my_nb[u] |= 1u << (d - 1);
+            if (d <= br && rb < my_rank[u]) my_nb[u] |= 1u << (4 + d);
+          }
+        }
         while (true) {   // states only ever move UNDECIDED -> final, so a neighbour's state read mid-update is either still valid
           int undecided = 0;
 #pragma unroll
@@ -399,13 +453,11 @@ __global__ __launch_bounds__(XT) void extract_kernel(FeatArgs A) {
             const int li = my_li[u];
             if (li < 0 || l_stat[li] != ST_UNDECIDED) continue;
             bool any_sel = false, any_und = false;
-            for (int d = 1; d <= 5; d++) {
-              if (l_brk[li + d - 1]) break;
-              if (l_rank[li + d] < my_rank[u]) { const int st = l_stat[li + d]; any_sel |= st == ST_PICKED; any_und |= st == ST_UNDECIDED; }
-            }
-            for (int d = 1; d <= 5; d++) {
-              if (l_brk[li - d]) break;
-              if (l_rank[li - d] < my_rank[u]) { const int st = l_stat[li - d]; any_sel |= st == ST_PICKED; any_und |= st == ST_UNDECIDED; }
+#pragma unroll
+            for (int d = 1; d <= 5; d++) {   // ten independent LDS reads
+              const int sf = l_stat[li + d], sb = l_stat[li - d];
+              if (my_nb[u] & (1u << (d - 1))) { any_sel |= sf == ST_PICKED; any_und |= sf == ST_UNDECIDED; }
+              if (my_nb[u] & (1u << (4 + d))) { any_sel |= sb == ST_PICKED; any_und |= sb == ST_UNDECIDED; }
             }
             if (any_sel) l_stat[li] = ST_OUT;
             else if (!any_und) l_stat[li] = ST_PICKED;
@@ -454,8 +506,9 @@ __global__ __launch_bounds__(XT) void extract_kernel(FeatArgs A) {
             l_label[li] = -1;
           }
           l_picked[li] = 1;
-          for (int d = 1; d <= 5; d++) { if (l_brk[li + d - 1]) break; l_picked[li + d] = 1; }
-          for (int d = 1; d <= 5; d++) { if (l_brk[li - d]) break; l_picked[li - d] = 1; }
+          const int rc = l_reach[li], fr = rc & 15, br = rc >> 4;
+#pragma unroll
+          for (int d = 1; d <= 5; d++) { if (d <= fr) l_picked[li + d] = 1; if (d <= br) l_picked[li - d] = 1; }
         }
         __syncthreads();
       }
@@ -542,6 +595,7 @@ __global__ __launch_bounds__(XT) void extract_kernel(FeatArgs A) {
       par ^= 1;
     }
   }
+  XT_STAMP(3);
   // write the ring's picked / label window back (the oracle's arrays after extraction)
   for (int i = t; i < wlen; i += XT) {
     const int gi = w0 + i;
@@ -598,7 +652,9 @@ __global__ __launch_bounds__(XT) void extract_kernel(FeatArgs A) {
     keys[i] = kv;
   }
   __syncthreads();
+  XT_STAMP(4);
   bitonic_sort_lds<XT>(keys, np2);  // std::sort by cell index, ties by point order
+  XT_STAMP(5);
   // run heads -> output slot; each head accumulates its run in order with float accumulators (pcl::CentroidPoint)
   if (t == 0) s_heads = 0;
   __syncthreads();
@@ -628,6 +684,7 @@ __global__ __launch_bounds__(XT) void extract_kernel(FeatArgs A) {
     if (t == XT - 1) s_heads = c + woff + inc;
     __syncthreads();
   }
+  XT_STAMP(6);
   if (t == 0) A.surf_cnt[ring] = s_heads;
 }
 
@@ -809,7 +866,7 @@ int front_extract_enqueue(Front* f, const rolo_front_params* P, hipStream_t s) {
   A.edge_threshold = P->edge_threshold; A.surf_threshold = P->surf_threshold; A.leaf = P->odometry_surf_leaf_size;
   A.corner_stage = f->corner_stage; A.corner_cnt = f->corner_cnt; A.surf_stage = f->surf_stage; A.surf_cnt = f->surf_cnt;
   const size_t WIN = FRONT_MAX_H + 32;
-  const size_t lds = sizeof(unsigned long long) * SORT_CAP + sizeof(int) * WIN * 7 + sizeof(int) * (FRONT_MAX_H + 16);
+  const size_t lds = sizeof(unsigned long long) * SORT_CAP + sizeof(int) * WIN * 8 + sizeof(int) * (FRONT_MAX_H + 16);
   static std::atomic<unsigned long long> attr_set{0};   // per device ordinal (bit d): the attribute belongs to the device's code object
   const unsigned long long dev_bit = 1ull << (f->device & 63);
   if (!(attr_set.load() & dev_bit)) { FCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(extract_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set.fetch_or(dev_bit); }
