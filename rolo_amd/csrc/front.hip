@@ -710,6 +710,15 @@ __global__ __launch_bounds__(256) void concat_kernel(const float4* __restrict__ 
   for (int i = t; i < c; i += 256) out[s_off + i] = stage[(size_t)g * group_cap + i];
 }
 
+// one launch instead of six fills per frame: owner = INT_MAX (npix), and zeros for col / range / curv / picked / label incl. their guard cells (np)
+__global__ __launch_bounds__(256) void front_clear_kernel(int* owner, size_t npix, int* col, float* range, float* curv, int* picked, int* label, size_t np) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nt = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = t; i < np; i += nt) {
+    if (i < npix) owner[i] = INT_MAX;
+    col[i] = 0; range[i] = 0.f; curv[i] = 0.f; picked[i] = 0; label[i] = 0;
+  }
+}
+
 __global__ void fill_int_kernel(int* p, int n, int v) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = v;
 }
@@ -732,6 +741,7 @@ struct Front {
   int *corner_cnt = nullptr, *surf_cnt = nullptr;
   int n_valid = 0; int n_scan = 0, H = 0;
   bool projected = false;
+  bool extract_cleared = false;   // the projection's clear launch already zeroed curv / picked / label for the extraction that follows
   // rolo_front_set_deskew: armed for the next projection only
   bool deskew_armed = false;
   int deskew_n = 0;   // length of the armed per-point time array
@@ -834,10 +844,9 @@ int front_project_enqueue(Front* f, const rolo_front_params* P, const float* d_p
     ctx_set_error("de-skew armed with fewer per-point times than the frame has points");
     return ROLO_EINVAL;
   }
-  fill_int_kernel<<<256, 256, 0, s>>>(f->owner, (int)npix, INT_MAX);
-  // guard cells of the per-point arrays are zero
-  FCHK(hipMemsetAsync(f->col, 0, sizeof(int) * (npix + 2 * FRONT_GUARD), s));
-  FCHK(hipMemsetAsync(f->range, 0, sizeof(float) * (npix + 2 * FRONT_GUARD), s));
+  // guard cells of the per-point arrays are zero; the three arrays of the extraction stage are cleared in the same launch
+  front_clear_kernel<<<512, 256, 0, s>>>(f->owner, npix, f->col, f->range, f->curv, f->picked, f->label, npix + 2 * FRONT_GUARD);
+  f->extract_cleared = true;
   if (n_raw > 0) project_kernel<<<(n_raw + 255) / 256, 256, 0, s>>>(d_pts, stride, d_ring, n_raw, *P, f->owner);
   ring_scan_kernel<<<NS, 256, 0, s>>>(f->owner, H, f->local_idx, f->ring_count);
   ring_scatter_kernel<<<NS, 256, 0, s>>>(d_pts, stride, d_ring, f->owner, f->local_idx, f->ring_count, NS, H, f->extracted + FRONT_GUARD,
@@ -854,9 +863,12 @@ int front_extract_enqueue(Front* f, const rolo_front_params* P, hipStream_t s) {
   const size_t npix = f->cap_pix;
   // guards of curvature / picked / label are zero; live entries are written by the smoothness kernel
   const size_t np = npix + 2 * FRONT_GUARD;
-  FCHK(hipMemsetAsync(f->curv, 0, sizeof(float) * np, s));
-  FCHK(hipMemsetAsync(f->picked, 0, sizeof(int) * np, s));
-  FCHK(hipMemsetAsync(f->label, 0, sizeof(int) * np, s));
+  if (!f->extract_cleared) {   // a projection loaded from the host (rolo_front_load_projection): nobody cleared them yet
+    FCHK(hipMemsetAsync(f->curv, 0, sizeof(float) * np, s));
+    FCHK(hipMemsetAsync(f->picked, 0, sizeof(int) * np, s));
+    FCHK(hipMemsetAsync(f->label, 0, sizeof(int) * np, s));
+  }
+  f->extract_cleared = false;
   const int grid = (int)(((size_t)NS * f->H + 255) / 256);  // N <= n_scan * Horizon_SCAN is only known on the device
   smoothness_kernel<<<grid, 256, 0, s>>>(f->range + FRONT_GUARD, f->counters, f->curv + FRONT_GUARD, f->picked + FRONT_GUARD, f->label + FRONT_GUARD);
   occlusion_kernel<<<grid, 256, 0, s>>>(f->range + FRONT_GUARD, f->col + FRONT_GUARD, f->counters, f->picked + FRONT_GUARD);
@@ -1042,6 +1054,7 @@ int rolo_front_load_projection(rolo_ctx* c, const rolo_front_params* P, const fl
   FCHK(hipStreamSynchronize(s));   // n_valid is a stack variable; pageable copies are staged anyway
   f->n_valid = n_valid;
   f->projected = true;
+  f->extract_cleared = false;
   return ROLO_OK;
 }
 
