@@ -710,6 +710,35 @@ __global__ __launch_bounds__(256) void concat_kernel(const float4* __restrict__ 
   for (int i = t; i < c; i += 256) out[s_off + i] = stage[(size_t)g * group_cap + i];
 }
 
+// fused frame path: corner groups (n_scan x 6 sectors, <= 20 each) then surface groups (one per ring) straight into *featureLast =
+// corner ++ surface (lidarOdometry.cpp:521-523) — the two concat launches and feature_concat_kernel in one; counts to counters[1], [2]
+__global__ __launch_bounds__(256) void feature_gather_kernel(const float4* __restrict__ corner_stage, const int* __restrict__ corner_cnt, int n_cgroups,
+                                                            const float4* __restrict__ surf_stage, const int* __restrict__ surf_cnt, int n_sgroups, int surf_cap,
+                                                            float4* __restrict__ out, int* __restrict__ counters) {
+  __shared__ int s_part[2][4], s_off;
+  const int g = blockIdx.x, t = threadIdx.x;
+  const bool is_surf = g >= n_cgroups;
+  const int gs = is_surf ? g - n_cgroups : g;
+  // corners before this group (every corner for a surface group) + surface points before this group
+  int pc = 0, ps = 0;
+  for (int r = t; r < (is_surf ? n_cgroups : gs); r += 256) pc += corner_cnt[r];
+  if (is_surf) for (int r = t; r < gs; r += 256) ps += surf_cnt[r];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { pc += __shfl_xor(pc, off, 64); ps += __shfl_xor(ps, off, 64); }
+  if ((t & 63) == 0) { s_part[0][t >> 6] = pc; s_part[1][t >> 6] = ps; }
+  __syncthreads();
+  if (t == 0) {
+    const int oc = s_part[0][0] + s_part[0][1] + s_part[0][2] + s_part[0][3], os = s_part[1][0] + s_part[1][1] + s_part[1][2] + s_part[1][3];
+    s_off = oc + os;
+    if (g == n_cgroups - 1) counters[1] = oc + corner_cnt[gs];
+    if (is_surf && gs == n_sgroups - 1) counters[2] = os + surf_cnt[gs];
+  }
+  __syncthreads();
+  const int c = is_surf ? surf_cnt[gs] : corner_cnt[gs];
+  const float4* __restrict__ src = is_surf ? surf_stage + (size_t)gs * surf_cap : corner_stage + (size_t)gs * 20;
+  for (int i = t; i < c; i += 256) out[s_off + i] = src[i];
+}
+
 // one launch instead of six fills per frame: owner = INT_MAX (npix), and zeros for col / range / curv / picked / label incl. their guard cells (np)
 __global__ __launch_bounds__(256) void front_clear_kernel(int* owner, size_t npix, int* col, float* range, float* curv, int* picked, int* label, size_t np) {
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nt = (size_t)gridDim.x * blockDim.x;
@@ -723,12 +752,6 @@ __global__ void fill_int_kernel(int* p, int n, int v) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = v;
 }
 
-// corner ++ surface (x, y, z, intensity) = *featureLast (lidarOdometry.cpp:521-523), counts read on the device
-__global__ __launch_bounds__(256) void feature_concat_kernel(const float4* __restrict__ corner, const float4* __restrict__ surf,
-                                                            const int* __restrict__ counters, float4* __restrict__ out) {
-  const int nc = counters[1], ns = counters[2];
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nc + ns; i += gridDim.x * blockDim.x) out[i] = i < nc ? corner[i] : surf[i - nc];
-}
 
 struct Front {
   int device = 0;
@@ -858,7 +881,7 @@ int front_project_enqueue(Front* f, const rolo_front_params* P, const float* d_p
 }
 
 // K3 + K4 on what front_project_enqueue left on the device; n_corner / n_surface land in counters[1] / [2]
-int front_extract_enqueue(Front* f, const rolo_front_params* P, hipStream_t s) {
+int front_extract_enqueue(Front* f, const rolo_front_params* P, hipStream_t s, float4* fused_out = nullptr) {
   const int NS = f->n_scan;
   const size_t npix = f->cap_pix;
   // guards of curvature / picked / label are zero; live entries are written by the smoothness kernel
@@ -883,8 +906,12 @@ int front_extract_enqueue(Front* f, const rolo_front_params* P, hipStream_t s) {
   const unsigned long long dev_bit = 1ull << (f->device & 63);
   if (!(attr_set.load() & dev_bit)) { FCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(extract_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set.fetch_or(dev_bit); }
   extract_kernel<<<NS, XT, lds, s>>>(A);
-  concat_kernel<<<NS * 6, 256, 0, s>>>(f->corner_stage, f->corner_cnt, NS * 6, 20, f->corner_out, f->counters + 1);
-  concat_kernel<<<NS, 256, 0, s>>>(f->surf_stage, f->surf_cnt, NS, FRONT_MAX_H, f->surf_out, f->counters + 2);
+  if (fused_out) {
+    feature_gather_kernel<<<NS * 7, 256, 0, s>>>(f->corner_stage, f->corner_cnt, NS * 6, f->surf_stage, f->surf_cnt, NS, FRONT_MAX_H, fused_out, f->counters);
+  } else {
+    concat_kernel<<<NS * 6, 256, 0, s>>>(f->corner_stage, f->corner_cnt, NS * 6, 20, f->corner_out, f->counters + 1);
+    concat_kernel<<<NS, 256, 0, s>>>(f->surf_stage, f->surf_cnt, NS, FRONT_MAX_H, f->surf_out, f->counters + 2);
+  }
   FCHK(hipGetLastError());
   return ROLO_OK;
 }
@@ -910,8 +937,7 @@ int front_frame_features_enqueue(rolo_ctx* c, const rolo_front_params* P, const 
     d_pts = f->raw; d_ring = f->ring;
   }
   if ((rc = front_project_enqueue(f, P, d_pts, stride, d_ring, n_raw, false, s))) return rc;
-  if ((rc = front_extract_enqueue(f, P, s))) return rc;
-  feature_concat_kernel<<<256, 256, 0, s>>>(f->corner_out, f->surf_out, f->counters, d_feat);
+  if ((rc = front_extract_enqueue(f, P, s, d_feat))) return rc;
   FCHK(hipGetLastError());
   FCHK(hipMemcpyAsync(h_counts3, f->counters, sizeof(int) * 3, hipMemcpyDeviceToHost, s));
   if (done) FCHK(hipEventRecord(done, s));
