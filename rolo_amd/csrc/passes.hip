@@ -684,6 +684,12 @@ ROLO_DEV void trans_step(LmState* __restrict__ st, const double* __restrict__ S,
 // this in the last workgroup of the pass (arrival ticket + agent-scope release: 26.2 us per trial vs 11.7 + 9.9), and
 // running it redundantly in the prologue of the next pass (every workgroup re-reduces the rows: faster alone,
 // slower when four contexts share the GPU).
+#ifdef ROLO_CTRL_STATS
+__device__ unsigned long long g_ctrl_t[8];   // accumulated shader-clock ticks per phase of ctrl_body + [7] = launches counted
+#define CT_STAMP(k) const long long ct##k = clock64()
+#else
+#define CT_STAMP(k)
+#endif
 // pub: pinned host copy of the state, written by the LAST controller launch of a frame's schedule whether or not it has a step to take
 // (replaces a device-to-host copy launch per frame)
 ROLO_DEV void ctrl_body(LmState* st, const double* __restrict__ partials, int nblocks, const double* __restrict__ sums_in,
@@ -697,6 +703,7 @@ ROLO_DEV void ctrl_body(LmState* st, const double* __restrict__ partials, int nb
   constexpr int NW = sizeof(LmState) / sizeof(int);
   constexpr int NWT = (NW + 255) / 256;
   constexpr int INFLIGHT = 64;
+  CT_STAMP(0);
   const int v = threadIdx.x & 31, q = threadIdx.x >> 5;  // 256 threads = 8 strided groups of 32 values
   // Everything this controller reads was written by other CUs a moment ago: every load is a ~1-2 us L2 / fabric round
   // trip. Issue ALL of them before the first use — the state copy and 64 partial rows per thread (the 512 rows of a
@@ -722,6 +729,7 @@ ROLO_DEV void ctrl_body(LmState* st, const double* __restrict__ partials, int nb
     if (pub) { int* h = reinterpret_cast<int*>(pub); const int* l = reinterpret_cast<const int*>(&sst); for (int i = threadIdx.x; i < NW; i += 256) h[i] = l[i]; }
     return;
   }
+  CT_STAMP(1);
   if (partials) {
     // fixed combination order => deterministic for a given grid
     double s0 = 0;
@@ -745,18 +753,33 @@ ROLO_DEV void ctrl_body(LmState* st, const double* __restrict__ partials, int nb
     sums[threadIdx.x] = sums_in[threadIdx.x];
   }
   __syncthreads();
+  CT_STAMP(2);
   if (threadIdx.x == 0) {
     if (stage == 1) rot_step(&sst, sums, trace);
     else trans_step(&sst, sums, trace);
   }
   __syncthreads();
+  CT_STAMP(3);
   {
     int* g = reinterpret_cast<int*>(st);
     const int* l = reinterpret_cast<const int*>(&sst);
     for (int i = threadIdx.x; i < NW; i += 256) g[i] = l[i];
     if (pub) { int* h = reinterpret_cast<int*>(pub); for (int i = threadIdx.x; i < NW; i += 256) h[i] = l[i]; }
   }
+#ifdef ROLO_CTRL_STATS
+  if (threadIdx.x == 0) {   // phases of a launch that had a step to take: loads issued -> first use | row sums | scalar step | write-back
+    const long long ct4 = clock64();
+    atomicAdd(&g_ctrl_t[0], (unsigned long long)(ct1 - ct0)); atomicAdd(&g_ctrl_t[1], (unsigned long long)(ct2 - ct1));
+    atomicAdd(&g_ctrl_t[2], (unsigned long long)(ct3 - ct2)); atomicAdd(&g_ctrl_t[3], (unsigned long long)(ct4 - ct3)); atomicAdd(&g_ctrl_t[7], 1ull);
+  }
+#endif
 }
+#ifdef ROLO_CTRL_STATS
+extern "C" int rolo_debug_ctrl_times(unsigned long long* out8) {
+  (void)hipDeviceSynchronize();
+  return hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_ctrl_t), sizeof(unsigned long long) * 8) == hipSuccess ? 0 : -1;
+}
+#endif
 
 __global__ __launch_bounds__(256) void ctrl_kernel(LmState* st, const double* __restrict__ partials, int nblocks,
                                                   const double* __restrict__ sums_in, rolo_trace_rec* trace, int stage, LmState* pub) {
