@@ -755,6 +755,7 @@ ROLO_DEV void ctrl_body(LmState* st, const double* __restrict__ partials, int nb
   __syncthreads();
   CT_STAMP(2);
   if (threadIdx.x == 0) {
+    // (the step on a private copy of the whole state instead of LDS: 256 VGPRs + 396 B of scratch, 2.2 -> 7.1 us)
     if (stage == 1) rot_step(&sst, sums, trace);
     else trans_step(&sst, sums, trace);
   }
