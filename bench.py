@@ -154,6 +154,51 @@ def pipeline_leg(args, torch, device):
     return res
 
 
+def backend_leg(args, device):
+    """Secondary measurement, not `value`: SURVEY 8f.4, the back end's scan-to-submap optimisation (rolo_scan2map_optimize) — a sub-map of
+    the corner / surface features of 5 key frames, the features of a 6th frame registered to it from a perturbed pose; host arrays in,
+    pose out (uploads, both sub-map trees, all Gauss-Newton iterations)."""
+    from rolo_amd import synth
+    from rolo_amd.backend import Scan2Map
+    from rolo_amd.frontend import FrontEnd, front_params
+    from rolo_amd.rotvgicp import RotVGICP
+    from scipy.spatial.transform import Rotation
+    sensor = args.sensor
+    S = synth.SENSORS[sensor]
+    fp = front_params(n_scan=S[0], horizon_scan=S[1])
+    ctx = RotVGICP(device); fe = FrontEnd(ctx, fp)
+    R = np.eye(3); t = np.zeros(3); mc, ms, last = [], [], None
+    for k in range(6):
+        fr = synth.make_frame(sensor, R, t, synth.SEED + k)
+        pr = fe.project(fr.xyz, fr.ring); ex = fe.extract(pr["n"])
+        c, su = ex["corner"].copy(), ex["surface"].copy()
+        if k < 5:
+            for a, dst in ((c, mc), (su, ms)):
+                a[:, :3] = (a[:, :3].astype(np.float64) @ R.T + t).astype(np.float32); dst.append(a)
+        else:
+            last = (c, su, R.copy(), t.copy())
+        t = t + R @ np.array([0.3, 0.02 * k, 0.0]); R = R @ synth.rpy_to_R(np.deg2rad(0.3), np.deg2rad(-0.2), np.deg2rad(2.0))
+    ctx.close()
+    mc = np.concatenate(mc); ms = np.concatenate(ms)
+    corner, surf, R6, t6 = last
+    truth = np.concatenate([Rotation.from_matrix(R6).as_euler("xyz"), t6]).astype(np.float32)
+    guess = (truth + np.array([0.004, -0.003, 0.01, 0.06, -0.04, 0.02], np.float32)).astype(np.float32)
+    g = Scan2Map(device)
+    for _ in range(2):
+        tf = g.scan2MapOptimization(corner, surf, mc, ms, guess)
+    reps = 5
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        tf = g.scan2MapOptimization(corner, surf, mc, ms, guess)
+    dt = (time.perf_counter() - t0) / reps
+    st = g.last_stats
+    out = {"workload": f"{sensor}: {corner.shape[0]} corner + {surf.shape[0]} surface features against a sub-map of {mc.shape[0]} + {ms.shape[0]} (5 key frames)",
+           "ms_per_call": 1e3 * dt, "iterations": int(st.iterations), "converged": int(st.converged),
+           "pose_error_vs_truth": {"rot_rad": float(np.abs(tf[:3] - truth[:3]).max()), "trans_m": float(np.abs(tf[3:] - truth[3:]).max())}}
+    g.close()
+    return out
+
+
 def _config5_pair(i):
     """pair i of BASELINE configs[4]: seed 20260926 + i, motion drawn U(+-2 deg), U(+-0.4 m)"""
     from rolo_amd import synth
@@ -534,6 +579,11 @@ def main():
             out["pipeline"] = pipeline_leg(args, torch, local_rank)
         except Exception as e:  # pragma: no cover
             out["pipeline"] = {"error": repr(e)}
+
+        try:
+            out["backend"] = backend_leg(args, local_rank)
+        except Exception as e:  # pragma: no cover
+            out["backend"] = {"error": repr(e)}
 
     # ---- CPU baselines: the oracle on this box's host cores (rank 0, N = 1 only) ----
     if rank == 0 and world == 1 and not args.no_cpu:
