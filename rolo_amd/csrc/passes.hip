@@ -361,7 +361,9 @@ ROLO_DEV void reduce_rows(const double* __restrict__ partials, int nblocks, doub
 #pragma unroll
     for (int u = 0; u < INFLIGHT; u++) {
       const int b = b0 + 8 * u;
-      r[u] = (b < nblocks) ? partials[(size_t)b * NV_MAX + v] : 0.0;
+      // an always-valid address and a select: `cond ? load : 0` compiles to one exec-masked branch per load (64 of them in front of the data)
+      const double x = partials[(size_t)min(b, nblocks - 1) * NV_MAX + v];
+      r[u] = (b < nblocks) ? x : 0.0;
     }
 #pragma unroll
     for (int u = 0; u < INFLIGHT; u++) s0 += r[u];
@@ -717,7 +719,9 @@ ROLO_DEV void ctrl_body(LmState* st, const double* __restrict__ partials, int nb
   double r[INFLIGHT];
   if (partials) {
 #pragma unroll
-    for (int u = 0; u < INFLIGHT; u++) { const int b = q + 8 * u; r[u] = (b < nblocks) ? partials[(size_t)b * NV_MAX + v] : 0.0; }
+    for (int u = 0; u < INFLIGHT; u++) {   // always-valid address + select: `cond ? load : 0` is an exec-masked branch per load, 64 of them in front of the data
+      const int b = q + 8 * u; const double x = partials[(size_t)min(b, nblocks - 1) * NV_MAX + v]; r[u] = (b < nblocks) ? x : 0.0;
+    }
   }
   {
     int* l = reinterpret_cast<int*>(&sst);
@@ -737,7 +741,7 @@ ROLO_DEV void ctrl_body(LmState* st, const double* __restrict__ partials, int nb
     for (int u = 0; u < INFLIGHT; u++) s0 += r[u];
     for (int b0 = q + 8 * INFLIGHT; b0 < nblocks; b0 += 8 * INFLIGHT) {   // clouds above 131k points
 #pragma unroll
-      for (int u = 0; u < INFLIGHT; u++) { const int b = b0 + 8 * u; r[u] = (b < nblocks) ? partials[(size_t)b * NV_MAX + v] : 0.0; }
+      for (int u = 0; u < INFLIGHT; u++) { const int b = b0 + 8 * u; const double x = partials[(size_t)min(b, nblocks - 1) * NV_MAX + v]; r[u] = (b < nblocks) ? x : 0.0; }
 #pragma unroll
       for (int u = 0; u < INFLIGHT; u++) s0 += r[u];
     }
@@ -809,7 +813,7 @@ ROLO_DEV void reduce_rows_compact(const double* __restrict__ rows, int nrows, in
   for (int b0 = q; b0 < nrows; b0 += GROUPS * INFLIGHT) {
     double r[INFLIGHT];
 #pragma unroll
-    for (int u = 0; u < INFLIGHT; u++) { const int b = b0 + GROUPS * u; r[u] = (b < nrows && v < nv) ? rows[(size_t)b * NV_MAX + v] : 0.0; }
+    for (int u = 0; u < INFLIGHT; u++) { const int b = b0 + GROUPS * u; const double x = rows[(size_t)min(b, nrows - 1) * NV_MAX + v]; r[u] = (b < nrows && v < nv) ? x : 0.0; }
 #pragma unroll
     for (int u = 0; u < INFLIGHT; u++) s0 += r[u];
   }
