@@ -238,9 +238,21 @@ ROLO_DEV void rot_pass_compute(const PassArgs& a, const LmState* __restrict__ st
   }
 }
 
+#ifdef ROLO_PASS_STATS
+__device__ unsigned long long g_pass_t[8];   // shader-clock ticks per phase of rot_pass_body, summed over thread 0 of every workgroup; [7] = count
+extern "C" int rolo_debug_pass_times(unsigned long long* out8) {
+  (void)hipDeviceSynchronize();
+  return hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_pass_t), sizeof(unsigned long long) * 8) == hipSuccess ? 0 : -1;
+}
+#define PT_STAMP(k) const long long pt##k = clock64()
+#else
+#define PT_STAMP(k)
+#endif
 template <int DOF>
 ROLO_DEV void rot_pass_body(const PassArgs& a, const LmState* __restrict__ st, const int block) {
+  PT_STAMP(0);
   if (st->stage != 1) return;
+  PT_STAMP(1);
   constexpr int NH = DOF * (DOF + 1) / 2;
   constexpr int NV = 3 + NH + DOF;
   double acc[NV];
@@ -251,6 +263,10 @@ ROLO_DEV void rot_pass_body(const PassArgs& a, const LmState* __restrict__ st, c
   PtIn in{};
   if (valid) in = load_pt(a, i);
   rot_pass_compute<DOF>(a, st, i, valid, in, acc);
+#ifdef ROLO_PASS_STATS
+  { double sink = 0; for (int v = 0; v < NV; v++) sink += acc[v]; asm volatile("" :: "v"(sink)); }   // the accumulators are final here
+#endif
+  PT_STAMP(2);
   int slot[NV];
   slot[0] = V_YI; slot[1] = V_Y; slot[2] = V_N;
 #pragma unroll
@@ -258,6 +274,13 @@ ROLO_DEV void rot_pass_body(const PassArgs& a, const LmState* __restrict__ st, c
 #pragma unroll
   for (int v = 0; v < DOF; v++) slot[3 + NH + v] = V_B + v;
   block_reduce_store<NV>(acc, slot, a.partials + (size_t)block * NV_MAX);
+#ifdef ROLO_PASS_STATS
+  if (threadIdx.x == 0) {   // state flag known | point data + voxel records in, accumulators final | block reduction + row store
+    const long long pt3 = clock64();
+    atomicAdd(&g_pass_t[0], (unsigned long long)(pt1 - pt0)); atomicAdd(&g_pass_t[1], (unsigned long long)(pt2 - pt1)); atomicAdd(&g_pass_t[2], (unsigned long long)(pt3 - pt2));
+    atomicAdd(&g_pass_t[7], 1ull);
+  }
+#endif
 }
 
 // translation stage: t3_linearize (B) + compute_t_error (A) on the correspondences of the last rotation
