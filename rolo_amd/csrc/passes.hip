@@ -525,12 +525,12 @@ ROLO_DEV void trace_push(LmState* __restrict__ st, rolo_trace_rec* __restrict__ 
 
 // ---- rotation / 6-dof stage -------------------------------------------------------------------------------
 ROLO_DEV bool delta_converged(const LmState* __restrict__ st, bool rot_only) {  // lsq_registration_impl.hpp:182-191 / :328-335
-  const double ir = 1.0 / st->rot_eps;   // (1.0 / eps) * |.| as the reference writes it; the quotient is formed once
+  const double ir = st->inv_rot_eps;   // (1.0 / eps) * |.| as the reference writes it; the quotient is formed once per frame (rot_begin_dev)
   double rmax = 0;
 #pragma unroll
   for (int i = 0; i < 9; i++) rmax = fmax(rmax, ir * fabs(st->delta_R[i] - ((i % 4 == 0) ? 1.0 : 0.0)));
   if (rot_only) return rmax < 1;
-  const double it = 1.0 / st->trans_eps;
+  const double it = st->inv_trans_eps;
   double tmax = 0;
 #pragma unroll
   for (int i = 0; i < 3; i++) tmax = fmax(tmax, it * fabs(st->delta_t[i]));
@@ -658,7 +658,7 @@ ROLO_DEV void rot_step(LmState* __restrict__ st, const double* __restrict__ S, r
 }
 
 ROLO_DEV bool t_converged(const LmState* __restrict__ st) {  // :142-148
-  const double it = 1.0 / st->trans_eps;
+  const double it = st->inv_trans_eps;
   double m = 0;
 #pragma unroll
   for (int i = 0; i < 3; i++) m = fmax(m, it * fabs(st->delta_t[i]));
@@ -954,6 +954,7 @@ ROLO_DEV void rot_begin_dev(LmState* st, const RotBegin& a) {
   st->trace_count = 0; st->error = 0; st->pending = 0;
   st->optimizer = a.optimizer; st->max_iterations = a.max_iterations; st->fixed_iterations = a.fixed_iterations;
   st->lm_max = a.lm_max; st->q2_intended = a.q2_intended; st->rot_eps = a.rot_eps; st->trans_eps = a.trans_eps; st->lm_init = a.lm_init;
+  st->inv_rot_eps = 1.0 / a.rot_eps; st->inv_trans_eps = 1.0 / a.trans_eps;
 }
 
 __global__ void rot_begin_kernel(LmState* st, RotBegin a) {

@@ -87,6 +87,7 @@ struct LmState {
   // parameters
   int optimizer, max_iterations, fixed_iterations, lm_max, q2_intended;
   double rot_eps, trans_eps, lm_init;
+  double inv_rot_eps, inv_trans_eps;   // 1.0 / eps, formed once per frame (the convergence tests used to divide in every trial)
 };
 
 struct PassArgs {
