@@ -600,7 +600,7 @@ hipError_t launch_knn_walk(const KnnPair& A, int k, int regularization_or_minus1
   const int g0 = (A.c[0].q_end - A.c[0].q_begin + QPB - 1) / QPB, g1 = A.n_clouds > 1 ? (A.c[1].q_end - A.c[1].q_begin + QPB - 1) / QPB : 0;
   if (g0 + g1 == 0) return hipSuccess;
   (void)vf;   // (insert workgroups appended to THIS launch made its wave-uniform leaf loads vector loads: a store anywhere in the kernel is a potential clobber)
-  static const int pad = [] { const char* e = getenv("ROLO_KNN_LDS_PAD"); return e ? atoi(e) : 0; }();   // experiment: occupancy limit through LDS
+  constexpr int pad = 0;   // (an LDS pad here limited the walk to 3 / 2 workgroups per CU: 0.216 / 0.259 ms against 0.196)
   if (k == 20) {
     if (regularization_or_minus1 >= 0) knn_walk_kernel<20, true><<<g0 + g1, 256, pad, s>>>(A, g0, k, regularization_or_minus1);
     else knn_walk_kernel<20, false><<<g0 + g1, 256, pad, s>>>(A, g0, k, -1);
