@@ -103,15 +103,17 @@ ROLO_DEV uint32_t hilbert30(uint32_t x, uint32_t y, uint32_t z) {
 
 // keys: 30-bit Morton code + the cloud number in bit 30, so one sort of both clouds leaves each cloud sorted in its own
 // range [0, n0) / [n0, n0 + n1) of the arrays
-// ---- key sort: a stable LSD radix sort in four 8-bit passes, written for this path (round 1 used rocPRIM's merge sort: 17 launches) --------
-// The keys are <= 31 bits and there are at most a few hundred thousand of them, so the array is cut into SORT_NB = 128 tiles (64 tiles x 4 elements per thread: build 0.090 ms, 128 x 2: 0.076, 256 x 2 on 512 threads: 0.078), one 1024-thread
-// workgroup each. A pass is a histogram launch (per tile: 256 digit counts by LDS atomics, plain stores; the first pass's are counted by the
-// key kernel, which uses the same tiling) and a scatter launch: the workgroup of tile b reads the 128 x 256 counts (their scan is a prologue,
-// not a kernel), ranks its elements stably — waves own consecutive 64-element runs, equal digits inside a run are matched with 8 ballots,
-// runs are ordered by a 16-step prefix per digit in LDS — and scatters keys and values. 1 + 7 launches, the result identical to a stable
-// sort by key (ties by original index) — what rocPRIM's radix_sort_pairs returned. (Counting the next pass's digits inside the scatter, one
-// global integer atomic per element on the counter of its destination tile, saved the three histogram launches and cost 18 us per pass:
-// 262 k device-scope atomics cross the fabric.)
+// ---- key sort: a stable LSD radix sort in three 9-bit passes, written for this path (round 1 used rocPRIM's merge sort: 17 launches) --------
+// The keys are 27 bits (the top 26 bits of the 30-bit curve index + the cloud bit: the walk does not care about the low bits of the index)
+// and there are at most a few hundred thousand of them, so the array is cut into SORT_NB = 128 tiles (64 tiles x 4 elements per thread: build
+// 0.090 ms, 128 x 2: 0.076, 256 x 2 on 512 threads: 0.078), one 1024-thread workgroup each. A pass is a histogram launch (per tile: 512
+// digit counts by LDS atomics, plain stores; the first pass's are counted by the key kernel, which uses the same tiling) and a scatter
+// launch: the workgroup of tile b reads the 128 x 512 counts (their scan is a prologue, not a kernel), ranks its elements stably — waves own
+// consecutive 64-element runs, equal digits inside a run are matched with 9 ballots, runs are ordered by a 16-step prefix per digit in LDS —
+// and scatters keys and values. 1 + 5 launches (four 8-bit passes of 31-bit keys: 1 + 7, build 0.071 against 0.065 ms), the result identical
+// to a stable sort by key (ties by original index) — what rocPRIM's radix_sort_pairs returns. (Counting the next pass's digits inside the
+// scatter, one global integer atomic per element on the counter of its destination tile, saved the histogram launches and cost 18 us per
+// pass: 262 k device-scope atomics cross the fabric.)
 #ifndef ROLO_SORT_NB
 #define ROLO_SORT_NB 128
 #endif
@@ -121,43 +123,53 @@ ROLO_DEV uint32_t hilbert30(uint32_t x, uint32_t y, uint32_t z) {
 #ifndef ROLO_SORT_EPT
 #define ROLO_SORT_EPT 2
 #endif
+#ifndef ROLO_SORT_BITS
+#define ROLO_SORT_BITS 9   // digit width; SORT_PASSES x SORT_BITS >= key bits. 3 x 9 = 27: the curve index is cut to 26 bits + the cloud bit (the walk is
+#endif                     // indifferent to the low bits of the curve index: 30 / 27 / 24 bits 0.1917 / 0.1917 / 0.1920 ms); 4 x 8 bits before
+#ifndef ROLO_SORT_PASSES
+#define ROLO_SORT_PASSES 3
+#endif
+constexpr int SORT_BITS = ROLO_SORT_BITS, SORT_PASSES = ROLO_SORT_PASSES, SORT_D = 1 << SORT_BITS, KEY_BITS = SORT_BITS * SORT_PASSES;
+static_assert(KEY_BITS >= 25 && KEY_BITS <= 31, "curve index + cloud bit");
 constexpr int SORT_NB = ROLO_SORT_NB, SORT_T = ROLO_SORT_T;
+static_assert(SORT_T % SORT_D == 0 || SORT_D % SORT_T == 0, "threads share the count prologue by digit");
 static_assert(SORT_T >= 12 * 64, "the key kernel folds the 12 box components with one wavefront each");
 ROLO_DEV int sort_tile(int n_total) { return ((n_total + SORT_NB - 1) / SORT_NB + SORT_T - 1) / SORT_T * SORT_T; }
 
 constexpr int SORT_EPT = ROLO_SORT_EPT;   // elements per thread and round: a wave ranks 256 consecutive elements between two workgroup barriers
 __global__ __launch_bounds__(SORT_T) void sort_scatter_kernel(const uint32_t* __restrict__ kin, const uint32_t* __restrict__ vin, uint32_t* __restrict__ kout,
-                                                             uint32_t* __restrict__ vout, int n, int tile, int pass, int* __restrict__ cnt /* [4][SORT_NB][256] */,
+                                                             uint32_t* __restrict__ vout, int n, int tile, int pass, int* __restrict__ cnt /* [SORT_PASSES][SORT_NB][SORT_D] */,
                                                              VoxelFuse vf) {
-  if ((int)blockIdx.x >= SORT_NB) {   // VoxelFuse: this pass's quarter of the target points goes into the voxel hash table on the CUs the sort leaves idle
-    const int nt = vf.n_tgt, quarter = (nt + 3) / 4;
+  if ((int)blockIdx.x >= SORT_NB) {   // VoxelFuse: this pass's share of the target points goes into the voxel hash table on the CUs the sort leaves idle
+    const int nt = vf.n_tgt, quarter = (nt + SORT_PASSES - 1) / SORT_PASSES;
     const int i = pass * quarter + ((int)blockIdx.x - SORT_NB) * SORT_T + (int)threadIdx.x;
     voxel_insert_point(vf.tab, vf.tgt_xyz, i < (pass + 1) * quarter ? nt : 0, i, vf.tgt_keys, vf.tgt_slot, vf.counters);
     return;
   }
-  __shared__ int wcnt[SORT_T / 64][256];
-  __shared__ int base[256], run[256], wsum[4];
+  __shared__ int wcnt[SORT_T / 64][SORT_D];
+  __shared__ int base[SORT_D], run[SORT_D], wsum[SORT_D / 64];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, blk = blockIdx.x;
-  const int* __restrict__ c = cnt + (size_t)pass * SORT_NB * 256;
-  for (int k = tid; k < (SORT_T / 64) * 256; k += SORT_T) (&wcnt[0][0])[k] = 0;
+  const int* __restrict__ c = cnt + (size_t)pass * SORT_NB * SORT_D;
+  for (int k = tid; k < (SORT_T / 64) * SORT_D; k += SORT_T) (&wcnt[0][0])[k] = 0;
   // digit totals over all tiles and over the tiles before this one: every thread sums a share of the tiles, the shares meet in LDS
-  constexpr int Q = SORT_T / 256;
-  __shared__ int part[2][Q][256];
+  constexpr int Q = SORT_T / SORT_D;
+  static_assert(Q >= 1, "at least one thread per digit");
+  __shared__ int part[2][Q][SORT_D];
   {
-    const int d = tid & 255, q = tid >> 8;
+    const int d = tid & (SORT_D - 1), q = tid / SORT_D;
     int tot = 0, bef = 0;
 #pragma unroll 16
-    for (int b = q; b < SORT_NB; b += Q) { const int v = c[b * 256 + d]; tot += v; bef += b < blk ? v : 0; }
+    for (int b = q; b < SORT_NB; b += Q) { const int v = c[b * SORT_D + d]; tot += v; bef += b < blk ? v : 0; }
     part[0][q][d] = tot; part[1][q][d] = bef;
   }
   __syncthreads();
   int t = 0;
-  if (tid < 256) {
+  if (tid < SORT_D) {
     int before = 0;
 #pragma unroll
     for (int q = 0; q < Q; q++) { t += part[0][q][tid]; before += part[1][q][tid]; }
     run[tid] = before;   // elements with this digit in earlier tiles (becomes the running offset inside the tile below)
-    // exclusive scan of the 256 digit totals: inside the wave by shuffles, across the four waves through LDS
+    // exclusive scan of the digit totals: inside the wave by shuffles, across the waves through LDS
     int incl = t;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(incl, off, 64); if (lane >= off) incl += o; }
@@ -165,9 +177,9 @@ __global__ __launch_bounds__(SORT_T) void sort_scatter_kernel(const uint32_t* __
     t = incl - t;   // exclusive inside the wave
   }
   __syncthreads();
-  if (tid < 256) { int add = 0; for (int w = 0; w < wv; w++) add += wsum[w]; base[tid] = t + add; }
+  if (tid < SORT_D) { int add = 0; for (int w = 0; w < wv; w++) add += wsum[w]; base[tid] = t + add; }
   __syncthreads();
-  const int shift = 8 * pass;
+  const int shift = SORT_BITS * pass;
   for (int r0 = 0; r0 < tile; r0 += SORT_T * SORT_EPT) {
     // the wave's run of this round: 256 consecutive elements, lane-contiguous in SORT_EPT sub-rounds of 64
     uint32_t key[SORT_EPT]; int off[SORT_EPT], e[SORT_EPT];
@@ -181,10 +193,10 @@ __global__ __launch_bounds__(SORT_T) void sort_scatter_kernel(const uint32_t* __
 #pragma unroll
     for (int j = 0; j < SORT_EPT; j++) {
       const bool valid = e[j] >= 0;
-      const int d = (int)((key[j] >> shift) & 255u);
+      const int d = (int)((key[j] >> shift) & (uint32_t)(SORT_D - 1));
       unsigned long long m = __ballot(valid);
 #pragma unroll
-      for (int bit = 0; bit < 8; bit++) {
+      for (int bit = 0; bit < SORT_BITS; bit++) {
         const bool one = (d >> bit) & 1;
         const unsigned long long bl = __ballot(one);
         m &= one ? bl : ~bl;
@@ -197,7 +209,7 @@ __global__ __launch_bounds__(SORT_T) void sort_scatter_kernel(const uint32_t* __
       off[j] = old + rank;   // position among this wave's elements of digit d so far
     }
     __syncthreads();
-    if (tid < 256) {
+    if (tid < SORT_D) {
       int acc = run[tid];
 #pragma unroll
       for (int w = 0; w < SORT_T / 64; w++) { const int v = wcnt[w][tid]; wcnt[w][tid] = acc; acc += v; }
@@ -207,14 +219,14 @@ __global__ __launch_bounds__(SORT_T) void sort_scatter_kernel(const uint32_t* __
 #pragma unroll
     for (int j = 0; j < SORT_EPT; j++) {
       if (e[j] >= 0) {
-        const int d = (int)((key[j] >> shift) & 255u);
+        const int d = (int)((key[j] >> shift) & (uint32_t)(SORT_D - 1));
         const int dest = base[d] + wcnt[wv][d] + off[j];
         kout[dest] = key[j]; vout[dest] = vin[e[j]];
       }
     }
     if (r0 + SORT_T * SORT_EPT < tile) {
       __syncthreads();
-      for (int k = tid; k < (SORT_T / 64) * 256; k += SORT_T) (&wcnt[0][0])[k] = 0;
+      for (int k = tid; k < (SORT_T / 64) * SORT_D; k += SORT_T) (&wcnt[0][0])[k] = 0;
       __syncthreads();
     }
   }
@@ -230,10 +242,10 @@ __global__ __launch_bounds__(SORT_T) void morton_kernel(KnnPair A, int* __restri
     if (blockIdx.x == SORT_NB && threadIdx.x < 3) vf.counters[threadIdx.x] = 0;   // counters[3] (max |coordinate|) is block 0's
     return;
   }
-  __shared__ int hist[256];
+  __shared__ int hist[SORT_D];
   __shared__ float par[2][4];   // per cloud: min x, y, z and the scale
   const int tid = threadIdx.x, blk = blockIdx.x;
-  if (tid < 256) hist[tid] = 0;
+  if (tid < SORT_D) hist[tid] = 0;
   __shared__ int fin[12];
   {  // fold the partial boxes: wave w < 12 owns component w % 6 of cloud w / 6
     const int w = tid >> 6, lane = tid & 63;
@@ -271,33 +283,33 @@ __global__ __launch_bounds__(SORT_T) void morton_kernel(KnnPair A, int* __restri
     const int iy = min(1023, max(0, (int)((q.y - mny) * sc)));
     const int iz = min(1023, max(0, (int)((q.z - mnz) * sc)));
 #ifndef ROLO_KNN_MORTON   // A/B builds: the Z-order curve this replaced (walk 0.274 ms against 0.230 ms for the 2 x 131 072-point pair)
-    const uint32_t key = hilbert30((uint32_t)ix, (uint32_t)iy, (uint32_t)iz) | ((uint32_t)which << 30);
+    const uint32_t key = (hilbert30((uint32_t)ix, (uint32_t)iy, (uint32_t)iz) >> (31 - KEY_BITS)) | ((uint32_t)which << (KEY_BITS - 1));   // the top KEY_BITS - 1 bits of the curve index
 #else
-    const uint32_t key = expand10(ix) | (expand10(iy) << 1) | (expand10(iz) << 2) | ((uint32_t)which << 30);
+    const uint32_t key = ((expand10(ix) | (expand10(iy) << 1) | (expand10(iz) << 2)) >> (31 - KEY_BITS)) | ((uint32_t)which << (KEY_BITS - 1));
 #endif
     keys[e] = key;
     vals[e] = (uint32_t)i;
-    atomicAdd(&hist[key & 255u], 1);
+    atomicAdd(&hist[key & (uint32_t)(SORT_D - 1)], 1);
   }
   __syncthreads();
-  if (cnt && tid < 256) cnt[blk * 256 + tid] = hist[tid];
+  if (cnt && tid < SORT_D) cnt[blk * SORT_D + tid] = hist[tid];
 }
 
 // digit counts of sort pass `pass` for every tile of the (partially sorted) keys: LDS atomics, plain stores — counting the next pass's digits
 // with global atomics inside the scatter cost 18 us per pass (262 k device-scope atomics cross the fabric), this launch costs 4
 __global__ __launch_bounds__(SORT_T) void sort_hist_kernel(const uint32_t* __restrict__ keys, int n, int tile, int pass, int* __restrict__ cnt) {
-  __shared__ int hist[256];
+  __shared__ int hist[SORT_D];
   const int tid = threadIdx.x, blk = blockIdx.x;
-  if (tid < 256) hist[tid] = 0;
+  if (tid < SORT_D) hist[tid] = 0;
   __syncthreads();
-  const int shift = 8 * pass;
+  const int shift = SORT_BITS * pass;
   for (int r = tid; r < tile; r += SORT_T) {
     const int e = blk * tile + r;
     if (e >= n) break;
-    atomicAdd(&hist[(keys[e] >> shift) & 255u], 1);
+    atomicAdd(&hist[(keys[e] >> shift) & (uint32_t)(SORT_D - 1)], 1);
   }
   __syncthreads();
-  if (tid < 256) cnt[(size_t)pass * SORT_NB * 256 + blk * 256 + tid] = hist[tid];
+  if (tid < SORT_D) cnt[(size_t)pass * SORT_NB * SORT_D + blk * SORT_D + tid] = hist[tid];
 }
 
 // one thread per leaf: gather its 8 points in Morton order, write them + the leaf box
@@ -539,7 +551,7 @@ size_t knn_sort_temp_bytes(int n) {  // for n points in total (one cloud or the 
   return bytes;
 #else
   (void)n;
-  return sizeof(int) * 4 * SORT_NB * 256;   // digit counters of the four passes
+  return sizeof(int) * SORT_PASSES * SORT_NB * SORT_D;   // digit counters of the passes
 #endif
 }
 
@@ -553,24 +565,23 @@ hipError_t launch_knn_build(const KnnPair& A, void* sort_tmp, size_t sort_tmp_by
   const int tile_ = ((n_total + SORT_NB - 1) / SORT_NB + SORT_T - 1) / SORT_T * SORT_T;
   bbox_kernel<<<BBOX_BLOCKS * nc, 256, 0, s>>>(A, bbox);
   morton_kernel<<<SORT_NB + (vf.enabled ? VF_CLEAR_BLOCKS : 0), SORT_T, 0, s>>>(A, bbox, keys0, vals0, n_total, tile_, nullptr, vf);
-  hipError_t e = rocprim::radix_sort_pairs(sort_tmp, sort_tmp_bytes, keys0, keys1, vals0, vals1, (size_t)n_total, 0, nc > 1 ? 31 : 30, s);
+  hipError_t e = rocprim::radix_sort_pairs(sort_tmp, sort_tmp_bytes, keys0, keys1, vals0, vals1, (size_t)n_total, 0, nc > 1 ? KEY_BITS : KEY_BITS - 1, s);
   if (e != hipSuccess) return e;
   const uint32_t* order = vals1;
 #else
   (void)sort_tmp_bytes;
   int* cnt = static_cast<int*>(sort_tmp);
-  const int gvf = vf.enabled ? ((vf.n_tgt + 3) / 4 + SORT_T - 1) / SORT_T : 0;   // insert workgroups per scatter launch
+  const int gvf = vf.enabled ? ((vf.n_tgt + SORT_PASSES - 1) / SORT_PASSES + SORT_T - 1) / SORT_T : 0;   // insert workgroups per scatter launch
   const int tile = ((n_total + SORT_NB - 1) / SORT_NB + SORT_T - 1) / SORT_T * SORT_T;
   bbox_kernel<<<BBOX_BLOCKS * nc, 256, 0, s>>>(A, bbox);
   morton_kernel<<<SORT_NB + (vf.enabled ? VF_CLEAR_BLOCKS : 0), SORT_T, 0, s>>>(A, bbox, keys0, vals0, n_total, tile, cnt, vf);
-  sort_scatter_kernel<<<SORT_NB + gvf, SORT_T, 0, s>>>(keys0, vals0, keys1, vals1, n_total, tile, 0, cnt, vf);
-  sort_hist_kernel<<<SORT_NB, SORT_T, 0, s>>>(keys1, n_total, tile, 1, cnt);
-  sort_scatter_kernel<<<SORT_NB + gvf, SORT_T, 0, s>>>(keys1, vals1, keys0, vals0, n_total, tile, 1, cnt, vf);
-  sort_hist_kernel<<<SORT_NB, SORT_T, 0, s>>>(keys0, n_total, tile, 2, cnt);
-  sort_scatter_kernel<<<SORT_NB + gvf, SORT_T, 0, s>>>(keys0, vals0, keys1, vals1, n_total, tile, 2, cnt, vf);
-  sort_hist_kernel<<<SORT_NB, SORT_T, 0, s>>>(keys1, n_total, tile, 3, cnt);
-  sort_scatter_kernel<<<SORT_NB + gvf, SORT_T, 0, s>>>(keys1, vals1, keys0, vals0, n_total, tile, 3, cnt, vf);
-  const uint32_t* order = vals0;
+  uint32_t *ki = keys0, *vi = vals0, *ko = keys1, *vo = vals1;
+  for (int p = 0; p < SORT_PASSES; p++) {
+    if (p > 0) sort_hist_kernel<<<SORT_NB, SORT_T, 0, s>>>(ki, n_total, tile, p, cnt);
+    sort_scatter_kernel<<<SORT_NB + gvf, SORT_T, 0, s>>>(ki, vi, ko, vo, n_total, tile, p, cnt, vf);
+    uint32_t* t1 = ki; ki = ko; ko = t1; t1 = vi; vi = vo; vo = t1;
+  }
+  const uint32_t* order = vi;   // wherever the last pass left the values
 #endif
   static_assert(256 % KNN_LEAF == 0 && (KNN_LEAF & (KNN_LEAF - 1)) == 0, "leaf_kernel reduces a leaf inside a wavefront");
   const int l0 = (A.c[0].P * KNN_LEAF + 255) / 256, l1 = nc > 1 ? (A.c[1].P * KNN_LEAF + 255) / 256 : 0;
