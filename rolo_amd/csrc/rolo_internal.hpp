@@ -113,7 +113,7 @@ struct KnnCloud { const float4* xyz; float4* sorted; float4* boxes; double* cov;
                   int q_begin, q_end; double* stage; int chunk, stage_off; size_t seg; };
 struct KnnPair { KnnCloud c[2]; int n_clouds; };
 // The target's voxel map built inside the search's launches (single GPU, covariances computed here and bounded): the table is cleared by
-// extra workgroups of the key kernel, the points are inserted by extra workgroups of the four sort-scatter launches (a quarter each, on
+// extra workgroups of the key kernel, the points are inserted by extra workgroups of the sort-scatter launches (a share each, on
 // the CUs the 128 sort tiles leave idle: nothing on the critical path), and the tail accumulates each target point's covariance straight
 // from registers, in curve order. Only voxel_finalize_kernel is left of the map build.
 struct VoxelFuse {
