@@ -192,7 +192,10 @@ int upload_cloud(rolo_ctx* c, CloudDev& cl, size_t& xyz_cap, const float* pts, i
     HIPCHK(hipMemcpyAsync(c->stage_in, pts, sizeof(float) * (size_t)n * stride, hipMemcpyHostToDevice, c->stream));
     dsrc = c->stage_in;
   }
-  HIPCHK(launch_pack_xyz(dsrc, stride, cl.xyz, n, c->stream));
+  const int nparts = (n + 255) / 256;
+  if ((rc = ensure(cl.bbox_part, cl.bbox_part_cap, (size_t)std::max(nparts, 1) * 6))) return rc;
+  HIPCHK(launch_pack_xyz(dsrc, stride, cl.xyz, n, c->stream, cl.bbox_part));
+  cl.n_bbox_part = nparts;
   cl.n = n;
   cl.have_cov = false;
   cl.have_sorted = false;
@@ -220,6 +223,7 @@ int prepare_cloud(rolo_ctx* c, CloudDev& cl, size_t& cov_cap, size_t& sorted_cap
   out.knn_idx = c->want_knn_lists ? cl.knn_idx : nullptr; out.knn_d2 = c->want_knn_lists ? cl.knn_d2 : nullptr;
   out.n = n; out.n_leaves = cl.n_leaves; out.P = P; out.n_sorted = KNN_LEAF * cl.n_leaves;
   out.q_begin = 0; out.q_end = out.n_sorted; out.stage = nullptr; out.chunk = out.n_sorted; out.stage_off = 0; out.seg = 0;
+  out.bpart = cl.n_bbox_part > 0 ? cl.bbox_part : nullptr; out.n_bpart = cl.n_bbox_part;
   return ROLO_OK;
 }
 
@@ -566,7 +570,7 @@ void rolo_ctx_destroy(rolo_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   rolo_front_destroy(c);
   if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
-  void* bufs[] = {c->src.xyz, c->src.cov, c->src.sorted, c->src.boxes, c->src.knn_idx, c->src.knn_d2, c->tgt.xyz, c->tgt.cov, c->tgt.sorted,
+  void* bufs[] = {c->src.bbox_part, c->tgt.bbox_part, c->src.xyz, c->src.cov, c->src.sorted, c->src.boxes, c->src.knn_idx, c->src.knn_d2, c->tgt.xyz, c->tgt.cov, c->tgt.sorted,
                   c->tgt.boxes, c->tgt.knn_idx, c->tgt.knn_d2, c->ks[0].sort_tmp, c->ks[0].keys0, c->ks[0].keys1, c->ks[0].vals0, c->ks[0].vals1, c->ks[0].bbox,
                   c->ks[1].sort_tmp, c->ks[1].keys0, c->ks[1].keys1, c->ks[1].vals0, c->ks[1].vals1, c->ks[1].bbox, c->ks[0].nbr, c->ks[1].nbr, c->ks[0].stage, c->ks[1].stage, c->tab.keys,
                   c->tab.ids, c->tab.rec, c->tab.id_keys, c->tgt_keys, c->tgt_slot, c->counters, c->corr[0], c->corr[1], c->partials, c->sums,

@@ -7,6 +7,11 @@
 
 namespace rolo {
 
+// floats as order-preserving ints (min / max by integer compare, atomics)
+ROLO_DEV int f2ord(float f) { int i = __float_as_int(f); return i >= 0 ? i : i ^ 0x7fffffff; }
+ROLO_DEV float ord2f(int k) { int i = k >= 0 ? k : k ^ 0x7fffffff; return __int_as_float(i); }
+
+
 struct Sym3 { double xx, xy, xz, yy, yz, zz; };
 struct Vec3 { double x, y, z; };
 struct Mat3 { double m[9]; };  // row-major

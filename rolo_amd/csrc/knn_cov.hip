@@ -25,8 +25,6 @@ namespace rolo {
 
 namespace {
 
-ROLO_DEV int f2ord(float f) { int i = __float_as_int(f); return i >= 0 ? i : i ^ 0x7fffffff; }
-ROLO_DEV float ord2f(int k) { int i = k >= 0 ? k : k ^ 0x7fffffff; return __int_as_float(i); }
 
 // Every kernel of the search takes a KnnPair: the source and the target cloud of a registration go through ONE chain of
 // launches (workgroups [0, split) belong to cloud 0, the rest to cloud 1) — half the launches of two separate chains,
@@ -252,7 +250,8 @@ __global__ __launch_bounds__(SORT_T) void morton_kernel(KnnPair A, int* __restri
     if (w < 6 * A.n_clouds) {
       const bool is_min = (w % 6) < 3;
       int v = is_min ? INT_MAX : INT_MIN;
-      for (int b = lane; b < BBOX_BLOCKS; b += 64) { const int o = bbox[BBOX_PART + ((w / 6) * BBOX_BLOCKS + b) * 6 + (w % 6)]; v = is_min ? min(v, o) : max(v, o); }
+      const int* __restrict__ bp = A.c[w / 6].bpart; const int nbp = A.c[w / 6].n_bpart;
+      for (int b = lane; b < nbp; b += 64) { const int o = bp[b * 6 + (w % 6)]; v = is_min ? min(v, o) : max(v, o); }
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(v, off, 64); v = is_min ? min(v, o) : max(v, o); }
       if (lane == 0) { fin[w] = v; if (blk == 0) bbox[w] = v; }   // the final box, for the voxel map's scales (separate map build)
@@ -557,13 +556,17 @@ size_t knn_sort_temp_bytes(int n) {  // for n points in total (one cloud or the 
 
 // Morton sort + implicit BVHs of the pair's clouds. sorted / boxes must be allocated for n_leaves / P of each cloud;
 // keys / vals hold n0 + n1 entries, bbox 12 ints.
-hipError_t launch_knn_build(const KnnPair& A, void* sort_tmp, size_t sort_tmp_bytes, uint32_t* keys0, uint32_t* keys1,
+hipError_t launch_knn_build(const KnnPair& A_in, void* sort_tmp, size_t sort_tmp_bytes, uint32_t* keys0, uint32_t* keys1,
                             uint32_t* vals0, uint32_t* vals1, int* bbox, const VoxelFuse& vf, hipStream_t s) {
+  KnnPair A = A_in;
+  bool have_parts = true;   // every cloud brings the partial boxes its pack kernel left: no bbox launch
+  for (int i = 0; i < A.n_clouds; i++) have_parts = have_parts && A.c[i].bpart != nullptr && A.c[i].n_bpart > 0;
+  if (!have_parts) for (int i = 0; i < A.n_clouds; i++) { A.c[i].bpart = bbox + BBOX_PART + i * BBOX_BLOCKS * 6; A.c[i].n_bpart = BBOX_BLOCKS; }
   const int nc = A.n_clouds;
   const int n_total = A.c[0].n + (nc > 1 ? A.c[1].n : 0);
 #ifdef ROLO_KNN_ROCPRIM_SORT
   const int tile_ = ((n_total + SORT_NB - 1) / SORT_NB + SORT_T - 1) / SORT_T * SORT_T;
-  bbox_kernel<<<BBOX_BLOCKS * nc, 256, 0, s>>>(A, bbox);
+  if (!have_parts) bbox_kernel<<<BBOX_BLOCKS * nc, 256, 0, s>>>(A, bbox);
   morton_kernel<<<SORT_NB + (vf.enabled ? VF_CLEAR_BLOCKS : 0), SORT_T, 0, s>>>(A, bbox, keys0, vals0, n_total, tile_, nullptr, vf);
   hipError_t e = rocprim::radix_sort_pairs(sort_tmp, sort_tmp_bytes, keys0, keys1, vals0, vals1, (size_t)n_total, 0, nc > 1 ? KEY_BITS : KEY_BITS - 1, s);
   if (e != hipSuccess) return e;
@@ -573,7 +576,7 @@ hipError_t launch_knn_build(const KnnPair& A, void* sort_tmp, size_t sort_tmp_by
   int* cnt = static_cast<int*>(sort_tmp);
   const int gvf = vf.enabled ? ((vf.n_tgt + SORT_PASSES - 1) / SORT_PASSES + SORT_T - 1) / SORT_T : 0;   // insert workgroups per scatter launch
   const int tile = ((n_total + SORT_NB - 1) / SORT_NB + SORT_T - 1) / SORT_T * SORT_T;
-  bbox_kernel<<<BBOX_BLOCKS * nc, 256, 0, s>>>(A, bbox);
+  if (!have_parts) bbox_kernel<<<BBOX_BLOCKS * nc, 256, 0, s>>>(A, bbox);
   morton_kernel<<<SORT_NB + (vf.enabled ? VF_CLEAR_BLOCKS : 0), SORT_T, 0, s>>>(A, bbox, keys0, vals0, n_total, tile, cnt, vf);
   uint32_t *ki = keys0, *vi = vals0, *ko = keys1, *vo = vals1;
   for (int p = 0; p < SORT_PASSES; p++) {

@@ -1,16 +1,42 @@
 // Small layout / utility kernels: strided PCL records -> float4, covariance SoA <-> Matrix4d, and the float
 // pcl::transformPointCloud used at reference src/lidarOdometry.cpp:459,492 and lsq_registration_impl.hpp:78,178.
 #include "rolo_internal.hpp"
+#include "dev_math.hpp"
+#include <cfloat>
 
 namespace rolo {
 
 namespace {
 
-__global__ __launch_bounds__(256) void pack_xyz_kernel(const float* __restrict__ in, int stride, float4* __restrict__ out, int n) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const float* p = in + (size_t)i * stride;
-  out[i] = make_float4(p[0], p[1], p[2], 1.0f);  // pcl::PointXYZI data[3] = 1
+// strided records -> float4 (x, y, z, 1); the same pass leaves the workgroup's partial bounding box (what the neighbour search's key kernel
+// folds — a separate bbox launch re-read the cloud for it)
+__global__ __launch_bounds__(256) void pack_xyz_kernel(const float* __restrict__ in, int stride, float4* __restrict__ out, int n, int* __restrict__ bbox_part) {
+  __shared__ float smn[4][3], smx[4][3];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  if (i < n) {
+    const float* p = in + (size_t)i * stride;
+    const float x = p[0], y = p[1], z = p[2];
+    out[i] = make_float4(x, y, z, 1.0f);  // pcl::PointXYZI data[3] = 1
+    mn[0] = mx[0] = x; mn[1] = mx[1] = y; mn[2] = mx[2] = z;
+  }
+  if (!bbox_part) return;   // uniform
+#pragma unroll
+  for (int d = 0; d < 3; d++) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { mn[d] = fminf(mn[d], __shfl_xor(mn[d], off, 64)); mx[d] = fmaxf(mx[d], __shfl_xor(mx[d], off, 64)); }
+  }
+  const int wv = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int d = 0; d < 3; d++) { smn[wv][d] = mn[d]; smx[wv][d] = mx[d]; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const int d = threadIdx.x;
+    bbox_part[blockIdx.x * 6 + d] = f2ord(fminf(fminf(smn[0][d], smn[1][d]), fminf(smn[2][d], smn[3][d])));
+    bbox_part[blockIdx.x * 6 + 3 + d] = f2ord(fmaxf(fmaxf(smx[0][d], smx[1][d]), fmaxf(smx[2][d], smx[3][d])));
+  }
 }
 
 __global__ __launch_bounds__(256) void cov_unpack_kernel(const double* __restrict__ soa, int n, double* __restrict__ m16) {
@@ -61,8 +87,8 @@ hipError_t launch_stamp(unsigned long long* buf, int slot, hipStream_t s) {
   return hipGetLastError();
 }
 
-hipError_t launch_pack_xyz(const float* in, int stride, float4* out, int n, hipStream_t s) {
-  if (n > 0) pack_xyz_kernel<<<(n + 255) / 256, 256, 0, s>>>(in, stride, out, n);
+hipError_t launch_pack_xyz(const float* in, int stride, float4* out, int n, hipStream_t s, int* bbox_part) {
+  if (n > 0) pack_xyz_kernel<<<(n + 255) / 256, 256, 0, s>>>(in, stride, out, n, bbox_part);
   return hipGetLastError();
 }
 hipError_t launch_cov_unpack(const double* soa, int n, double* m16, hipStream_t s) {

@@ -54,6 +54,8 @@ struct CloudDev {          // one point cloud resident in HBM
   int n_leaves = 0, P = 0;
   bool have_sorted = false;     // sorted / boxes belong to the current xyz
   const int* bbox6 = nullptr;   // bounding box of the current xyz left by the search (device, 6 order-preserving ints); nullptr: unknown
+  int* bbox_part = nullptr;     // partial boxes of the current xyz left by the pack kernel: n_bbox_part x 6 order-preserving ints (0: none)
+  size_t bbox_part_cap = 0; int n_bbox_part = 0;
   int32_t* knn_idx = nullptr;   // debug: n x k
   float* knn_d2 = nullptr;
 };
@@ -110,7 +112,8 @@ struct BatchSlot { PassArgs a; LmState* st; rolo_trace_rec* trace; int grid; int
 // whole cloud otherwise). stage != nullptr: the covariances of the slice go to an exchange buffer in sorted order (6 doubles per
 // position; position j lives in segment j / chunk at stage + (j / chunk) * seg + stage_off + (j % chunk) * 6) instead of cov[].
 struct KnnCloud { const float4* xyz; float4* sorted; float4* boxes; double* cov; int32_t* knn_idx; float* knn_d2; int32_t* nbr; int n, n_leaves, P, n_sorted;
-                  int q_begin, q_end; double* stage; int chunk, stage_off; size_t seg; };
+                  int q_begin, q_end; double* stage; int chunk, stage_off; size_t seg;
+                  const int* bpart; int n_bpart; };   // partial bounding boxes to fold (the pack kernel's, or bbox_kernel's in the scratch buffer)
 struct KnnPair { KnnCloud c[2]; int n_clouds; };
 // The target's voxel map built inside the search's launches (single GPU, covariances computed here and bounded): the table is cleared by
 // extra workgroups of the key kernel, the points are inserted by extra workgroups of the sort-scatter launches (a share each, on
@@ -170,7 +173,8 @@ hipError_t launch_t3_eval_begin(LmState* st, const TransBegin& a, int phase, hip
 
 hipError_t launch_transform_cloud(const float* in, float* out, int n, int stride, const float* T16_dev_or_null,
                                   const float* T16_host, hipStream_t s);
-hipError_t launch_pack_xyz(const float* in, int stride, float4* out, int n, hipStream_t s);
+// bbox_part != nullptr: one partial bounding box (6 order-preserving ints) per workgroup of 256 points goes there
+hipError_t launch_pack_xyz(const float* in, int stride, float4* out, int n, hipStream_t s, int* bbox_part = nullptr);
 hipError_t launch_cov_unpack(const double* soa, int n, double* m16, hipStream_t s);   // 6 SoA -> n x 16
 hipError_t launch_cov_pack(const double* m16, int n, double* soa, hipStream_t s);     // n x 16 -> 6 SoA
 
