@@ -208,6 +208,29 @@ def test_odd_sizes_through_the_sort_tree_and_fused_map(n):
     g.close()
 
 
+@pytest.mark.parametrize("k,overlap", [(10, True), (27, False), (32, True)])
+def test_fused_map_with_other_k_and_search_modes(k, overlap):
+    """the map built inside the search's launches for k != 20 (the 32-slot kernels) and with one search chain per cloud: same bits as
+    the separate launches, also when a second registration finds the covariances already there"""
+    src, tgt, _ = synth.dense_pair("os1-64", col_stride=4)
+    def ctx():
+        g = RotVGICP(); g.setResolution(1.0); g.setCorrespondenceRandomness(k); g.setOverlapKnn(overlap); g.setInputTarget(tgt); g.setInputSource(src)
+        return g
+    g = ctx(); g.buildVoxelMap()
+    kk, c, m, v = g.voxels(); o = np.lexsort(kk.T[::-1]); ref = (kk[o], c[o], m[o], v[o]); cov = g.getTargetCovariances().copy()
+    g.close()
+    g = ctx(); z = np.zeros(3)
+    for it in range(3):
+        if it == 1:
+            g.setInputTarget(tgt); g.setInputSource(src)   # it == 2: same clouds again, covariances kept
+        g.register_async(None, z, z, z, 0.1, 0.1, 0.3); g.register_wait()
+        kk, c, m, v = g.voxels(); o = np.lexsort(kk.T[::-1])
+        for a, b in zip(ref, (kk[o], c[o], m[o], v[o])):
+            assert np.array_equal(a, b)
+        assert np.array_equal(cov, g.getTargetCovariances())
+    g.close()
+
+
 def test_linearize_stages(pair):
     _, src, tgt, cfg = pair
     o, g = make_both(src, tgt, cfg)
