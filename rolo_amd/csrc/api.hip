@@ -206,7 +206,7 @@ int upload_cloud(rolo_ctx* c, CloudDev& cl, size_t& xyz_cap, const float* pts, i
 // search structures of one cloud: geometry + allocations
 int prepare_cloud(rolo_ctx* c, CloudDev& cl, size_t& cov_cap, size_t& sorted_cap, size_t& boxes_cap, size_t& knn_cap, size_t& knnd_cap, KnnCloud& out, bool tree_only = false) {
   const int n = cl.n, k = tree_only ? 1 : c->P.k_correspondences;
-  if (k < 1 || k > 32) { g_err = "k_correspondences must be in [1,32]"; return ROLO_EUNSUPPORTED; }
+  if (k < 1 || k > 64) { g_err = "k_correspondences must be in [1,64]"; return ROLO_EUNSUPPORTED; }
   if (n < k) { g_err = "cloud has fewer points than k_correspondences"; return ROLO_ETOOFEW; }
   cl.n_leaves = (n + KNN_LEAF - 1) / KNN_LEAF;
   int P = 2; while (P < cl.n_leaves) P <<= 1;
@@ -254,8 +254,9 @@ int build_clouds(rolo_ctx* c, bool do_src, bool do_tgt, hipStream_t stream, bool
   if ((rc = ensure(S.vals0, S.vals0_cap, n_total))) return rc;
   if ((rc = ensure(S.vals1, S.vals1_cap, n_total))) return rc;
   if ((rc = ensure(S.bbox, S.bbox_cap, knn_bbox_ints()))) return rc;
-  if ((rc = ensure(S.nbr, S.nbr_cap, 32 * ((size_t)A.c[0].n_sorted + (nc > 1 ? (size_t)A.c[1].n_sorted : 0))))) return rc;
-  A.c[0].nbr = S.nbr; if (nc > 1) A.c[1].nbr = S.nbr + 32 * (size_t)A.c[0].n_sorted;
+  const size_t kslots = c->P.k_correspondences > 32 ? 64 : 32;   // slot-major neighbour lists: KMAX slots per sorted position
+  if ((rc = ensure(S.nbr, S.nbr_cap, kslots * ((size_t)A.c[0].n_sorted + (nc > 1 ? (size_t)A.c[1].n_sorted : 0))))) return rc;
+  A.c[0].nbr = S.nbr; if (nc > 1) A.c[1].nbr = S.nbr + kslots * (size_t)A.c[0].n_sorted;
   const size_t tmp = knn_sort_temp_bytes((int)n_total);
   if ((rc = ensure(S.sort_tmp, S.sort_tmp_cap, tmp + 256))) return rc;
   // Multi-GPU ("K5 shards by query point with the full cloud replicated"): every rank sorts and builds the BVH of the whole

@@ -620,7 +620,10 @@ hipError_t launch_knn_walk(const KnnPair& A, int k, int regularization_or_minus1
     else knn_walk_kernel<20, false><<<g0 + g1, 256, pad, s>>>(A, g0, k, -1);
   }
   else {
-    if (regularization_or_minus1 >= 0) knn_walk_kernel<32, true><<<g0 + g1, 256, pad, s>>>(A, g0, k, regularization_or_minus1);
+    if (k > 32) {   // up to 64 neighbours: 128 key registers per lane — correct, not tuned (the reference accepts any k; its default is 20)
+      if (regularization_or_minus1 >= 0) knn_walk_kernel<64, true><<<g0 + g1, 256, pad, s>>>(A, g0, k, regularization_or_minus1);
+      else knn_walk_kernel<64, false><<<g0 + g1, 256, pad, s>>>(A, g0, k, -1);
+    } else if (regularization_or_minus1 >= 0) knn_walk_kernel<32, true><<<g0 + g1, 256, pad, s>>>(A, g0, k, regularization_or_minus1);
     else knn_walk_kernel<32, false><<<g0 + g1, 256, pad, s>>>(A, g0, k, -1);
   }
   return hipGetLastError();
@@ -638,7 +641,8 @@ hipError_t launch_knn_tail(const KnnPair& A, int k, int regularization, const Vo
   const int g0 = slice_blocks(A.c[0]), g1 = A.n_clouds > 1 ? slice_blocks(A.c[1]) : 0;
   if (g0 + g1 == 0) return hipSuccess;
   if (k == 20) knn_tail_kernel<20><<<g0 + g1, 256, 0, s>>>(A, g0, k, regularization, vf);
-  else knn_tail_kernel<32><<<g0 + g1, 256, 0, s>>>(A, g0, k, regularization, vf);
+  else if (k <= 32) knn_tail_kernel<32><<<g0 + g1, 256, 0, s>>>(A, g0, k, regularization, vf);
+  else knn_tail_kernel<64><<<g0 + g1, 256, 0, s>>>(A, g0, k, regularization, vf);
   return hipGetLastError();
 }
 

@@ -231,6 +231,26 @@ def test_fused_map_with_other_k_and_search_modes(k, overlap):
     g.close()
 
 
+def test_forty_eight_neighbours():
+    """k above 32 (the reference takes any k): the 64-slot kernels — neighbour lists bit-exact against the oracle, covariances and pose agree"""
+    src, tgt, cfg = make_pair("os64_uniform")
+    p = pyorc.default_params(polar_resolution=cfg["polar"], voxel_type=cfg["voxel_type"], voxel_resolution=cfg["leaf"], k_correspondences=48)
+    o = pyorc.Reg(p); o.set_target(tgt); o.set_source(src)
+    g = RotVGICP(); g.setResolution(cfg["leaf"]); g.setCorrespondenceRandomness(48); g.setInputTarget(tgt); g.setInputSource(src)
+    idx_o, d2_o = pyorc.knn(src, 48)
+    idx_g, d2_g = g.knn(0)
+    assert np.array_equal(idx_g, idx_o) and np.array_equal(d2_g, d2_o)
+    assert o.compute_covariances() == 0
+    g.computeCovariances()
+    for co, cg in ((o.source_covs(), g.getSourceCovariances()), (o.target_covs(), g.getTargetCovariances())):
+        assert np.abs(cg - co).max() < 1e-9
+    rc, _, Td_o, _, _ = o.align(None)
+    assert rc == 0
+    g.align(None)
+    assert rot_angle(np.asarray(g.final_transformation_d)[:3, :3], Td_o[:3, :3]) <= 1e-5
+    g.close()
+
+
 def test_linearize_stages(pair):
     _, src, tgt, cfg = pair
     o, g = make_both(src, tgt, cfg)
