@@ -417,7 +417,7 @@ int enqueue_pass(rolo_ctx* c, const PassArgs& a, int grid, int stage, bool publi
 }
 
 // k fused trials + the closing launch; the state starts and ends in c->state[0] (see passes.hip lm_kernel)
-int enqueue_lm_chunk(rolo_ctx* c, const PassArgs& a, int k) {
+int enqueue_lm_chunk(rolo_ctx* c, const PassArgs& a, int k, bool publish = false) {
   LmState* sb[2] = {c->state, c->state + 1};
   const int nrows = c->lm_rows;
   double* rb[2] = {c->partials, c->partials + (size_t)nrows * NV_MAX};
@@ -427,7 +427,7 @@ int enqueue_lm_chunk(rolo_ctx* c, const PassArgs& a, int k) {
     HIPCHK(launch_lm(dof, T, lm_ppt(), a, sb[j & 1], sb[(j + 1) & 1], rb[(j + 1) & 1], rb[j & 1], nrows, c->trace, 1, c->stream));
   }
   ProfScope ps(c, ROLO_PROF_LM_PASS);
-  HIPCHK(launch_lm(dof, T, lm_ppt(), a, sb[k & 1], sb[0], rb[(k + 1) & 1], rb[k & 1], nrows, c->trace, 0, c->stream));
+  HIPCHK(launch_lm(dof, T, lm_ppt(), a, sb[k & 1], sb[0], rb[(k + 1) & 1], rb[k & 1], nrows, c->trace, 0, c->stream, publish ? c->h_state : nullptr));
   return ROLO_OK;
 }
 
@@ -935,7 +935,7 @@ static int enqueue_frame(rolo_ctx* c) {
   int nrot, ntrans; frame_chunks(c, nrot, ntrans);
   if (lm_fused(c)) {
     // both stages are the same launches (the device decides which pass a launch evaluates); each hint carries one spare
-    if ((rc = enqueue_lm_chunk(c, a, std::max(nrot + ntrans - 1, 2)))) return rc;
+    if ((rc = enqueue_lm_chunk(c, a, std::max(nrot + ntrans - 1, 2), true))) return rc;   // the closing launch leaves the state in pinned memory
   } else {
     for (int i = 0; i < nrot; i++) if ((rc = enqueue_pass(c, a, grid, 1))) return rc;
     STAMP(3);
@@ -943,7 +943,7 @@ static int enqueue_frame(rolo_ctx* c) {
   }
   STAMP(4);
   if (stamp_env()) HIPCHK(hipMemcpyAsync(c->h_stamps, c->stamps, sizeof(unsigned long long) * 8, hipMemcpyDeviceToHost, c->stream));
-  if (lm_fused(c) || c->comm || ntrans == 0) HIPCHK(hipMemcpyAsync(c->h_state, c->state, sizeof(LmState), hipMemcpyDeviceToHost, c->stream));
+  if ((c->comm && !lm_fused(c)) || (!lm_fused(c) && ntrans == 0)) HIPCHK(hipMemcpyAsync(c->h_state, c->state, sizeof(LmState), hipMemcpyDeviceToHost, c->stream));
   return ROLO_OK;
 }
 

@@ -714,7 +714,7 @@ __global__ __launch_bounds__(256) void concat_kernel(const float4* __restrict__ 
 // corner ++ surface (lidarOdometry.cpp:521-523) — the two concat launches and feature_concat_kernel in one; counts to counters[1], [2]
 __global__ __launch_bounds__(256) void feature_gather_kernel(const float4* __restrict__ corner_stage, const int* __restrict__ corner_cnt, int n_cgroups,
                                                             const float4* __restrict__ surf_stage, const int* __restrict__ surf_cnt, int n_sgroups, int surf_cap,
-                                                            float4* __restrict__ out, int* __restrict__ counters) {
+                                                            float4* __restrict__ out, int* __restrict__ counters, int* __restrict__ pub3) {
   __shared__ int s_part[2][4], s_off;
   const int g = blockIdx.x, t = threadIdx.x;
   const bool is_surf = g >= n_cgroups;
@@ -730,8 +730,9 @@ __global__ __launch_bounds__(256) void feature_gather_kernel(const float4* __res
   if (t == 0) {
     const int oc = s_part[0][0] + s_part[0][1] + s_part[0][2] + s_part[0][3], os = s_part[1][0] + s_part[1][1] + s_part[1][2] + s_part[1][3];
     s_off = oc + os;
-    if (g == n_cgroups - 1) counters[1] = oc + corner_cnt[gs];
-    if (is_surf && gs == n_sgroups - 1) counters[2] = os + surf_cnt[gs];
+    // pub3: the caller's pinned (n_valid, n_corner, n_surface) — written here instead of by a copy launch behind this kernel
+    if (g == n_cgroups - 1) { const int v = oc + corner_cnt[gs]; counters[1] = v; if (pub3) { pub3[1] = v; pub3[0] = counters[0]; } }
+    if (is_surf && gs == n_sgroups - 1) { const int v = os + surf_cnt[gs]; counters[2] = v; if (pub3) pub3[2] = v; }
   }
   __syncthreads();
   const int c = is_surf ? surf_cnt[gs] : corner_cnt[gs];
@@ -881,7 +882,7 @@ int front_project_enqueue(Front* f, const rolo_front_params* P, const float* d_p
 }
 
 // K3 + K4 on what front_project_enqueue left on the device; n_corner / n_surface land in counters[1] / [2]
-int front_extract_enqueue(Front* f, const rolo_front_params* P, hipStream_t s, float4* fused_out = nullptr) {
+int front_extract_enqueue(Front* f, const rolo_front_params* P, hipStream_t s, float4* fused_out = nullptr, int* pub3 = nullptr) {
   const int NS = f->n_scan;
   const size_t npix = f->cap_pix;
   // guards of curvature / picked / label are zero; live entries are written by the smoothness kernel
@@ -907,7 +908,7 @@ int front_extract_enqueue(Front* f, const rolo_front_params* P, hipStream_t s, f
   if (!(attr_set.load() & dev_bit)) { FCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(extract_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set.fetch_or(dev_bit); }
   extract_kernel<<<NS, XT, lds, s>>>(A);
   if (fused_out) {
-    feature_gather_kernel<<<NS * 7, 256, 0, s>>>(f->corner_stage, f->corner_cnt, NS * 6, f->surf_stage, f->surf_cnt, NS, FRONT_MAX_H, fused_out, f->counters);
+    feature_gather_kernel<<<NS * 7, 256, 0, s>>>(f->corner_stage, f->corner_cnt, NS * 6, f->surf_stage, f->surf_cnt, NS, FRONT_MAX_H, fused_out, f->counters, pub3);
   } else {
     concat_kernel<<<NS * 6, 256, 0, s>>>(f->corner_stage, f->corner_cnt, NS * 6, 20, f->corner_out, f->counters + 1);
     concat_kernel<<<NS, 256, 0, s>>>(f->surf_stage, f->surf_cnt, NS, FRONT_MAX_H, f->surf_out, f->counters + 2);
@@ -937,9 +938,8 @@ int front_frame_features_enqueue(rolo_ctx* c, const rolo_front_params* P, const 
     d_pts = f->raw; d_ring = f->ring;
   }
   if ((rc = front_project_enqueue(f, P, d_pts, stride, d_ring, n_raw, false, s))) return rc;
-  if ((rc = front_extract_enqueue(f, P, s, d_feat))) return rc;
+  if ((rc = front_extract_enqueue(f, P, s, d_feat, h_counts3))) return rc;   // h_counts3 is pinned: the gather kernel writes the counts there itself
   FCHK(hipGetLastError());
-  FCHK(hipMemcpyAsync(h_counts3, f->counters, sizeof(int) * 3, hipMemcpyDeviceToHost, s));
   if (done) FCHK(hipEventRecord(done, s));
   f->projected = false;  // the staged rolo_extract_features must not run on top of a fused frame
   return ROLO_OK;

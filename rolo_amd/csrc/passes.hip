@@ -854,7 +854,7 @@ ROLO_DEV void reduce_rows_compact(const double* __restrict__ rows, int nrows, in
 template <int DOF, int THREADS>
 __global__ __launch_bounds__(THREADS) void lm_kernel(PassArgs a, const LmState* __restrict__ st_in, LmState* __restrict__ st_out,
                                                     const double* __restrict__ rows_in, double* __restrict__ rows_out, int nrows,
-                                                    rolo_trace_rec* trace, int do_body, int ppt) {
+                                                    rolo_trace_rec* trace, int do_body, int ppt, LmState* pub) {
   __shared__ LmState sst;
   __shared__ double part[THREADS];
   __shared__ double csum[NV_MAX];   // compact: yi, y, n, H (lower triangle), b
@@ -907,6 +907,7 @@ __global__ __launch_bounds__(THREADS) void lm_kernel(PassArgs a, const LmState* 
     int* g = reinterpret_cast<int*>(st_out);
     const int* l = reinterpret_cast<const int*>(&sst);
     for (int w = threadIdx.x; w < NW; w += THREADS) g[w] = l[w];
+    if (pub) { int* h = reinterpret_cast<int*>(pub); for (int w = threadIdx.x; w < NW; w += THREADS) h[w] = l[w]; }   // pinned host copy (closing launch)
   }
   if (!body) return;
   double* out_row = rows_out + (size_t)blockIdx.x * NV_MAX;
@@ -1049,14 +1050,14 @@ hipError_t launch_batch_begin(const BatchSlot* slots, const FrameArgs* args, int
   return hipGetLastError();
 }
 hipError_t launch_lm(int dof, int threads, int ppt, const PassArgs& a, const LmState* st_in, LmState* st_out, const double* rows_in, double* rows_out, int nrows,
-                     rolo_trace_rec* trace, int do_body, hipStream_t s) {
+                     rolo_trace_rec* trace, int do_body, hipStream_t s, LmState* pub) {
   const int grid = do_body ? nrows : 1;
   if (threads == 1024) {
-    if (dof == 3) lm_kernel<3, 1024><<<grid, 1024, 0, s>>>(a, st_in, st_out, rows_in, rows_out, nrows, trace, do_body, ppt);
-    else lm_kernel<6, 1024><<<grid, 1024, 0, s>>>(a, st_in, st_out, rows_in, rows_out, nrows, trace, do_body, ppt);
+    if (dof == 3) lm_kernel<3, 1024><<<grid, 1024, 0, s>>>(a, st_in, st_out, rows_in, rows_out, nrows, trace, do_body, ppt, pub);
+    else lm_kernel<6, 1024><<<grid, 1024, 0, s>>>(a, st_in, st_out, rows_in, rows_out, nrows, trace, do_body, ppt, pub);
   } else {
-    if (dof == 3) lm_kernel<3, 512><<<grid, 512, 0, s>>>(a, st_in, st_out, rows_in, rows_out, nrows, trace, do_body, ppt);
-    else lm_kernel<6, 512><<<grid, 512, 0, s>>>(a, st_in, st_out, rows_in, rows_out, nrows, trace, do_body, ppt);
+    if (dof == 3) lm_kernel<3, 512><<<grid, 512, 0, s>>>(a, st_in, st_out, rows_in, rows_out, nrows, trace, do_body, ppt, pub);
+    else lm_kernel<6, 512><<<grid, 512, 0, s>>>(a, st_in, st_out, rows_in, rows_out, nrows, trace, do_body, ppt, pub);
   }
   return hipGetLastError();
 }

@@ -151,7 +151,7 @@ hipError_t launch_trans_pass(const PassArgs& a, const LmState* st, int grid, hip
 // fused trial (passes.hip lm_kernel): finish the pending trial (rows_in, st_in), write the new state to st_out (!= st_in unless grid 1),
 // evaluate the next pass into rows_out; threads in {256, 512, 1024}; nrows = workgroups of a pass; do_body = 0: closing launch
 hipError_t launch_lm(int dof, int threads, int ppt /* slabs of `threads` points per workgroup */, const PassArgs& a, const LmState* st_in, LmState* st_out, const double* rows_in, double* rows_out, int nrows,
-                     rolo_trace_rec* trace, int do_body, hipStream_t s);
+                     rolo_trace_rec* trace, int do_body, hipStream_t s, LmState* pub = nullptr /* pinned host copy of the state written by workgroup 0 */);
 hipError_t launch_reduce(const double* partials, int nblocks, double* sums, const LmState* st, int stage, hipStream_t s);
 // controller: sums the rows of `partials` itself (single GPU) or takes all-reduced `sums` (partials == nullptr)
 // pub != nullptr: also leave the state in that (pinned host) copy, step or no step
