@@ -62,6 +62,11 @@ def parse():
     ap.add_argument("--no-config5", action="store_true", help="skip the 512-pair OS1-64 leg (BASELINE configs[4])")
     ap.add_argument("--config5-pairs", type=int, default=512)
     ap.add_argument("--single-round", action="store_true", help="one timed round only (profiling runs)")
+    ap.add_argument("--pool", type=int, default=8,
+                    help="DISTINCT frame pairs resident in HBM that the contexts rotate through (pair 0 = the nominal pair of SURVEY 8d; "
+                         "1 = every context registers the same pair over and over, round 2's headline)")
+    ap.add_argument("--shard-exchange", default="peer", choices=["peer", "rccl", "both"],
+                    help="sharded leg / --mode shard: peer = mailbox exchange inside the controller kernel (rolo_peer_*), rccl = ncclAllReduce per pass")
     ap.add_argument("--batch", type=int, default=int(os.environ.get("ROLO_BENCH_BATCH", "1")),
                     help="frame pairs per registration call (rolo_batch_*: shared LM launches); 1 = one operator per frame")
     return ap.parse_args()
@@ -199,6 +204,24 @@ def backend_leg(args, device):
     return out
 
 
+def _pool_pair(a):
+    """pair i of the headline pool: the nominal motion of SURVEY 8d seen from stand point i of the hall (i = 0: the nominal pair itself)"""
+    from rolo_amd import synth
+    sensor, seed, i = a
+    src, tgt, _ = synth.dense_pair(sensor, seed=seed + 2 * i, origin=synth.pool_origin(i))
+    return src, tgt
+
+
+def cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
 def _config5_pair(i):
     """pair i of BASELINE configs[4]: seed 20260926 + i, motion drawn U(+-2 deg), U(+-0.4 m)"""
     from rolo_amd import synth
@@ -223,6 +246,7 @@ def config5_leg(args, torch, dist, rank, world, local_rank, new_ctx, barrier):
     guess = -np.asarray(synth.PREV_STEP_T, np.float64); last = guess * 0.97; zero3 = np.zeros(3)
     ctxs = [new_ctx(leaf=1.0) for _ in range(max(args.streams, 1))]
     results = [None] * len(dev)
+    npass = np.zeros(len(dev), int)
 
     def enqueue(g, k):
         s, t, ns, nt = dev[k]
@@ -237,12 +261,14 @@ def config5_leg(args, torch, dist, rank, world, local_rank, new_ctx, barrier):
         while inflight:
             g, k = inflight.pop(0)
             Tf, Td, t = g.register_wait()
+            npass[k] = g.last_stats.n_passes + g.last_translation_stats.n_passes
             if store:
                 results[k] = (Td.copy(), t.copy())
             if nxt < len(dev):
                 enqueue(g, nxt); inflight.append((g, nxt)); nxt += 1
 
     sweep(False)  # warm-up sweep: allocations, graph capture
+    c0 = [g.counters() for g in ctxs]
     import gc
     times = []
     for rep in range(3):
@@ -258,6 +284,11 @@ def config5_leg(args, torch, dist, rank, world, local_rank, new_ctx, barrier):
     out = {"workload": f"{npairs} distinct os1-64 pairs (65 536 rays each, seeds {synth.SEED}+i, motions U(+-2 deg), U(+-0.4 m)), UNIFORM leaf 1.0 m, "
                        f"20 SO(3) LM iterations + CT translation, resident in HBM, {len(ctxs)} contexts per GPU, hipGraph replay",
            "scans_per_s_batch512": npairs / dt, "sweep_ms": [1e3 * x for x in times], "pairs_per_rank": len(mine), "generation_s": gen_s}
+    c1 = [g.counters() for g in ctxs]
+    out["passes_per_pair"] = {"min": int(npass.min()), "median": float(np.median(npass)), "max": int(npass.max())}
+    # over the three timed sweeps: how many frames replayed the graph, were re-captured (the schedule length follows the pairs' needs),
+    # or needed host round trips because the schedule was too short
+    out["schedule_timed_sweeps"] = {k_: int(sum(b_[k_] - a_[k_] for a_, b_ in zip(c0, c1))) for k_ in ("frames", "graph_replays", "graph_captures", "eager_frames", "topup_frames")}
     if rank == 0 and not args.no_cpu:
         from oracle import pyorc
         p = pyorc.default_params(voxel_type=pyorc.VOXEL_UNIFORM, voxel_resolution=1.0, fixed_iterations=20, num_threads=usable_cores())
@@ -303,14 +334,14 @@ def cpu_baseline_legs(args, src, tgt, guess, last):
 
     p = pyorc.default_params(voxel_type=pyorc.VOXEL_UNIFORM, voxel_resolution=args.leaf, fixed_iterations=20, num_threads=cores)
     frames, cdt, st = sample(p, src, tgt, args.cpu_seconds, 200)
-    out = {"cpu_baseline": {"value": frames / cdt, "unit": "scans/s", "cores": cores, "kind": "port",
+    out = {"cpu_baseline": {"value": frames / cdt, "unit": "scans/s", "cores": cores, "cpu_model": cpu_model(), "kind": "port",
                             "sample": f"{frames} frame pair(s) of the same workload (kd-tree build, 20-NN covariances, voxel map, 20 SO(3) LM iterations, "
                                       f"CT translation) on oracle/librolo_oracle.so, OMP threads = {cores} (cgroup CPU quota of this box; os.cpu_count() = "
                                       f"{os.cpu_count()}), {cdt:.1f} s", "stage_ms": st}}
     s16, t16, _ = synth.dense_pair("vlp16")
     p1 = pyorc.default_params(polar_resolution=(0.175, 0.175, 2.0), num_threads=1)
     f1, c1, st1 = sample(p1, s16, t16, min(args.cpu_seconds, 6.0), 100)
-    out["cpu_baseline_1thread"] = {"value": f1 / c1, "unit": "scans/s", "cores": 1, "kind": "port",
+    out["cpu_baseline_1thread"] = {"value": f1 / c1, "unit": "scans/s", "cores": 1, "cpu_model": cpu_model(), "kind": "port",
                                    "sample": f"BASELINE configs[0]: {f1} VLP-16 pair(s) ({s16.shape[0]} points), POLAR voxels 0.175/0.175/2.0, reference convergence "
                                              f"rule, 1 OMP thread, {c1:.1f} s", "stage_ms": st1}
     return out
@@ -341,11 +372,19 @@ def main():
         return
 
     # ---- synthetic inputs (rank-specific seed in replicas mode: independent frames) ----
-    seed = synth.SEED + (rank if args.mode == "replicas" else 0)
-    src, tgt, _ = synth.dense_pair(args.sensor, seed=seed)
+    seed = synth.SEED + (1000 * rank if args.mode == "replicas" else 0)
+    npool = max(1, args.pool) if args.mode == "replicas" else 1
+    if npool > 1:
+        import multiprocessing as mp
+        with mp.get_context("spawn").Pool(min(usable_cores(), npool)) as pool_:
+            pairs = pool_.map(_pool_pair, [(args.sensor, seed, i) for i in range(npool)])
+    else:
+        pairs = [_pool_pair((args.sensor, seed, 0))]
+    src, tgt = pairs[0]
     n = src.shape[0]
-    d_src = torch.from_numpy(src).cuda()
-    d_tgt = torch.from_numpy(tgt).cuda()
+    d_pool = [(torch.from_numpy(s_).cuda(), torch.from_numpy(t_).cuda(), s_.shape[0]) for s_, t_ in pairs]
+    assert all(p_[2] == n for p_ in d_pool)
+    d_src, d_tgt = d_pool[0][0], d_pool[0][1]
     guess = -np.asarray(synth.PREV_STEP_T, np.float64)
     last = guess * 0.97
 
@@ -390,20 +429,34 @@ def main():
         g.setInputSourceDevice(ds.data_ptr(), npts, 4)
         g.register_async(None, zero3, guess, last, 0.1, 0.1, 0.3)
 
+    pass_log = []   # (rotation passes, translation passes) of every frame waited for while `pass_log_on`
+    pass_log_on = [False]
+    cursor = [0]    # next pair of the pool
+
     def run_steps(gs, k, data):
         """k steps; one step = one frame pair on every context of `gs`. Contexts are serviced round-robin
-        (wait for a context's frame, immediately enqueue its next one) so the GPU always has work queued."""
+        (wait for a context's frame, immediately enqueue its next one) so the GPU always has work queued.
+        data = a list of resident pairs: every enqueue takes the NEXT pair of the pool, so the contexts in flight hold different
+        pairs at any time and a context sees a different pair every frame."""
         if not isinstance(gs, (list, tuple)):
             gs = [gs]
         if k <= 0:
             return
+
+        def nxt():
+            if not isinstance(data, list):
+                return data
+            d = data[cursor[0] % len(data)]; cursor[0] += 1
+            return d
         for g in gs:
-            enqueue(g, data)
+            enqueue(g, nxt())
         for it in range(k):
             for g in gs:
                 g.register_wait()
+                if pass_log_on[0] and not isinstance(g, Batch):
+                    pass_log.append((g.last_stats.n_passes, g.last_translation_stats.n_passes))
                 if it + 1 < k:
-                    enqueue(g, data)
+                    enqueue(g, nxt())
 
     def timed_round(g, steps, data):
         import gc
@@ -434,7 +487,7 @@ def main():
                 break
         return float(np.median(rounds)), rounds
 
-    data = (d_src, d_tgt, n)
+    data = d_pool if len(d_pool) > 1 else (d_src, d_tgt, n)
     g = new_ctx()
     ctxs = [g] + [new_ctx() for _ in range(max(args.streams, 1) - 1)]
     B = max(args.batch, 1)
@@ -443,13 +496,31 @@ def main():
     else:
         B = 1
     rccl_ranks = None
-    if args.mode == "shard" and world > 1:
-        ctxs = [g]
+
+    def connect(gc, kind, max_points):
+        """point-shard context gc over the ranks: kind "peer" = rolo_peer_* (64-byte hipIpc handles all-gathered through torch.distributed),
+        "rccl" = rolo_comm_init. Returns what the library reports back."""
+        if kind == "peer":
+            h = gc.peer_export(world, max_points)
+            mine = torch.frombuffer(bytearray(h), dtype=torch.uint8).cuda()
+            allh = [torch.empty(64, dtype=torch.uint8, device="cuda") for _ in range(world)]
+            dist.all_gather(allh, mine)
+            gc.peer_connect([bytes(t_.cpu().numpy().tobytes()) for t_ in allh], rank, world)
+            r_, w_, kind_ = gc.peer_info()
+            return {"exchange": "peer mailboxes (rolo_peer_*)", "ranks": w_, "mailbox_memory": kind_}
         uid = [RotVGICP.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
-        g.comm_init(uid[0], rank, world)
-        rccl_ranks = g.comm_info()[1]
+        gc.comm_init(uid[0], rank, world)
+        return {"exchange": "RCCL (ncclAllGather + ncclAllReduce per pass)", "ranks": gc.comm_info()[1]}
+
+    shard_info = None
+    if args.mode == "shard" and world > 1:
+        ctxs = [g]
+        shard_info = connect(g, "rccl" if args.shard_exchange == "rccl" else "peer", 2 * n)
+        rccl_ranks = shard_info["ranks"]
+    pass_log_on[0] = True
     dt, rounds = timed(ctxs, args.steps, args.warmup, data)
+    pass_log_on[0] = False
     frames_total = args.steps * len(ctxs) * B * (world if args.mode == "replicas" else 1)
     value = frames_total / dt
     rs, ts = ctxs[0].last_stats, ctxs[0].last_translation_stats
@@ -474,12 +545,26 @@ def main():
         "config": {"workload": f"{args.sensor} dense frame pair, {n} pts/cloud, k=20 PLANE covariances, UNIFORM voxel leaf "
                                f"{args.leaf} m, 20 SO(3) LM iterations + CT translation LM", "mode": args.mode,
                    "parallelism": f"{args.mode}{world}" + (" (one frame pair per rank and context, no data-path collective)" if args.mode == "replicas" else
-                                                            " (K5 by query point + all-gather, passes by source point + all-reduce of 32 fp64)"),
+                                                            " (K5 by query point + covariance exchange, passes by source point + exchange of 32 fp64 per pass)"),
                    "streams_per_gpu": len(ctxs), "frames_per_call": B, "hip_graph": not args.no_graph, "rot_outer": rs.n_outer, "trans_outer": ts.n_outer,
                    "passes_per_frame": passes, "n_correspondences": rs.n_correspondences},
     }
-    if rccl_ranks is not None:
-        out["config"]["rccl_ranks"] = rccl_ranks
+    if shard_info is not None:
+        out["config"]["shard"] = shard_info
+    # what the frames of the timed rounds needed (distinct pairs need different numbers of LM trials): fused pass launches per frame,
+    # and how often the first launch schedule of a frame was too short (rolo_register_wait then tops up through host round trips)
+    if pass_log:
+        pl = np.array(pass_log)
+        tot = pl.sum(axis=1)
+        cnt = [c_.counters() for c_ in ctxs if not isinstance(c_, Batch)]
+        out["config"]["inputs"] = (f"{len(d_pool)} distinct resident frame pairs rotated through the contexts (pair 0 = the nominal pair of SURVEY 8d; pair i = the same "
+                                   "motion from stand point i of the hall, own noise)") if len(d_pool) > 1 else "one resident frame pair registered by every context"
+        out["config"]["passes_per_frame_stats"] = {"min": int(tot.min()), "median": float(np.median(tot)), "max": int(tot.max()),
+                                                   "rotation": {"min": int(pl[:, 0].min()), "max": int(pl[:, 0].max())},
+                                                   "translation": {"min": int(pl[:, 1].min()), "max": int(pl[:, 1].max())}, "frames_logged": int(pl.shape[0])}
+        out["config"]["schedule"] = {k_: int(sum(c_[k_] for c_ in cnt)) for k_ in ("frames", "graph_replays", "graph_captures", "eager_frames", "topup_frames")}
+        passes = int(round(float(np.median(tot))))
+        out["config"]["passes_per_frame"] = passes
 
     # ---- frame-level HBM figures of BASELINE.json's metric ("scans/sec ...; achieved HBM GB/s") -------------------------------------
     # algorithmic: SURVEY.md 8d's bytes of one frame — 360 B/pt covariances for both clouds, 136 B/pt + 96 B/voxel map build, and
@@ -545,16 +630,29 @@ def main():
         try:
             s2, t2, _ = synth.dense_pair("os1-128x2048", seed=synth.SEED)
             d2 = (torch.from_numpy(s2).cuda(), torch.from_numpy(t2).cuda(), s2.shape[0])
-            gs = new_ctx(alone=True)
-            uid = [RotVGICP.comm_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(uid, src=0)
-            gs.comm_init(uid[0], rank, world)
-            dts, rds = timed(gs, max(5, args.steps // 2), 2, d2)
             stp = max(5, args.steps // 2)
-            out["sharded"] = {"value": stp / dts, "unit": "scans/s", "ms_per_frame": 1e3 * dts / stp, "rccl_ranks": gs.comm_info()[1], "scaling": "strong",
-                              "workload": f"os1-128x2048 dense frame pair, {s2.shape[0]} pts/cloud, leaf {args.leaf} m, 20 SO(3) LM iterations + CT translation",
-                              "note": "one frame: Morton sort / BVH / voxel map replicated on every rank, K5 searched by 1/W of the queries + ncclAllGather of the 48 B/pt "
-                                      "covariances, LM passes over 1/W of the source points + ncclAllReduce of 32 fp64 per pass", "passes": gs.last_stats.n_passes + gs.last_translation_stats.n_passes}
+            kinds = ["peer", "rccl"] if args.shard_exchange == "both" else [args.shard_exchange]
+            out["sharded"] = {"workload": f"os1-128x2048 dense frame pair, {s2.shape[0]} pts/cloud, leaf {args.leaf} m, 20 SO(3) LM iterations + CT translation", "scaling": "strong",
+                              "note": "one frame: Hilbert sort / BVH / voxel map replicated on every rank, K5 searched by 1/W of the queries + exchange of the 48 B/pt "
+                                      "covariances, LM passes over 1/W of the source points + exchange of 32 fp64 per pass (peer: mailbox words written by the controller kernel "
+                                      "itself, summed in rank order, hipGraph replay; rccl: reduce launch + ncclAllReduce + controller launch per pass, eager)"}
+            for kind in kinds:
+                try:
+                    gs = new_ctx(alone=True)
+                    info = connect(gs, kind, 2 * s2.shape[0])
+                    dts, rds = timed(gs, stp, 2, d2)
+                    leg = {"value": stp / dts, "unit": "scans/s", "ms_per_frame": 1e3 * dts / stp, "passes": gs.last_stats.n_passes + gs.last_translation_stats.n_passes,
+                           "schedule": gs.counters()}
+                    leg.update(info)
+                    barrier()
+                    gs.close()
+                except Exception as e:  # pragma: no cover
+                    leg = {"error": repr(e)}
+                out["sharded"][kind] = leg
+                barrier()
+            first = out["sharded"].get(kinds[0], {})
+            if "value" in first:   # the headline of this leg = the first exchange kind asked for
+                out["sharded"].update({"value": first["value"], "unit": "scans/s", "ms_per_frame": first["ms_per_frame"], "ranks": first.get("ranks")})
             # the same frame on ONE rank's GPU alone, for the strong-scaling ratio (rank 0 only runs it while the others wait)
             barrier()
             if rank == 0:

@@ -200,6 +200,32 @@ int rolo_comm_destroy(rolo_ctx* ctx);
 /* rank and size read back from the RCCL communicator itself (ncclCommUserRank / ncclCommCount); world = 0 without one */
 int rolo_comm_info(rolo_ctx* ctx, int* rank, int* world);
 
+/* The same exchange WITHOUT a collective library ("every GPU peer-writes its partial into a slot on each peer, fixed-rank-
+ * order local sum"): every rank exports one device allocation (its "mailbox": slots for the 32 fp64 sums of an LM pass + the covariance
+ * exchange area), the ranks swap the 64-byte handles by any means (torch.distributed all_gather, a file, a pipe), and connect. From then on
+ *   - the LM controller kernel of every trial writes its shard's sums into its slot of EVERY rank's mailbox and adds all slots of its own
+ *     mailbox in rank order (bit-identical on every rank): no reduce launch, no library call, one launch per trial as on one GPU, and the
+ *     frame's launch schedule stays hipGraph-capturable;
+ *   - K5's covariances of the own query slice are copied into every peer's exchange area by a kernel (replaces ncclAllGather).
+ * Handles come from hipIpcGetMemHandle (processes of one node; HSA_ENABLE_IPC_MODE_LEGACY=0 on this driver); contexts of ONE process
+ * (several GPUs driven by one process, or two contexts on one device) are recognised and use each other's pointers directly. A rank that
+ * does not answer within ROLO_PEER_TIMEOUT_MS (default 10 000) makes the waiting ranks end the registration with ROLO_ECOMM — a lost peer
+ * never hangs the GPU. world <= 8 (one node). max_points >= source + target points of the largest frame (sizes the covariance area).
+ * Mutually exclusive with rolo_comm_init (RCCL), which stays as the A/B. Reference loop that is split over the GPUs:
+ * rot_vgicp_impl.hpp:313-382 (the per-thread Hs / bs / sum_errors of so3_linearize summed at :377-382). */
+#define ROLO_PEER_HANDLE_BYTES 64
+int rolo_peer_export(rolo_ctx* ctx, int world, int max_points, void* handle64);
+int rolo_peer_connect(rolo_ctx* ctx, const void* handles /* world x 64 bytes, rank order */, int rank, int world);
+int rolo_peer_disconnect(rolo_ctx* ctx);
+/* rank / world of the connection (world 0: none); mem_kind16 (optional, 16 chars): "uncached" | "finegrained" | "coarse" */
+int rolo_peer_info(rolo_ctx* ctx, int* rank, int* world, char* mem_kind16);
+
+/* Bookkeeping of rolo_register_async / _wait on this context since its creation (what bench.py reports next to the throughput):
+ * out[0] frames registered, [1] of them replayed from the hipGraph, [2] captured, [3] enqueued eagerly, [4] frames whose first launch
+ * schedule was too short (rolo_register_wait had to top up with host round trips), [5] synchronous chunks of predicated passes enqueued
+ * by the drivers (top-ups + rolo_align / rolo_compute_translation), [6] / [7] passes the next frame's first schedule holds per stage. */
+int rolo_ctx_counters(rolo_ctx* ctx, long long* out, int n);
+
 /* Per-kernel timing with HIP events on the context's stream (bench.py's "roofline" object). While enabled, every
  * launch of the listed kernels is bracketed by an event pair; rolo_prof_read synchronises the stream and returns
  * the durations (ms) of one slot in launch order, then forgets them. Returns the number of launches recorded. */

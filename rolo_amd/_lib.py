@@ -148,6 +148,11 @@ SYMBOLS = {
     "rolo_comm_unique_id": (C.c_int, [vp]),
     "rolo_comm_init": (C.c_int, [vp, vp, C.c_int, C.c_int]),
     "rolo_comm_destroy": (C.c_int, [vp]),
+    "rolo_peer_export": (C.c_int, [vp, C.c_int, C.c_int, vp]),
+    "rolo_peer_connect": (C.c_int, [vp, vp, C.c_int, C.c_int]),
+    "rolo_peer_disconnect": (C.c_int, [vp]),
+    "rolo_peer_info": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p]),
+    "rolo_ctx_counters": (C.c_int, [vp, C.POINTER(C.c_longlong), C.c_int]),
     "rolo_prof_enable": (C.c_int, [vp, C.c_int]),
     "rolo_prof_read": (C.c_int, [vp, C.c_int, fp, C.c_int]),
     "rolo_odom_create": (C.c_int, [vp, C.c_float, C.POINTER(vp)]),

@@ -12,6 +12,9 @@
 #include <vector>
 #include <algorithm>
 #include <atomic>
+#include <array>
+#include <map>
+#include <mutex>
 
 using namespace rolo;
 
@@ -83,6 +86,28 @@ extern "C" void rolo_shard_range(int n, int rank, int world, int* begin, int* en
   if (end) *end = (int)(N * (rank + 1) / world);
 }
 
+// ---- peer exchange: process-local registry of exported mailboxes (two contexts of ONE process must not go through hipIpcOpenMemHandle:
+// a handle cannot be opened by the process that exported it) ----
+namespace {
+struct PeerExport { void* base; int device; };
+std::mutex g_peer_mu;
+std::map<std::array<char, ROLO_PEER_HANDLE_BYTES>, PeerExport> g_peer_exports;
+}  // namespace
+
+struct rolo_peer_state {
+  void* base = nullptr;          // own mailbox + the two covariance exchange areas (one allocation, exported)
+  size_t bytes = 0, area_bytes = 0;
+  std::array<char, ROLO_PEER_HANDLE_BYTES> handle{};
+  int export_world = 0;
+  bool connected = false;
+  void* mapped[PEER_MAX] = {};   // every rank's mailbox as mapped here
+  bool ipc_opened[PEER_MAX] = {};
+  PeerArgs args{};
+  unsigned long long cov_count = 0;   // covariance exchanges enqueued (eagerly): the exchange area alternates
+  int* h_err = nullptr;          // pinned: ROLO_ECOMM written by a kernel whose poll timed out
+  const char* mem_kind = "";
+};
+
 struct rolo_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -139,10 +164,12 @@ struct rolo_ctx {
   int* h_counters = nullptr;
   // multi-GPU
   void* comm = nullptr;
+  rolo_peer_state peer;     // rolo_peer_*: the exchange without a collective library
   int rank = 0, world = 1;
   bool shard_knn = false;   // rolo_set_shard_knn: K5 by query slice without a communicator (test hook)
   // async registration bookkeeping
   bool async_pending = false;
+  long long n_frames = 0, n_replays = 0, n_captures = 0, n_eager = 0, n_topup_frames = 0, n_topup_chunks = 0;   // rolo_ctx_counters
   // hipGraph of one whole frame (rolo_register_async): captured on the second frame with an unchanged key, replayed after
   FrameArgs* h_args = nullptr;   // pinned; a captured H2D copy refreshes d_args on every replay
   FrameArgs* d_args = nullptr; size_t d_args_cap = 0;
@@ -176,6 +203,15 @@ struct ProfScope {
   }
   ~ProfScope() { if (idx >= 0) (void)hipEventRecord(c->prof[idx].b, s); }
 };
+
+inline bool peers(const rolo_ctx* c) { return c->peer.connected && c->peer.args.world > 1; }
+inline const PeerArgs* peer_args(const rolo_ctx* c) { return peers(c) ? &c->peer.args : nullptr; }
+
+// a kernel's poll of the peers' words timed out (it left ROLO_ECOMM in pinned memory): report it once the host has synchronised
+inline int peer_check(rolo_ctx* c) {
+  if (c->peer.h_err && *c->peer.h_err != 0) { g_err = "peer exchange timed out (a rank of the node did not answer)"; return ROLO_ECOMM; }
+  return ROLO_OK;
+}
 
 inline int n_offsets(const rolo_params& P) { return P.neighbor_search == ROLO_DIRECT1 ? 1 : (P.neighbor_search == ROLO_DIRECT7 ? 7 : 27); }
 
@@ -262,7 +298,8 @@ int build_clouds(rolo_ctx* c, bool do_src, bool do_tgt, hipStream_t stream, bool
   // Multi-GPU ("K5 shards by query point with the full cloud replicated"): every rank sorts and builds the BVH of the whole
   // cloud (cheap, identical on all ranks), searches only its slice of the Morton-sorted queries — whole 256-query workgroups, equal
   // slices — and the 48-byte covariances are all-gathered once per frame in sorted order, then scattered to cov[] by original index.
-  const bool sharded = c->comm != nullptr || (c->world > 1 && c->shard_knn);
+  const bool sharded = c->comm != nullptr || peers(c) || (c->world > 1 && c->shard_knn);
+  size_t peer_area_off = 0;
   if (sharded) {
     size_t seg = 0;
     for (int i = 0; i < nc; i++) {
@@ -274,8 +311,16 @@ int build_clouds(rolo_ctx* c, bool do_src, bool do_tgt, hipStream_t stream, bool
       K.stage_off = (int)seg;
       seg += (size_t)K.chunk * 6;
     }
-    if ((rc = ensure(S.stage, S.stage_cap, seg * (size_t)c->world))) return rc;
-    for (int i = 0; i < nc; i++) { A.c[i].seg = seg; A.c[i].stage = S.stage; }
+    double* stage;
+    if (peers(c)) {   // the exchange area the peers write into: inside the exported mailbox allocation, two areas alternating
+      if (seg * (size_t)c->world * sizeof(double) > c->peer.area_bytes) { g_err = "peer exchange area too small for this frame: rolo_peer_export with a larger max_points"; return ROLO_EINVAL; }
+      peer_area_off = PEER_STAGE_OFFSET + (size_t)(c->peer.cov_count & 1ull) * c->peer.area_bytes;
+      stage = reinterpret_cast<double*>(static_cast<char*>(c->peer.base) + peer_area_off);
+    } else {
+      if ((rc = ensure(S.stage, S.stage_cap, seg * (size_t)c->world))) return rc;
+      stage = S.stage;
+    }
+    for (int i = 0; i < nc; i++) { A.c[i].seg = seg; A.c[i].stage = stage; }
   }
   // the build overwrites this scratch set's bounding boxes: whoever still pointed at them (a cloud searched earlier) loses them
   if (c->src.bbox6 >= S.bbox && c->src.bbox6 < S.bbox + 12) c->src.bbox6 = nullptr;
@@ -295,13 +340,16 @@ int build_clouds(rolo_ctx* c, bool do_src, bool do_tgt, hipStream_t stream, bool
   { ProfScope ps(c, ROLO_PROF_KNN_WALK, stream); HIPCHK(launch_knn_walk(A, c->P.k_correspondences, split_tail ? -1 : c->P.regularization, vf, stream)); }
   if (split_tail) { ProfScope ps(c, ROLO_PROF_KNN_TAIL, stream); HIPCHK(launch_knn_tail(A, c->P.k_correspondences, c->P.regularization, vf, stream)); }
   if (sharded) {
-    if (c->comm) {
-      const size_t seg = A.c[0].seg;
+    const size_t seg = A.c[0].seg;
+    if (peers(c)) {   // every rank pushes its segment into every peer's area, flags, and waits for the others' flags (peer.hip)
+      HIPCHK(launch_peer_cov_exchange(c->peer.args, peer_area_off, seg, c->peer.h_err, stream));
+      c->peer.cov_count++;
+    } else if (c->comm) {
       int e = g_rccl.AllGather(S.stage + (size_t)c->rank * seg, S.stage, seg, NCCL_FLOAT64, c->comm, stream);
       if (e != 0) { g_err = std::string("ncclAllGather: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "?"); return ROLO_ECOMM; }
     }
-    // without a communicator (rolo_set_shard test hook) only the own slice is valid afterwards
-    HIPCHK(launch_knn_unstage(A, c->comm == nullptr, stream));
+    // without a communicator / peers (rolo_set_shard test hook) only the own slice is valid afterwards
+    HIPCHK(launch_knn_unstage(A, c->comm == nullptr && !peers(c), stream));
   }
   if (do_src) { c->src.have_cov = true; c->src.have_sorted = true; c->src.cov_user = false; c->src.bbox6 = S.bbox; }
   if (do_tgt) { c->tgt.have_cov = true; c->tgt.have_sorted = true; c->tgt.cov_user = false; c->tgt.bbox6 = S.bbox + (do_src ? 6 : 0); }
@@ -359,6 +407,7 @@ int ensure_map(rolo_ctx* c) {
   { ProfScope ps(c, ROLO_PROF_VOXEL_BUILD); HIPCHK(launch_voxel_build(c->tgt, c->tab, c->tgt_keys, c->tgt_slot, c->counters, voxel_morton_order(c), voxel_fixed_cov(c), c->tgt.bbox6, false, c->stream)); }
   HIPCHK(hipMemcpyAsync(c->h_counters, c->counters, 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
+  if ((rc = peer_check(c))) return rc;
   if (c->h_counters[1] != 0) { g_err = "voxel coordinate outside the packed key range"; return c->h_counters[1]; }
   c->n_voxels = c->h_counters[0];
   c->n_edge = c->h_counters[2];
@@ -379,7 +428,7 @@ int lm_ppt() {
 bool lm_fused(const rolo_ctx* c) {
   static const int force = [] { const char* e = getenv("ROLO_LM_FUSED"); return e ? atoi(e) : -1; }();   // A/B runs: 0 / 1 overrides the parameter
   // with a communicator the sums pass through the all-reduce between pass and controller
-  return !c->comm && (force >= 0 ? force != 0 : c->P.fused_lm != 0);
+  return !c->comm && !peers(c) && (force >= 0 ? force != 0 : c->P.fused_lm != 0);
 }
 
 void shard(const rolo_ctx* c, int& begin, int& end) { rolo_shard_range(c->src.n, c->rank, c->world, &begin, &end); }
@@ -411,7 +460,8 @@ int enqueue_pass(rolo_ctx* c, const PassArgs& a, int grid, int stage, bool publi
     if (e != 0) { g_err = std::string("ncclAllReduce: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "?"); return ROLO_ECOMM; }
     HIPCHK(launch_ctrl(c->state, nullptr, 0, c->sums, c->trace, stage, c->stream, publish ? c->h_state : nullptr));
   } else {
-    HIPCHK(launch_ctrl(c->state, c->partials, grid, nullptr, c->trace, stage, c->stream, publish ? c->h_state : nullptr));
+    // with peers the controller itself exchanges its row sums through the mailboxes: still ONE launch, still graph-capturable
+    HIPCHK(launch_ctrl(c->state, c->partials, grid, nullptr, c->trace, stage, c->stream, publish ? c->h_state : nullptr, peer_args(c)));
   }
   return ROLO_OK;
 }
@@ -480,6 +530,7 @@ int run_stage(rolo_ctx* c, const PassArgs& a, int grid, int stage, int first_chu
     if (lm_fused(c)) { int rc = enqueue_lm_chunk(c, a, chunk); if (rc) return rc; }
     else for (int i = 0; i < chunk; i++) { int rc = enqueue_pass(c, a, grid, stage); if (rc) return rc; }
     issued += chunk;
+    c->n_topup_chunks++;
     int rc = fetch_state(c);
     if (rc) return rc;
     const bool done = (stage == 1) ? (c->h_state->rot_done != 0) : (c->h_state->trans_done != 0);
@@ -487,6 +538,29 @@ int run_stage(rolo_ctx* c, const PassArgs& a, int grid, int stage, int first_chu
     if (issued > hard_cap) { g_err = "LM stage did not terminate"; return ROLO_ESTATE; }
     chunk = 8;
   }
+}
+
+// unmap the peers' mailboxes, free the own one
+void peer_disconnect_impl(rolo_ctx* c) {
+  rolo_peer_state& P = c->peer;
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  for (int r = 0; r < PEER_MAX; r++) {
+    if (P.ipc_opened[r] && P.mapped[r]) (void)hipIpcCloseMemHandle(P.mapped[r]);
+    P.mapped[r] = nullptr; P.ipc_opened[r] = false;
+  }
+  if (P.connected) { c->rank = 0; c->world = 1; c->have_corr = false; c->src.have_cov = false; c->tgt.have_cov = false; c->have_map = false; }
+  P.connected = false; P.args = PeerArgs{};
+  if (c->graph_exec) { (void)hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }   // a captured schedule holds the peers' pointers
+  c->gseen_valid = false;
+}
+void peer_release(rolo_ctx* c) {
+  rolo_peer_state& P = c->peer;
+  peer_disconnect_impl(c);
+  if (P.base) {
+    { std::lock_guard<std::mutex> lk(g_peer_mu); g_peer_exports.erase(P.handle); }
+    (void)hipFree(P.base); P.base = nullptr; P.bytes = 0;
+  }
+  if (P.h_err) { (void)hipHostFree(P.h_err); P.h_err = nullptr; }
 }
 
 }  // namespace
@@ -570,6 +644,7 @@ void rolo_ctx_destroy(rolo_ctx* c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   rolo_front_destroy(c);
+  peer_release(c);
   if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
   void* bufs[] = {c->src.bbox_part, c->tgt.bbox_part, c->src.xyz, c->src.cov, c->src.sorted, c->src.boxes, c->src.knn_idx, c->src.knn_d2, c->tgt.xyz, c->tgt.cov, c->tgt.sorted,
                   c->tgt.boxes, c->tgt.knn_idx, c->tgt.knn_d2, c->ks[0].sort_tmp, c->ks[0].keys0, c->ks[0].keys1, c->ks[0].vals0, c->ks[0].vals1, c->ks[0].bbox,
@@ -661,7 +736,9 @@ int rolo_clear_target(rolo_ctx* c) { if (!c) return ROLO_EINVAL; c->tgt.n = 0; c
 int rolo_compute_covariances(rolo_ctx* c) {
   if (!c) return ROLO_EINVAL;
   int rc = set_device(c); if (rc) return rc;
-  return ensure_covs(c);
+  if ((rc = ensure_covs(c))) return rc;
+  if (peers(c)) { HIPCHK(hipStreamSynchronize(c->stream)); return peer_check(c); }   // a timed-out exchange surfaces here
+  return ROLO_OK;
 }
 
 static int get_covs(rolo_ctx* c, CloudDev& cl, double* covs) {
@@ -777,10 +854,11 @@ static int eval_rot(rolo_ctx* c, const double* T, int dof_optimizer, int mode, d
   if (c->comm) {
     int e = g_rccl.AllReduce(c->sums, c->sums, NV_MAX, NCCL_FLOAT64, NCCL_SUM, c->comm, c->stream);
     if (e != 0) { g_err = "ncclAllReduce failed"; return ROLO_ECOMM; }
-  }
+  } else if (peers(c)) HIPCHK(launch_peer_allreduce(c->sums, c->peer.args, c->peer.h_err, c->stream));
   HIPCHK(launch_eval_end(c->state, c->sums, mode, c->stream));
   HIPCHK(hipMemcpyAsync(c->h_sums, c->sums, sizeof(double) * NV_MAX, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
+  if ((rc = peer_check(c))) return rc;
   const double* S = c->h_sums;
   if (mode == 0) {
     c->have_corr = true;
@@ -835,10 +913,11 @@ static int eval_t3(rolo_ctx* c, const double* t3, const double* g3, const double
   if (c->comm) {
     int e = g_rccl.AllReduce(c->sums, c->sums, NV_MAX, NCCL_FLOAT64, NCCL_SUM, c->comm, c->stream);
     if (e != 0) { g_err = "ncclAllReduce failed"; return ROLO_ECOMM; }
-  }
+  } else if (peers(c)) HIPCHK(launch_peer_allreduce(c->sums, c->peer.args, c->peer.h_err, c->stream));
   HIPCHK(launch_eval_end(c->state, c->sums, 1, c->stream));
   HIPCHK(hipMemcpyAsync(c->h_sums, c->sums, sizeof(double) * NV_MAX, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
+  if ((rc = peer_check(c))) return rc;
   const double* S = c->h_sums;
   if (phase == 0) {
     if (err) *err = S[V_Y];
@@ -978,6 +1057,7 @@ static int register_async_impl(rolo_ctx* c, const float* guess16, const double* 
     };
     if (c->graph_exec && same(key, c->gkey)) {
       HIPCHK(hipGraphLaunch(c->graph_exec, c->stream));
+      c->n_replays++;
       c->src.have_cov = true; c->tgt.have_cov = true; c->src.have_sorted = true; c->tgt.have_sorted = true;
       c->async_pending = true;
       return ROLO_OK;
@@ -993,6 +1073,7 @@ static int register_async_impl(rolo_ctx* c, const float* guess16, const double* 
       if (rc == ROLO_OK && e == hipSuccess && gph && !epoch_moved && hipGraphInstantiate(&c->graph_exec, gph, nullptr, nullptr, 0) == hipSuccess) {
         c->graph = gph; c->gkey = key;
         HIPCHK(hipGraphLaunch(c->graph_exec, c->stream));
+        c->n_captures++;
         c->async_pending = true;
         return ROLO_OK;
       }
@@ -1007,13 +1088,14 @@ static int register_async_impl(rolo_ctx* c, const float* guess16, const double* 
   }
   if ((rc = enqueue_frame(c))) return rc;
   if (graphable) c->gseen.epoch = g_alloc_epoch;  // the eager frame did the allocations the capture must not do
+  c->n_eager++;
   c->async_pending = true;
   return ROLO_OK;
 }
 
 int rolo_register_async(rolo_ctx* c, const float* guess16, const double* trans_start, const double* g3, const double* l3, double dtn, double dtn1, float lam) {
   const int rc = register_async_impl(c, guess16, trans_start, g3, l3, dtn, dtn1, lam);
-  if (rc == ROLO_OK && c->async_pending) HIPCHK(hipEventRecord(c->ev_done, c->stream));
+  if (rc == ROLO_OK && c->async_pending) { c->n_frames++; HIPCHK(hipEventRecord(c->ev_done, c->stream)); }
   return rc;
 }
 
@@ -1023,6 +1105,7 @@ int rolo_register_wait(rolo_ctx* c, float* Tf, double* Td, double* trans_out, ro
   int rc = set_device(c); if (rc) return rc;
   c->async_pending = false;
   HIPCHK(hipEventSynchronize(c->ev_done));
+  if ((rc = peer_check(c))) return rc;
   if (c->h_counters[1] != 0) { g_err = "voxel coordinate outside the packed key range"; return c->h_counters[1]; }
   c->n_voxels = c->h_counters[0];
   c->n_edge = c->h_counters[2];
@@ -1030,6 +1113,7 @@ int rolo_register_wait(rolo_ctx* c, float* Tf, double* Td, double* trans_out, ro
   PassArgs a; int grid;
   if ((rc = prepare_pass(c, a, grid))) return rc;
   // the common case finished inside the first enqueue; otherwise keep feeding predicated passes
+  if (!c->h_state->rot_done || (!c->h_state->trans_done && !c->h_state->error)) c->n_topup_frames++;   // the first schedule was too short: host round trips
   if (!c->h_state->rot_done) { if ((rc = run_stage(c, a, grid, 1, 8))) return rc; }
   if (!c->h_state->trans_done && !c->h_state->error) { if ((rc = run_stage(c, a, grid, 2, 8))) return rc; }
   c->have_corr = true;
@@ -1073,6 +1157,13 @@ int rolo_transform_cloud(rolo_ctx* c, const float* in, float* out, int n, int st
   HIPCHK(launch_transform_cloud(c->stage_in, c->stage_out, n, stride, nullptr, T16, c->stream));
   HIPCHK(hipMemcpyAsync(out, c->stage_out, sizeof(float) * (size_t)n * stride, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
+  return ROLO_OK;
+}
+
+int rolo_ctx_counters(rolo_ctx* c, long long* out, int n) {
+  if (!c || !out || n < 0) return ROLO_EINVAL;
+  const long long v[8] = {c->n_frames, c->n_replays, c->n_captures, c->n_eager, c->n_topup_frames, c->n_topup_chunks, c->hint_rot, c->hint_trans};
+  for (int i = 0; i < n && i < 8; i++) out[i] = v[i];
   return ROLO_OK;
 }
 
@@ -1242,7 +1333,7 @@ int rolo_batch_register_async(rolo_batch* b, const float* guess16, const double*
   for (int i = 0; i < b->n; i++) {
     rolo_ctx* c = b->m[i];
     if (c->src.n <= 0 || c->tgt.n <= 0) { g_err = "batch member without source/target"; return ROLO_ESTATE; }
-    if (c->comm || c->async_pending) { g_err = "batch members must be idle single-GPU contexts"; return ROLO_ESTATE; }
+    if (c->comm || peers(c) || c->async_pending) { g_err = "batch members must be idle single-GPU contexts"; return ROLO_ESTATE; }
     if (c->P.optimizer != b->m[0]->P.optimizer || c->P.fixed_iterations != b->m[0]->P.fixed_iterations) { g_err = "batch members must share optimizer and iteration settings"; return ROLO_EUNSUPPORTED; }
     double R[9], t[3]; guess_to_Rt(guess16 ? guess16 + 16 * (size_t)i : nullptr, R, t);
     b->h_args[i].rot = make_rot_begin(c, R, t, 1);
@@ -1347,6 +1438,7 @@ int rolo_comm_unique_id(void* uid128) {
 
 int rolo_comm_init(rolo_ctx* c, const void* uid128, int rank, int world) {
   if (!c || !uid128 || world < 1 || rank < 0 || rank >= world) return ROLO_EINVAL;
+  if (c->peer.connected) { g_err = "context is connected to peers (rolo_peer_connect): disconnect first"; return ROLO_ESTATE; }
   int rc = set_device(c); if (rc) return rc;
   // world == 1 is a real (loopback) communicator too: the single-GPU test drives the whole collective path with it
   if ((rc = load_rccl())) return rc;
@@ -1373,6 +1465,105 @@ int rolo_comm_destroy(rolo_ctx* c) {
   if (c->comm && g_rccl.CommDestroy) { (void)hipStreamSynchronize(c->stream); g_rccl.CommDestroy(c->comm); }
   c->comm = nullptr; c->rank = 0; c->world = 1;
   c->have_corr = false; c->src.have_cov = false; c->tgt.have_cov = false; c->have_map = false;
+  return ROLO_OK;
+}
+
+// ---- peer exchange without a collective library -------------------------------------------------------------------
+int rolo_peer_export(rolo_ctx* c, int world, int max_points, void* handle64) {
+  if (!c || !handle64 || world < 1 || world > PEER_MAX || max_points < 0) { g_err = "rolo_peer_export: bad arguments (1 <= world <= 8)"; return ROLO_EINVAL; }
+  if (c->comm) { g_err = "context already holds an RCCL communicator"; return ROLO_ESTATE; }
+  if (c->async_pending) { g_err = "a registration is in flight on this context"; return ROLO_ESTATE; }
+  int rc = set_device(c); if (rc) return rc;
+  peer_release(c);
+  rolo_peer_state& P = c->peer;
+  // per area: one segment per rank, a segment = the rank's share of whole 256-query workgroups of both clouds, 6 doubles per position
+  P.area_bytes = ((size_t)max_points + (size_t)(2 * 256 + 2 * KNN_LEAF) * world + 512) * 6 * sizeof(double);
+  P.area_bytes = (P.area_bytes + 4095) & ~(size_t)4095;
+  P.bytes = PEER_STAGE_OFFSET + 2 * P.area_bytes;
+  // Uncached (MTYPE_UC) device memory first: what the peers write must never be served from a stale L2 line; the words of the LM exchange
+  // are read with system-scope atomics either way. Fine-grained, then ordinary device memory as fall-backs (ROLO_PEER_MEM = uncached |
+  // finegrained | coarse forces one).
+  const char* want = getenv("ROLO_PEER_MEM");
+  hipError_t e = hipErrorUnknown;
+  if (!want || !strcmp(want, "uncached")) { e = hipExtMallocWithFlags(&P.base, P.bytes, hipDeviceMallocUncached); P.mem_kind = "uncached"; }
+  if (e != hipSuccess && (!want || !strcmp(want, "finegrained"))) { (void)hipGetLastError(); e = hipExtMallocWithFlags(&P.base, P.bytes, hipDeviceMallocFinegrained); P.mem_kind = "finegrained"; }
+  if (e != hipSuccess && (!want || !strcmp(want, "coarse"))) { (void)hipGetLastError(); e = hipMalloc(&P.base, P.bytes); P.mem_kind = "coarse"; }
+  if (e != hipSuccess) { P.base = nullptr; return fail_hip(e, "peer mailbox allocation"); }
+  hipIpcMemHandle_t h;
+  static_assert(sizeof(hipIpcMemHandle_t) == ROLO_PEER_HANDLE_BYTES, "hipIpcMemHandle_t is 64 bytes");
+  e = hipIpcGetMemHandle(&h, P.base);
+  if (e != hipSuccess && strcmp(P.mem_kind, "coarse") != 0 && !want) {   // this allocation kind cannot be exported here: ordinary device memory can
+    (void)hipGetLastError(); (void)hipFree(P.base); P.base = nullptr;
+    e = hipMalloc(&P.base, P.bytes); P.mem_kind = "coarse";
+    if (e == hipSuccess) e = hipIpcGetMemHandle(&h, P.base);
+  }
+  if (e != hipSuccess) { if (P.base) { (void)hipFree(P.base); P.base = nullptr; } return fail_hip(e, "hipIpcGetMemHandle (HSA_ENABLE_IPC_MODE_LEGACY=0 set?)"); }
+  HIPCHK(hipMemsetAsync(P.base, 0, PEER_STAGE_OFFSET, c->stream));
+  if (!P.h_err) HIPCHK(hipHostMalloc((void**)&P.h_err, sizeof(int)));
+  *P.h_err = 0;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  memcpy(P.handle.data(), &h, ROLO_PEER_HANDLE_BYTES);
+  { std::lock_guard<std::mutex> lk(g_peer_mu); g_peer_exports[P.handle] = PeerExport{P.base, c->device}; }
+  P.export_world = world;
+  memcpy(handle64, &h, ROLO_PEER_HANDLE_BYTES);
+  return ROLO_OK;
+}
+
+int rolo_peer_connect(rolo_ctx* c, const void* handles, int rank, int world) {
+  if (!c || !handles || world < 1 || world > PEER_MAX || rank < 0 || rank >= world) return ROLO_EINVAL;
+  rolo_peer_state& P = c->peer;
+  if (!P.base || P.export_world != world) { g_err = "rolo_peer_connect: call rolo_peer_export with the same world first"; return ROLO_ESTATE; }
+  if (c->async_pending) { g_err = "a registration is in flight on this context"; return ROLO_ESTATE; }
+  int rc = set_device(c); if (rc) return rc;
+  peer_disconnect_impl(c);
+  const char* hb = static_cast<const char*>(handles);
+  if (memcmp(hb + (size_t)rank * ROLO_PEER_HANDLE_BYTES, P.handle.data(), ROLO_PEER_HANDLE_BYTES) != 0) { g_err = "rolo_peer_connect: handles[rank] is not this context's export"; return ROLO_EINVAL; }
+  for (int r = 0; r < world; r++) {
+    std::array<char, ROLO_PEER_HANDLE_BYTES> key; memcpy(key.data(), hb + (size_t)r * ROLO_PEER_HANDLE_BYTES, ROLO_PEER_HANDLE_BYTES);
+    if (r == rank) { P.mapped[r] = P.base; continue; }
+    PeerExport local{nullptr, -1};
+    { std::lock_guard<std::mutex> lk(g_peer_mu); auto it = g_peer_exports.find(key); if (it != g_peer_exports.end()) local = it->second; }
+    if (local.base) {   // a context of this process (one process driving several GPUs, or the in-process test)
+      if (local.device != c->device) {
+        hipError_t e = hipDeviceEnablePeerAccess(local.device, 0);
+        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { peer_disconnect_impl(c); return fail_hip(e, "hipDeviceEnablePeerAccess"); }
+        (void)hipGetLastError();
+      }
+      P.mapped[r] = local.base;
+    } else {
+      hipIpcMemHandle_t h; memcpy(&h, key.data(), ROLO_PEER_HANDLE_BYTES);
+      void* ptr = nullptr;
+      hipError_t e = hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess);
+      if (e != hipSuccess) { peer_disconnect_impl(c); return fail_hip(e, "hipIpcOpenMemHandle"); }
+      P.mapped[r] = ptr; P.ipc_opened[r] = true;
+    }
+  }
+  P.args = PeerArgs{};
+  P.args.rank = rank; P.args.world = world;
+  for (int r = 0; r < world; r++) P.args.box[r] = static_cast<unsigned long long*>(P.mapped[r]);
+  int khz = 0;
+  if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->device) != hipSuccess || khz <= 0) khz = 100000;   // 100 MHz
+  const char* tm = getenv("ROLO_PEER_TIMEOUT_MS");
+  const double ms = tm ? atof(tm) : 10000.0;
+  P.args.timeout_ticks = (unsigned long long)(std::max(ms, 1.0) * (double)khz);
+  P.connected = true; P.cov_count = 0;
+  c->rank = rank; c->world = world;
+  c->have_corr = false; c->src.have_cov = false; c->tgt.have_cov = false; c->have_map = false;
+  return ROLO_OK;
+}
+
+int rolo_peer_disconnect(rolo_ctx* c) {
+  if (!c) return ROLO_EINVAL;
+  int rc = set_device(c); if (rc) return rc;
+  peer_release(c);
+  return ROLO_OK;
+}
+
+int rolo_peer_info(rolo_ctx* c, int* rank, int* world, char* mem_kind16) {
+  if (!c) return ROLO_EINVAL;
+  if (rank) *rank = c->peer.connected ? c->peer.args.rank : 0;
+  if (world) *world = c->peer.connected ? c->peer.args.world : 0;
+  if (mem_kind16) { strncpy(mem_kind16, c->peer.base ? c->peer.mem_kind : "", 15); mem_kind16[15] = 0; }
   return ROLO_OK;
 }
 

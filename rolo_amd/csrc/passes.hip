@@ -20,6 +20,7 @@
 #include "rolo_internal.hpp"
 #include "dev_math.hpp"
 #include "voxel_dev.hpp"
+#include "peer_dev.hpp"
 #include <cfloat>
 #include <type_traits>
 
@@ -717,8 +718,9 @@ __device__ unsigned long long g_ctrl_t[8];   // accumulated shader-clock ticks p
 #endif
 // pub: pinned host copy of the state, written by the LAST controller launch of a frame's schedule whether or not it has a step to take
 // (replaces a device-to-host copy launch per frame)
+template <bool PEER = false>
 ROLO_DEV void ctrl_body(LmState* st, const double* __restrict__ partials, int nblocks, const double* __restrict__ sums_in,
-                        rolo_trace_rec* trace, int stage, LmState* pub = nullptr) {
+                        rolo_trace_rec* trace, int stage, LmState* pub = nullptr, const PeerArgs* peer = nullptr) {
   __shared__ double sums[NV_MAX];
   __shared__ double part[8][NV_MAX];
   // the scalar LM step touches ~150 fields: stage the whole state through LDS (one coalesced read, one write)
@@ -780,10 +782,20 @@ ROLO_DEV void ctrl_body(LmState* st, const double* __restrict__ partials, int nb
     sums[threadIdx.x] = sums_in[threadIdx.x];
   }
   __syncthreads();
+  bool peer_ok = true;
+  if constexpr (PEER) {
+    // multi-GPU: this rank's sums cover its shard of the source points — exchange them through the peers' mailboxes and add all ranks'
+    // values in rank order (peer_dev.hpp); every rank then runs the identical scalar step below
+    __shared__ unsigned xw[PEER_MAX * PEER_SLOT_WORDS];
+    __shared__ int bad;
+    peer_ok = peer_allreduce_block<256>(sums, xw, &bad, *peer);
+  }
   CT_STAMP(2);
   if (threadIdx.x == 0) {
     // (the step on a private copy of the whole state instead of LDS: 256 VGPRs + 396 B of scratch, 2.2 -> 7.1 us)
-    if (stage == 1) rot_step(&sst, sums, trace);
+    if (!peer_ok) {   // a peer did not answer within the timeout: end the registration with ROLO_ECOMM instead of waiting forever
+      sst.error = ROLO_ECOMM; sst.stage = 0; sst.rot_done = 1; sst.rot_failed = 1; sst.trans_done = 1; sst.trans_failed = 1;
+    } else if (stage == 1) rot_step(&sst, sums, trace);
     else trans_step(&sst, sums, trace);
   }
   __syncthreads();
@@ -812,6 +824,10 @@ extern "C" int rolo_debug_ctrl_times(unsigned long long* out8) {
 __global__ __launch_bounds__(256) void ctrl_kernel(LmState* st, const double* __restrict__ partials, int nblocks,
                                                   const double* __restrict__ sums_in, rolo_trace_rec* trace, int stage, LmState* pub) {
   ctrl_body(st, partials, nblocks, sums_in, trace, stage, pub);
+}
+__global__ __launch_bounds__(256) void ctrl_peer_kernel(LmState* st, const double* __restrict__ partials, int nblocks, rolo_trace_rec* trace, int stage,
+                                                       LmState* pub, PeerArgs peer) {
+  ctrl_body<true>(st, partials, nblocks, nullptr, trace, stage, pub, &peer);
 }
 __global__ __launch_bounds__(256) void ctrl_batch_kernel(const BatchSlot* __restrict__ slots, int stage) {
   const BatchSlot& S = slots[blockIdx.x];
@@ -1065,8 +1081,10 @@ hipError_t launch_reduce(const double* partials, int nblocks, double* sums, cons
   reduce_kernel<<<1, 256, 0, s>>>(partials, nblocks, sums, st, stage);
   return hipGetLastError();
 }
-hipError_t launch_ctrl(LmState* st, const double* partials, int nblocks, const double* sums, rolo_trace_rec* trace, int stage, hipStream_t s, LmState* pub) {
-  ctrl_kernel<<<1, 256, 0, s>>>(st, partials, nblocks, sums, trace, stage, pub);
+hipError_t launch_ctrl(LmState* st, const double* partials, int nblocks, const double* sums, rolo_trace_rec* trace, int stage, hipStream_t s, LmState* pub,
+                       const PeerArgs* peer) {
+  if (peer && peer->world > 1 && partials) ctrl_peer_kernel<<<1, 256, 0, s>>>(st, partials, nblocks, trace, stage, pub, *peer);
+  else ctrl_kernel<<<1, 256, 0, s>>>(st, partials, nblocks, sums, trace, stage, pub);
   return hipGetLastError();
 }
 hipError_t launch_rot_begin(LmState* st, const RotBegin& a, hipStream_t s) {

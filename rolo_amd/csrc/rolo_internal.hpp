@@ -103,6 +103,28 @@ struct PassArgs {
   VoxelTable tab;
 };
 
+// ---- peer exchange (multi-GPU): every rank owns one "mailbox" allocation that all ranks of the node map (hipIpc
+// handles between processes, plain pointers inside one process). A rank WRITES its 32 fp64 partial sums of an LM pass into its slot of
+// every rank's mailbox and READS only its own mailbox; the sum over the slots is taken in rank order, so every rank gets the same bits
+// and takes the same LM decision — no collective library call, no extra launch, and the frame's schedule stays graph-capturable.
+// Words are 64-bit {epoch : 32 | half a double : 32} written / polled with relaxed system-scope 64-bit atomics (each word validates
+// itself — the LL idea of NCCL — so no fence sits on the path); slots are double-buffered by epoch parity (a rank can run at most one
+// exchange ahead of a peer). The same allocation carries the K5 covariance exchange buffer (peer-written, flag per rank).
+constexpr int PEER_MAX = 8;                 // ranks of one node
+constexpr int PEER_SLOT_WORDS = 2 * NV_MAX; // 64 words of 8 bytes per (parity, rank)
+constexpr int PEER_W_LM_EPOCH = 0;          // own counter of LM exchanges done (only the local controller touches it)
+constexpr int PEER_W_COV_EPOCH = 1;         // own counter of covariance exchanges done
+constexpr int PEER_W_TICKET = 2;            // arrival ticket of the covariance push kernel
+constexpr int PEER_W_COV_FLAG = 8;          // [PEER_MAX] flag of rank r: epoch of the last covariance segment r pushed here
+constexpr int PEER_W_SLOTS = 64;            // [2][PEER_MAX][PEER_SLOT_WORDS]
+constexpr size_t PEER_STAGE_OFFSET = 16384; // bytes: covariance exchange area behind the header (2 * 8 * 512 B of slots end at 8704)
+static_assert((PEER_W_SLOTS + 2 * PEER_MAX * PEER_SLOT_WORDS) * 8 <= PEER_STAGE_OFFSET, "mailbox header");
+struct PeerArgs {
+  int rank, world;                          // world <= 1: no exchange
+  unsigned long long* box[PEER_MAX];        // mailbox of every rank as mapped here (box[rank] = the own one)
+  unsigned long long timeout_ticks;         // wall_clock64 ticks (100 MHz) a poll may last before the rank gives up with ROLO_ECOMM
+};
+
 // one member of a batch (rolo_batch_*): the arguments of its pass kernels, its LM state and trace, its row count
 struct BatchSlot { PassArgs a; LmState* st; rolo_trace_rec* trace; int grid; int pad; };
 
@@ -155,7 +177,15 @@ hipError_t launch_lm(int dof, int threads, int ppt /* slabs of `threads` points 
 hipError_t launch_reduce(const double* partials, int nblocks, double* sums, const LmState* st, int stage, hipStream_t s);
 // controller: sums the rows of `partials` itself (single GPU) or takes all-reduced `sums` (partials == nullptr)
 // pub != nullptr: also leave the state in that (pinned host) copy, step or no step
-hipError_t launch_ctrl(LmState* st, const double* partials, int nblocks, const double* sums, rolo_trace_rec* trace, int stage, hipStream_t s, LmState* pub = nullptr);
+// peer != nullptr (world > 1): the row sums go through the peer exchange before the step (every rank sums all ranks' values in rank order)
+hipError_t launch_ctrl(LmState* st, const double* partials, int nblocks, const double* sums, rolo_trace_rec* trace, int stage, hipStream_t s, LmState* pub = nullptr,
+                       const PeerArgs* peer = nullptr);
+// peer.hip: sums[NV_MAX] (device) <- sum over the ranks, in rank order (stage-level evaluations); *err_flag (device int) is set on a timeout
+hipError_t launch_peer_allreduce(double* sums, const PeerArgs& peer, int* err_flag, hipStream_t s);
+// peer.hip: covariance exchange of one frame — push the own segment [rank * seg_doubles, +seg_doubles) of the local exchange area (area_off
+// bytes behind the mailbox base; two areas alternate) into every peer's area and raise the own flag there (last workgroup), then wait
+// (one wavefront) for every rank's flag of this epoch
+hipError_t launch_peer_cov_exchange(const PeerArgs& peer, size_t area_off, size_t seg_doubles, int* err_flag, hipStream_t s);
 
 struct RotBegin { double R[9], t[3]; int optimizer, max_iterations, fixed_iterations, lm_max, q2_intended; double rot_eps, trans_eps, lm_init; int run_trans; };
 struct TransBegin { double t0[3], g[3], l[3], dtn, dtn1; float ct_lambda; int direct; /* 1: start now (rotation already done) */ };

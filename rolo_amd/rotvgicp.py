@@ -328,6 +328,12 @@ class RotVGICP:
         check(lib().rolo_transform_cloud(self._h, _f(a), _f(out), a.shape[0], a.shape[1], _f(Tm)), "rolo_transform_cloud")
         return out
 
+    def counters(self) -> dict:
+        """rolo_ctx_counters as a dict"""
+        v = (C.c_longlong * 8)()
+        check(lib().rolo_ctx_counters(self._h, v, 8), "rolo_ctx_counters")
+        return dict(zip(("frames", "graph_replays", "graph_captures", "eager_frames", "topup_frames", "sync_chunks", "hint_rot", "hint_trans"), [int(x) for x in v]))
+
     @property
     def stream(self) -> int:
         return int(lib().rolo_ctx_stream(self._h) or 0)
@@ -348,6 +354,26 @@ class RotVGICP:
         r, w = C.c_int(), C.c_int()
         check(lib().rolo_comm_info(self._h, C.byref(r), C.byref(w)), "rolo_comm_info")
         return r.value, w.value
+
+    # peer exchange (rolo_peer_*): the sharded path without a collective library — export a mailbox, swap the 64-byte handles, connect
+    def peer_export(self, world: int, max_points: int) -> bytes:
+        buf = C.create_string_buffer(64)
+        check(lib().rolo_peer_export(self._h, world, int(max_points), buf), "rolo_peer_export")
+        return buf.raw
+
+    def peer_connect(self, handles, rank: int, world: int):
+        blob = b"".join(bytes(h) for h in handles)
+        assert len(blob) == 64 * world
+        check(lib().rolo_peer_connect(self._h, C.create_string_buffer(blob, len(blob)), rank, world), "rolo_peer_connect")
+
+    def peer_disconnect(self):
+        check(lib().rolo_peer_disconnect(self._h), "rolo_peer_disconnect")
+
+    def peer_info(self):
+        """(rank, world, memory kind of the mailbox); world 0 = not connected"""
+        r, w = C.c_int(), C.c_int(); k = C.create_string_buffer(16)
+        check(lib().rolo_peer_info(self._h, C.byref(r), C.byref(w), k), "rolo_peer_info")
+        return r.value, w.value, k.value.decode()
 
 
 class RotVGICPBatch:

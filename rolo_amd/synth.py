@@ -185,13 +185,36 @@ MOTION_T = (0.30, 0.05, 0.02)
 PREV_STEP_T = (0.28, 0.04, 0.02)
 
 
-def make_pair(sensor: str, seed: int = SEED, rpy_deg=MOTION_RPY_DEG, t=MOTION_T, **kw):
-    """Frame k at identity and frame k+1 at the given pose. Returns (frame_k, frame_k1, (R, t))."""
+def make_pair(sensor: str, seed: int = SEED, rpy_deg=MOTION_RPY_DEG, t=MOTION_T, origin=None, **kw):
+    """Frame k at identity and frame k+1 at the given pose. Returns (frame_k, frame_k1, (R, t)).
+    origin = (x, y, yaw_deg): where in the hall frame k stands (default: the centre, facing +x) — the motion stays relative to frame k."""
     R = rpy_to_R(*np.deg2rad(rpy_deg))
     t = np.asarray(t, float)
-    f0 = make_frame(sensor, np.eye(3), np.zeros(3), seed, **kw)
-    f1 = make_frame(sensor, R, t, seed + 1, **kw)
+    R0, t0 = np.eye(3), np.zeros(3)
+    if origin is not None:
+        R0 = rpy_to_R(0.0, 0.0, np.deg2rad(origin[2])); t0 = np.array([origin[0], origin[1], 0.0])
+    f0 = make_frame(sensor, R0, t0, seed, **kw)
+    f1 = make_frame(sensor, R0 @ R, t0 + R0 @ t, seed + 1, **kw)
     return f0, f1, (R, t)
+
+
+def pool_origin(i: int):
+    """Deterministic stand points for pools of DISTINCT frame pairs (bench.py): pair 0 is the nominal pair of SURVEY 8d at the centre of
+    the hall, pair i > 0 stands somewhere else, facing elsewhere (different geometry in view, different noise)."""
+    if i == 0:
+        return None
+    g = np.random.default_rng(SEED + 7919 * i)
+    while True:   # keep 3 m clear of every obstacle's footprint
+        x, y, yaw = float(g.uniform(-18.0, 18.0)), float(g.uniform(-10.0, 10.0)), float(g.uniform(-180.0, 180.0))
+        clear = True
+        for ob in OBSTACLES:
+            if ob[0] == "box":
+                dx, dy = max(abs(x - ob[1]) - ob[3], 0.0), max(abs(y - ob[2]) - ob[4], 0.0)
+                clear &= (dx * dx + dy * dy) ** 0.5 >= 3.0
+            else:
+                clear &= ((x - ob[1]) ** 2 + (y - ob[2]) ** 2) ** 0.5 - ob[3] >= 3.0
+        if clear:
+            return (x, y, yaw)
 
 
 def dense_pair(sensor: str, seed: int = SEED, **kw):

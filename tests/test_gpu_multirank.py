@@ -128,3 +128,163 @@ def test_two_ranks_one_device_rccl_allgather_allreduce(tmp_path):
         # the all-gathered covariances are the unsharded ones, bit for bit
         assert np.array_equal(r[38:], ref.getSourceCovariances().reshape(-1)[:4096])
     assert np.array_equal(res[0], res[1])  # identical LM decisions on both ranks
+
+
+# ---- peer exchange (rolo_peer_*): the sharded path without a collective library -------------------------------------------------------
+def _peer_rank_body(g, rank, world, exchange_handles, frames):
+    """What every rank runs: export, swap handles, connect, then `frames` whole-frame registrations + the stage-level calls.
+    Returns a flat vector of everything that must agree across the ranks and with the unsharded run."""
+    from rolo_amd._lib import lib
+    src, tgt = _pair()
+    g.setResolution(1.0)
+    h = g.peer_export(world, src.shape[0] + tgt.shape[0])
+    handles = exchange_handles(rank, h)
+    g.peer_connect(handles, rank, world)
+    assert g.peer_info()[:2] == (rank, world)
+    out = []
+    for _ in range(frames):   # frame 1 eager, frame 2 captured, frame 3 replayed from the hipGraph
+        g.setInputTarget(tgt); g.setInputSource(src)
+        g.register_async(None, np.zeros(3), G, L0)
+        Tf, Td, t = g.register_wait()
+        out.append(np.concatenate([Td.reshape(-1), t, [g.last_stats.n_passes, g.last_translation_stats.n_passes]]))
+    # stage-level evaluations go through peer_allreduce_kernel
+    T = np.eye(4); T[:3, :3] = synth.rpy_to_R(0.002, -0.001, 0.004)
+    e, H, b = g.so3_linearize(T)
+    e2 = g.compute_error(T)
+    out.append(np.concatenate([H.reshape(-1), b, [e, e2]]))
+    cov = np.concatenate([g.getSourceCovariances().reshape(-1), g.getTargetCovariances().reshape(-1)])
+    return np.concatenate(out), cov
+
+
+def _unsharded_reference(frames):
+    from rolo_amd.rotvgicp import RotVGICP
+    src, tgt = _pair()
+    ref = RotVGICP(); ref.setResolution(1.0)
+    out = []
+    for _ in range(frames):
+        ref.setInputTarget(tgt); ref.setInputSource(src)
+        ref.register_async(None, np.zeros(3), G, L0); Tf, Td, t = ref.register_wait()
+        out.append(np.concatenate([Td.reshape(-1), t, [ref.last_stats.n_passes, ref.last_translation_stats.n_passes]]))
+    T = np.eye(4); T[:3, :3] = synth.rpy_to_R(0.002, -0.001, 0.004)
+    e, H, b = ref.so3_linearize(T); e2 = ref.compute_error(T)
+    out.append(np.concatenate([H.reshape(-1), b, [e, e2]]))
+    cov = np.concatenate([ref.getSourceCovariances().reshape(-1), ref.getTargetCovariances().reshape(-1)])
+    ref.close()
+    return np.concatenate(out), cov
+
+
+def _check_against_unsharded(res, frames):
+    want, wcov = _unsharded_reference(frames)
+    for vec, cov in res:
+        assert np.array_equal(cov, wcov)                      # exchanged covariances: the unsharded ones, bit for bit
+        rel = np.abs(vec - want) / np.maximum(np.abs(want), 1.0)
+        assert rel[:-14].max() < 1e-9, rel[:-14].max()        # poses, translations, pass counts (sums differ in the order of additions only)
+        assert rel[-14:].max() < 1e-9, rel[-14:].max()        # H, b, err of the stage-level calls
+    for vec, cov in res[1:]:
+        assert np.array_equal(vec, res[0][0])                 # every rank took bit-identical LM decisions
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_peer_exchange_contexts_of_one_process(world):
+    """W contexts of ONE process on the one device, one host thread per rank (the handles resolve through the process-local registry)."""
+    import threading
+    from rolo_amd.rotvgicp import RotVGICP
+    bar = threading.Barrier(world)
+    table = [None] * world
+    res = [None] * world
+    errs = []
+
+    def exchange(rank, h):
+        table[rank] = h
+        bar.wait(timeout=60)
+        return list(table)
+
+    def body(rank):
+        try:
+            g = RotVGICP(0)
+            res[rank] = _peer_rank_body(g, rank, world, exchange, frames=3)
+            bar.wait(timeout=120)   # nobody frees its mailbox while a peer may still write into it
+            g.close()
+        except Exception as e:  # noqa: BLE001
+            errs.append((rank, repr(e)))
+            bar.abort()
+
+    th = [threading.Thread(target=body, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=300)
+    assert not errs, errs
+    _check_against_unsharded(res, 3)
+
+
+def _peer_proc_main(rank, world, dirpath):
+    import time
+    from rolo_amd.rotvgicp import RotVGICP
+
+    def exchange(r, h):
+        with open(os.path.join(dirpath, f"h{r}.tmp"), "wb") as f:
+            f.write(h)
+        os.replace(os.path.join(dirpath, f"h{r}.tmp"), os.path.join(dirpath, f"h{r}.bin"))
+        hs = []
+        for q in range(world):
+            p = os.path.join(dirpath, f"h{q}.bin"); t0 = time.time()
+            while not os.path.exists(p):
+                if time.time() - t0 > 120:
+                    raise SystemExit(3)
+                time.sleep(0.02)
+            hs.append(open(p, "rb").read())
+        return hs
+
+    g = RotVGICP(0)
+    vec, cov = _peer_rank_body(g, rank, world, exchange, frames=3)
+    np.save(os.path.join(dirpath, f"vec{rank}.npy"), vec); np.save(os.path.join(dirpath, f"cov{rank}.npy"), cov)
+    kind = g.peer_info()[2]
+    open(os.path.join(dirpath, f"done{rank}"), "w").write(kind)
+    t0 = time.time()   # keep the mailbox alive until every rank is done
+    while not all(os.path.exists(os.path.join(dirpath, f"done{q}")) for q in range(world)) and time.time() - t0 < 120:
+        time.sleep(0.02)
+    g.close()
+
+
+def test_two_processes_one_device_peer_exchange(tmp_path):
+    """TWO processes, hipIpc handles, one device: the whole N > 1 path — K5 by query slice + peer-written covariance exchange, passes by
+    source shard + mailbox all-reduce in the controller — against the unsharded registration."""
+    import subprocess
+    world = 2
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", ROLO_PEER_TIMEOUT_MS="20000")
+    code = "import sys; sys.path.insert(0, %r); from tests.test_gpu_multirank import _peer_proc_main; _peer_proc_main(int(sys.argv[1]), %d, %r)" % (ROOT, world, str(tmp_path))
+    procs = [subprocess.Popen([sys.executable, "-c", code, str(r)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=240)[0].decode(errors="replace"))
+    except subprocess.TimeoutExpired:
+        for p in procs:
+            p.kill()
+        pytest.fail("peer ranks did not finish within 240 s")
+    assert all(p.returncode == 0 for p in procs), " | ".join(o[-600:] for o in outs)
+    res = [(np.load(tmp_path / f"vec{r}.npy"), np.load(tmp_path / f"cov{r}.npy")) for r in range(world)]
+    _check_against_unsharded(res, 3)
+
+
+def test_peer_timeout_is_an_error_not_a_hang(monkeypatch):
+    """A rank whose peer never shows up gives up after ROLO_PEER_TIMEOUT_MS with ROLO_ECOMM (-9)."""
+    import time
+    from rolo_amd.rotvgicp import RotVGICP
+    from rolo_amd._lib import RoloError
+    monkeypatch.setenv("ROLO_PEER_TIMEOUT_MS", "150")
+    src, tgt = _pair()
+    a, b = RotVGICP(0), RotVGICP(0)
+    for g in (a, b):
+        g.setResolution(1.0)
+    ha, hb = a.peer_export(2, src.shape[0] + tgt.shape[0]), b.peer_export(2, src.shape[0] + tgt.shape[0])
+    a.peer_connect([ha, hb], 0, 2)   # b never connects, never runs
+    a.setInputTarget(tgt); a.setInputSource(src)
+    t0 = time.time()
+    with pytest.raises(RoloError) as ei:
+        a.register_async(None, np.zeros(3), G, L0)
+        a.register_wait()
+    assert time.time() - t0 < 20
+    assert ei.value.code == -9
+    a.close(); b.close()
