@@ -141,6 +141,12 @@ public:
     rolo_deskew d{deskewEnabled ? 1 : 0, {odomIncreRPY[0], odomIncreRPY[1], odomIncreRPY[2]}, scanPeriod, odomTimeDiff};
     check(rolo_odom_set_deskew(odom_, &d, rel_time, n, 0), "rolo_odom_set_deskew");
   }
+  // extracted_corner ++ extracted_surface of the last collected fused frame (n x 4 floats, corners first)
+  void getFeatures(std::vector<float>& features, int& n_corner, int& n_surface) {
+    check(rolo_odom_get_features(odom_, nullptr, 0, &n_corner, &n_surface), "rolo_odom_get_features");
+    features.assign((size_t)(n_corner + n_surface > 0 ? n_corner + n_surface : 1) * 4, 0.f);
+    check(rolo_odom_get_features(odom_, features.data(), n_corner + n_surface, &n_corner, &n_surface), "rolo_odom_get_features");
+  }
   void setReuseCovariances(bool on) { check(rolo_odom_set_option(odom_, ROLO_ODOM_REUSE_COVARIANCES, on ? 1 : 0), "rolo_odom_set_option"); }
 
   std::array<float, 6> LaserOdomPose{};   // x, y, z, roll, pitch, yaw — what pubMessage publishes (:680-684)

@@ -52,6 +52,9 @@ struct CloudInfoStamp {   // msg/CloudInfoStamp.msg:1-28, same order
 
 struct Pose { double position[3] = {0, 0, 0}; double orientation[4] = {0, 0, 0, 0}; /* x, y, z, w */ };
 struct PoseStamped { Header header; Pose pose; };
+struct Path { Header header; std::vector<PoseStamped> poses; };                                          // nav_msgs/Path
+struct Float32 { float data = 0.f; };                                                                   // std_msgs/Float32
+struct PoseWithCovarianceStamped { Header header; Pose pose; double covariance[36] = {0}; };            // geometry_msgs/PoseWithCovarianceStamped
 struct Odometry {   // nav_msgs/Odometry
   Header header; std::string child_frame_id; Pose pose; double pose_covariance[36] = {0};
   double twist_linear[3] = {0, 0, 0}, twist_angular[3] = {0, 0, 0}; double twist_covariance[36] = {0};
@@ -131,6 +134,18 @@ inline void read(Reader& r, Odometry& m) {
   read(r, m.header); m.child_frame_id = r.str(); read(r, m.pose); r.raw(m.pose_covariance, sizeof(m.pose_covariance));
   r.raw(m.twist_linear, sizeof(m.twist_linear)); r.raw(m.twist_angular, sizeof(m.twist_angular)); r.raw(m.twist_covariance, sizeof(m.twist_covariance));
 }
+
+inline void write(Writer& w, const Path& m) { write(w, m.header); w.pod<uint32_t>((uint32_t)m.poses.size()); for (const auto& p : m.poses) write(w, p); }
+inline void read(Reader& r, Path& m) {
+  read(r, m.header);
+  const uint32_t cnt = r.pod<uint32_t>();
+  m.poses.clear();
+  for (uint32_t i = 0; i < cnt && r.ok(); i++) { PoseStamped p; read(r, p); if (r.ok()) m.poses.push_back(p); }
+}
+inline void write(Writer& w, const Float32& m) { w.pod(m.data); }
+inline void read(Reader& r, Float32& m) { m.data = r.pod<float>(); }
+inline void write(Writer& w, const PoseWithCovarianceStamped& m) { write(w, m.header); write(w, m.pose); w.raw(m.covariance, sizeof(m.covariance)); }
+inline void read(Reader& r, PoseWithCovarianceStamped& m) { read(r, m.header); read(r, m.pose); r.raw(m.covariance, sizeof(m.covariance)); }
 
 template <typename M> std::vector<uint8_t> serialize(const M& m) { std::vector<uint8_t> out; Writer w(out); write(w, m); return out; }
 // true iff the whole buffer is one well-formed message

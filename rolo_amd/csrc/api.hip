@@ -177,6 +177,7 @@ struct rolo_ctx {
   // passes the last frames needed per stage (+1): the next frame enqueues that many predicated pass/controller pairs up
   // front instead of a fixed worst-case chunk; rolo_register_wait tops up if a frame needs more
   int hint_rot = 0, hint_trans = 0;
+  struct NeedWindow { int need[16] = {0}; int n = 0, pos = 0; } win_rot, win_trans;   // passes the last 16 frames needed per stage
   bool gseen_valid = false;
   hipGraph_t graph = nullptr;
   hipGraphExec_t graph_exec = nullptr;
@@ -516,8 +517,15 @@ void frame_chunks(const rolo_ctx* c, int& nrot, int& ntrans) {
   nrot = c->hint_rot > 0 ? c->hint_rot : rot_first_chunk(c);
   ntrans = c->hint_trans > 0 ? c->hint_trans : 12;
 }
-void update_hint(int& hint, int used) {
-  const int want = std::min(std::max(used + 1, 2), 96);
+// The first schedule of the next frame holds (the most passes any of the last 16 frames needed) + 1 predicated pass / controller pairs.
+// A stream of DIFFERENT frame pairs needs different numbers of LM trials (BASELINE configs[4]: 24 ... 41 per pair): following the last
+// frame alone made every other frame either re-capture its hipGraph (the schedule length is part of the graph's key) or top up through
+// host round trips — 351 top-ups, 297 captures and 753 eager frames in 1536; a predicated no-op pair costs ~5 us of GPU time.
+void update_hint(int& hint, rolo_ctx::NeedWindow& w, int used) {
+  w.need[w.pos] = used; w.pos = (w.pos + 1) % 16; if (w.n < 16) w.n++;
+  int mx = 0;
+  for (int i = 0; i < w.n; i++) mx = std::max(mx, w.need[i]);
+  const int want = std::min(std::max(mx + 1, 2), 96);
   if (hint == 0 || want > hint || want < hint - 2) hint = want;  // hysteresis: a captured hipGraph stays valid while the need wobbles by one or two
 }
 
@@ -1118,7 +1126,7 @@ int rolo_register_wait(rolo_ctx* c, float* Tf, double* Td, double* trans_out, ro
   if (!c->h_state->trans_done && !c->h_state->error) { if ((rc = run_stage(c, a, grid, 2, 8))) return rc; }
   c->have_corr = true;
   const LmState* s = c->h_state;
-  if (!s->error) { update_hint(c->hint_rot, s->rot_passes); update_hint(c->hint_trans, s->trans_passes); }
+  if (!s->error) { update_hint(c->hint_rot, c->win_rot, s->rot_passes); update_hint(c->hint_trans, c->win_trans, s->trans_passes); }
   fill_rot_outputs(s, Tf, Td, rs);
   if (trans_out) for (int i = 0; i < 3; i++) trans_out[i] = s->t0[i];
   if (ts) { ts->n_outer = s->trans_outer; ts->converged = s->trans_failed ? 0 : 1; ts->lm_failed = s->trans_failed; ts->n_passes = s->trans_passes; ts->n_correspondences = s->tr_n_corr; }

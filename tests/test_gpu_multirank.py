@@ -142,8 +142,8 @@ def _peer_rank_body(g, rank, world, exchange_handles, frames):
     g.peer_connect(handles, rank, world)
     assert g.peer_info()[:2] == (rank, world)
     out = []
-    for _ in range(frames):   # frame 1 eager, frame 2 captured, frame 3 replayed from the hipGraph
-        g.setInputTarget(tgt); g.setInputSource(src)
+    for _ in range(frames):   # frames 1 and 2 eager (the schedule length settles), frame 3 captured, frame 4 replayed from the hipGraph
+        g.setInputTarget(tgt.copy()); g.setInputSource(src.copy())   # a new array object: setInput* really uploads, K5 runs every frame
         g.register_async(None, np.zeros(3), G, L0)
         Tf, Td, t = g.register_wait()
         out.append(np.concatenate([Td.reshape(-1), t, [g.last_stats.n_passes, g.last_translation_stats.n_passes]]))
@@ -153,6 +153,8 @@ def _peer_rank_body(g, rank, world, exchange_handles, frames):
     e2 = g.compute_error(T)
     out.append(np.concatenate([H.reshape(-1), b, [e, e2]]))
     cov = np.concatenate([g.getSourceCovariances().reshape(-1), g.getTargetCovariances().reshape(-1)])
+    cnt = g.counters()
+    assert cnt["frames"] == frames and cnt["graph_replays"] >= 1 and cnt["topup_frames"] == 0, cnt   # the sharded frame does replay its hipGraph
     return np.concatenate(out), cov
 
 
@@ -162,7 +164,7 @@ def _unsharded_reference(frames):
     ref = RotVGICP(); ref.setResolution(1.0)
     out = []
     for _ in range(frames):
-        ref.setInputTarget(tgt); ref.setInputSource(src)
+        ref.setInputTarget(tgt.copy()); ref.setInputSource(src.copy())
         ref.register_async(None, np.zeros(3), G, L0); Tf, Td, t = ref.register_wait()
         out.append(np.concatenate([Td.reshape(-1), t, [ref.last_stats.n_passes, ref.last_translation_stats.n_passes]]))
     T = np.eye(4); T[:3, :3] = synth.rpy_to_R(0.002, -0.001, 0.004)
@@ -184,9 +186,11 @@ def _check_against_unsharded(res, frames):
         assert np.array_equal(vec, res[0][0])                 # every rank took bit-identical LM decisions
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2])
 def test_peer_exchange_contexts_of_one_process(world):
-    """W contexts of ONE process on the one device, one host thread per rank (the handles resolve through the process-local registry)."""
+    """Two contexts of ONE process on the one device, one host thread per rank (the handles resolve through the process-local registry).
+    (Not more than two: HIP deals a process's streams to four hardware queues, a third context's stream would sit BEHIND the first
+    one's on the same queue and its kernels could not start while that one polls for them — ranks of a real job are processes.)"""
     import threading
     from rolo_amd.rotvgicp import RotVGICP
     bar = threading.Barrier(world)
@@ -202,7 +206,7 @@ def test_peer_exchange_contexts_of_one_process(world):
     def body(rank):
         try:
             g = RotVGICP(0)
-            res[rank] = _peer_rank_body(g, rank, world, exchange, frames=3)
+            res[rank] = _peer_rank_body(g, rank, world, exchange, frames=4)
             bar.wait(timeout=120)   # nobody frees its mailbox while a peer may still write into it
             g.close()
         except Exception as e:  # noqa: BLE001
@@ -215,7 +219,7 @@ def test_peer_exchange_contexts_of_one_process(world):
     for t in th:
         t.join(timeout=300)
     assert not errs, errs
-    _check_against_unsharded(res, 3)
+    _check_against_unsharded(res, 4)
 
 
 def _peer_proc_main(rank, world, dirpath):
@@ -237,7 +241,7 @@ def _peer_proc_main(rank, world, dirpath):
         return hs
 
     g = RotVGICP(0)
-    vec, cov = _peer_rank_body(g, rank, world, exchange, frames=3)
+    vec, cov = _peer_rank_body(g, rank, world, exchange, frames=4)
     np.save(os.path.join(dirpath, f"vec{rank}.npy"), vec); np.save(os.path.join(dirpath, f"cov{rank}.npy"), cov)
     kind = g.peer_info()[2]
     open(os.path.join(dirpath, f"done{rank}"), "w").write(kind)
@@ -247,11 +251,11 @@ def _peer_proc_main(rank, world, dirpath):
     g.close()
 
 
-def test_two_processes_one_device_peer_exchange(tmp_path):
-    """TWO processes, hipIpc handles, one device: the whole N > 1 path — K5 by query slice + peer-written covariance exchange, passes by
+@pytest.mark.parametrize("world", [2, 3])
+def test_ranks_in_processes_one_device_peer_exchange(tmp_path, world):
+    """W processes, hipIpc handles, one device: the whole N > 1 path — K5 by query slice + peer-written covariance exchange, passes by
     source shard + mailbox all-reduce in the controller — against the unsharded registration."""
     import subprocess
-    world = 2
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", ROLO_PEER_TIMEOUT_MS="20000")
     code = "import sys; sys.path.insert(0, %r); from tests.test_gpu_multirank import _peer_proc_main; _peer_proc_main(int(sys.argv[1]), %d, %r)" % (ROOT, world, str(tmp_path))
     procs = [subprocess.Popen([sys.executable, "-c", code, str(r)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
@@ -265,7 +269,7 @@ def test_two_processes_one_device_peer_exchange(tmp_path):
         pytest.fail("peer ranks did not finish within 240 s")
     assert all(p.returncode == 0 for p in procs), " | ".join(o[-600:] for o in outs)
     res = [(np.load(tmp_path / f"vec{r}.npy"), np.load(tmp_path / f"cov{r}.npy")) for r in range(world)]
-    _check_against_unsharded(res, 3)
+    _check_against_unsharded(res, 4)
 
 
 def test_peer_timeout_is_an_error_not_a_hang(monkeypatch):
