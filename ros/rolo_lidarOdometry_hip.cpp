@@ -1,6 +1,10 @@
-// rolo_lidarOdometry on MI355X — replaces the LidarOdometry half of src/lidarOdometry.cpp of sdwyc/ROLO: same topics, queue sizes,
-// frames and TF (:394-405, :645-697, :715-729); the work is rolo::ros1::LidarOdometryNode. The TransformFusion half of the reference
-// node (20 Hz ESKF-smoothed odomTopic, :47-323) runs on rolo_fusion_* (include/rolo_fusion.h) in the same process.
+// rolo_lidarOdometry on MI355X — replaces src/lidarOdometry.cpp of sdwyc/ROLO, BOTH classes its main() instantiates (:715-729):
+//   LidarOdometryRos    = LidarOdometry (:325-713): same topics, queue sizes, frames and TF (:394-405, :645-697); the work is
+//                         rolo::ros1::LidarOdometryNode on the HIP registration;
+//   TransformFusionRos  = TransformFusion (:47-323): subscribers / publishers / timers of :96-105, handlers :109-322 on
+//                         rolo::ros1::TransformFusionNode (rolo_fusion_* / PoseESEKF in librolo_hip.so) — the 20 Hz ESKF-smoothed odomTopic every
+//                         downstream consumer reads, odomTopic + "/speed", the 1 s path, future_path / future_pose_lidar at 30 Hz, the
+//                         map -> odom and odom -> base_link transforms.
 // Built only inside a catkin workspace; here it is type-checked against mock ROS headers (tests/test_ros_sources_compile.py).
 #include <algorithm>
 #include <mutex>
@@ -9,6 +13,7 @@
 #include <tf/transform_broadcaster.h>
 
 #include "rolo_ros_convert.hpp"
+#include "rolo_transform_fusion_ros.hpp"
 
 class LidarOdometryRos {
 public:
@@ -72,6 +77,7 @@ int main(int argc, char** argv) {
   if (!ok) { ros::shutdown(); return 1; }
   ROS_INFO("\033[1;32m----> Laser Odometry Started (HIP).\033[0m");
   LidarOdometryRos LO(nh, P);
+  TransformFusionRos TF(nh, P);   // lidarOdometry.cpp:720-721: both objects in one process, two spinner threads
   ros::MultiThreadedSpinner spinner(2);
   spinner.spin();
   return 0;

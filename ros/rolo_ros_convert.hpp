@@ -4,7 +4,9 @@
 // API (tests/test_ros_sources_compile.py; no ROS in the image) — the logic the nodes run lives in include/rolo_ros_nodes.hpp.
 #pragma once
 #include <geometry_msgs/PoseStamped.h>
+#include <geometry_msgs/PoseWithCovarianceStamped.h>
 #include <nav_msgs/Odometry.h>
+#include <nav_msgs/Path.h>
 #include <ros/ros.h>
 #include <sensor_msgs/PointCloud2.h>
 
@@ -86,6 +88,20 @@ inline nav_msgs::Odometry to_ros(const wire::Odometry& m) {
 }
 inline geometry_msgs::PoseStamped to_ros(const wire::PoseStamped& m) { geometry_msgs::PoseStamped o; o.header = to_ros(m.header); o.pose = to_ros(m.pose); return o; }
 
+inline nav_msgs::Path to_ros(const wire::Path& m) {
+  nav_msgs::Path o;
+  o.header = to_ros(m.header);
+  o.poses.reserve(m.poses.size());
+  for (const auto& p : m.poses) o.poses.push_back(to_ros(p));
+  return o;
+}
+inline geometry_msgs::PoseWithCovarianceStamped to_ros(const wire::PoseWithCovarianceStamped& m) {
+  geometry_msgs::PoseWithCovarianceStamped o;
+  o.header = to_ros(m.header); o.pose.pose = to_ros(m.pose);
+  for (int i = 0; i < 36; i++) o.pose.covariance[i] = m.covariance[i];
+  return o;
+}
+
 // ParamLoader (include/rolo/utility.h:267-333): the keys these three nodes read, same names and defaults
 inline NodeParams load_params(ros::NodeHandle& nh, bool& ok) {
   NodeParams P; ok = true;
@@ -94,6 +110,7 @@ inline NodeParams load_params(ros::NodeHandle& nh, bool& ok) {
   nh.param<std::string>("rolo/lidarFrame", P.lidarFrame, "base_link");
   nh.param<std::string>("rolo/baselinkFrame", P.baselinkFrame, "base_link");
   nh.param<std::string>("rolo/odometryFrame", P.odometryFrame, "odom");
+  nh.param<std::string>("rolo/mapFrame", P.mapFrame, "map");
   std::string sensorStr;
   nh.param<std::string>("rolo/sensor", sensorStr, "");
   if (sensorStr == "velodyne") P.sensor = LidarType::VELODYNE;

@@ -6,7 +6,10 @@
 #include <sstream>
 #include <string>
 namespace ros {
-struct Time { uint32_t sec = 0, nsec = 0; static Time now() { return Time(); } double toSec() const { return sec + 1e-9 * nsec; } };
+struct Time { uint32_t sec = 0, nsec = 0; Time() {} explicit Time(double) {} static Time now() { return Time(); } double toSec() const { return sec + 1e-9 * nsec; } };
+struct Duration { explicit Duration(double = 0.0) {} };
+struct TimerEvent {};
+struct Timer {};
 struct TransportHints { TransportHints& tcpNoDelay(bool = true) { return *this; } };
 struct Subscriber {};
 struct Publisher {
@@ -18,6 +21,7 @@ struct NodeHandle {
   template <class T, class D> bool param(const std::string&, T& v, const D& d) const { v = T(d); return false; }
   template <class M, class C> Subscriber subscribe(const std::string&, uint32_t, void (C::*)(const boost::shared_ptr<M const>&), C*, const TransportHints& = TransportHints()) { return Subscriber(); }
   template <class M> Publisher advertise(const std::string&, uint32_t, bool = false) { return Publisher(); }
+  template <class C> Timer createTimer(Duration, void (C::*)(const TimerEvent&), C*, bool = false, bool = true) { return Timer(); }
 };
 inline void init(int&, char**, const std::string&) {}
 inline void shutdown() {}

@@ -61,6 +61,42 @@ def main():
     out = os.path.join(ROOT, "tests", "golden", "test_odom_bag.npz")
     np.savez_compressed(out, sec=sec, nsec=nsec, pose=pose.astype(np.float64), pose_cov_diag=covd, accepted=accepted, filtered_every8=filt[::8], filtered_last=filt[-1], final_P=kf.P)
     print(n, "messages ->", out, os.path.getsize(out), "bytes; accepted", int(accepted.sum()), "span %.1f s" % (stamp[-1] - stamp[0]))
+    fusion_fixture(stamp, pose)
+
+
+FUSION_N = 400                      # the first messages of the bag
+FUSION_MAPPING_AT = (50, 200)       # before these messages the back end publishes (at the stamp of message k - 3)
+FUSION_BACKEND_P = (0.5, -0.2, 0.1)
+FUSION_BACKEND_RPY = (0.01, -0.02, 0.3)
+
+
+def fusion_fixture(stamp, pose):
+    """TransformFusion over the head of the bag, the twin's view: what tests/cpp/ros_wire_demo.cpp `fusion` must reproduce as odomTopic bytes.
+    Stamps are the float64 seconds a ROS header carries (sec + 1e-9 nsec); timer ticks at stamp + 0.02 and + 0.045, rounded to whole
+    nanoseconds as ros::Time holds them."""
+    from scipy.spatial.transform import Rotation
+    tw = twin_eskf.TransformFusion()
+    bq = Rotation.from_euler("xyz", FUSION_BACKEND_RPY).as_quat()
+    rows = []; fut = []
+    tick = 0
+    for k in range(FUSION_N):
+        if k in FUSION_MAPPING_AT:
+            tw.mapping_odometry(stamp[k - 3], np.array(FUSION_BACKEND_P), bq)
+        tw.lidar_odometry(stamp[k], pose[k, :3], pose[k, 3:])
+        for dt in (0.02, 0.045):
+            t = stamp[k] + dt
+            sec = np.floor(t); nsec = np.round((t - sec) * 1e9)          # ros::Time::fromSec
+            now = sec + 1e-9 * nsec
+            w = tw.timer(now)
+            if w is not None:
+                rows.append(np.concatenate([[tick, now], w["position"], w["orientation"], w["velocity"], [w["speed"], float(w["path_appended"]), w["path_length"]]]))
+            tick += 1
+        wp = tw.predict_timer()
+        if wp:
+            fut.append(np.concatenate([[k, len(wp)], wp[-1]["position"], Rotation.from_matrix(wp[-1]["R"]).as_quat()]))
+    out = os.path.join(ROOT, "tests", "golden", "test_odom_bag_fusion.npz")
+    np.savez_compressed(out, n=FUSION_N, mapping_at=np.array(FUSION_MAPPING_AT), backend_p=np.array(FUSION_BACKEND_P), backend_q=bq, ticks=np.array(rows), future=np.array(fut))
+    print("fusion fixture:", len(rows), "published ticks of", tick, "->", out, os.path.getsize(out), "bytes")
 
 
 if __name__ == "__main__":

@@ -92,6 +92,32 @@ def parse_odometry(b):
     return m
 
 
+def pack_odometry(m):
+    """nav_msgs/Odometry: header, child_frame_id, PoseWithCovariance (7 + 36 doubles), TwistWithCovariance (6 + 36 doubles)"""
+    return (pack_header(m["header"]) + _str(m.get("child_frame_id", "")) + struct.pack("<7d", *m["position"], *m["orientation"]) +
+            struct.pack("<36d", *m.get("pose_covariance", [0.0] * 36)) + struct.pack("<6d", *m.get("twist", [0.0] * 6)) +
+            struct.pack("<36d", *m.get("twist_covariance", [0.0] * 36)))
+
+
+def parse_path(b):
+    """nav_msgs/Path: header, PoseStamped[]"""
+    r = _R(b)
+    m = dict(header=_header(r), poses=[])
+    for _ in range(r.u("<I")):
+        h = _header(r)
+        m["poses"].append(dict(header=h, position=np.array(r.u("<ddd")), orientation=np.array(r.u("<dddd"))))
+    assert r.i == len(b)
+    return m
+
+
+def parse_pose_cov_stamped(b):
+    """geometry_msgs/PoseWithCovarianceStamped"""
+    r = _R(b)
+    m = dict(header=_header(r), position=np.array(r.u("<ddd")), orientation=np.array(r.u("<dddd")), covariance=np.array(r.u("<36d")))
+    assert r.i == len(b)
+    return m
+
+
 def xyzi_of(pc2):
     """pcl::fromROSMsg for PointXYZI records"""
     n = pc2["height"] * pc2["width"]

@@ -40,7 +40,8 @@ def test_serialized_cloud_in_serialized_odometry_out(demo, tmp_path, sensor, kin
     out = tmp_path / "out"; out.mkdir()
     r = subprocess.run([demo, "chain", kind, str(cfg["n_scan"]), str(cfg["horizon_scan"]), "0", "4", str(out)] + paths, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
-    lines = r.stdout.strip().splitlines()
+    all_lines = r.stdout.strip().splitlines()
+    lines = [l for l in all_lines if not l.startswith("fusion")]
     # cachePointCloud: nothing until the third message; then cloud k is processed when message k + 2 arrives
     assert lines[0] == "msg 0 imageProjection 1" and lines[1] == "msg 1 imageProjection 1"
     got_frames = [int(l.split()[-1]) for l in lines[2:7]]
@@ -91,3 +92,70 @@ def test_serialized_cloud_in_serialized_odometry_out(demo, tmp_path, sensor, kin
         assert oc["odomAvailable"] == 1 and np.abs(oc["initialGuess"] - pose_o).max() < 2e-6
         assert np.array_equal(oc["initialGuess"][:3].astype(np.float64), od["position"])   # the same LaserOdomPose floats on both topics
         assert np.array_equal(W.xyzi_of(oc["extracted_corner"]), eo["corner"])
+
+
+    # ---- the other half of the rolo_lidarOdometry process: TransformFusion on the odometry the node itself published (8f.1) ----------------
+    # the twin (oracle/twin_eskf.py) is fed the SAME messages — parsed from the bytes the node emitted — and ticked at the same times
+    from oracle import twin_eskf
+    tw = twin_eskf.TransformFusion()
+    fus = {tuple(int(x) for x in l.split()[1:3]): int(l.split()[3]) for l in all_lines if l.startswith("fusion")}
+    assert len(fus) == 2 * len(frames)
+    n_pub = 0
+    for idx in range(len(frames)):
+        if idx == 4:
+            tw.mapping_odometry(stamps[idx], np.zeros(3), np.array([0.0, 0.0, 0.0, 1.0]))
+        k = idx - 2   # the cloud processed when message idx arrives
+        if k >= 1:
+            od = W.parse_odometry((out / f"odom_{k}.bin").read_bytes())
+            tw.lidar_odometry(od["header"]["sec"] + 1e-9 * od["header"]["nsec"], od["position"], od["orientation"])
+        for j, dt in enumerate((0.02, 0.045)):
+            t = stamps[idx] + dt; sec = np.floor(t); now = sec + 1e-9 * np.round((t - sec) * 1e9)
+            w = tw.timer(now)
+            assert fus[(idx, j)] == (1 if w is not None else 0)
+            if w is None:
+                continue
+            n_pub += 1
+            m = W.parse_odometry((out / f"fused_{idx}_{j}.bin").read_bytes())
+            assert m["header"]["frame_id"] == "odom" and m["child_frame_id"] == "base_link" and abs(m["header"]["sec"] + 1e-9 * m["header"]["nsec"] - now) < 2e-9
+            assert np.abs(m["position"] - w["position"]).max() < 2e-5
+            assert np.abs(Rotation.from_quat(m["orientation"]).as_matrix() - Rotation.from_quat(w["orientation"]).as_matrix()).max() < 2e-6
+            assert np.abs(m["twist"][:3] - w["velocity"]).max() < 1e-5
+            sp = np.frombuffer((out / f"speed_{idx}_{j}.bin").read_bytes(), "<f4")
+            assert sp.shape == (1,) and abs(float(sp[0]) - w["speed"]) < 1e-5
+            assert (out / f"path_{idx}_{j}.bin").exists() == w["path_appended"]
+            if w["path_appended"]:
+                pm = W.parse_path((out / f"path_{idx}_{j}.bin").read_bytes())
+                assert len(pm["poses"]) == w["path_length"] and np.array_equal(pm["poses"][-1]["position"], m["position"])
+    assert n_pub >= 4   # the filter runs once the back end has spoken and a newer front-end pose exists
+
+
+@pytest.mark.parametrize("sensor,kind,cfg,ring_stride", [("vlp16", "velodyne", dict(n_scan=16, horizon_scan=1800), 1),
+                                                         ("os1-64", "ouster", dict(n_scan=64, horizon_scan=1024), 2)])
+def test_fused_front_end_node_publishes_what_the_three_node_chain_publishes(demo, tmp_path, sensor, kind, cfg, ring_stride):
+    """SURVEY 8f.2 at message level: the same serialized clouds through ONE FusedFrontEndNode (payload unpacked on the device, clouds resident in
+    HBM) and through the chain of three node cores: the odometry messages agree (same frames gated / registered, poses to float rounding) and the
+    feature clouds carried on odomTopic + "/cloud_info" are the same bits."""
+    poses = trajectory(7)
+    frames = [synth.make_frame(sensor, R, t, synth.SEED + k, ring_stride=ring_stride) for k, (R, t) in enumerate(poses)]
+    stamps = [100.0 + 0.1 * k for k in range(len(frames))]
+    paths = []
+    for k, fr in enumerate(frames):
+        msg = W.velodyne_msg(fr, stamps[k], seq=k) if kind == "velodyne" else W.ouster_msg(fr, stamps[k], seq=k)
+        p = tmp_path / f"msg{k}.bin"; p.write_bytes(W.pack_pc2(msg)); paths.append(str(p))
+    outs = {}
+    for mode in ("chain", "fused"):
+        out = tmp_path / mode; out.mkdir()
+        r = subprocess.run([demo, mode, kind, str(cfg["n_scan"]), str(cfg["horizon_scan"]), "0", "4", str(out)] + paths, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        outs[mode] = (out, [l for l in r.stdout.strip().splitlines() if l.startswith("msg")])
+    fl = outs["fused"][1]
+    assert fl[0] == "msg 0 queued" and fl[1] == "msg 1 queued"
+    assert [int(l.split()[-1]) for l in fl[2:7]] == [int(l.split()[-1]) for l in outs["chain"][1][2:7]] == [0, 1, 2, 2, 2]
+    for k in range(1, 5):
+        a = W.parse_odometry((outs["chain"][0] / f"odom_{k}.bin").read_bytes()); b = W.parse_odometry((outs["fused"][0] / f"odom_{k}.bin").read_bytes())
+        assert a["header"] == b["header"] and a["child_frame_id"] == b["child_frame_id"]
+        assert np.abs(a["position"] - b["position"]).max() <= 2e-6 and np.abs(a["orientation"] - b["orientation"]).max() <= 2e-6
+        ca = W.parse_cloud_info((outs["chain"][0] / f"odom_cloud_{k}.bin").read_bytes()); cb = W.parse_cloud_info((outs["fused"][0] / f"odom_cloud_{k}.bin").read_bytes())
+        assert np.array_equal(W.xyzi_of(ca["extracted_corner"]), W.xyzi_of(cb["extracted_corner"]))
+        assert np.array_equal(W.xyzi_of(ca["extracted_surface"]), W.xyzi_of(cb["extracted_surface"]))
+        assert cb["odomAvailable"] == 1 and np.abs(ca["initialGuess"] - cb["initialGuess"]).max() <= 2e-6

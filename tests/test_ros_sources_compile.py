@@ -7,7 +7,7 @@ import subprocess
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-NODES = ["rolo_imageProjection_hip", "rolo_featureExtraction_hip", "rolo_lidarOdometry_hip"]
+NODES = ["rolo_imageProjection_hip", "rolo_featureExtraction_hip", "rolo_lidarOdometry_hip", "rolo_front_fused_hip"]
 
 
 @pytest.mark.parametrize("node", NODES)

@@ -86,3 +86,65 @@ def test_quaternion_from_rpy_matches_scipy(demo, rpy):
     want = Rotation.from_euler("xyz", rpy).as_quat()   # extrinsic x, y, z = Rz(yaw) Ry(pitch) Rx(roll); (x, y, z, w)
     assert min(np.abs(q - want).max(), np.abs(q + want).max()) < 1e-15
     assert np.abs(Rotation.from_euler("xyz", back).as_matrix() - Rotation.from_euler("xyz", rpy).as_matrix()).max() < 1e-14
+
+
+def test_transform_fusion_node_bytes_on_the_reference_bag(demo, tmp_path):
+    """The TransformFusion half of the rolo_lidarOdometry node (src/lidarOdometry.cpp:47-323) at message level, no GPU: the head of the
+    reference's own resource/test_odom.bag as serialized nav_msgs/Odometry on odomTopic + "_incremental", the back end's message twice, timer
+    ticks in between — and the serialized odomTopic / speed / path / future_pose_lidar messages against the independent twin's fixture
+    (tests/golden/test_odom_bag_fusion.npz, made by tests/golden/make_golden_eskf.py)."""
+    z = np.load(os.path.join(ROOT, "tests", "golden", "test_odom_bag.npz")); f = np.load(os.path.join(ROOT, "tests", "golden", "test_odom_bag_fusion.npz"))
+    n = int(f["n"])
+    blob = b""
+    for k in range(n):
+        m = W.pack_odometry(dict(header=dict(seq=k, sec=int(z["sec"][k]), nsec=int(z["nsec"][k]), frame_id="odom"), child_frame_id="lidar_odometry",
+                                 position=z["pose"][k, :3], orientation=z["pose"][k, 3:], pose_covariance=np.arange(36.0), twist=[0, 0, 0, 0.1, 0.2, 0.3]))
+        blob += struct.pack("<I", len(m)) + m
+    (tmp_path / "msgs.bin").write_bytes(blob)
+    (tmp_path / "backend.bin").write_bytes(W.pack_odometry(dict(header=dict(seq=0, sec=0, nsec=0, frame_id="map"), position=f["backend_p"], orientation=f["backend_q"])))
+    out = tmp_path / "out"; out.mkdir()
+    r = subprocess.run([demo, "fusion", str(tmp_path / "backend.bin"), str(out), ",".join(str(int(a)) for a in f["mapping_at"]), str(tmp_path / "msgs.bin")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.split()[:3] == ["ok", str(n), "messages"], r.stdout + r.stderr
+    want = f["ticks"]
+    scale = max(1.0, float(np.abs(z["pose"][:n, :3]).max()))
+    raw = (out / "fused.bin").read_bytes(); i = 0; got = []
+    while i < len(raw):
+        tick, ln = struct.unpack_from("<II", raw, i); i += 8
+        got.append((tick, W.parse_odometry(raw[i:i + ln]))); i += ln
+    assert [t for t, _ in got] == [int(t) for t in want[:, 0]]            # the same ticks publish / return early
+    sp = np.frombuffer((out / "speed.bin").read_bytes(), dtype=[("tick", "<u4"), ("v", "<f4")])
+    pl = np.frombuffer((out / "path_len.bin").read_bytes(), dtype="<u4").reshape(-1, 2)
+    assert len(sp) == len(got) == len(pl)
+    for j, (tick, m) in enumerate(got):
+        w = want[j]
+        now = m["header"]["sec"] + 1e-9 * m["header"]["nsec"]
+        assert abs(now - w[1]) < 1e-9 and m["header"]["frame_id"] == "odom" and m["child_frame_id"] == "base_link"
+        assert m["header"]["seq"] == tick // 2                                # the template: the latest odomTopic + "_incremental" message ...
+        assert np.array_equal(m["pose_covariance"], np.arange(36.0)) and np.array_equal(m["twist"][3:], [0.1, 0.2, 0.3])   # ... incl. what the handler does not touch
+        # float Affine3f chain (front^-1 * back, then mapping * increment) on coordinates of up to ~70 m: a few float32 ulps of THOSE
+        assert np.abs(m["position"] - w[2:5]).max() < 6e-7 * scale
+        Ra = Rotation.from_quat(m["orientation"]).as_matrix(); Rb = Rotation.from_quat(w[5:9]).as_matrix()
+        assert np.abs(Ra - Rb).max() < 2e-6
+        assert np.abs(m["twist"][:3] - w[9:12]).max() < 1e-5 and abs(float(sp["v"][j]) - w[12]) < 1e-5
+        assert bool(pl[j, 1] >> 31) == bool(w[13]) and int(pl[j, 1] & 0x7fffffff) == int(w[14])
+    # future_pose_lidar: the last propagated pose in the lidar frame
+    raw = (out / "future.bin").read_bytes(); i = 0; fut = []
+    while i < len(raw):
+        k, npts, ln = struct.unpack_from("<III", raw, i); i += 12
+        fut.append((k, npts, W.parse_pose_cov_stamped(raw[i:i + ln]))); i += ln
+    wf = f["future"]
+    assert [(k, npts) for k, npts, _ in fut] == [(int(a[0]), int(a[1])) for a in wf]
+    for (k, npts, m), a in zip(fut, wf):
+        assert m["header"]["frame_id"] == "lidar_link" and not m["covariance"].any()
+        assert np.abs(m["position"] - a[2:5]).max() < 1e-5 and m["position"][2] == 0.0
+        assert np.abs(Rotation.from_quat(m["orientation"]).as_matrix() - Rotation.from_quat(a[5:9]).as_matrix()).max() < 1e-6
+
+
+def test_path_and_small_messages_round_trip():
+    """nav_msgs/Path, std_msgs/Float32 layouts by hand"""
+    hdr = struct.pack("<III", 1, 2, 3) + struct.pack("<I", 1) + b"o"
+    pose = struct.pack("<7d", 1, 2, 3, 0, 0, 0, 1)
+    raw = hdr + struct.pack("<I", 2) + hdr + pose + hdr + pose
+    m = W.parse_path(raw)
+    assert len(m["poses"]) == 2 and m["poses"][1]["position"][2] == 3.0
