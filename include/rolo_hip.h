@@ -261,6 +261,11 @@ int rolo_front_set_deskew(rolo_ctx* ctx, const rolo_deskew* d, const float* rel_
 /* lidarOdomAffineFront.inverse() * lidarOdomAffineBack -> pcl::getTranslationAndEulerAngles (:345-351); poses and increment as
  * x, y, z, roll, pitch, yaw (float) */
 void rolo_odom_increment(const float* front6, const float* back6, float* incre6);
+/* Eigen::Affine3f::rotation() of the row-major 4x4 T — what `Rotation = transformation_interpolated.rotation().cast<double>()` reads
+ * (src/lidarOdometry.cpp:474, :548; TransformFusion::affineToPose :130). For an Affine (not Isometry) transform this is
+ * computeRotationScaling(): JacobiSVD<Matrix3f> of the linear part in float, U V^T with the determinant sign fix — the polar factor, which
+ * differs from the linear part in the last float ulps. Host code (the pose chain of the odometry driver uses it); R9 row-major. */
+void rolo_affine3f_rotation(const float* T16, float* R9);
 /* The input of FeatureExtraction::laserCloudInfoHandler (src/featureExtraction.cpp:71-85) when that node runs as its own process: the arrays
  * of the received rolo/cloud_info — extracted[n_valid*4] = fromROSMsg(cloud_projected) as x, y, z, intensity; pointColInd, pointRange
  * (first n_valid entries), startRingIndex / endRingIndex [n_scan] — go where rolo_project_frame would have left them on the device;

@@ -172,6 +172,66 @@ inline void jacobi_svd3(const M3& A, M3& U, V3& sv, M3& V) {
   }
 }
 
+// ---- Eigen::Transform<float,3,Affine>::rotation(), src/lidarOdometry.cpp:130,474,548 ---------------------------------------------
+// For an Affine (not Isometry) transform rotation() is computeRotationScaling(): JacobiSVD<Matrix3f>(linear(), FullU | FullV) in FLOAT,
+// x = det(U V^T) < 0 ? -1 : 1, U.col(2) *= x, rotation = U V^T — the polar factor of the linear part, not the linear part.
+// The same two-sided Jacobi as above, on float, flat row-major arrays.
+inline void rotation_of_affine3f(const float* L /* 3x3 row-major linear part */, float* R) {
+  typedef float T;
+  T W[3][3], U[3][3], V[3][3];
+  T scale = 0;
+  for (int i = 0; i < 9; i++) scale = std::max(scale, std::fabs(L[i]));
+  if (!(scale > 0) || !std::isfinite(scale)) scale = 1;
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { W[i][j] = L[i * 3 + j] / scale; U[i][j] = V[i][j] = (i == j) ? T(1) : T(0); }
+  const T precision = T(2) * std::numeric_limits<T>::epsilon(), tiny = std::numeric_limits<T>::min();
+  T max_diag = std::max(std::fabs(W[0][0]), std::max(std::fabs(W[1][1]), std::fabs(W[2][2])));
+  bool finished = false;
+  int guard = 0;
+  while (!finished && guard++ < 100) {
+    finished = true;
+    for (int p = 1; p < 3; p++) for (int q = 0; q < p; q++) {
+      const T threshold = std::max(tiny, precision * max_diag);
+      if (!(std::fabs(W[p][q]) > threshold || std::fabs(W[q][p]) > threshold)) continue;
+      finished = false;
+      // real_2x2_jacobi_svd
+      const T m00 = W[p][p], m01 = W[p][q], m10 = W[q][p], m11 = W[q][q];
+      T c1, s1;
+      const T t = m00 + m11, d = m10 - m01;
+      if (std::fabs(d) < tiny) { s1 = 0; c1 = 1; } else { const T u = t / d, tmp = std::sqrt(T(1) + u * u); s1 = T(1) / tmp; c1 = u / tmp; }
+      const T n00 = c1 * m00 + s1 * m10, n01 = c1 * m01 + s1 * m11, n11 = -s1 * m01 + c1 * m11;
+      T cr, sr;   // makeJacobi(n00, n01, n11)
+      const T deno = T(2) * std::fabs(n01);
+      if (deno < tiny) { cr = 1; sr = 0; }
+      else {
+        const T tau = (n00 - n11) / deno, w = std::sqrt(tau * tau + T(1));
+        const T tt = tau > 0 ? T(1) / (tau + w) : T(1) / (tau - w);
+        const T sign_t = tt > 0 ? T(1) : T(-1), n = T(1) / std::sqrt(tt * tt + T(1));
+        sr = -sign_t * (n01 / std::fabs(n01)) * std::fabs(tt) * n; cr = n;
+      }
+      const T cl = c1 * cr + s1 * sr, sl = -c1 * sr + s1 * cr;   // j_left = rot1 * j_right^T
+      for (int k = 0; k < 3; k++) { const T x = W[p][k], y = W[q][k]; W[p][k] = cl * x + sl * y; W[q][k] = -sl * x + cl * y; }      // W.applyOnTheLeft(p, q, j_left)
+      for (int k = 0; k < 3; k++) { const T x = U[k][p], y = U[k][q]; U[k][p] = cl * x + sl * y; U[k][q] = -sl * x + cl * y; }      // U.applyOnTheRight(p, q, j_left^T)
+      for (int k = 0; k < 3; k++) { const T x = W[k][p], y = W[k][q]; W[k][p] = cr * x - sr * y; W[k][q] = sr * x + cr * y; }      // W.applyOnTheRight(p, q, j_right)
+      for (int k = 0; k < 3; k++) { const T x = V[k][p], y = V[k][q]; V[k][p] = cr * x - sr * y; V[k][q] = sr * x + cr * y; }      // V.applyOnTheRight(p, q, j_right)
+      max_diag = std::max(max_diag, std::max(std::fabs(W[p][p]), std::fabs(W[q][q])));
+    }
+  }
+  T sv[3];
+  for (int i = 0; i < 3; i++) { const T a = std::fabs(W[i][i]); sv[i] = a; if (a != 0) { const T sgn = W[i][i] / a; for (int k = 0; k < 3; k++) U[k][i] *= sgn; } }
+  for (int i = 0; i < 3; i++) {
+    int pos = i; T mx = sv[i];
+    for (int k = i + 1; k < 3; k++) if (sv[k] > mx) { mx = sv[k]; pos = k; }
+    if (mx == 0) break;
+    if (pos != i) { std::swap(sv[i], sv[pos]); for (int k = 0; k < 3; k++) { std::swap(U[k][i], U[k][pos]); std::swap(V[k][i], V[k][pos]); } }
+  }
+  T M[3][3];
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) M[i][j] = U[i][0] * V[j][0] + U[i][1] * V[j][1] + U[i][2] * V[j][2];
+  const T det = M[0][0] * (M[1][1] * M[2][2] - M[1][2] * M[2][1]) - M[0][1] * (M[1][0] * M[2][2] - M[1][2] * M[2][0]) + M[0][2] * (M[1][0] * M[2][1] - M[1][1] * M[2][0]);
+  const T x = det < 0 ? T(-1) : T(1);
+  for (int k = 0; k < 3; k++) U[k][2] *= x;
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) R[i * 3 + j] = U[i][0] * V[j][0] + U[i][1] * V[j][1] + U[i][2] * V[j][2];
+}
+
 // ---- Eigen::LDLT<Matrix<double,N,N>> (lower, diagonal pivoting), lsq_registration_impl.hpp:102,213,236,288 ----
 // solve A x = rhs for symmetric A (lower triangle read). Returns false if a zero pivot is met.
 template <int N>

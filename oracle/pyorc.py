@@ -371,6 +371,16 @@ def get_transformation(x, y, z, roll, pitch, yaw):
     return T
 
 
+def affine3f_rotation(T):
+    """Eigen::Affine3f::rotation() of a 4x4 (or 3x3) float matrix"""
+    A = np.eye(4, dtype=np.float32); T = np.asarray(T, np.float32); A[:T.shape[0], :T.shape[1]] = T
+    R = np.zeros((3, 3), np.float32)
+    f = lib().orc_affine3f_rotation
+    f.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_float)]; f.restype = None
+    f(_f(A), _f(R))
+    return R
+
+
 def get_translation_and_euler(T16):
     T = np.ascontiguousarray(T16, np.float32).reshape(16); o = np.zeros(6, np.float32)
     f = lib().orc_get_translation_and_euler

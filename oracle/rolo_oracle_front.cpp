@@ -7,6 +7,7 @@
 // (VoxelGrid, getTransformation, getTranslationAndEulerAngles, transformPointCloud) are restated from
 // their documented behaviour (PCL >=1.10 is not under /root/reference).
 #include "rolo_oracle_front.h"
+#include "orc_linalg.hpp"
 #include <cmath>
 #include <cfloat>
 #include <cstring>
@@ -231,6 +232,12 @@ void orc_get_transformation(float x, float y, float z, float roll, float pitch, 
   t[8] = -D;    t[9] = C * F;          t[10] = C * E;         t[11] = z;
   t[12] = 0; t[13] = 0; t[14] = 0; t[15] = 1;
 }
+// Eigen::Affine3f::rotation() of the row-major 4x4 T (lidarOdometry.cpp:130, 474, 548)
+void orc_affine3f_rotation(const float* T16, float* R9) {
+  float L[9];
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) L[i * 3 + j] = T16[i * 4 + j];
+  orc::rotation_of_affine3f(L, R9);
+}
 void orc_get_translation_and_euler(const float* t, float* o) {
   o[0] = t[3]; o[1] = t[7]; o[2] = t[11];
   o[3] = std::atan2(t[9], t[10]);
@@ -349,7 +356,12 @@ int orc_odom_cloud(orc_odom* o, double stamp, const float* corner, int n_corner,
     if (!rc) rc = orc_reg_align(reg, nullptr, Tf, nullptr, nullptr, nullptr);
     if (rc < 0) { orc_reg_destroy(reg); return rc; }
     mat4f_mul(o->transformation_interpolated, Tf, o->transformation_interpolated);
-    for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) o->Rotation[i * 3 + j] = (double)o->transformation_interpolated[i * 4 + j]; o->Translation[i] = (double)o->transformation_interpolated[i * 4 + 3]; }
+    {   // :474-475: Rotation = transformation_interpolated.rotation().cast<double>() — Eigen's float polar factor (orc_linalg.hpp)
+      float L[9], Rf[9];
+      for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) L[i * 3 + j] = o->transformation_interpolated[i * 4 + j];
+      orc::rotation_of_affine3f(L, Rf);
+      for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) o->Rotation[i * 3 + j] = (double)Rf[i * 3 + j]; o->Translation[i] = (double)o->transformation_interpolated[i * 4 + 3]; }
+    }
     double reg_t[3] = {0, 0, 0};
     rc = orc_reg_compute_translation(reg, reg_t, o->Translation, o->TranslationOld, 0.1, 0.1, o->ct_lambda, nullptr);
     orc_reg_destroy(reg);

@@ -75,6 +75,8 @@ int orc_odom_cloud(orc_odom* o, double stamp, const float* corner, int n_corner,
 /* pcl::getTransformation / getTranslationAndEulerAngles (float) */
 void orc_get_transformation(float x, float y, float z, float roll, float pitch, float yaw, float* T16);
 void orc_get_translation_and_euler(const float* T16, float* xyzrpy6);
+/* Eigen::Transform<float,3,Affine>::rotation() — the float polar factor of the linear part (lidarOdometry.cpp:130, 474, 548) */
+void orc_affine3f_rotation(const float* T16, float* R9);
 
 #ifdef __cplusplus
 }

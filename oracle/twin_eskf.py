@@ -209,7 +209,9 @@ class TransformFusion:
 
     @staticmethod
     def _pose(T):
-        q = Rotation.from_matrix(T[:3, :3].astype(np.float64)).as_quat()   # normalised; Eigen's sign convention is fixed below by comparing rotations
+        # affine.rotation() = the polar factor of the float linear part (Eigen: a float Jacobi SVD; scipy: an SVD-based orthonormalisation
+        # in double — the same matrix to float rounding); Quaterniond(...).normalize(). Eigen's sign convention is fixed by comparing rotations
+        q = Rotation.from_matrix(T[:3, :3].astype(np.float64)).as_quat()
         return T[:3, 3].astype(np.float64), q
 
     def timer(self, now):

@@ -5,7 +5,8 @@ stateLinearPropagation :700-712, scanRegeistration :448-501, updateTransform :57
 top of the registration twin (oracle/twin.py) and the float pose algebra of oracle/twin_front.py — a second opinion for
 orc_odom_* in oracle/rolo_oracle_front.cpp. float32 where the reference uses Affine3f / float; numpy's float32 sin / cos and
 its LAPACK 3x3 inverse differ from glibc / Eigen by ulps, so comparisons against the C++ oracle carry a ~1e-6 tolerance.
-Conventions shared with the C++ oracle: cloudTimeLast starts at 0 (SURVEY Q3); Affine3f::rotation() is taken as the linear part.
+Conventions shared with the C++ oracle: cloudTimeLast starts at 0 (SURVEY Q3). Affine3f::rotation() is Eigen's polar factor of the linear part
+(computeRotationScaling: float SVD, U V^T with the sign fix) — here through LAPACK's float SVD instead of Eigen's Jacobi sweeps.
 """
 from __future__ import annotations
 
@@ -36,6 +37,14 @@ def affine_inverse_f(T):
     out[:3, :3] = inv
     out[:3, 3] = -(inv @ T[:3, 3].astype(F)).astype(F)
     return out
+
+
+def rotation_of_affine3f(T):
+    """Eigen::Transform<float,3,Affine>::rotation(): JacobiSVD of the linear part in float, x = sign(det(U V^T)), U[:, 2] *= x, U V^T."""
+    U, _, Vt = np.linalg.svd(np.asarray(T, F)[:3, :3])
+    if np.linalg.det((U @ Vt).astype(np.float64)) < 0:
+        U = U.copy(); U[:, 2] = -U[:, 2]
+    return (U.astype(F) @ Vt.astype(F)).astype(F)
 
 
 def transform_cloud_f(cloud4, T):
@@ -97,7 +106,7 @@ class TwinOdom:
         x0, _, _, _ = tw.align()
         step = x0.astype(F)                                       # getFinalTransformation() is a Matrix4f
         self.transformation_interpolated = mat4_mul_f(self.transformation_interpolated, step)
-        self.Rotation = self.transformation_interpolated[:3, :3].astype(np.float64)
+        self.Rotation = rotation_of_affine3f(self.transformation_interpolated).astype(np.float64)   # :474
         self.Translation = self.transformation_interpolated[:3, 3].astype(np.float64)
         reg_t, _, _ = tw.compute_translation(np.zeros(3), self.Translation, self.TranslationOld, 0.1, 0.1, self.ct_lambda)
         self.Translation = self.Translation + reg_t               # :500

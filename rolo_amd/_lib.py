@@ -167,6 +167,7 @@ SYMBOLS = {
     "rolo_odom_set_option": (C.c_int, [vp, C.c_int, C.c_int]),
     "rolo_odom_set_deskew": (C.c_int, [vp, C.POINTER(Deskew), vp, C.c_int, C.c_int]),
     "rolo_odom_increment": (None, [fp, fp, fp]),
+    "rolo_affine3f_rotation": (None, [fp, fp]),
     "rolo_front_set_deskew": (C.c_int, [vp, C.POINTER(Deskew), vp, C.c_int, C.c_int]),
     "rolo_front_default_params": (None, [C.POINTER(FrontParams)]),
     "rolo_project_frame": (C.c_int, [vp, C.POINTER(FrontParams), fp, C.c_int, C.POINTER(C.c_uint16), C.c_int, fp, ip, fp,

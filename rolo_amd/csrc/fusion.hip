@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "../../include/rolo_fusion.h"
+#include "polar_f32.hpp"
 #include "../../include/rolo_hip.h"
 
 namespace {
@@ -330,12 +331,15 @@ Aff odom2affine(const double* p, const double* q) {
   double r, pi, y; get_rpy(q, r, pi, y);
   return get_transformation((float)p[0], (float)p[1], (float)p[2], (float)r, (float)pi, (float)y);
 }
-// affineToPose :127-136. affine.rotation() is Eigen's polar factor of the linear part; the matrices here are rotations up to float
-// rounding, so the linear part is taken (same simplification as rolo_amd/csrc/odometry.hip).
+// affineToPose :127-136. affine.rotation() of an Affine3f is Eigen's float polar factor of the linear part (polar_f32.hpp), cast to double,
+// then Quaterniond(rotation).normalize()
 void affine_to_pose(const Aff& a, double* pos, Quat& q) {
   pos[0] = a.m[3]; pos[1] = a.m[7]; pos[2] = a.m[11];
+  float L[9], Rf[9];
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) L[i * 3 + j] = a.m[i * 4 + j];
+  rolo::polar::rotation_f32(L, Rf);
   double R[9];
-  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) R[i * 3 + j] = (double)a.m[i * 4 + j];
+  for (int i = 0; i < 9; i++) R[i] = (double)Rf[i];
   q = qnormalized(R_to_q(R));
 }
 

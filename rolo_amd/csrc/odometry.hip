@@ -6,6 +6,7 @@
 // The fp32 pose algebra restates pcl::getTransformation / getTranslationAndEulerAngles / Eigen::Affine3f products
 // (PCL, Eigen: not vendored by the reference).
 #include "rolo_internal.hpp"
+#include "polar_f32.hpp"
 #include <cmath>
 #include <cstring>
 #include <vector>
@@ -90,6 +91,14 @@ struct rolo_odom {
 };
 
 namespace {
+// Rotation = transformation_interpolated.rotation().cast<double>(); Translation = ....translation().cast<double>() (lidarOdometry.cpp:474-475).
+// Affine3f::rotation() is Eigen's float polar factor of the linear part (polar_f32.hpp), not the linear part itself.
+void set_rotation_translation(rolo_odom* o) {
+  float L[9], R[9];
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) L[i * 3 + j] = o->transformation_interpolated.m[i * 4 + j];
+  rolo::polar::rotation_f32(L, R);
+  for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) o->Rotation[i * 3 + j] = (double)R[i * 3 + j]; o->Translation[i] = (double)o->transformation_interpolated.m[i * 4 + 3]; }
+}
 void update_transform(rolo_odom* o) {  // lidarOdometry.cpp:572-626, pose part
   Aff step;
   for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) step.m[i * 4 + j] = (float)o->Rotation[i * 3 + j]; step.m[i * 4 + 3] = (float)o->Translation[i]; }
@@ -121,6 +130,12 @@ void rolo_odom_destroy(rolo_odom* o) {
   delete o;
 }
 
+void rolo_affine3f_rotation(const float* T16, float* R9) {   // lidarOdometry.cpp:474
+  if (!T16 || !R9) return;
+  float L[9];
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) L[i * 3 + j] = T16[i * 4 + j];
+  rolo::polar::rotation_f32(L, R9);
+}
 void rolo_odom_increment(const float* front6, const float* back6, float* incre6) {  // imageProjection.cpp:345-351
   const Aff F = get_transformation(front6[0], front6[1], front6[2], front6[3], front6[4], front6[5]);
   const Aff B = get_transformation(back6[0], back6[1], back6[2], back6[3], back6[4], back6[5]);
@@ -201,7 +216,7 @@ int rolo_odom_cloud(rolo_odom* o, double stamp, const float* corner, int n_corne
     if ((rc = rolo_register_wait(o->ctx, Tf, nullptr, reg_t, &o->last_rot, &o->last_trans))) return rc;
     Aff step; memcpy(step.m, Tf, sizeof(Tf));
     o->transformation_interpolated = aff_mul(o->transformation_interpolated, step);  // :472
-    for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) o->Rotation[i * 3 + j] = (double)o->transformation_interpolated.m[i * 4 + j]; o->Translation[i] = (double)o->transformation_interpolated.m[i * 4 + 3]; }
+    set_rotation_translation(o);   // :474-475
     for (int i = 0; i < 3; i++) o->Translation[i] += reg_t[i];  // :500
     update_transform(o);
     o->featureOld.swap(featureLast);
@@ -301,7 +316,7 @@ int rolo_odom_collect(rolo_odom* o, float* pose6, double* rot9, double* trans3, 
     o->cov_chain = true;  // the context now holds the covariances of d_featNew as its target's
     Aff step; memcpy(step.m, Tf, sizeof(Tf));
     o->transformation_interpolated = aff_mul(o->transformation_interpolated, step);  // :472
-    for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) o->Rotation[i * 3 + j] = (double)o->transformation_interpolated.m[i * 4 + j]; o->Translation[i] = (double)o->transformation_interpolated.m[i * 4 + 3]; }
+    set_rotation_translation(o);   // :474-475
     for (int i = 0; i < 3; i++) o->Translation[i] += reg_t[i];  // :500
     update_transform(o);
     ret = 2;

@@ -164,10 +164,10 @@ def test_transform_fusion_timers_match_twin():
         npt = L.rolo_fusion_predict_timer(h, pts, 512); wp = tw.predict_timer()
         assert npt == len(wp)
         for i in range(npt):
-            # the measurements reach the filter through float Affine3f matrices (odom2affine); the twin re-orthonormalises them (as Eigen's
-            # rotation() does), the library takes the linear part: agreement at float rounding, 1e-6
+            # the measurements reach the filter through float Affine3f matrices (odom2affine) and Affine3f::rotation(): the library restates
+            # Eigen's float Jacobi SVD (polar factor), the twin orthonormalises in double: agreement at float rounding, a few 1e-7
             assert np.abs(np.array(pts[i].position) - wp[i]["position"]).max() < 1e-5 and pts[i].position[2] == 0.0
-            assert np.abs(Rotation.from_quat(np.array(pts[i].orientation)).as_matrix() - wp[i]["R"]).max() < 1e-6
+            assert np.abs(Rotation.from_quat(np.array(pts[i].orientation)).as_matrix() - wp[i]["R"]).max() < 5e-6   # (a 1e-7 difference of a measured rotation shows up amplified in the propagated future poses)
             assert abs(pts[i].longitudinal_velocity_mps - wp[i]["longitudinal"]) < 1e-5 and abs(pts[i].heading_rate_rps - wp[i]["heading_rate"]) < 1e-5
             assert bool(pts[i].is_final) == wp[i]["is_final"]
     assert n_pub > 100
