@@ -222,6 +222,27 @@ def cpu_model() -> str:
     return "unknown"
 
 
+def shim_leg(tmp="/tmp"):
+    """Secondary measurement, not `value`: the LITERAL unchanged caller — src/lidarOdometry.cpp:460-494 constructs fast_gicp::RotVGICP inside
+    scanRegeistration, once per frame — through the C++ drop-in class (include/rot_vgicp_hip.hpp) in a C++-only process: milliseconds per
+    frame with the object constructed per frame (context pool behind the constructor), with one persistent object, and what an unpooled
+    rolo_ctx_create + rolo_ctx_destroy would add. VLP-16 pair, POLAR voxels, the reference's convergence rule, host clouds in (PCIe included)."""
+    import tempfile
+    from rolo_amd import synth
+    d = tempfile.mkdtemp(prefix="shim_", dir=tmp)
+    exe = os.path.join(d, "shim_demo")
+    cmd = ["g++", "-std=c++17", "-O2", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "shim_demo.cpp"), "-o", exe,
+           "-L", os.path.join(ROOT, "rolo_amd"), "-lrolo_hip", "-Wl,-rpath," + os.path.join(ROOT, "rolo_amd"), "-Wl,-rpath,/opt/rocm/lib"]
+    subprocess.run(cmd, check=True, capture_output=True)
+    src, tgt, _ = synth.dense_pair("vlp16")
+    src.astype(np.float32).tofile(os.path.join(d, "s.bin")); tgt.astype(np.float32).tofile(os.path.join(d, "t.bin"))
+    r = subprocess.run([exe, "loop", os.path.join(d, "s.bin"), os.path.join(d, "t.bin"), "50"], capture_output=True, text=True, check=True)
+    a, b, c, sa, sb = r.stdout.split()
+    return {"workload": f"vlp16 dense pair ({src.shape[0]} points), POLAR voxels, convergence-driven, host clouds, C++-only process, 50 frames",
+            "ms_per_frame_object_constructed_per_frame": float(a), "ms_per_frame_persistent_object": float(b),
+            "ms_unpooled_ctx_create_destroy": float(c), "results_identical_across_frames": sa == "1" and sb == "1"}
+
+
 def _config5_pair(i):
     """pair i of BASELINE configs[4]: seed 20260926 + i, motion drawn U(+-2 deg), U(+-0.4 m)"""
     from rolo_amd import synth
@@ -682,6 +703,10 @@ def main():
             out["backend"] = backend_leg(args, local_rank)
         except Exception as e:  # pragma: no cover
             out["backend"] = {"error": repr(e)}
+        try:
+            out["cpp_operator_per_frame"] = shim_leg()
+        except Exception as e:  # pragma: no cover
+            out["cpp_operator_per_frame"] = {"error": repr(e)}
 
     # ---- CPU baselines: the oracle on this box's host cores (rank 0, N = 1 only) ----
     if rank == 0 and world == 1 and not args.no_cpu:

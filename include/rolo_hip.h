@@ -83,6 +83,15 @@ int rolo_device_count(void);
 /* RotVGICP() / ~RotVGICP(): rot_vgicp_impl.hpp:20-42. `device` = HIP device ordinal. */
 int rolo_ctx_create(int device, rolo_ctx** out);
 void rolo_ctx_destroy(rolo_ctx* ctx);
+/* The same for callers that construct one operator PER FRAME, as the reference does (src/lidarOdometry.cpp:460 — `RotVGICP rot_vgicp;` inside
+ * scanRegeistration): rolo_ctx_release parks the context (streams, events, pinned and device buffers, the captured hipGraph of a frame) in a
+ * small per-process pool after resetting everything a fresh object would not have — parameters back to the defaults, no clouds, no
+ * covariances, no map, no correspondences — and rolo_ctx_acquire hands a parked context of that device out again (or creates one). The C++
+ * drop-in class (include/rot_vgicp_hip.hpp) constructs / destructs through this pair, so lidarOdometry.cpp:460-494 runs unchanged WITHOUT a
+ * hipMalloc per frame. rolo_ctx_pool_clear destroys what is parked (call before process exit if the HIP runtime should see every free). */
+int rolo_ctx_acquire(int device, rolo_ctx** out);
+void rolo_ctx_release(rolo_ctx* ctx);
+void rolo_ctx_pool_clear(void);
 void rolo_default_params(rolo_params* p);
 int rolo_set_params(rolo_ctx* ctx, const rolo_params* p);
 /* the HIP stream all work of this context is enqueued on (hipStream_t as void*), for event timing */
@@ -217,7 +226,7 @@ int rolo_comm_info(rolo_ctx* ctx, int* rank, int* world);
 int rolo_peer_export(rolo_ctx* ctx, int world, int max_points, void* handle64);
 int rolo_peer_connect(rolo_ctx* ctx, const void* handles /* world x 64 bytes, rank order */, int rank, int world);
 int rolo_peer_disconnect(rolo_ctx* ctx);
-/* rank / world of the connection (world 0: none); mem_kind16 (optional, 16 chars): "uncached" | "finegrained" | "coarse" */
+/* rank / world of the connection (world 0: none); mem_kind16 (optional, 16 chars): "finegrained" | "coarse" */
 int rolo_peer_info(rolo_ctx* ctx, int* rank, int* world, char* mem_kind16);
 
 /* Bookkeeping of rolo_register_async / _wait on this context since its creation (what bench.py reports next to the throughput):

@@ -91,12 +91,15 @@ public:
 #endif
   static_assert(sizeof(PointSource) % sizeof(float) == 0 && sizeof(PointTarget) % sizeof(float) == 0, "points must be float records");
 
+  // The reference constructs this object once per frame (src/lidarOdometry.cpp:460): construction / destruction go through the library's
+  // context pool (rolo_ctx_acquire / _release) — a released context keeps its streams and device buffers and comes back reset to a fresh
+  // object's state, so the per-frame object costs no hipMalloc / hipFree.
   explicit RotVGICP(int device = 0) {
-    if (rolo_ctx_create(device, &ctx_) != ROLO_OK) throw std::runtime_error(std::string("RotVGICP(HIP): ") + rolo_last_error());
+    if (rolo_ctx_acquire(device, &ctx_) != ROLO_OK) throw std::runtime_error(std::string("RotVGICP(HIP): ") + rolo_last_error());
     rolo_default_params(&p_);
     for (int i = 0; i < 16; i++) final_[i] = (i % 5 == 0) ? 1.f : 0.f;
   }
-  ~RotVGICP() { rolo_ctx_destroy(ctx_); }
+  ~RotVGICP() { rolo_ctx_release(ctx_); }
   RotVGICP(const RotVGICP&) = delete;
   RotVGICP& operator=(const RotVGICP&) = delete;
 

@@ -98,6 +98,9 @@ SYMBOLS = {
     "rolo_device_count": (C.c_int, []),
     "rolo_ctx_create": (C.c_int, [C.c_int, C.POINTER(vp)]),
     "rolo_ctx_destroy": (None, [vp]),
+    "rolo_ctx_acquire": (C.c_int, [C.c_int, C.POINTER(vp)]),
+    "rolo_ctx_release": (None, [vp]),
+    "rolo_ctx_pool_clear": (None, []),
     "rolo_default_params": (None, [C.POINTER(Params)]),
     "rolo_set_params": (C.c_int, [vp, C.POINTER(Params)]),
     "rolo_ctx_stream": (vp, [vp]),

@@ -675,6 +675,57 @@ void rolo_ctx_destroy(rolo_ctx* c) {
   delete c;
 }
 
+// ---- context pool: RotVGICP() / ~RotVGICP() per frame without per-frame allocation ------------------------------------------------------
+// The reference constructs its operator inside scanRegeistration — one object per frame (src/lidarOdometry.cpp:460) — which for a HIP context
+// means 2 streams, 3 events, 4 pinned and ~45 device allocations per frame. rolo_ctx_acquire hands out a released context of the same device
+// instead (buffers, streams and a captured hipGraph of the frame kept; parameters, clouds and every cached result reset to a fresh object's).
+namespace {
+std::mutex g_pool_mu;
+std::vector<rolo_ctx*> g_pool;
+constexpr size_t POOL_MAX = 8;
+void reset_to_fresh(rolo_ctx* c) {
+  rolo_default_params(&c->P);
+  c->src.n = 0; c->tgt.n = 0;
+  c->src.have_cov = c->tgt.have_cov = false; c->src.have_sorted = c->tgt.have_sorted = false; c->src.cov_user = c->tgt.cov_user = false;
+  c->src.bbox6 = c->tgt.bbox6 = nullptr; c->src.n_bbox_part = c->tgt.n_bbox_part = 0;
+  c->have_map = false; c->have_corr = false; c->n_voxels = 0; c->n_edge = 0;
+  c->want_knn_lists = false; c->prof_on = false; c->shard_knn = false;
+  c->rank = 0; c->world = 1;
+  // (schedule hints and the captured graph stay: they are keyed on sizes, buffers and parameters, not on the object's identity)
+}
+}  // namespace
+
+int rolo_ctx_acquire(int device, rolo_ctx** out) {
+  if (!out) return ROLO_EINVAL;
+  {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    for (size_t i = 0; i < g_pool.size(); i++) {
+      if (g_pool[i]->device != device) continue;
+      *out = g_pool[i];
+      g_pool.erase(g_pool.begin() + (long)i);
+      return ROLO_OK;
+    }
+  }
+  return rolo_ctx_create(device, out);
+}
+
+void rolo_ctx_release(rolo_ctx* c) {
+  if (!c) return;
+  // a context with a communicator / peers, a frame in flight or event timers is not worth keeping: destroy
+  if (c->comm || c->peer.base || c->async_pending || !c->prof.empty()) { rolo_ctx_destroy(c); return; }
+  {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    if (g_pool.size() < POOL_MAX) { reset_to_fresh(c); g_pool.push_back(c); return; }
+  }
+  rolo_ctx_destroy(c);
+}
+
+void rolo_ctx_pool_clear(void) {
+  std::vector<rolo_ctx*> all;
+  { std::lock_guard<std::mutex> lk(g_pool_mu); all.swap(g_pool); }
+  for (rolo_ctx* c : all) rolo_ctx_destroy(c);
+}
+
 void* rolo_ctx_stream(rolo_ctx* c) { return c ? (void*)c->stream : nullptr; }
 
 int rolo_set_params(rolo_ctx* c, const rolo_params* p) {
@@ -1488,13 +1539,15 @@ int rolo_peer_export(rolo_ctx* c, int world, int max_points, void* handle64) {
   P.area_bytes = ((size_t)max_points + (size_t)(2 * 256 + 2 * KNN_LEAF) * world + 512) * 6 * sizeof(double);
   P.area_bytes = (P.area_bytes + 4095) & ~(size_t)4095;
   P.bytes = PEER_STAGE_OFFSET + 2 * P.area_bytes;
-  // Uncached (MTYPE_UC) device memory first: what the peers write must never be served from a stale L2 line; the words of the LM exchange
-  // are read with system-scope atomics either way. Fine-grained, then ordinary device memory as fall-backs (ROLO_PEER_MEM = uncached |
-  // finegrained | coarse forces one).
+  // Fine-grained device memory: what the peers write here while a kernel of this rank polls must not be served from a stale L2 line — the
+  // memory type RCCL keeps its flags in; the words of the LM exchange are read with system-scope atomics either way. Ordinary (coarse)
+  // device memory is the fall-back when the allocation or its export fails (ROLO_PEER_MEM = finegrained | coarse forces one).
+  // NOT hipDeviceMallocUncached: measured on MI355X / ROCm 7.2 — after such an allocation is freed, later ordinary hipMalloc blocks of the
+  // same process that land on its pages lose kernel writes (an unrelated context created afterwards read back covariances that were partly
+  // zero, differently every run); fine-grained and coarse allocations do not leave that behind.
   const char* want = getenv("ROLO_PEER_MEM");
   hipError_t e = hipErrorUnknown;
-  if (!want || !strcmp(want, "uncached")) { e = hipExtMallocWithFlags(&P.base, P.bytes, hipDeviceMallocUncached); P.mem_kind = "uncached"; }
-  if (e != hipSuccess && (!want || !strcmp(want, "finegrained"))) { (void)hipGetLastError(); e = hipExtMallocWithFlags(&P.base, P.bytes, hipDeviceMallocFinegrained); P.mem_kind = "finegrained"; }
+  if (!want || !strcmp(want, "finegrained")) { e = hipExtMallocWithFlags(&P.base, P.bytes, hipDeviceMallocFinegrained); P.mem_kind = "finegrained"; }
   if (e != hipSuccess && (!want || !strcmp(want, "coarse"))) { (void)hipGetLastError(); e = hipMalloc(&P.base, P.bytes); P.mem_kind = "coarse"; }
   if (e != hipSuccess) { P.base = nullptr; return fail_hip(e, "peer mailbox allocation"); }
   hipIpcMemHandle_t h;

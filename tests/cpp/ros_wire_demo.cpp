@@ -179,13 +179,15 @@ int main(int argc, char** argv) {
         if (TF.predictTimerHandler(stamp, po)) spit(outdir + "/future_" + std::to_string(idx) + ".bin", wire::serialize(po.future_pose_lidar));
       };
       int processed = 0;
+      std::vector<wire::Time> seen_stamps;
       for (int k = 8; k < argc; k++) {
         const int idx = k - 8;
         const std::vector<uint8_t> raw = slurp(argv[k]);
         wire::PointCloud2 msg;
         if (!wire::deserialize(raw.data(), raw.size(), msg)) { std::printf("msg %d malformed\n", idx); return 3; }
-        if (idx == backend_at) {
-          wire::Odometry mapped; mapped.header.stamp = msg.header.stamp; mapped.pose.orientation[3] = 1.0;
+        seen_stamps.push_back(msg.header.stamp);
+        if (idx == backend_at) {   // the back end's pose belongs to an OLDER scan (three messages back), as its latency makes it in the reference
+          wire::Odometry mapped; mapped.header.stamp = seen_stamps[idx >= 3 ? idx - 3 : 0]; mapped.pose.orientation[3] = 1.0;
           C.odometryHandler(mapped); TF.mappingOdometryHandler(mapped);
         }
         wire::CloudInfoStamp infoA;

@@ -1,9 +1,16 @@
 // C++ host-side check of the drop-in: drives fast_gicp::RotVGICP (include/rot_vgicp_hip.hpp) exactly as
 // LidarOdometry::scanRegeistration does (reference src/lidarOdometry.cpp:460-500), with no Python / torch in the process.
 // Reads two clouds (n x 4 float32: x y z intensity) from binary files, prints the results as one line of numbers.
+//
+//   shim_demo source.bin target.bin              one registration + the accessor / error-behaviour checks (three lines of output)
+//   shim_demo loop source.bin target.bin N       N frames three ways, milliseconds per frame: the operator constructed INSIDE the frame as
+//                                                lidarOdometry.cpp:460 does (the library's context pool behind the constructor), one persistent
+//                                                operator, and a raw rolo_ctx_create / rolo_ctx_destroy per frame (no pool: what round 2 shipped)
+#include <chrono>
 #include <cstdio>
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 #include "rot_vgicp_hip.hpp"
 
@@ -21,8 +28,53 @@ static rolo::Cloud::Ptr load(const char* path) {
   return c;
 }
 
+// scanRegeistration's use of the operator (src/lidarOdometry.cpp:460-494) on a given object
+static void one_frame(fast_gicp::RotVGICP<>& rot_vgicp, const rolo::Cloud::Ptr& source, const rolo::Cloud::Ptr& target, std::array<float, 16>& T, std::array<double, 3>& reg_t) {
+  rolo::Cloud aligned;
+  rot_vgicp.setPolarResolution(0.175, 0.175, 2.0);
+  rot_vgicp.setNumThreads(0);
+  rot_vgicp.clearTarget(); rot_vgicp.clearSource();
+  rot_vgicp.setInputTarget(target);
+  rot_vgicp.setInputSource(source);
+  rot_vgicp.align(aligned);
+  T = rot_vgicp.getFinalTransformation();
+  reg_t = {0, 0, 0};
+  const std::array<double, 3> guess{-0.28, -0.04, -0.02}, last{-0.28, -0.04, -0.02};
+  rot_vgicp.computeTranslation(aligned, reg_t, guess, last, 0.1, 0.1, 0.3f);
+}
+
+static int loop_mode(const char* srcp, const char* tgtp, int n) {
+  rolo::Cloud::Ptr source = load(srcp), target = load(tgtp);
+  using clk = std::chrono::steady_clock;
+  std::array<float, 16> T0{}, T{}; std::array<double, 3> t0{}, t{};
+  auto ms = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+  // warm-up: allocations, code objects
+  for (int k = 0; k < 3; k++) { fast_gicp::RotVGICP<> g; one_frame(g, source, target, T0, t0); }
+  // (a) the operator constructed inside the frame, as the reference does: context pool behind the constructor
+  auto a0 = clk::now();
+  for (int k = 0; k < n; k++) { fast_gicp::RotVGICP<> g; one_frame(g, source, target, T, t); }
+  auto a1 = clk::now();
+  const bool same_a = std::memcmp(T.data(), T0.data(), sizeof(float) * 16) == 0 && t == t0;
+  // (b) one persistent operator
+  double pb;
+  { fast_gicp::RotVGICP<> g; one_frame(g, source, target, T, t);
+    auto b0 = clk::now();
+    for (int k = 0; k < n; k++) one_frame(g, source, target, T, t);
+    pb = ms(b0, clk::now()) / n; }
+  const bool same_b = std::memcmp(T.data(), T0.data(), sizeof(float) * 16) == 0 && t == t0;
+  // (c) what an unpooled constructor costs on top: a context created and destroyed (streams, events, pinned + device buffers)
+  rolo_ctx_pool_clear();
+  auto c0 = clk::now();
+  const int nc = n < 10 ? n : 10;
+  for (int k = 0; k < nc; k++) { rolo_ctx* c = nullptr; if (rolo_ctx_create(0, &c) != ROLO_OK) return 5; rolo_ctx_destroy(c); }
+  const double pc = ms(c0, clk::now()) / nc;
+  std::printf("%.4f %.4f %.4f %d %d\n", ms(a0, a1) / n, pb, pc, same_a ? 1 : 0, same_b ? 1 : 0);
+  return 0;
+}
+
 int main(int argc, char** argv) {
-  if (argc < 3) { std::fprintf(stderr, "usage: shim_demo source.bin target.bin\n"); return 1; }
+  if (argc == 5 && std::strcmp(argv[1], "loop") == 0) return loop_mode(argv[2], argv[3], std::atoi(argv[4]));
+  if (argc < 3) { std::fprintf(stderr, "usage: shim_demo source.bin target.bin | shim_demo loop source.bin target.bin N\n"); return 1; }
   rolo::Cloud::Ptr source = load(argv[1]), target = load(argv[2]);
   rolo::Cloud aligned;
   fast_gicp::RotVGICP<> rot_vgicp;

@@ -102,8 +102,8 @@ def test_serialized_cloud_in_serialized_odometry_out(demo, tmp_path, sensor, kin
     assert len(fus) == 2 * len(frames)
     n_pub = 0
     for idx in range(len(frames)):
-        if idx == 4:
-            tw.mapping_odometry(stamps[idx], np.zeros(3), np.array([0.0, 0.0, 0.0, 1.0]))
+        if idx == 4:   # the back end's message carries the stamp of the scan three messages back
+            tw.mapping_odometry(stamps[idx - 3], np.zeros(3), np.array([0.0, 0.0, 0.0, 1.0]))
         k = idx - 2   # the cloud processed when message idx arrives
         if k >= 1:
             od = W.parse_odometry((out / f"odom_{k}.bin").read_bytes())
