@@ -30,6 +30,8 @@ extern "C" {
 #define ROLO_EALIAS (-8)        /* reference: std::invalid_argument, rot_vgicp_impl.hpp:150-152 */
 #define ROLO_ECOMM (-9)         /* RCCL error */
 #define ROLO_EKEYRANGE (-10)    /* voxel coordinate outside +-2^20 (packed 3x21-bit key) */
+#define ROLO_ENONFINITE (-11)   /* a non-finite point / covariance (degenerate neighbourhood) reached the voxel map's fixed-point sums; the
+                                   reference would carry the NaN into the voxel and on into H */
 
 /* enum orders follow include/rot_gicp/gicp/gicp_settings.hpp:6-13 and lsq_registration.hpp:13 */
 enum { ROLO_REG_NONE = 0, ROLO_REG_MIN_EIG, ROLO_REG_NORMALIZED_MIN_EIG, ROLO_REG_PLANE, ROLO_REG_FROBENIUS, ROLO_REG_PLANE_S };
@@ -331,6 +333,10 @@ int rolo_odom_submit_msg(rolo_odom* o, const rolo_front_params* P, double stamp,
 int rolo_odom_get_features(rolo_odom* o, float* features, int cap_points, int* n_corner, int* n_surface);
 /* options of the fused path: ROLO_ODOM_REUSE_COVARIANCES (default 0) = rolo_adopt_target_covariances between frames */
 #define ROLO_ODOM_REUSE_COVARIANCES 1
+/* ROLO_ODOM_FUSED_LM (default 1): the driver's registrations use one launch per LM trial (rolo_params.fused_lm) — it registers one frame at a
+ * time, where that is the shortest chain (frame latency -9 %). The driver asserts the option on its context right before each registration it
+ * enqueues; it does not depend on, and is not reverted by, the parameter block the caller hands to rolo_set_params. */
+#define ROLO_ODOM_FUSED_LM 2
 int rolo_odom_set_option(rolo_odom* o, int option, int value);
 /* rolo_front_set_deskew for the next rolo_odom_submit / rolo_odom_frame of the fused path */
 int rolo_odom_set_deskew(rolo_odom* o, const rolo_deskew* d, const float* rel_time, int n_raw, int rel_time_on_device);
@@ -342,7 +348,7 @@ int rolo_odom_set_deskew(rolo_odom* o, const rolo_deskew* d, const float* rel_ti
  * from and updating transformTobeMapped = (roll, pitch, yaw, x, y, z). Up to 30 Gauss-Newton iterations, each one kernel over the points
  * (exact 5-NN in the sub-map's BVH, line / plane fit, Jacobian row, J^T J reduction) and a 6 x 6 float solve on the host.
  * edge_min / surf_min = edgeFeatureMinValidNum / surfFeatureMinValidNum (utility.h: 10 / 100): with fewer features the call does nothing
- * (stats->skipped). The context's source / target clouds are used as scratch for the sub-map trees: use a context of its own.
+ * (stats->skipped = 1); a sub-map with fewer than five points cannot answer the 5-NN association: also nothing (stats->skipped = 2). The context's source / target clouds are used as scratch for the sub-map trees: use a context of its own.
  * transformUpdate()'s clamps (:1060-1068; tolerances FLT_MAX in every shipped config) are left to the caller.
  * selected_out[n_corner + n_surf] / coeff_out[(n_corner + n_surf) * 4] (optional): laserCloudOri*Flag and coeffSel of the LAST iteration. */
 typedef struct rolo_scan2map_stats { int skipped, iterations, converged, degenerate, n_selected; } rolo_scan2map_stats;

@@ -9,7 +9,7 @@ for sensor, stride in (("os1-128", 1), ("os1-128", 3)):
     g = RotVGICP(); g.setResolution(0.5)
     for it in range(3):
         g.setInputTarget(tgt); g.setInputSource(src); g.computeCovariances()
-    rec = np.zeros((16384, 6), np.uint32)
+    rec = np.zeros((16384, 8), np.uint32)
     fr(rec.ctypes.data)
     QPB = 4 * int(os.environ.get('PACKET', '64')); nblk = 2 * ((src.shape[0] + QPB - 1) // QPB)
     nw = 4 * nblk
@@ -23,6 +23,11 @@ for sensor, stride in (("os1-128", 1), ("os1-128", 3)):
     for name, x in (("nodes", rec[:, 0]), ("leaves", rec[:, 1]), ("ins", rec[:, 2]), ("push", rec[:, 3]), ("start", st), ("end", en), ("dur", dur)):
         x = x.astype(np.float64)[ok]
         print(f"{name:7s} mean {x.mean():9.1f} p50 {np.percentile(x,50):9.1f} p90 {np.percentile(x,90):9.1f} p99 {np.percentile(x,99):9.1f} max {x.max():9.1f}")
+    # the insert alone: how many of the 64 lanes are live in an execution (the executions are the UNION over the lanes of the candidates that
+    # beat a lane's bound), and what a per-lane queue would execute instead (per leaf the MAXIMUM over the lanes of the candidates accepted)
+    ins = rec[:, 2].astype(np.float64)[ok]; lanes = rec[:, 6].astype(np.float64)[ok]; mx = rec[:, 7].astype(np.float64)[ok]
+    print("insert executions per wave %.1f, live lanes per execution %.1f of 64 (%.1f %%), max-per-lane executions per wave %.1f (%.2f x the union)" % (
+        ins.mean(), lanes.sum() / max(ins.sum(), 1), 100 * lanes.sum() / max(64 * ins.sum(), 1), mx.mean(), mx.sum() / max(ins.sum(), 1)))
     A = np.c_[rec[:, 0], rec[:, 1], rec[:, 2], np.ones(nw)].astype(np.float64)[ok]
     coef, *_ = np.linalg.lstsq(A, dur[ok], rcond=None)
     print("dur_us ~ %.3f*nodes + %.3f*leaves + %.3f*ins + %.1f   (corr of fit %.3f)" % (*coef, np.corrcoef(A @ coef, dur[ok])[0, 1]))

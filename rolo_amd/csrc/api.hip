@@ -187,6 +187,7 @@ struct rolo_ctx {
   std::vector<ProfEv> prof;
   // front end (front.hip)
   void* front = nullptr;
+  void* s2m = nullptr;   // scan2map.hip scratch
 };
 
 namespace {
@@ -409,7 +410,7 @@ int ensure_map(rolo_ctx* c) {
   HIPCHK(hipMemcpyAsync(c->h_counters, c->counters, 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   if ((rc = peer_check(c))) return rc;
-  if (c->h_counters[1] != 0) { g_err = "voxel coordinate outside the packed key range"; return c->h_counters[1]; }
+  if (c->h_counters[1] != 0) { g_err = c->h_counters[1] == ROLO_ENONFINITE ? "non-finite point or covariance in the voxel map build" : "voxel coordinate outside the packed key range"; return c->h_counters[1]; }
   c->n_voxels = c->h_counters[0];
   c->n_edge = c->h_counters[2];
   c->have_map = true;
@@ -576,6 +577,7 @@ void peer_release(rolo_ctx* c) {
 namespace rolo {
 // accessors for front.hip / odometry.hip (the context layout is private to this file)
 void** ctx_front_slot(rolo_ctx* c) { return &c->front; }
+void** ctx_s2m_slot(rolo_ctx* c) { return &c->s2m; }
 hipStream_t ctx_stream(rolo_ctx* c) { return c->stream; }
 int ctx_device(rolo_ctx* c) { return c->device; }
 void ctx_set_error(const char* msg) { g_err = msg ? msg : ""; }
@@ -646,12 +648,14 @@ int rolo_ctx_create(int device, rolo_ctx** out) {
 }
 
 void rolo_front_destroy(rolo_ctx* c);  // front.hip
+void rolo_s2m_destroy(rolo_ctx* c);    // scan2map.hip
 
 void rolo_ctx_destroy(rolo_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   rolo_front_destroy(c);
+  rolo_s2m_destroy(c);
   peer_release(c);
   if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
   void* bufs[] = {c->src.bbox_part, c->tgt.bbox_part, c->src.xyz, c->src.cov, c->src.sorted, c->src.boxes, c->src.knn_idx, c->src.knn_d2, c->tgt.xyz, c->tgt.cov, c->tgt.sorted,
@@ -1165,7 +1169,7 @@ int rolo_register_wait(rolo_ctx* c, float* Tf, double* Td, double* trans_out, ro
   c->async_pending = false;
   HIPCHK(hipEventSynchronize(c->ev_done));
   if ((rc = peer_check(c))) return rc;
-  if (c->h_counters[1] != 0) { g_err = "voxel coordinate outside the packed key range"; return c->h_counters[1]; }
+  if (c->h_counters[1] != 0) { g_err = c->h_counters[1] == ROLO_ENONFINITE ? "non-finite point or covariance in the voxel map build" : "voxel coordinate outside the packed key range"; return c->h_counters[1]; }
   c->n_voxels = c->h_counters[0];
   c->n_edge = c->h_counters[2];
   c->have_map = true;
@@ -1450,7 +1454,7 @@ int rolo_batch_register_wait(rolo_batch* b, float* Tf, double* Td, double* trans
   int first_err = ROLO_OK;
   for (int i = 0; i < b->n; i++) {
     rolo_ctx* c = b->m[i];
-    if (c->h_counters[1] != 0) { g_err = "voxel coordinate outside the packed key range"; if (!first_err) first_err = c->h_counters[1]; continue; }
+    if (c->h_counters[1] != 0) { g_err = c->h_counters[1] == ROLO_ENONFINITE ? "non-finite point or covariance in the voxel map build" : "voxel coordinate outside the packed key range"; if (!first_err) first_err = c->h_counters[1]; continue; }
     c->n_voxels = c->h_counters[0];
     c->n_edge = c->h_counters[2];
     c->have_map = true;

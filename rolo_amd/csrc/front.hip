@@ -1060,6 +1060,20 @@ int rolo_front_load_projection(rolo_ctx* c, const rolo_front_params* P, const fl
                                const int32_t* start_ring, const int32_t* end_ring, int n_valid) {
   if (!c || !P || n_valid < 0 || !start_ring || !end_ring || (n_valid > 0 && (!extracted || !point_col_ind || !point_range))) return ROLO_EINVAL;
   if ((size_t)n_valid > (size_t)P->n_scan * P->horizon_scan) { ctx_set_error("more valid points than range-image pixels"); return ROLO_EINVAL; }
+  // The kernels use these values as array indices: a malformed message (or an N_SCAN / Horizon_SCAN mismatch between the projection and the
+  // feature process) must not become an out-of-bounds device access that takes the whole GPU context down. cloudExtraction writes
+  // startRingIndex[i] = count - 1 + 5 before ring i and endRingIndex[i] = count - 1 - 5 after it (imageProjection.cpp:481-503), count running
+  // from 0 to N; pointColInd is a column of the range image.
+  {
+    int prev = 0;
+    for (int i = 0; i < P->n_scan; i++) {
+      const long long before = (long long)start_ring[i] - 4, after = (long long)end_ring[i] + 6;
+      if (before < prev || after < before || after > n_valid) { ctx_set_error("startRingIndex / endRingIndex are not the running counts of a projection of n_valid points"); return ROLO_EINVAL; }
+      prev = (int)after;
+    }
+    for (int i = 0; i < n_valid; i++)
+      if (point_col_ind[i] < 0 || point_col_ind[i] >= P->horizon_scan) { ctx_set_error("pointColInd outside [0, Horizon_SCAN)"); return ROLO_EINVAL; }
+  }
   Front* f = nullptr;
   int rc = front_prepare(c, P, 0, 4, false, &f);
   if (rc) return rc;

@@ -3,10 +3,10 @@
 // pcl::search::KdTree::nearestKSearch (FLANN, exact, float L2, query included) + centred 4x20 outer product +
 // Eigen::JacobiSVD + regularisation.
 //
-// MI355X design: no pointer-chasing kd-tree. The cloud is sorted along a 30-bit Morton curve (rocPRIM radix
-// sort — a plain library sort), groups of 8 consecutive points become the leaves of an *implicit* complete
+// MI355X design: no pointer-chasing kd-tree. The cloud is sorted along a Hilbert curve (hand-written LSD radix sort of the
+// 27-bit keys, below), groups of KNN_LEAF = 16 consecutive points become the leaves of an *implicit* complete
 // binary BVH stored in heap order (children of h are 2h, 2h+1; both child boxes sit in one 64-byte line), built
-// bottom-up in LDS. The search itself is a wavefront-wide packet traversal (knn_walk.hpp): 64 Morton-adjacent
+// bottom-up in LDS. The search itself is a wavefront-wide packet traversal (knn_walk.hpp): 64 curve-adjacent
 // queries share one walk. Exactness: distances are float ((dx*dx)+(dy*dy))+(dz*dz) with FMA contraction off,
 // box bounds use the same operation order so they are true lower bounds, ties are explored (<=) and broken by
 // original point index — the neighbour set is the same pure function of the cloud the oracle computes.
@@ -17,7 +17,9 @@
 #include "rolo_internal.hpp"
 #include "dev_math.hpp"
 #include "voxel_dev.hpp"
-#include <rocprim/rocprim.hpp>
+#ifdef ROLO_KNN_ROCPRIM_SORT
+#include <rocprim/rocprim.hpp>   // only the A/B build of the key sort uses a library kernel
+#endif
 #include <cfloat>
 #include <climits>
 
@@ -99,7 +101,7 @@ ROLO_DEV uint32_t hilbert30(uint32_t x, uint32_t y, uint32_t z) {
   return (expand10(X[0]) << 2) | (expand10(X[1]) << 1) | expand10(X[2]);
 }
 
-// keys: 30-bit Morton code + the cloud number in bit 30, so one sort of both clouds leaves each cloud sorted in its own
+// keys: curve index (Hilbert; Morton in the -DROLO_KNN_MORTON A/B build) + the cloud number in the top bit, so one sort of both clouds leaves each cloud sorted in its own
 // range [0, n0) / [n0, n0 + n1) of the arrays
 // ---- key sort: a stable LSD radix sort in three 9-bit passes, written for this path (round 1 used rocPRIM's merge sort: 17 launches) --------
 // The keys are 27 bits (the top 26 bits of the 30-bit curve index + the cloud bit: the walk does not care about the low bits of the index)
@@ -311,7 +313,7 @@ __global__ __launch_bounds__(SORT_T) void sort_hist_kernel(const uint32_t* __res
   if (tid < SORT_D) cnt[(size_t)pass * SORT_NB * SORT_D + blk * SORT_D + tid] = hist[tid];
 }
 
-// one thread per leaf: gather its 8 points in Morton order, write them + the leaf box
+// one thread per slot of the sorted copy: gather the point in curve order, write it + (first lane of a leaf) the leaf box
 __global__ __launch_bounds__(256) void leaf_kernel(KnnPair A, int split, const uint32_t* __restrict__ order) {
   // one thread per slot of the sorted copy (a thread per leaf gathered its 16 points one after the other: 13 us); the leaf box is a min / max
   // over the 16 lanes of the leaf — exact, so the order of the reduction does not matter
@@ -554,7 +556,7 @@ size_t knn_sort_temp_bytes(int n) {  // for n points in total (one cloud or the 
 #endif
 }
 
-// Morton sort + implicit BVHs of the pair's clouds. sorted / boxes must be allocated for n_leaves / P of each cloud;
+// curve sort + implicit BVHs of the pair's clouds. sorted / boxes must be allocated for n_leaves / P of each cloud;
 // keys / vals hold n0 + n1 entries, bbox 12 ints.
 hipError_t launch_knn_build(const KnnPair& A_in, void* sort_tmp, size_t sort_tmp_bytes, uint32_t* keys0, uint32_t* keys1,
                             uint32_t* vals0, uint32_t* vals1, int* bbox, const VoxelFuse& vf, hipStream_t s) {
@@ -601,9 +603,9 @@ hipError_t launch_knn_build(const KnnPair& A_in, void* sort_tmp, size_t sort_tmp
 }
 
 #ifdef ROLO_KNN_STATS
-extern "C" int rolo_debug_wave_records(unsigned* out /* 16384 x 6 */) {
+extern "C" int rolo_debug_wave_records(unsigned* out /* 16384 x 8 */) {
   (void)hipDeviceSynchronize();
-  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_knn_wave_rec), sizeof(unsigned) * 16384 * 6) == hipSuccess ? 0 : -1;
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_knn_wave_rec), sizeof(unsigned) * 16384 * 8) == hipSuccess ? 0 : -1;
 }
 #endif
 

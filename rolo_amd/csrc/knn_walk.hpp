@@ -1,14 +1,14 @@
 // K5 search kernels: exact k-nearest neighbours by *packet traversal* — one wavefront walks the implicit
-// BVH once for its 64 Morton-adjacent queries. Included by knn_cov.hip (needs box_d2 and the covariance tail).
+// BVH once for its 64 curve-adjacent (Hilbert order) queries. Included by knn_cov.hip (needs box_d2 and the covariance tail).
 //
 // Why a packet: with one independent walk per lane the wavefront executes the union of 64 divergent walks and
 // pays the sorted-insert (the expensive part) on almost every visited point because *some* lane accepts it;
 // measured 2.45 ms per 131k-point cloud, vs 0.59 ms for the packet. Here every control decision is wave-uniform:
-//   * seed: the wavefront's own 64 points (8 consecutive leaves) are scored first, so every lane starts the walk
+//   * seed: the wavefront's own 64 points (64 / KNN_LEAF = 4 consecutive leaves of 16) are scored first, so every lane starts the walk
 //     with a finite search radius;
 //   * a node is expanded if ANY lane's search sphere reaches its box (ballot); of two live children the one
 //     nearer to the majority of interested lanes goes first, the other is pushed on ONE small per-wave stack in LDS;
-//   * node boxes and leaf points are fetched through wave-uniform addresses, so a leaf's 8 points are loaded
+//   * node boxes and leaf points are fetched through wave-uniform addresses, so a leaf's 16 points are loaded
 //     once per wave, not once per lane;
 //   * each lane keeps its k best as packed 64-bit keys  (float_bits(d2) << 32) | index : for non-negative floats
 //     the unsigned order of the key IS the (d2, index) lexicographic order of the oracle, and — the patterns being
@@ -48,7 +48,8 @@ ROLO_DEV int xcd_contiguous_block(int b, int G) {
 // clock builtin or a volatile asm before the loop is a potential memory clobber to the compiler: after it the wave-uniform box / leaf loads are
 // no longer provably unclobbered and turn into vector loads — 64 more VGPRs, spills, a 5-10x slower walk. That is what a first version measured.)
 #ifdef ROLO_KNN_STATS
-__device__ unsigned g_knn_wave_rec[16384][6];   // nodes, leaves, insert executions, pushes, start, end (100 MHz wall clock)
+__device__ unsigned g_knn_wave_rec[16384][8];   // nodes, leaves, insert executions, pushes, start, end (100 MHz wall clock), lanes live summed over the
+                                                 // insert executions, per-leaf maximum over the lanes of the candidates accepted at leaf entry (summed)
 #define KNN_STAT(x) x
 #else
 #define KNN_STAT(x)
@@ -64,22 +65,24 @@ ROLO_DEV int key_idx(double k) { return (int)(unsigned)((unsigned long long)__do
 // quieting) — our operands are never NaN by construction. Pure VALU, no memory: safe as inline asm.
 ROLO_DEV double vmin_f64(double a, double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 ROLO_DEV double vmax_f64(double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
-// score the 8 points of leaf g against this lane's query and insert the ones that beat its current k-th best
+// score the KNN_LEAF (16) points of leaf g against this lane's query and insert the ones that beat its current k-th best
 template <int KMAX>
 ROLO_DEV void knn_score_leaf(const float4* __restrict__ sorted, int g, const float4& q, double (&K)[KMAX], int kk, double& bkey, float& bd,
                              unsigned& n_ins, unsigned& lane_acc, unsigned& rounds) {
-  // fetch the whole leaf first: the address is wave-uniform, so these are 8 scalar loads in flight behind ONE wait
-  // (loading inside the loop serialised 8 scalar-cache round trips per leaf behind the insert branch)
+  // fetch the whole leaf first: the address is wave-uniform, so these are KNN_LEAF scalar loads in flight behind ONE wait
+  // (loading inside the loop serialised the scalar-cache round trips of a leaf behind the insert branch)
   float4 pts[KNN_LEAF];
 #pragma unroll
   for (int u = 0; u < KNN_LEAF; u++) pts[u] = sorted[KNN_LEAF * (size_t)g + u];
+  KNN_STAT(const double bkey0 = bkey; unsigned my_acc = 0;)   // accepted against the bound at leaf entry: what a per-lane queue would hold
 #pragma unroll
   for (int u = 0; u < KNN_LEAF; u++) {
     const float4 c = pts[u];
     const float dx = q.x - c.x, dy = q.y - c.y, dz = q.z - c.z;
     const float cd = ((dx * dx) + (dy * dy)) + (dz * dz);  // file is compiled with -ffp-contract=off
     const double ck = key_pack(cd, __float_as_int(c.w));
-    KNN_STAT(if (__any(ck < bkey)) n_ins++;)
+    KNN_STAT(if (__any(ck < bkey)) { n_ins++; lane_acc += (unsigned)__popcll(__ballot(ck < bkey)); })
+    KNN_STAT(if (ck < bkey0) my_acc++;)
     if (ck < bkey) {
       // sorted insert, descending slot order so every step reads not-yet-overwritten neighbours — in four tiers: a slot whose lower
       // neighbour is already <= the candidate in EVERY lane keeps its value (min(ck, K[s]) = K[s] and K[s-1] <= K[s]), so the lower tiers
@@ -106,6 +109,61 @@ ROLO_DEV void knn_score_leaf(const float4* __restrict__ sorted, int g, const flo
       bd = key_d2(bkey);
     }
   }
+#ifdef ROLO_KNN_STATS
+  { unsigned m = my_acc;   // wave maximum: the drain iterations of a per-lane queue for this leaf
+    for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off, 64));
+    rounds += m; }
+#endif
+}
+
+// The same leaf scored through a per-lane LDS queue (-DROLO_KNN_LANE_QUEUE, an A/B): every lane first appends the candidates that beat its
+// bound AT LEAF ENTRY to its own queue (16 predicated ds_write_b64), then the wavefront drains the queues together — one sorted insert per
+// iteration with ALL lanes live, max-over-lanes iterations instead of one partial-exec insert per point ANY lane accepts (the union over
+// lanes). A queued key that no longer beats the (tighter) bound when it is popped is a no-op in the min / max network, so the neighbour
+// lists are unchanged.
+template <int KMAX>
+ROLO_DEV void knn_score_leaf_queue(const float4* __restrict__ sorted, int g, const float4& q, double (&K)[KMAX], int kk, double& bkey, float& bd, double sentinel) {
+  // declared HERE, not passed in: through a (generic) pointer parameter the compiler no longer knows the stores go to LDS, every later
+  // wave-uniform leaf load becomes a potential clobber victim and turns into a vector load (128 VGPRs + 209 spilled: the clobber rule of DESIGN.md section 4)
+  __shared__ double qbuf_all[4][KNN_LEAF * 64];
+  double* qbuf = qbuf_all[threadIdx.x >> 6];
+  float4 pts[KNN_LEAF];
+#pragma unroll
+  for (int u = 0; u < KNN_LEAF; u++) pts[u] = sorted[KNN_LEAF * (size_t)g + u];
+  const int lane = threadIdx.x & 63;
+  int cnt = 0;
+#pragma unroll
+  for (int u = 0; u < KNN_LEAF; u++) {
+    const float4 c = pts[u];
+    const float dx = q.x - c.x, dy = q.y - c.y, dz = q.z - c.z;
+    float cd = ((dx * dx) + (dy * dy)) + (dz * dz);
+    asm("" : "+v"(cd), "+v"(cnt));   // one candidate at a time: without this ordering the 16 keys are formed up front (32 more VGPRs, 209 spills)
+    const double ck = key_pack(cd, __float_as_int(c.w));
+    if (ck < bkey) { qbuf[cnt * 64 + lane] = ck; cnt++; }
+  }
+  while (__any(cnt > 0)) {
+    double ck = sentinel;
+    if (cnt > 0) { cnt--; ck = qbuf[cnt * 64 + lane]; }
+    constexpr int T = KMAX / 4;
+#pragma unroll
+    for (int s = KMAX - 1; s >= 3 * T; s--) K[s] = vmax_f64(K[s - 1], vmin_f64(ck, K[s]));
+    if (__any(ck < K[3 * T - 1])) {
+#pragma unroll
+      for (int s = 3 * T - 1; s >= 2 * T; s--) K[s] = vmax_f64(K[s - 1], vmin_f64(ck, K[s]));
+      if (__any(ck < K[2 * T - 1])) {
+#pragma unroll
+        for (int s = 2 * T - 1; s >= T; s--) K[s] = vmax_f64(K[s - 1], vmin_f64(ck, K[s]));
+        if (__any(ck < K[T - 1])) {
+#pragma unroll
+          for (int s = T - 1; s >= 1; s--) K[s] = vmax_f64(K[s - 1], vmin_f64(ck, K[s]));
+          K[0] = vmin_f64(ck, K[0]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < KMAX; s++) if (s == kk - 1) bkey = K[s];
+  bd = key_d2(bkey);
 }
 
 // The walk keeps only the 20 packed keys and the query live (58 VGPRs): cut for 8 wavefronts per SIMD. Neighbour indices
@@ -148,10 +206,15 @@ __global__ __launch_bounds__(256, ROLO_KNN_WALK_OCC) void knn_walk_kernel(KnnPai
   float bd = active ? INFINITY : -1.0f;
   double bkey = active ? sentinel : key_pack(0.f, 0);
 
-  // ---- seed: the wavefront's own 8 leaves ----
+  // ---- seed: the wavefront's own 64 / KNN_LEAF leaves ----
   const int g_own0 = __builtin_amdgcn_readfirstlane(j / KNN_LEAF);  // lane 0 of the wave: j is a multiple of 64
   const int g_own1 = min(g_own0 + ROLO_KNN_PACKET / KNN_LEAF, n_leaves);
-  for (int g = g_own0; g < g_own1; g++) { knn_score_leaf<KMAX>(sorted, g, q, K, kk, bkey, bd, st_ins, st_lane, st_rounds); st_leaves++; }
+#ifdef ROLO_KNN_LANE_QUEUE
+#define KNN_SCORE(g) knn_score_leaf_queue<KMAX>(sorted, g, q, K, kk, bkey, bd, sentinel)
+#else
+#define KNN_SCORE(g) knn_score_leaf<KMAX>(sorted, g, q, K, kk, bkey, bd, st_ins, st_lane, st_rounds)
+#endif
+  for (int g = g_own0; g < g_own1; g++) { KNN_SCORE(g); st_leaves++; }
 
   // ---- packet walk ----
   // (a stack in one vector register — slot i in lane i, v_writelane / v_readlane — measured the same as this LDS stack: 0.202 vs 0.200 ms;
@@ -198,7 +261,7 @@ __global__ __launch_bounds__(256, ROLO_KNN_WALK_OCC) void knn_walk_kernel(KnnPai
       if (mr != 0ull) { h = 2 * h + 1; continue; }
     } else {
       const int g = h - P;
-      if (g < g_own0 || g >= g_own1) { knn_score_leaf<KMAX>(sorted, g, q, K, kk, bkey, bd, st_ins, st_lane, st_rounds); st_leaves++; }
+      if (g < g_own0 || g >= g_own1) { KNN_SCORE(g); st_leaves++; }
     }
     if (sp == 0) break;
     sp--;
@@ -209,7 +272,7 @@ __global__ __launch_bounds__(256, ROLO_KNN_WALK_OCC) void knn_walk_kernel(KnnPai
     const unsigned wid = blockIdx.x * 4 + (threadIdx.x >> 6);
     if ((threadIdx.x & 63) == 0 && wid < 16384) {
       g_knn_wave_rec[wid][0] = st_nodes; g_knn_wave_rec[wid][1] = st_leaves; g_knn_wave_rec[wid][2] = st_ins; g_knn_wave_rec[wid][3] = st_push;
-      g_knn_wave_rec[wid][4] = (unsigned)wt0; g_knn_wave_rec[wid][5] = (unsigned)wt1;
+      g_knn_wave_rec[wid][4] = (unsigned)wt0; g_knn_wave_rec[wid][5] = (unsigned)wt1; g_knn_wave_rec[wid][6] = st_lane; g_knn_wave_rec[wid][7] = st_rounds;
     } }
 #endif
   (void)st_nodes; (void)st_leaves; (void)st_ins; (void)st_lane; (void)st_rounds;
@@ -273,7 +336,7 @@ __global__ __launch_bounds__(256, ROLO_KNN_TAIL_OCC) void knn_tail_kernel(KnnPai
   if (fuse) {   // every lane of the wavefront takes part in the segmented fold
     int id = -1;
     if (act) { const int slot = vf.tgt_slot[qi]; if (slot >= 0) id = vf.tab.ids[slot]; }
-    accumulate_point(vf.tab, id, sp, c6, fix_scales(cl.n, vf.counters), true);
+    accumulate_point(vf.tab, id, sp, c6, fix_scales(cl.n, vf.counters), true, const_cast<int*>(vf.counters) + 1);
   }
 }
 

@@ -87,6 +87,7 @@ struct rolo_odom {
   struct Slot { double stamp = 0; int* h_counts = nullptr; hipEvent_t done = nullptr; } q[2];
   int q_head = 0, q_len = 0;
   bool reuse_cov = false, cov_chain = false;  // cov_chain: the context's target covariances belong to d_feat[old_buf]
+  bool fused_lm = true;   // ROLO_ODOM_FUSED_LM: one launch per LM trial for this driver's registrations (one frame at a time: the shortest chain)
   rolo_stats last_rot{}, last_trans{};
 };
 
@@ -117,7 +118,9 @@ int rolo_odom_create(rolo_ctx* ctx, float ct_lambda, rolo_odom** out) {
   if (!ctx || !out) return ROLO_EINVAL;
   rolo_odom* o = new rolo_odom();
   o->ctx = ctx; o->ct_lambda = ct_lambda;
-  rolo::ctx_set_fused_lm(ctx, 1);   // one frame at a time: the shortest LM chain (rolo_params.fused_lm)
+  // (rolo_params.fused_lm is NOT switched behind the caller's back here: the driver asserts its own option right before every registration it
+  // enqueues — a later rolo_set_params with the caller's own parameter block cannot silently revert it, nor does creating a driver change
+  // what a plain rolo_register_async on the same context does afterwards beyond the frames the driver itself runs)
   *out = o;
   return ROLO_OK;
 }
@@ -165,6 +168,7 @@ int rolo_odom_set_deskew(rolo_odom* o, const rolo_deskew* d, const float* rel_ti
 int rolo_odom_set_option(rolo_odom* o, int option, int value) {
   if (!o) return ROLO_EINVAL;
   if (option == ROLO_ODOM_REUSE_COVARIANCES) { o->reuse_cov = value != 0; o->cov_chain = false; return ROLO_OK; }
+  if (option == ROLO_ODOM_FUSED_LM) { o->fused_lm = value != 0; return ROLO_OK; }
   return ROLO_EINVAL;
 }
 
@@ -211,6 +215,7 @@ int rolo_odom_cloud(rolo_odom* o, double stamp, const float* corner, int n_corne
     double guess_t[3];  // Translation after the rotation stage = translation of T_interp * T_rot = that of T_interp
     for (int i = 0; i < 3; i++) guess_t[i] = (double)o->transformation_interpolated.m[i * 4 + 3];
     const double zero3[3] = {0, 0, 0};
+    rolo::ctx_set_fused_lm(o->ctx, o->fused_lm ? 1 : 0);
     if ((rc = rolo_register_async(o->ctx, nullptr, zero3, guess_t, o->TranslationOld, 0.1, 0.1, o->ct_lambda))) return rc;
     float Tf[16]; double reg_t[3];
     if ((rc = rolo_register_wait(o->ctx, Tf, nullptr, reg_t, &o->last_rot, &o->last_trans))) return rc;
@@ -310,6 +315,7 @@ int rolo_odom_collect(rolo_odom* o, float* pose6, double* rot9, double* trans3, 
     for (int i = 0; i < 3; i++) guess_t[i] = (double)o->transformation_interpolated.m[i * 4 + 3];
     const double zero3[3] = {0, 0, 0};
     o->cov_chain = false;
+    rolo::ctx_set_fused_lm(o->ctx, o->fused_lm ? 1 : 0);
     if ((rc = rolo_register_async(o->ctx, nullptr, zero3, guess_t, o->TranslationOld, 0.1, 0.1, o->ct_lambda))) return rc;
     float Tf[16]; double reg_t[3];
     if ((rc = rolo_register_wait(o->ctx, Tf, nullptr, reg_t, &o->last_rot, &o->last_trans))) return rc;

@@ -868,7 +868,7 @@ ROLO_DEV void reduce_rows_compact(const double* __restrict__ rows, int nrows, in
 }
 
 template <int DOF, int THREADS>
-__global__ __launch_bounds__(THREADS) void lm_kernel(PassArgs a, const LmState* __restrict__ st_in, LmState* __restrict__ st_out,
+__global__ __launch_bounds__(THREADS) void lm_kernel(PassArgs a, const LmState* st_in, LmState* st_out /* the closing launch of an even chunk passes st_in == st_out: no __restrict__ */,
                                                     const double* __restrict__ rows_in, double* __restrict__ rows_out, int nrows,
                                                     rolo_trace_rec* trace, int do_body, int ppt, LmState* pub) {
   __shared__ LmState sst;

@@ -356,6 +356,18 @@ using namespace rolo;
 
 #define SCHK(x) do { hipError_t _e = (x); if (_e != hipSuccess) { ctx_set_error((std::string(#x) + ": " + hipGetErrorString(_e)).c_str()); return ROLO_EHIP; } } while (0)
 
+namespace rolo {
+void** ctx_s2m_slot(rolo_ctx* c);   // api.hip
+struct S2mScratch { float4* feat = nullptr; double *part = nullptr, *sum = nullptr; unsigned char* sel = nullptr; float4* coeff = nullptr;
+                    size_t feat_cap = 0, part_cap = 0, sum_cap = 0, sel_cap = 0, coeff_cap = 0; };
+}  // namespace rolo
+extern "C" void rolo_s2m_destroy(rolo_ctx* c) {   // called by rolo_ctx_destroy
+  S2mScratch* W = static_cast<S2mScratch*>(*ctx_s2m_slot(c));
+  if (!W) return;
+  for (void* p : {(void*)W->feat, (void*)W->part, (void*)W->sum, (void*)W->sel, (void*)W->coeff}) if (p) (void)hipFree(p);
+  delete W; *ctx_s2m_slot(c) = nullptr;
+}
+
 extern "C" int rolo_scan2map_optimize(rolo_ctx* c, const float* corner, int n_corner, const float* surf, int n_surf, const float* map_corner, int m_corner,
                                       const float* map_surf, int m_surf, float* transformTobeMapped, int edge_min, int surf_min, rolo_scan2map_stats* stats,
                                       unsigned char* selected_out, float* coeff_out) {
@@ -366,18 +378,30 @@ extern "C" int rolo_scan2map_optimize(rolo_ctx* c, const float* corner, int n_co
   if (stats) *stats = st;
   // :689 — "if (laserCloudCornerLastDSNum > edgeFeatureMinValidNum && laserCloudSurfLastDSNum > surfFeatureMinValidNum)"
   if (!(n_corner > edge_min && n_surf > surf_min)) { st.skipped = 1; if (stats) *stats = st; return ROLO_OK; }
-  if (m_corner < 5 || m_surf < 5) { ctx_set_error("sub-maps need at least 5 points each"); return ROLO_ETOOFEW; }
+  // a sub-map without five points cannot answer a 5-NN query: the reference's association then selects nothing from it (and reads
+  // pointSearchSqDis[4] of a shorter result, :745 / :852) — nothing to optimise against; report it as skipped instead of an error
+  if (m_corner < 5 || m_surf < 5) { st.skipped = 2; if (stats) *stats = st; return ROLO_OK; }
   KnnPair maps{};
   int rc = ctx_build_map_trees(c, map_corner, m_corner, map_surf, m_surf, 4, &maps);
   if (rc) return rc;
   hipStream_t s = ctx_stream(c);
   const int n = n_corner + n_surf;
   const int grid = (n + S2M_THREADS - 1) / S2M_THREADS;
-  float4* d_feat = nullptr; double *d_part = nullptr, *d_sum = nullptr; unsigned char* d_sel = nullptr; float4* d_coeff = nullptr;
-  auto cleanup = [&]() { if (d_feat) (void)hipFree(d_feat); if (d_part) (void)hipFree(d_part); if (d_sum) (void)hipFree(d_sum); if (d_sel) (void)hipFree(d_sel); if (d_coeff) (void)hipFree(d_coeff); };
-  if (hipMalloc((void**)&d_feat, sizeof(float4) * (size_t)n) != hipSuccess || hipMalloc((void**)&d_part, sizeof(double) * S2M_NV * (size_t)grid) != hipSuccess ||
-      hipMalloc((void**)&d_sum, sizeof(double) * S2M_NV) != hipSuccess || (selected_out && hipMalloc((void**)&d_sel, (size_t)n) != hipSuccess) ||
-      (coeff_out && hipMalloc((void**)&d_coeff, sizeof(float4) * (size_t)n) != hipSuccess)) { cleanup(); ctx_set_error("hipMalloc failed (scan2map)"); return ROLO_EHIP; }
+  // scratch lives with the context and only grows: hipFree is a device-wide synchronisation that would stall the frames other contexts have in flight
+  S2mScratch* W = static_cast<S2mScratch*>(*ctx_s2m_slot(c));
+  if (!W) { W = new S2mScratch(); *ctx_s2m_slot(c) = W; }
+  auto grow = [&](void** p, size_t& cap, size_t bytes) -> bool {
+    if (bytes <= cap && *p) return true;
+    if (*p) { (void)hipFree(*p); *p = nullptr; cap = 0; }
+    const size_t want = bytes + bytes / 4 + 256;
+    if (hipMalloc(p, want) != hipSuccess) return false;
+    cap = want; return true;
+  };
+  if (!grow((void**)&W->feat, W->feat_cap, sizeof(float4) * (size_t)n) || !grow((void**)&W->part, W->part_cap, sizeof(double) * S2M_NV * (size_t)grid) ||
+      !grow((void**)&W->sum, W->sum_cap, sizeof(double) * S2M_NV) || (selected_out && !grow((void**)&W->sel, W->sel_cap, (size_t)n)) ||
+      (coeff_out && !grow((void**)&W->coeff, W->coeff_cap, sizeof(float4) * (size_t)n))) { ctx_set_error("hipMalloc failed (scan2map)"); return ROLO_EHIP; }
+  float4* d_feat = W->feat; double *d_part = W->part, *d_sum = W->sum; unsigned char* d_sel = selected_out ? W->sel : nullptr; float4* d_coeff = coeff_out ? W->coeff : nullptr;
+  auto cleanup = [&]() {};
   if (hipMemcpyAsync(d_feat, corner, sizeof(float4) * (size_t)n_corner, hipMemcpyHostToDevice, s) != hipSuccess ||
       hipMemcpyAsync(d_feat + n_corner, surf, sizeof(float4) * (size_t)n_surf, hipMemcpyHostToDevice, s) != hipSuccess) { cleanup(); ctx_set_error("upload failed (scan2map)"); return ROLO_EHIP; }
   S2mArgs A{};
@@ -397,7 +421,9 @@ extern "C" int rolo_scan2map_optimize(rolo_ctx* c, const float* corner, int n_co
     }
     A.srx = std::sin(tf[1]); A.crx = std::cos(tf[1]); A.sry = std::sin(tf[2]); A.cry = std::cos(tf[2]); A.srz = std::sin(tf[0]); A.crz = std::cos(tf[0]);
     s2m_kernel<<<grid, S2M_THREADS, 0, s>>>(A);
+    SCHK(hipGetLastError());
     s2m_sum_kernel<<<1, 64, 0, s>>>(d_part, grid, d_sum);
+    SCHK(hipGetLastError());
     if (hipMemcpyAsync(h_sum, d_sum, sizeof(h_sum), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { cleanup(); ctx_set_error("scan2map iteration failed"); return ROLO_EHIP; }
     st.iterations = iterCount + 1;
     st.n_selected = (int)(h_sum[27] + 0.5);
@@ -424,9 +450,8 @@ extern "C" int rolo_scan2map_optimize(rolo_ctx* c, const float* corner, int n_co
     if (deltaR < 0.05f && deltaT < 0.05f) { st.converged = 1; break; }
   }
   st.degenerate = isDegenerate ? 1 : 0;
-  if (selected_out) (void)hipMemcpy(selected_out, d_sel, (size_t)n, hipMemcpyDeviceToHost);
-  if (coeff_out) (void)hipMemcpy(coeff_out, d_coeff, sizeof(float4) * (size_t)n, hipMemcpyDeviceToHost);
-  cleanup();
+  if (selected_out) SCHK(hipMemcpy(selected_out, d_sel, (size_t)n, hipMemcpyDeviceToHost));
+  if (coeff_out) SCHK(hipMemcpy(coeff_out, d_coeff, sizeof(float4) * (size_t)n, hipMemcpyDeviceToHost));
   if (stats) *stats = st;
   return ROLO_OK;
 }

@@ -96,8 +96,19 @@ ROLO_DEV long long shfl_up_ll(long long v, int off) {
 // one point -> (id, 10 values) -> wave-level fold of runs of equal id -> one atomic per run and value.
 // fixed_cov: covariances go through the integer sums too (bounded entries); otherwise they keep fp64 atomics (options the
 // reference never selects, or covariances handed in by the caller: unbounded entries).
-ROLO_DEV void accumulate_point(const VoxelTable& tab, int id, const float4& p, const double (&c)[6], const FixScale& S, bool fixed_cov) {
+// err (counters + 1, may be nullptr): a point or covariance that cannot go through the fixed-point sums — non-finite (a degenerate
+// neighbourhood, e.g. PLANE_S with a zero singular-value sum; the reference's fp64 sums would carry the NaN into the voxel and on into H), or
+// an entry outside the bound the scale assumes — raises ROLO_ENONFINITE there instead of becoming a finite but wrong voxel.
+ROLO_DEV void accumulate_point(const VoxelTable& tab, int id, const float4& p, const double (&c)[6], const FixScale& S, bool fixed_cov, int* err = nullptr) {
   const int lane = threadIdx.x & 63;
+  if (id >= 0 && err) {
+    bool ok = fabsf(p.x) < INFINITY && fabsf(p.y) < INFINITY && fabsf(p.z) < INFINITY;   // false for NaN too
+    if (fixed_cov) {
+#pragma unroll
+      for (int d = 0; d < 6; d++) ok = ok && (fabs(c[d]) <= 1.0 + 1e-9);
+    }
+    if (!ok) *err = ROLO_ENONFINITE;
+  }
   long long q[10];
   double cv[6];
 #pragma unroll

@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void voxel_insert_kernel(const float4* __restr
 
 // wave-level segmented combine: lanes holding the same voxel id as their predecessor fold into the run head
 __global__ __launch_bounds__(256) void voxel_accum_kernel(const float4* __restrict__ pts, const double* __restrict__ cov, int n,
-                                                         VoxelTable tab, const int* __restrict__ tgt_slot, const int* __restrict__ counters, int fixed_cov) {
+                                                         VoxelTable tab, const int* __restrict__ tgt_slot, int* counters, int fixed_cov) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   int id = -1;
   float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void voxel_accum_kernel(const float4* __restri
       for (int d = 0; d < 6; d++) c[d] = cov[(size_t)d * n + i];
     }
   }
-  accumulate_point(tab, id, p, c, fix_scales(n, counters), fixed_cov != 0);
+  accumulate_point(tab, id, p, c, fix_scales(n, counters), fixed_cov != 0, counters + 1);
 }
 
 // ---- the same two kernels over the target in MORTON order (CloudDev::sorted of the neighbour search) -----------------
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void voxel_insert_sorted_kernel(const float4* 
 }
 
 __global__ __launch_bounds__(256) void voxel_accum_sorted_kernel(const float4* __restrict__ sorted, const double* __restrict__ cov, int n, int n_sorted,
-                                                                VoxelTable tab, const int* __restrict__ slot_sorted, const int* __restrict__ counters, int fixed_cov) {
+                                                                VoxelTable tab, const int* __restrict__ slot_sorted, int* counters, int fixed_cov) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   int id = -1;
   float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) void voxel_accum_sorted_kernel(const float4* _
       for (int d = 0; d < 6; d++) c[d] = cov[(size_t)d * n + i];
     }
   }
-  accumulate_point(tab, id, p, c, fix_scales(n, counters), fixed_cov != 0);
+  accumulate_point(tab, id, p, c, fix_scales(n, counters), fixed_cov != 0, counters + 1);
 }
 
 __global__ __launch_bounds__(256) void voxel_finalize_kernel(VoxelTable tab, const int* counters, int n_pts, int fixed_cov, int* pub_counters) {

@@ -15,7 +15,7 @@ class LidarOdometry:
     def __init__(self, device: int = 0, ct_lambda: float = 0.3, polar_resolution=(0.175, 0.175, 2.0)):
         self.reg = RotVGICP(device)
         self.reg.setPolarResolution(*polar_resolution)  # lidarOdometry.cpp:462
-        self.reg.setFusedLm(True)   # one frame at a time: one launch per LM trial (rolo_params.fused_lm)
+        # (one launch per LM trial is the driver's own option, ROLO_ODOM_FUSED_LM, on by default: nothing to set on the operator)
         h = C.c_void_p()
         check(lib().rolo_odom_create(self.reg._h, ct_lambda, C.byref(h)), "rolo_odom_create")
         self._h = h
@@ -33,6 +33,7 @@ class LidarOdometry:
             pass
 
     REUSE_COVARIANCES = 1
+    FUSED_LM = 2
 
     def setDeskew(self, dsk, rel_time):
         """deskewPoint for the next submit() / frame(): rel_time[i] = fabs(point.time) of raw point i (numpy array)."""

@@ -188,3 +188,33 @@ def test_deskew_with_azimuth_times():
     assert pg["n"] == po["n"] and np.array_equal(pg["point_col_ind"], po["point_col_ind"]) and np.array_equal(pg["point_range"], po["point_range"])
     assert np.abs(po["extracted"][:, :3] - raw["extracted"][:, :3]).max() > 0.05
     assert np.abs(pg["extracted"][:, :3] - po["extracted"][:, :3]).max() <= 6e-6
+
+
+def test_load_projection_refuses_indices_that_would_leave_the_arrays():
+    """rolo_front_load_projection (the feature node's input when it runs as its own process): startRingIndex / endRingIndex / pointColInd are
+    used as array indices on the device — a malformed rolo/cloud_info is ROLO_EINVAL, not an out-of-bounds access."""
+    import ctypes as C
+    from rolo_amd._lib import lib, FrontParams
+    from rolo_amd.rotvgicp import RotVGICP
+    g = RotVGICP()
+    P = FrontParams(); lib().rolo_front_default_params(C.byref(P)); P.n_scan = 16; P.horizon_scan = 1800
+    n = 1000
+    ext = np.zeros((n, 4), np.float32); col = (np.arange(n) % 1800).astype(np.int32); rng = np.ones(n, np.float32)
+    cnt = np.linspace(0, n, 17).astype(np.int32)
+    start = (cnt[:-1] - 1 + 5).astype(np.int32); end = (cnt[1:] - 1 - 5).astype(np.int32)
+    fp, ip = C.POINTER(C.c_float), C.POINTER(C.c_int32)
+
+    def call(s_, e_, c_):
+        return lib().rolo_front_load_projection(g._h, C.byref(P), ext.ctypes.data_as(fp), c_.ctypes.data_as(ip), rng.ctypes.data_as(fp), s_.ctypes.data_as(ip), e_.ctypes.data_as(ip), n)
+    assert call(start, end, col) == 0
+    bad = start.copy(); bad[3] = 10 ** 6
+    assert call(bad, end, col) == -1
+    bad = end.copy(); bad[15] = n + 50
+    assert call(start, bad, col) == -1
+    bad = end.copy(); bad[2] = -100
+    assert call(start, bad, col) == -1
+    bad = col.copy(); bad[17] = 1800
+    assert call(start, end, bad) == -1
+    bad = col.copy(); bad[0] = -1
+    assert call(start, end, bad) == -1
+    g.close()

@@ -396,7 +396,7 @@ def test_async_register_equals_two_calls(pair):
     _, g2 = make_both(src, tgt, cfg, fixed=20)
     g2.register_async(None, np.zeros(3), G, L0)
     Tf, Td, t2 = g2.register_wait()
-    # same kernels in the same order; only the fp64 atomic accumulation order of the voxel map may differ
+    # same kernels in the same order (the voxel sums are order-independent 64-bit integers: nothing in the two runs may differ beyond rounding)
     assert np.abs(Td - T1).max() < 1e-12 and np.abs(t2 - t1).max() < 1e-12
     assert g2.last_stats.n_outer == 20
 
@@ -509,7 +509,7 @@ def test_full_size_properties(sensor, leaf):
     assert g.last_stats.n_outer == 20
     assert np.abs(T1[:3, :3] @ T1[:3, :3].T - np.eye(3)).max() < 1e-12 and np.all(T1[:3, 3] == 0)
     g.align()
-    assert np.abs(g.final_transformation_d - T1).max() < 1e-10   # the voxel sums are fp64 atomics: the order of additions is free
+    assert np.abs(g.final_transformation_d - T1).max() < 1e-10   # (the voxel sums are order-independent integers; the tolerance covers the different row shapes of the passes)
     # (5) and agrees with the oracle end to end at full size
     p = pyorc.default_params(voxel_type=1, voxel_resolution=leaf, fixed_iterations=20)
     o = pyorc.Reg(p); o.set_target(tgt); o.set_source(src)
@@ -632,6 +632,109 @@ def test_context_pool_hands_out_fresh_objects():
     g.setInputTarget(tgt); g.setInputSource(tgt.copy()); g.computeCovariances()
     assert np.array_equal(c2.reshape(-1, 4, 4), g.getTargetCovariances())
     L.rolo_ctx_release(h2); L.rolo_ctx_pool_clear(); g.close()
+
+
+@pytest.mark.parametrize("guess_deg", [0.0, 4.0])
+def test_fused_lm_equals_pass_plus_controller_launches(guess_deg):
+    """rolo_params.fused_lm (one launch per LM trial) against the pass + controller launches on every driver that can run it: rolo_align +
+    rolo_compute_translation (synchronous chunks of 8 — an EVEN chunk, whose closing launch reads and writes the same state buffer — and, with
+    a guess 4 degrees off, several top-up chunks), and rolo_register_async (odd first schedule, top-ups in rolo_register_wait). Same trial
+    sequence, poses equal to rounding (the two forms sum the per-workgroup rows in different shapes)."""
+    src, tgt, cfg = make_pair("os64_uniform")
+    guess = np.eye(4, dtype=np.float32); guess[:3, :3] = synth.rpy_to_R(0.0, 0.0, np.deg2rad(guess_deg))
+    out = []
+    for fused in (0, 1):
+        g = RotVGICP(); g.setResolution(cfg["leaf"]); g.setFusedLm(bool(fused)); g.setUseGraph(False)
+        g.setInputTarget(tgt); g.setInputSource(src)
+        g.align(guess)
+        Td = g.final_transformation_d.copy(); st = (g.last_stats.n_outer, g.last_stats.n_passes, g.last_stats.converged)
+        t = g.computeTranslation(np.zeros(3), G, L0)
+        tr = g.trace()
+        g2 = RotVGICP(); g2.setResolution(cfg["leaf"]); g2.setFusedLm(bool(fused)); g2.setUseGraph(False)
+        res = []
+        for k in range(3):   # frame 1: first schedule from the defaults; later frames: from the hints (odd / even lengths both occur)
+            g2.setInputTarget(tgt.copy()); g2.setInputSource(src.copy())
+            g2.register_async(guess, np.zeros(3), G, L0)
+            Tf2, Td2, t2 = g2.register_wait()
+            res.append((Td2.copy(), t2.copy(), g2.last_stats.n_passes, g2.last_translation_stats.n_passes))
+        out.append((Td, st, t, tr, res, g2.counters()))
+        g.close(); g2.close()
+    (Ta, sa, ta, tra, ra, ca), (Tb, sb, tb, trb, rb, cb) = out
+    assert sa == sb and len(tra) == len(trb)
+    assert [(r["stage"], r["outer"], r["trial"], r["accepted"]) for r in tra] == [(r["stage"], r["outer"], r["trial"], r["accepted"]) for r in trb]
+    assert np.abs(Ta - Tb).max() < 1e-11 and np.abs(ta - tb).max() < 1e-11
+    for (Tda, t_a, pa, qa), (Tdb, t_b, pb, qb) in zip(ra, rb):
+        assert (pa, qa) == (pb, qb) and np.abs(Tda - Tdb).max() < 1e-11 and np.abs(t_a - t_b).max() < 1e-11
+        assert np.abs(Tda - Ta).max() < 1e-11   # and the asynchronous driver agrees with the synchronous ones
+    if guess_deg > 0:
+        assert sa[1] > 8   # the rotation stage did need more than the first chunk: the top-up path ran
+
+
+def test_non_finite_covariance_in_the_voxel_build_is_an_error():
+    """a NaN covariance (degenerate neighbourhood) must not become a finite but wrong voxel: ROLO_ENONFINITE (-11)"""
+    from rolo_amd._lib import RoloError
+    src, tgt, cfg = make_pair("vlp16_polar")
+    g = RotVGICP(); g.setPolarResolution(0.175, 0.175, 2.0)
+    g.setInputTarget(tgt); g.setInputSource(src)
+    g.computeCovariances()
+    ct = g.getTargetCovariances().copy(); ct[7, :3, :3] = np.nan
+    g.setTargetCovariances(ct)     # handed-in covariances go through fp64 atomics: the NaN propagates as in the reference (no error)
+    g.buildVoxelMap()
+    g2 = RotVGICP(); g2.setPolarResolution(0.175, 0.175, 2.0)
+    bad = tgt.copy(); bad[5, 0] = np.inf
+    g2.setInputTarget(bad); g2.setInputSource(src)
+    with pytest.raises(RoloError) as ei:
+        g2.register_async(None, np.zeros(3), G, L0); g2.register_wait()
+    assert ei.value.code in (-11, -10)   # the non-finite point is caught by the fixed-point sums or, first, by the key range check
+    g.close(); g2.close()
+
+
+def test_config5_distinct_full_size_pairs_through_four_contexts_with_graph_replay():
+    """BASELINE configs[4] in its one-GPU form, under pytest: 32 DISTINCT full-size OS1-64 pairs (65 536 points per cloud, seeds 20260926 + i,
+    motions U(+-2 deg), U(+-0.4 m)), UNIFORM leaf 1.0 m, 20 SO(3) LM iterations + CT translation, resident in HBM, streamed through four
+    contexts that replay the hipGraph of their frame — EVERY pose against the oracle (bar: 1e-5 rad / 1e-4 m)."""
+    import multiprocessing as mp
+    import torch
+    import bench
+    npairs = 32
+    with mp.get_context("spawn").Pool(min(bench.usable_cores(), 16)) as pool:
+        pairs = pool.map(bench._config5_pair, list(range(npairs)), chunksize=2)
+    dev = [(torch.from_numpy(s).cuda(), torch.from_numpy(t).cuda(), s.shape[0], t.shape[0]) for s, t in pairs]
+    assert all(d[2] == 65536 and d[3] == 65536 for d in dev)
+    ctxs = []
+    for _ in range(4):
+        g = RotVGICP(); g.setResolution(1.0); g.setFixedIterations(20); ctxs.append(g)
+    zero3 = np.zeros(3)
+    results = [None] * npairs
+
+    def enqueue(g, k):
+        s, t, ns, nt = dev[k]
+        g.setInputTargetDevice(t.data_ptr(), nt, 4); g.setInputSourceDevice(s.data_ptr(), ns, 4)
+        g.register_async(None, zero3, G, L0, 0.1, 0.1, 0.3)
+    for sweep in range(2):   # the second sweep runs on replayed graphs throughout
+        nxt = 0; inflight = []
+        for g in ctxs:
+            enqueue(g, nxt); inflight.append((g, nxt)); nxt += 1
+        while inflight:
+            g, k = inflight.pop(0)
+            Tf, Td, t = g.register_wait()
+            results[k] = (Td.copy(), t.copy())
+            if nxt < npairs:
+                enqueue(g, nxt); inflight.append((g, nxt)); nxt += 1
+    cnt = [g.counters() for g in ctxs]
+    assert sum(c["graph_replays"] for c in cnt) >= npairs   # the graphs were replayed, not re-captured frame after frame
+    p = pyorc.default_params(voxel_type=pyorc.VOXEL_UNIFORM, voxel_resolution=1.0, fixed_iterations=20, num_threads=bench.usable_cores())
+    worst_r = worst_t = 0.0
+    for k in range(npairs):
+        o = pyorc.Reg(p); o.set_target(pairs[k][1]); o.set_source(pairs[k][0])
+        rc, _, Td, _, _ = o.align(); rc2, to, _ = o.compute_translation(np.zeros(3), G, L0)
+        assert rc == 0 and rc2 == 0
+        Tg, tg = results[k]
+        dR = Tg[:3, :3] @ Td[:3, :3].T
+        worst_r = max(worst_r, float(np.arccos(np.clip((np.trace(dR) - 1) / 2, -1, 1)))); worst_t = max(worst_t, float(np.abs(tg - to).max()))
+    assert worst_r <= 1e-5 and worst_t <= 1e-4, (worst_r, worst_t)
+    for g in ctxs:
+        g.close()
 
 
 def test_graph_replay_equals_eager():
