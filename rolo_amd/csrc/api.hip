@@ -460,10 +460,10 @@ int enqueue_pass(rolo_ctx* c, const PassArgs& a, int grid, int stage, bool publi
     HIPCHK(launch_reduce(c->partials, grid, c->sums, c->state, stage, c->stream));
     int e = g_rccl.AllReduce(c->sums, c->sums, NV_MAX, NCCL_FLOAT64, NCCL_SUM, c->comm, c->stream);
     if (e != 0) { g_err = std::string("ncclAllReduce: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "?"); return ROLO_ECOMM; }
-    HIPCHK(launch_ctrl(c->state, nullptr, 0, c->sums, c->trace, stage, c->stream, publish ? c->h_state : nullptr));
+    HIPCHK(launch_ctrl(c->state, nullptr, 0, c->sums, c->trace, stage, c->stream, publish ? c->h_state : nullptr, nullptr, c->P.optimizer == ROLO_OPT_SO3_LM ? 3 : 6));
   } else {
     // with peers the controller itself exchanges its row sums through the mailboxes: still ONE launch, still graph-capturable
-    HIPCHK(launch_ctrl(c->state, c->partials, grid, nullptr, c->trace, stage, c->stream, publish ? c->h_state : nullptr, peer_args(c)));
+    HIPCHK(launch_ctrl(c->state, c->partials, grid, nullptr, c->trace, stage, c->stream, publish ? c->h_state : nullptr, peer_args(c), c->P.optimizer == ROLO_OPT_SO3_LM ? 3 : 6));
   }
   return ROLO_OK;
 }

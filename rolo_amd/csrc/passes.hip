@@ -22,6 +22,7 @@
 #include "voxel_dev.hpp"
 #include "peer_dev.hpp"
 #include <cfloat>
+#include <cstdlib>
 #include <type_traits>
 
 namespace rolo {
@@ -456,6 +457,34 @@ ROLO_DEV void ldlt_solve(const double* Hfull /* 6x6 storage, row stride 6 */, do
   for (int i = 0; i < N; i++) x[i] = y[i];
 }
 
+// sin / cos of a small angle by their Taylor series (|x| <= 0.5: the 10th term is below 2e-23 relative) — the half angle of an LM step is
+// a few 1e-2 at most; the library sincos() is ~150 instructions of range reduction on the controller's one serial lane. Agrees with libm
+// to the last ulp or two, far inside what the LM decisions can see (the oracle comparison of the traces is the test).
+ROLO_DEV void sincos_small(double x, double* s, double* c) {
+  if (fabs(x) > 0.5) { sincos(x, s, c); return; }
+  const double z = x * x;
+  double ps = -1.0 / 121645100408832000.0;            // -1/19!
+  ps = fma(ps, z, 1.0 / 355687428096000.0);           //  1/17!
+  ps = fma(ps, z, -1.0 / 1307674368000.0);            // -1/15!
+  ps = fma(ps, z, 1.0 / 6227020800.0);                //  1/13!
+  ps = fma(ps, z, -1.0 / 39916800.0);                 // -1/11!
+  ps = fma(ps, z, 1.0 / 362880.0);                    //  1/9!
+  ps = fma(ps, z, -1.0 / 5040.0);                     // -1/7!
+  ps = fma(ps, z, 1.0 / 120.0);                       //  1/5!
+  ps = fma(ps, z, -1.0 / 6.0);                        // -1/3!
+  *s = fma(x * z, ps, x);
+  double pc = 1.0 / 6402373705728000.0;               //  1/18!
+  pc = fma(pc, z, -1.0 / 20922789888000.0);           // -1/16!
+  pc = fma(pc, z, 1.0 / 87178291200.0);               //  1/14!
+  pc = fma(pc, z, -1.0 / 479001600.0);                // -1/12!
+  pc = fma(pc, z, 1.0 / 3628800.0);                   //  1/10!
+  pc = fma(pc, z, -1.0 / 40320.0);                    // -1/8!
+  pc = fma(pc, z, 1.0 / 720.0);                       //  1/6!
+  pc = fma(pc, z, -1.0 / 24.0);                       // -1/4!
+  pc = fma(pc, z, 0.5);                               //  1/2!
+  *c = fma(-z, pc, 1.0);
+}
+
 ROLO_DEV void so3_exp_R(const double* w, double* R) {  // so3.hpp:59-77 + Quaterniond::toRotationMatrix
   const double theta_sq = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
   double imag, real;
@@ -466,7 +495,7 @@ ROLO_DEV void so3_exp_R(const double* w, double* R) {  // so3.hpp:59-77 + Quater
   } else {
     const double theta = sqrt(theta_sq), half = 0.5 * theta;
     double sh, ch;
-    sincos(half, &sh, &ch);
+    sincos_small(half, &sh, &ch);
     imag = sh / theta;
     real = ch;
   }
@@ -718,7 +747,10 @@ __device__ unsigned long long g_ctrl_t[8];   // accumulated shader-clock ticks p
 #endif
 // pub: pinned host copy of the state, written by the LAST controller launch of a frame's schedule whether or not it has a step to take
 // (replaces a device-to-host copy launch per frame)
-template <bool PEER = false>
+// MODE: -1 = decided at run time from `stage` and the state's optimizer (batched launches); 0 = rotation stage, SO(3) optimiser; 1 = rotation
+// stage, 6-dof optimisers; 2 = translation stage. The specialised instances carry ONE step function instead of four: the generic kernel
+// is ~11 k instructions of which a launch executes ~700 along a branchy path — on a cold instruction cache every taken branch is a fetch.
+template <bool PEER = false, int MODE = -1>
 ROLO_DEV void ctrl_body(LmState* st, const double* __restrict__ partials, int nblocks, const double* __restrict__ sums_in,
                         rolo_trace_rec* trace, int stage, LmState* pub = nullptr, const PeerArgs* peer = nullptr) {
   __shared__ double sums[NV_MAX];
@@ -795,7 +827,10 @@ ROLO_DEV void ctrl_body(LmState* st, const double* __restrict__ partials, int nb
     // (the step on a private copy of the whole state instead of LDS: 256 VGPRs + 396 B of scratch, 2.2 -> 7.1 us)
     if (!peer_ok) {   // a peer did not answer within the timeout: end the registration with ROLO_ECOMM instead of waiting forever
       sst.error = ROLO_ECOMM; sst.stage = 0; sst.rot_done = 1; sst.rot_failed = 1; sst.trans_done = 1; sst.trans_failed = 1;
-    } else if (stage == 1) rot_step(&sst, sums, trace);
+    } else if constexpr (MODE == 0) rot_step_t<3>(&sst, sums, trace);
+    else if constexpr (MODE == 1) rot_step_t<6>(&sst, sums, trace);
+    else if constexpr (MODE == 2) trans_step(&sst, sums, trace);
+    else if (stage == 1) rot_step(&sst, sums, trace);
     else trans_step(&sst, sums, trace);
   }
   __syncthreads();
@@ -821,13 +856,15 @@ extern "C" int rolo_debug_ctrl_times(unsigned long long* out8) {
 }
 #endif
 
+template <int MODE>
 __global__ __launch_bounds__(256) void ctrl_kernel(LmState* st, const double* __restrict__ partials, int nblocks,
                                                   const double* __restrict__ sums_in, rolo_trace_rec* trace, int stage, LmState* pub) {
-  ctrl_body(st, partials, nblocks, sums_in, trace, stage, pub);
+  ctrl_body<false, MODE>(st, partials, nblocks, sums_in, trace, stage, pub);
 }
+template <int MODE>
 __global__ __launch_bounds__(256) void ctrl_peer_kernel(LmState* st, const double* __restrict__ partials, int nblocks, rolo_trace_rec* trace, int stage,
                                                        LmState* pub, PeerArgs peer) {
-  ctrl_body<true>(st, partials, nblocks, nullptr, trace, stage, pub, &peer);
+  ctrl_body<true, MODE>(st, partials, nblocks, nullptr, trace, stage, pub, &peer);
 }
 __global__ __launch_bounds__(256) void ctrl_batch_kernel(const BatchSlot* __restrict__ slots, int stage) {
   const BatchSlot& S = slots[blockIdx.x];
@@ -1082,9 +1119,16 @@ hipError_t launch_reduce(const double* partials, int nblocks, double* sums, cons
   return hipGetLastError();
 }
 hipError_t launch_ctrl(LmState* st, const double* partials, int nblocks, const double* sums, rolo_trace_rec* trace, int stage, hipStream_t s, LmState* pub,
-                       const PeerArgs* peer) {
-  if (peer && peer->world > 1 && partials) ctrl_peer_kernel<<<1, 256, 0, s>>>(st, partials, nblocks, trace, stage, pub, *peer);
-  else ctrl_kernel<<<1, 256, 0, s>>>(st, partials, nblocks, sums, trace, stage, pub);
+                       const PeerArgs* peer, int dof) {
+  static const bool generic = [] { const char* e = getenv("ROLO_CTRL_GENERIC"); return e && atoi(e) != 0; }();   // A/B: the one-size-fits-all kernel of round 2
+  const int mode = generic ? -1 : (stage == 2 ? 2 : (dof == 3 ? 0 : (dof == 6 ? 1 : -1)));
+  const bool p = peer && peer->world > 1 && partials;
+  switch (mode) {
+    case 0: if (p) ctrl_peer_kernel<0><<<1, 256, 0, s>>>(st, partials, nblocks, trace, stage, pub, *peer); else ctrl_kernel<0><<<1, 256, 0, s>>>(st, partials, nblocks, sums, trace, stage, pub); break;
+    case 1: if (p) ctrl_peer_kernel<1><<<1, 256, 0, s>>>(st, partials, nblocks, trace, stage, pub, *peer); else ctrl_kernel<1><<<1, 256, 0, s>>>(st, partials, nblocks, sums, trace, stage, pub); break;
+    case 2: if (p) ctrl_peer_kernel<2><<<1, 256, 0, s>>>(st, partials, nblocks, trace, stage, pub, *peer); else ctrl_kernel<2><<<1, 256, 0, s>>>(st, partials, nblocks, sums, trace, stage, pub); break;
+    default: if (p) ctrl_peer_kernel<-1><<<1, 256, 0, s>>>(st, partials, nblocks, trace, stage, pub, *peer); else ctrl_kernel<-1><<<1, 256, 0, s>>>(st, partials, nblocks, sums, trace, stage, pub);
+  }
   return hipGetLastError();
 }
 hipError_t launch_rot_begin(LmState* st, const RotBegin& a, hipStream_t s) {

@@ -178,8 +178,9 @@ hipError_t launch_reduce(const double* partials, int nblocks, double* sums, cons
 // controller: sums the rows of `partials` itself (single GPU) or takes all-reduced `sums` (partials == nullptr)
 // pub != nullptr: also leave the state in that (pinned host) copy, step or no step
 // peer != nullptr (world > 1): the row sums go through the peer exchange before the step (every rank sums all ranks' values in rank order)
+// dof: 3 / 6 = degrees of freedom of the rotation-stage optimiser (picks the specialised controller), 0 = unknown (generic kernel)
 hipError_t launch_ctrl(LmState* st, const double* partials, int nblocks, const double* sums, rolo_trace_rec* trace, int stage, hipStream_t s, LmState* pub = nullptr,
-                       const PeerArgs* peer = nullptr);
+                       const PeerArgs* peer = nullptr, int dof = 0);
 // peer.hip: sums[NV_MAX] (device) <- sum over the ranks, in rank order (stage-level evaluations); *err_flag (device int) is set on a timeout
 hipError_t launch_peer_allreduce(double* sums, const PeerArgs& peer, int* err_flag, hipStream_t s);
 // peer.hip: covariance exchange of one frame — push the own segment [rank * seg_doubles, +seg_doubles) of the local exchange area (area_off

@@ -645,12 +645,16 @@ def test_fused_lm_equals_pass_plus_controller_launches(guess_deg):
     out = []
     for fused in (0, 1):
         g = RotVGICP(); g.setResolution(cfg["leaf"]); g.setFusedLm(bool(fused)); g.setUseGraph(False)
+        if guess_deg > 0:
+            g.setRotationEpsilon(1e-9); g.setInitialLambdaFactor(100.0)   # heavily damped steps, iterated long after the reference's 2e-3 would stop: more passes than the first chunk of 8 holds
         g.setInputTarget(tgt); g.setInputSource(src)
         g.align(guess)
         Td = g.final_transformation_d.copy(); st = (g.last_stats.n_outer, g.last_stats.n_passes, g.last_stats.converged)
         t = g.computeTranslation(np.zeros(3), G, L0)
         tr = g.trace()
         g2 = RotVGICP(); g2.setResolution(cfg["leaf"]); g2.setFusedLm(bool(fused)); g2.setUseGraph(False)
+        if guess_deg > 0:
+            g2.setRotationEpsilon(1e-9); g2.setInitialLambdaFactor(100.0)
         res = []
         for k in range(3):   # frame 1: first schedule from the defaults; later frames: from the hints (odd / even lengths both occur)
             g2.setInputTarget(tgt.copy()); g2.setInputSource(src.copy())
