@@ -65,8 +65,12 @@ def parse():
     ap.add_argument("--pool", type=int, default=8,
                     help="DISTINCT frame pairs resident in HBM that the contexts rotate through (pair 0 = the nominal pair of SURVEY 8d; "
                          "1 = every context registers the same pair over and over, round 2's headline)")
-    ap.add_argument("--shard-exchange", default="peer", choices=["peer", "rccl", "both"],
-                    help="sharded leg / --mode shard: peer = mailbox exchange inside the controller kernel (rolo_peer_*), rccl = ncclAllReduce per pass")
+    ap.add_argument("--shard-exchange", default="peer", choices=["peer", "rccl", "both", "peer-inproc"],
+                    help="sharded leg: peer = mailbox exchange inside the controller kernel (rolo_peer_*), ranks in CHILD processes (handles through files, no "
+                         "torch / RCCL: a crash or a hang there cannot take the bench line down); peer-inproc = the same inside the torch.distributed ranks; "
+                         "rccl = ncclAllGather + ncclAllReduce per pass inside the ranks; both = peer + rccl. --mode shard uses peer-inproc or rccl")
+    ap.add_argument("--sharded-children-test", type=int, default=0,
+                    help="self-test on a one-GPU box: run the sharded leg's child ranks (this many) all on device 0, print their results and exit")
     ap.add_argument("--batch", type=int, default=int(os.environ.get("ROLO_BENCH_BATCH", "1")),
                     help="frame pairs per registration call (rolo_batch_*: shared LM launches); 1 = one operator per frame")
     return ap.parse_args()
@@ -243,6 +247,30 @@ def shim_leg(tmp="/tmp"):
             "ms_unpooled_ctx_create_destroy": float(c), "results_identical_across_frames": sa == "1" and sb == "1"}
 
 
+def sharded_children(world, sensor, frames, leaf, timeout=420, one_device=False):
+    """BASELINE configs[3] through the peer exchange with one CHILD process per GPU (python -m rolo_amd.peerbench: the C ABI only, mailbox handles
+    and barriers through files). Returns the per-rank dicts or {"error": ...}; a crashed or hung child is killed and reported, never propagated."""
+    import tempfile
+    d = tempfile.mkdtemp(prefix="rolo_sharded_")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK", "LOCAL_WORLD_SIZE", "TORCHELASTIC_RUN_ID"):
+        env.pop(k, None)
+    procs = [subprocess.Popen([sys.executable, "-m", "rolo_amd.peerbench", str(r), str(world), d, sensor, str(frames), str(leaf), str(0 if one_device else r)], env=env, cwd=ROOT,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+    t0 = time.time(); out = [b""] * world
+    try:
+        for i, p in enumerate(procs):
+            out[i] = p.communicate(timeout=max(5.0, timeout - (time.time() - t0)))[0]
+    except subprocess.TimeoutExpired:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        return {"error": f"sharded child ranks did not finish within {timeout} s"}
+    if any(p.returncode != 0 for p in procs):
+        return {"error": "sharded child rank failed: " + " | ".join(f"rank {i} rc {p.returncode}: {o[-300:].decode(errors='replace')}" for i, (p, o) in enumerate(zip(procs, out)) if p.returncode != 0)}
+    return [json.load(open(os.path.join(d, f"res{r}.json"))) for r in range(world)]
+
+
 def _config5_pair(i):
     """pair i of BASELINE configs[4]: seed 20260926 + i, motion drawn U(+-2 deg), U(+-0.4 m)"""
     from rolo_amd import synth
@@ -370,6 +398,9 @@ def cpu_baseline_legs(args, src, tgt, guess, last):
 
 def main():
     args = parse()
+    if args.sharded_children_test > 1:
+        print(json.dumps(sharded_children(args.sharded_children_test, "os1-128x2048", max(5, args.steps // 2), args.leaf, one_device=True)))
+        return
     maybe_spawn(args)
     import torch  # device memory, streams and torch.distributed only
     import torch.distributed as dist
@@ -537,7 +568,7 @@ def main():
     shard_info = None
     if args.mode == "shard" and world > 1:
         ctxs = [g]
-        shard_info = connect(g, "rccl" if args.shard_exchange == "rccl" else "peer", 2 * n)
+        shard_info = connect(g, "rccl" if args.shard_exchange in ("rccl", "both") else "peer", 2 * n)
         rccl_ranks = shard_info["ranks"]
     pass_log_on[0] = True
     dt, rounds = timed(ctxs, args.steps, args.warmup, data)
@@ -657,10 +688,38 @@ def main():
                               "note": "one frame: Hilbert sort / BVH / voxel map replicated on every rank, K5 searched by 1/W of the queries + exchange of the 48 B/pt "
                                       "covariances, LM passes over 1/W of the source points + exchange of 32 fp64 per pass (peer: mailbox words written by the controller kernel "
                                       "itself, summed in rank order, hipGraph replay; rccl: reduce launch + ncclAllReduce + controller launch per pass, eager)"}
+            def host_wait(tag):
+                """everybody waits for rank 0 on the HOST (the rendezvous store), not in an RCCL kernel: while the child ranks own the GPUs the
+                parents must not keep a collective's kernel spinning on them"""
+                store = dist.distributed_c10d._get_default_store()
+                if rank == 0:
+                    store.set(tag, "1")
+                else:
+                    store.wait([tag])
+
             for kind in kinds:
+                if kind == "peer":
+                    torch.cuda.synchronize()
+                    if rank == 0:
+                        res = sharded_children(world, "os1-128x2048", stp, args.leaf)
+                        if isinstance(res, dict):
+                            leg = res
+                        else:
+                            ms = max(r_["ms_per_frame"] for r_ in res)
+                            leg = {"value": 1e3 / ms, "unit": "scans/s", "ms_per_frame": ms, "passes": res[0]["passes"], "schedule": res[0]["counters"],
+                                   "exchange": "peer mailboxes (rolo_peer_*), one child process per GPU, hipGraph replay", "ranks": len(res), "mailbox_memory": res[0]["mailbox"],
+                                   "per_launch_us_rank0": {k_: res[0][k_]["mean"] for k_ in res[0] if k_.endswith("_us")},
+                                   "ranks_agree": all(r_["pose_head"] == res[0]["pose_head"] for r_ in res)}
+                    else:
+                        leg = None
+                    host_wait("rolo_sharded_children_done")
+                    barrier()
+                    if rank == 0:
+                        out["sharded"][kind] = leg
+                    continue
                 try:
                     gs = new_ctx(alone=True)
-                    info = connect(gs, kind, 2 * s2.shape[0])
+                    info = connect(gs, "peer" if kind == "peer-inproc" else kind, 2 * s2.shape[0])
                     dts, rds = timed(gs, stp, 2, d2)
                     leg = {"value": stp / dts, "unit": "scans/s", "ms_per_frame": 1e3 * dts / stp, "passes": gs.last_stats.n_passes + gs.last_translation_stats.n_passes,
                            "schedule": gs.counters()}
