@@ -328,7 +328,10 @@ int build_clouds(rolo_ctx* c, bool do_src, bool do_tgt, hipStream_t stream, bool
   if (c->src.bbox6 >= S.bbox && c->src.bbox6 < S.bbox + 12) c->src.bbox6 = nullptr;
   if (c->tgt.bbox6 >= S.bbox && c->tgt.bbox6 < S.bbox + 12) c->tgt.bbox6 = nullptr;
   VoxelFuse vf = c->vf;
-  vf.enabled = vf.enabled && do_tgt && !sharded && !tree_only && !fused_tail_env();
+  // sharded with every rank's covariances exchanged (peers / RCCL): the map is still built inside the search's launches — clear and insert ride
+  // on the key / sort launches each rank runs on the whole cloud anyway, the accumulation moves from the tail to the scatter after the exchange
+  const bool all_ranks = c->comm != nullptr || peers(c);
+  vf.enabled = vf.enabled && do_tgt && (!sharded || all_ranks) && !tree_only && !fused_tail_env();
   if (vf.enabled) { vf.which = do_src ? 1 : 0; vf.bbox6 = S.bbox + 6 * vf.which; vf.tgt_xyz = c->tgt.xyz; vf.n_tgt = c->tgt.n; }
   c->vf_done = vf.enabled != 0;
   { ProfScope ps(c, ROLO_PROF_KNN_BUILD, stream); HIPCHK(launch_knn_build(A, S.sort_tmp, tmp, S.keys0, S.keys1, S.vals0, S.vals1, S.bbox, vf, stream)); }
@@ -351,7 +354,7 @@ int build_clouds(rolo_ctx* c, bool do_src, bool do_tgt, hipStream_t stream, bool
       if (e != 0) { g_err = std::string("ncclAllGather: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "?"); return ROLO_ECOMM; }
     }
     // without a communicator / peers (rolo_set_shard test hook) only the own slice is valid afterwards
-    HIPCHK(launch_knn_unstage(A, c->comm == nullptr && !peers(c), stream));
+    HIPCHK(launch_knn_unstage(A, c->comm == nullptr && !peers(c), vf, stream));
   }
   if (do_src) { c->src.have_cov = true; c->src.have_sorted = true; c->src.cov_user = false; c->src.bbox6 = S.bbox; }
   if (do_tgt) { c->tgt.have_cov = true; c->tgt.have_sorted = true; c->tgt.cov_user = false; c->tgt.bbox6 = S.bbox + (do_src ? 6 : 0); }

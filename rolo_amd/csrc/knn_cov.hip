@@ -631,11 +631,13 @@ hipError_t launch_knn_walk(const KnnPair& A, int k, int regularization_or_minus1
   return hipGetLastError();
 }
 
-hipError_t launch_knn_unstage(const KnnPair& A, bool own_slice_only, hipStream_t s) {
+hipError_t launch_knn_unstage(const KnnPair& A, bool own_slice_only, const VoxelFuse& vf, hipStream_t s) {
   const int g0 = own_slice_only ? slice_blocks(A.c[0]) : (A.c[0].n_sorted + 255) / 256;
   const int g1 = A.n_clouds > 1 ? (own_slice_only ? slice_blocks(A.c[1]) : (A.c[1].n_sorted + 255) / 256) : 0;
   if (g0 + g1 == 0) return hipSuccess;
-  knn_unstage_kernel<<<g0 + g1, 256, 0, s>>>(A, g0, own_slice_only ? 1 : 0);
+  VoxelFuse v = vf;
+  if (own_slice_only) v.enabled = 0;   // a slice alone cannot build the map
+  knn_unstage_kernel<<<g0 + g1, 256, 0, s>>>(A, g0, own_slice_only ? 1 : 0, v);
   return hipGetLastError();
 }
 

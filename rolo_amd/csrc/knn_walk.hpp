@@ -314,7 +314,8 @@ __global__ __launch_bounds__(256, ROLO_KNN_TAIL_OCC) void knn_tail_kernel(KnnPai
   const KnnCloud& cl = A.c[which];
   const int n_sorted = cl.n_sorted;
   const int j = cl.q_begin + (blk - (which ? split : 0)) * 256 + threadIdx.x;
-  const bool fuse = vf.enabled && which == vf.which;   // workgroup-uniform: this workgroup's points also go into the voxel map
+  const bool fuse = vf.enabled && which == vf.which && !cl.stage;   // workgroup-uniform: this workgroup's points also go into the voxel map
+                                                                    // (sharded: only a slice is here — the scatter after the exchange accumulates)
   float4 sp = make_float4(0.f, 0.f, 0.f, 0.f);
   int qi = INT_MAX;
   if (j < cl.q_end) { sp = cl.sorted[j]; qi = __float_as_int(sp.w); }
@@ -340,18 +341,32 @@ __global__ __launch_bounds__(256, ROLO_KNN_TAIL_OCC) void knn_tail_kernel(KnnPai
   }
 }
 
-// exchange buffer -> cov[] (SoA by original index) for every sorted position (after the all-gather) or the own slice only
-__global__ __launch_bounds__(256) void knn_unstage_kernel(KnnPair A, int split, int own_only) {
+// exchange buffer -> cov[] (SoA by original index) for every sorted position (after the all-gather) or the own slice only.
+// vf.enabled (sharded registration with all ranks' covariances present): the target's points also go into the voxel map right here —
+// the covariance is in registers, the positions come in curve order (long runs of equal voxels per wavefront) — as the tail kernel does on
+// one GPU; clear + insert rode on the key / sort launches, which every rank runs on the whole cloud anyway.
+__global__ __launch_bounds__(256) void knn_unstage_kernel(KnnPair A, int split, int own_only, VoxelFuse vf) {
   const int which = (int)blockIdx.x >= split ? 1 : 0;
   const KnnCloud& cl = A.c[which];
   const int j = (own_only ? cl.q_begin : 0) + ((int)blockIdx.x - (which ? split : 0)) * 256 + threadIdx.x;
-  if (j >= (own_only ? cl.q_end : cl.n_sorted)) return;
-  const int qi = __float_as_int(cl.sorted[j].w);
-  if (qi == INT_MAX) return;
-  const double* __restrict__ o = cl.stage + (size_t)(j / cl.chunk) * cl.seg + cl.stage_off + (size_t)(j % cl.chunk) * 6;
-  const size_t pitch = (size_t)cl.n;
+  const bool fuse = vf.enabled && which == vf.which;   // workgroup-uniform
+  float4 sp = make_float4(0.f, 0.f, 0.f, 0.f);
+  int qi = INT_MAX;
+  if (j < (own_only ? cl.q_end : cl.n_sorted)) { sp = cl.sorted[j]; qi = __float_as_int(sp.w); }
+  const bool act = qi != INT_MAX;
+  if (!act && !fuse) return;
+  double c6[6] = {0, 0, 0, 0, 0, 0};
+  if (act) {
+    const double* __restrict__ o = cl.stage + (size_t)(j / cl.chunk) * cl.seg + cl.stage_off + (size_t)(j % cl.chunk) * 6;
+    const size_t pitch = (size_t)cl.n;
 #pragma unroll
-  for (int v = 0; v < 6; v++) cl.cov[v * pitch + qi] = o[v];
+    for (int v = 0; v < 6; v++) { c6[v] = o[v]; cl.cov[v * pitch + qi] = c6[v]; }
+  }
+  if (fuse) {   // every lane of the wavefront takes part in the segmented fold
+    int id = -1;
+    if (act) { const int slot = vf.tgt_slot[qi]; if (slot >= 0) id = vf.tab.ids[slot]; }
+    accumulate_point(vf.tab, id, sp, c6, fix_scales(cl.n, vf.counters), true, const_cast<int*>(vf.counters) + 1);
+  }
 }
 
 }  // namespace

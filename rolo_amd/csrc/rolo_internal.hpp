@@ -158,7 +158,8 @@ size_t knn_bbox_ints();   // ints of the bounding-box buffer: 12 for the final b
 hipError_t launch_knn_walk(const KnnPair& A, int k, int regularization_or_minus1, const VoxelFuse& vf, hipStream_t s);
 hipError_t launch_knn_tail(const KnnPair& A, int k, int regularization, const VoxelFuse& vf, hipStream_t s);   // covariances from A.c[].nbr
 // multi-GPU: exchange buffer (sorted order, all ranks' slices after the all-gather, or [q_begin, q_end) only) -> cov[] by original index
-hipError_t launch_knn_unstage(const KnnPair& A, bool own_slice_only, hipStream_t s);
+// vf.enabled: the target's points are accumulated into the voxel map by this scatter (sharded VoxelFuse)
+hipError_t launch_knn_unstage(const KnnPair& A, bool own_slice_only, const VoxelFuse& vf, hipStream_t s);
 
 // fixed_cov: the covariance sums go through 64-bit fixed point as the positions always do (entries bounded by 1); false: fp64 atomics
 // bbox6: the target's bounding box as the neighbour search leaves it on the device (6 order-preserving ints), or nullptr
