@@ -41,7 +41,8 @@ def main(paths):
                round(mean(a["SQ_INSTS_SALU"]) / waves, 1) if waves else "", round(mean(a["SQ_INSTS_SMEM"]) / waves, 1) if waves else "", round(wc / waves) if waves else "",
                round(mean(a["SQ_BUSY_CYCLES"])), round(mean(a["SQ_WAIT_INST_ANY"]) / wc, 3) if wc else "",
                round(mean(a["SQ_WAIT_ANY"]) / wc, 3) if wc and a["SQ_WAIT_ANY"] else "",
-               round(mean(a["SQ_THREAD_CYCLES_VALU"]) / (64 * mean(a["SQ_ACTIVE_INST_VALU"])), 3)   # live lanes per issued VALU instruction / 64 (round 2 divided by 64 * 4: that column saturated at 0.25) if a["SQ_THREAD_CYCLES_VALU"] and a["SQ_ACTIVE_INST_VALU"] else ""]
+               round(mean(a["SQ_THREAD_CYCLES_VALU"]) / (64 * mean(a["SQ_ACTIVE_INST_VALU"])), 3) if a["SQ_THREAD_CYCLES_VALU"] and a["SQ_ACTIVE_INST_VALU"] else ""]
+        # (valu_thread_utilisation = live lanes per issued VALU instruction / 64; round 2 divided by 64 * 4 and the column saturated at 0.25)
         w.writerow(row)
 
 
