@@ -337,6 +337,13 @@ int rolo_odom_get_features(rolo_odom* o, float* features, int cap_points, int* n
  * time, where that is the shortest chain (frame latency -9 %). The driver asserts the option on its context right before each registration it
  * enqueues; it does not depend on, and is not reverted by, the parameter block the caller hands to rolo_set_params. */
 #define ROLO_ODOM_FUSED_LM 2
+/* ROLO_ODOM_EARLY_SOURCE (default 0): when a frame is submitted with nothing else in flight (rolo_odom_frame, or submit / collect one frame at
+ * a time), the propagated previous features — the SOURCE of the coming registration, known at submit time — are moved and searched on the
+ * registration stream while K1-K4 of the new frame run on the front-end stream; collect searches the target alone. Same results (the search
+ * of a cloud does not depend on what it is launched with), but MEASURED SLOWER on MI355X: the search of a 48 k-point cloud lasts as long
+ * as its heaviest packets, alone nearly as long as together with the other cloud — two chains cost 0.68 ms per frame against 0.58 ms for the
+ * pair chain after K1-K4. Kept as an A/B (env ROLO_ODOM_EARLY_SOURCE=1 arms it in every driver). */
+#define ROLO_ODOM_EARLY_SOURCE 3
 int rolo_odom_set_option(rolo_odom* o, int option, int value);
 /* rolo_front_set_deskew for the next rolo_odom_submit / rolo_odom_frame of the fused path */
 int rolo_odom_set_deskew(rolo_odom* o, const rolo_deskew* d, const float* rel_time, int n_raw, int rel_time_on_device);

@@ -8,6 +8,7 @@
 #include "rolo_internal.hpp"
 #include "polar_f32.hpp"
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -15,6 +16,7 @@ namespace rolo {
 void ctx_set_error(const char* msg);
 int ctx_device(rolo_ctx* c);
 void ctx_set_fused_lm(rolo_ctx* c, int on);
+int ctx_create_high_priority(int device, rolo_ctx** out);
 }
 
 namespace {
@@ -87,6 +89,11 @@ struct rolo_odom {
   struct Slot { double stamp = 0; int* h_counts = nullptr; hipEvent_t done = nullptr; } q[2];
   int q_head = 0, q_len = 0;
   bool reuse_cov = false, cov_chain = false;  // cov_chain: the context's target covariances belong to d_feat[old_buf]
+  // Early source (frame-at-a-time use of submit / collect / frame): the source of a registration is the PREVIOUS frame's features moved by the
+  // forward prediction — known when the new frame is submitted, long before its features exist. Its neighbour search then runs on the
+  // registration stream while K1-K4 of the new frame run on the front-end stream; collect only has the target left to search.
+  bool early_src = false; double early_stamp = 0; Aff early_T = aff_identity();
+  bool early_source_enabled = false;  // ROLO_ODOM_EARLY_SOURCE (off: measured slower, see rolo_hip.h)
   bool fused_lm = true;   // ROLO_ODOM_FUSED_LM: one launch per LM trial for this driver's registrations (one frame at a time: the shortest chain)
   rolo_stats last_rot{}, last_trans{};
 };
@@ -118,6 +125,7 @@ int rolo_odom_create(rolo_ctx* ctx, float ct_lambda, rolo_odom** out) {
   if (!ctx || !out) return ROLO_EINVAL;
   rolo_odom* o = new rolo_odom();
   o->ctx = ctx; o->ct_lambda = ct_lambda;
+  if (const char* e = getenv("ROLO_ODOM_EARLY_SOURCE")) o->early_source_enabled = atoi(e) != 0;   // A/B runs
   // (rolo_params.fused_lm is NOT switched behind the caller's back here: the driver asserts its own option right before every registration it
   // enqueues — a later rolo_set_params with the caller's own parameter block cannot silently revert it, nor does creating a driver change
   // what a plain rolo_register_async on the same context does afterwards beyond the frames the driver itself runs)
@@ -147,7 +155,8 @@ void rolo_odom_increment(const float* front6, const float* back6, float* incre6)
 
 static int ensure_front_ctx(rolo_odom* o) {
   if (o->fctx) return ROLO_OK;
-  int rc = rolo_ctx_create(rolo::ctx_device(o->ctx), &o->fctx);
+  static const bool plain = [] { const char* e = getenv("ROLO_ODOM_FRONT_PRIORITY"); return e && atoi(e) == 0; }();   // A/B: 0 = a normal-priority front-end stream (round 2)
+  int rc = plain ? rolo_ctx_create(rolo::ctx_device(o->ctx), &o->fctx) : rolo::ctx_create_high_priority(rolo::ctx_device(o->ctx), &o->fctx);
   if (rc) return rc;
   for (auto& sl : o->q) {
     if (hipHostMalloc((void**)&sl.h_counts, 4 * sizeof(int)) != hipSuccess || hipEventCreateWithFlags(&sl.done, hipEventDisableTiming) != hipSuccess) {
@@ -169,6 +178,7 @@ int rolo_odom_set_option(rolo_odom* o, int option, int value) {
   if (!o) return ROLO_EINVAL;
   if (option == ROLO_ODOM_REUSE_COVARIANCES) { o->reuse_cov = value != 0; o->cov_chain = false; return ROLO_OK; }
   if (option == ROLO_ODOM_FUSED_LM) { o->fused_lm = value != 0; return ROLO_OK; }
+  if (option == ROLO_ODOM_EARLY_SOURCE) { o->early_source_enabled = value != 0; return ROLO_OK; }
   return ROLO_EINVAL;
 }
 
@@ -233,6 +243,17 @@ int rolo_odom_cloud(rolo_odom* o, double stamp, const float* corner, int n_corne
   return ret;
 }
 
+// stateLinearPropagation :700-712 for a frame stamped `stamp`, from the driver's current state (does not change it)
+static Aff predicted_transform(const rolo_odom* o, double stamp) {
+  const double latestInterval = stamp - o->cloudTimeLast;
+  const double ratio = latestInterval / o->lastMappingInterval;
+  float v[6];
+  get_translation_and_euler(o->lidarMappingAffine, v);
+  v[3] = v[4] = v[5] = 0;
+  for (int i = 0; i < 6; i++) v[i] *= (float)ratio;
+  return get_transformation(v[0], v[1], v[2], v[3], v[4], v[5]);
+}
+
 static int submit_common(rolo_odom* o, const rolo_front_params* P, double stamp, const void* pts, int stride, const uint16_t* ring,
                          const rolo_cloud_layout* layout, int n_raw, int on_device) {
   if (o->q_len == 2) { rolo::ctx_set_error("two frames are already in flight: collect one first"); return ROLO_ESTATE; }
@@ -255,6 +276,18 @@ static int submit_common(rolo_odom* o, const rolo_front_params* P, double stamp,
   else rc = rolo::front_frame_features_enqueue(o->fctx, P, static_cast<const float*>(pts), stride, ring, n_raw, on_device != 0, o->d_feat[buf], sl.h_counts, sl.done);
   if (rc) return rc;
   sl.stamp = stamp;
+  // nothing else in flight and the next collect will register: start on the source now (see early_src)
+  o->early_src = false;
+  if (o->early_source_enabled && o->q_len == 0 && !o->first && o->lastOdomTime != -1.0 && o->nOld > 0 && !(o->reuse_cov && o->cov_chain)) {
+    const Aff T = predicted_transform(o, stamp);
+    hipStream_t s = (hipStream_t)rolo_ctx_stream(o->ctx);
+    float4* d_featOld = o->d_feat[o->old_buf];
+    if (rolo::launch_transform_cloud(reinterpret_cast<const float*>(d_featOld), reinterpret_cast<float*>(o->d_prop), o->nOld, 4, nullptr, T.m, s) == hipSuccess &&
+        rolo_set_source_device(o->ctx, reinterpret_cast<const float*>(o->d_prop), o->nOld, 4) == ROLO_OK &&
+        rolo_compute_covariances(o->ctx) == ROLO_OK) {   // the context's target (the previous frame's) keeps its covariances: only the source is searched, asynchronously
+      o->early_src = true; o->early_stamp = stamp; o->early_T = T;
+    }
+  }
   o->q_len++;
   return ROLO_OK;
 }
@@ -294,22 +327,21 @@ int rolo_odom_collect(rolo_odom* o, float* pose6, double* rot9, double* trans3, 
     ret = 1;
   } else {
     const double latestInterval = o->cloudTimeCur - o->cloudTimeLast;
-    const double ratio = latestInterval / o->lastMappingInterval;  // stateLinearPropagation :700-712
-    float v[6];
-    get_translation_and_euler(o->lidarMappingAffine, v);
-    v[3] = v[4] = v[5] = 0;
-    for (int i = 0; i < 6; i++) v[i] *= (float)ratio;
-    o->transformation_interpolated = get_transformation(v[0], v[1], v[2], v[3], v[4], v[5]);
+    o->transformation_interpolated = predicted_transform(o, o->cloudTimeCur);  // stateLinearPropagation :700-712
     o->cloudTimeLast = o->cloudTimeCur;
     o->lastMappingInterval = latestInterval;
     // scanRegeistration :448-501 on device-resident clouds
     hipStream_t s = (hipStream_t)rolo_ctx_stream(o->ctx);
-    if (o->nOld > 0 && rolo::launch_transform_cloud(reinterpret_cast<const float*>(d_featOld), reinterpret_cast<float*>(o->d_prop), o->nOld, 4, nullptr,
-                                                    o->transformation_interpolated.m, s) != hipSuccess) {
-      rolo::ctx_set_error("transform kernel launch failed"); return ROLO_EHIP;
+    const bool early = o->early_src && o->early_stamp == o->cloudTimeCur && memcmp(o->early_T.m, o->transformation_interpolated.m, sizeof(o->early_T.m)) == 0;
+    o->early_src = false;
+    if (!early) {   // (early: the propagated source is in d_prop already and its covariances are on their way)
+      if (o->nOld > 0 && rolo::launch_transform_cloud(reinterpret_cast<const float*>(d_featOld), reinterpret_cast<float*>(o->d_prop), o->nOld, 4, nullptr,
+                                                      o->transformation_interpolated.m, s) != hipSuccess) {
+        rolo::ctx_set_error("transform kernel launch failed"); return ROLO_EHIP;
+      }
+      if ((rc = rolo_set_source_device(o->ctx, reinterpret_cast<const float*>(o->d_prop), o->nOld, 4))) return rc;
+      if (o->reuse_cov && o->cov_chain) { if ((rc = rolo_adopt_target_covariances(o->ctx))) return rc; }
     }
-    if ((rc = rolo_set_source_device(o->ctx, reinterpret_cast<const float*>(o->d_prop), o->nOld, 4))) return rc;
-    if (o->reuse_cov && o->cov_chain) { if ((rc = rolo_adopt_target_covariances(o->ctx))) return rc; }
     if ((rc = rolo_set_target_device(o->ctx, reinterpret_cast<const float*>(d_featNew), nNew, 4))) return rc;
     double guess_t[3];
     for (int i = 0; i < 3; i++) guess_t[i] = (double)o->transformation_interpolated.m[i * 4 + 3];

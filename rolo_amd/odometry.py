@@ -34,6 +34,7 @@ class LidarOdometry:
 
     REUSE_COVARIANCES = 1
     FUSED_LM = 2
+    EARLY_SOURCE = 3
 
     def setDeskew(self, dsk, rel_time):
         """deskewPoint for the next submit() / frame(): rel_time[i] = fabs(point.time) of raw point i (numpy array)."""
