@@ -763,6 +763,13 @@ def main():
 
     # ---- BASELINE configs[4]: 512 distinct OS1-64 pairs streamed through the contexts ----
     if args.mode == "replicas" and not args.no_config5:
+        # the headline's contexts go first: HIP deals a process's streams to its four hardware queues in creation order, and four MORE contexts
+        # next to four idle ones land in the layout that measured 2.1 k instead of 2.9 k scans/s — config5 ran like that until round 3
+        for c_ in ctxs:
+            try:
+                (c_.b if isinstance(c_, Batch) else c_).close()
+            except Exception:
+                pass
         try:
             out["config5"] = config5_leg(args, torch, dist, rank, world, local_rank, new_ctx, barrier)
         except Exception as e:  # pragma: no cover

@@ -177,7 +177,7 @@ struct rolo_ctx {
   // passes the last frames needed per stage (+1): the next frame enqueues that many predicated pass/controller pairs up
   // front instead of a fixed worst-case chunk; rolo_register_wait tops up if a frame needs more
   int hint_rot = 0, hint_trans = 0;
-  struct NeedWindow { int need[16] = {0}; int n = 0, pos = 0; } win_rot, win_trans;   // passes the last 16 frames needed per stage
+  struct NeedWindow { int need[64] = {0}; int n = 0, pos = 0; } win_rot, win_trans;   // passes the last 64 frames needed per stage
   bool gseen_valid = false;
   hipGraph_t graph = nullptr;
   hipGraphExec_t graph_exec = nullptr;
@@ -521,16 +521,19 @@ void frame_chunks(const rolo_ctx* c, int& nrot, int& ntrans) {
   nrot = c->hint_rot > 0 ? c->hint_rot : rot_first_chunk(c);
   ntrans = c->hint_trans > 0 ? c->hint_trans : 12;
 }
-// The first schedule of the next frame holds (the most passes any of the last 16 frames needed) + 1 predicated pass / controller pairs.
-// A stream of DIFFERENT frame pairs needs different numbers of LM trials (BASELINE configs[4]: 24 ... 41 per pair): following the last
-// frame alone made every other frame either re-capture its hipGraph (the schedule length is part of the graph's key) or top up through
-// host round trips — 351 top-ups, 297 captures and 753 eager frames in 1536; a predicated no-op pair costs ~5 us of GPU time.
+// The first schedule of the next frame holds (the most passes any of the last 64 frames needed) + 1 predicated pass / controller pairs, rounded
+// up to an even count; it grows at once and shrinks only when the window's maximum has fallen 6 below it.
+// A stream of DIFFERENT frame pairs needs different numbers of LM trials (BASELINE configs[4]: 24 ... 41 per pair). Round 2 followed the last
+// frame alone: every other frame either re-captured its hipGraph (the schedule length is part of the graph's key) or topped up through
+// host round trips — 351 top-ups, 297 captures and 753 eager frames in 1536. A 16-frame window still re-captured 90 times (the maximum slides
+// in and out of a short window) and a capture is milliseconds of host time; a predicated no-op pair costs ~5 us of GPU time.
 void update_hint(int& hint, rolo_ctx::NeedWindow& w, int used) {
-  w.need[w.pos] = used; w.pos = (w.pos + 1) % 16; if (w.n < 16) w.n++;
+  constexpr int WN = 64;
+  w.need[w.pos] = used; w.pos = (w.pos + 1) % WN; if (w.n < WN) w.n++;
   int mx = 0;
   for (int i = 0; i < w.n; i++) mx = std::max(mx, w.need[i]);
-  const int want = std::min(std::max(mx + 1, 2), 96);
-  if (hint == 0 || want > hint || want < hint - 2) hint = want;  // hysteresis: a captured hipGraph stays valid while the need wobbles by one or two
+  const int want = std::min((std::max(mx + 1, 2) + 1) & ~1, 96);
+  if (hint == 0 || want > hint || want <= hint - 6) hint = want;
 }
 
 // drive a stage to completion: enqueue predicated passes in chunks, look at the device flags between chunks
