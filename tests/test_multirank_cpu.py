@@ -97,3 +97,21 @@ def test_two_rank_partial_sums_allreduce_gloo():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert sorted(res) == [(0, True), (1, True)]
+
+
+def test_bench_sharded_leg_reports_a_failed_child_instead_of_raising():
+    """bench.py's sharded leg runs its ranks in child processes (python -m rolo_amd.peerbench). Here there is no GPU, so every child fails at
+    rolo_ctx_create — the harness must hand back an error record (which lands in the JSON line), not raise and not hang."""
+    import importlib
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    from rolo_amd._lib import lib
+    if lib().rolo_device_count() > 0:
+        import pytest
+        pytest.skip("a GPU is visible: the children would run")
+    bench = importlib.import_module("bench")
+    res = bench.sharded_children(2, "vlp16", 2, 0.5, timeout=120)
+    assert isinstance(res, dict) and "error" in res and "rank" in res["error"]
