@@ -97,7 +97,9 @@ def roofline(g, run_one_step, n_src, n_tgt, passes_per_frame, hbm_peak_gbs, reps
             traffic = json.load(open(pmc)).get(dom + "_kernel", {}).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
+    # the same kernel per profiled step (bench.py profiles one step per pair of its input pool, in pool order: step 0 = the nominal pair of SURVEY 8d)
+    per_step_ms = [float(r.mean()) for r in real_runs.get(dom, []) if len(r)]
     return {"bound": "hbm", "kernel": dom + "_kernel", "achieved": achieved, "peak": hbm_peak_gbs, "unit": "GB/s",
-            "frac": achieved / hbm_peak_gbs, "traffic": traffic,
+            "frac": achieved / hbm_peak_gbs, "traffic": traffic, "avg_launch_ms_per_profiled_step": per_step_ms,
             "traffic_source": "profiles/pmc_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, (2 FETCH + WRITE) KB; not measured in this run)",
             "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": avg_ms[dom], "top3": top3, "per_frame_ms": per_frame_ms, "avg_ms": avg_ms}
