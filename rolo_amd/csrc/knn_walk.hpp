@@ -88,18 +88,24 @@ ROLO_DEV void knn_score_leaf(const float4* __restrict__ sorted, int g, const flo
       // neighbour is already <= the candidate in EVERY lane keeps its value (min(ck, K[s]) = K[s] and K[s-1] <= K[s]), so the lower tiers
       // run only if some lane's candidate sorts below them. Late in the walk candidates barely beat the k-th best: most executions stop
       // after the first tier (fp64 min / max issue at half the fp32 rate — the insert is two thirds of the walk's VALU cycles).
-      constexpr int T = KMAX / 4;
+      // tier boundaries (slots [B1, KMAX) always, then [B2, B1), [B3, B2), [0, B3)); tunable for KMAX = 20 (-DROLO_KNN_B1/B2/B3)
+#ifndef ROLO_KNN_B1
+#define ROLO_KNN_B1 15
+#define ROLO_KNN_B2 10
+#define ROLO_KNN_B3 5
+#endif
+      constexpr int B1 = KMAX == 20 ? ROLO_KNN_B1 : 3 * (KMAX / 4), B2 = KMAX == 20 ? ROLO_KNN_B2 : 2 * (KMAX / 4), B3 = KMAX == 20 ? ROLO_KNN_B3 : KMAX / 4;
 #pragma unroll
-      for (int s = KMAX - 1; s >= 3 * T; s--) K[s] = vmax_f64(K[s - 1], vmin_f64(ck, K[s]));
-      if (__any(ck < K[3 * T - 1])) {
+      for (int s = KMAX - 1; s >= B1; s--) K[s] = vmax_f64(K[s - 1], vmin_f64(ck, K[s]));
+      if (__any(ck < K[B1 - 1])) {
 #pragma unroll
-        for (int s = 3 * T - 1; s >= 2 * T; s--) K[s] = vmax_f64(K[s - 1], vmin_f64(ck, K[s]));
-        if (__any(ck < K[2 * T - 1])) {
+        for (int s = B1 - 1; s >= B2; s--) K[s] = vmax_f64(K[s - 1], vmin_f64(ck, K[s]));
+        if (__any(ck < K[B2 - 1])) {
 #pragma unroll
-          for (int s = 2 * T - 1; s >= T; s--) K[s] = vmax_f64(K[s - 1], vmin_f64(ck, K[s]));
-          if (__any(ck < K[T - 1])) {
+          for (int s = B2 - 1; s >= B3; s--) K[s] = vmax_f64(K[s - 1], vmin_f64(ck, K[s]));
+          if (__any(ck < K[B3 - 1])) {
 #pragma unroll
-            for (int s = T - 1; s >= 1; s--) K[s] = vmax_f64(K[s - 1], vmin_f64(ck, K[s]));
+            for (int s = B3 - 1; s >= 1; s--) K[s] = vmax_f64(K[s - 1], vmin_f64(ck, K[s]));
             K[0] = vmin_f64(ck, K[0]);
           }
         }
