@@ -253,6 +253,41 @@ __global__ __launch_bounds__(256, ROLO_KNN_WALK_OCC) void knn_walk_kernel(KnnPai
     it++;
     if (it == 1) asm("s_setprio 3" : "+s"(it)); else if (it == 32) asm("s_setprio 2" : "+s"(it)); else if (it == 64) asm("s_setprio 1" : "+s"(it)); else if (it == 96) asm("s_setprio 0" : "+s"(it));
 #endif
+#ifdef ROLO_KNN_WIDE
+    // Two levels per step where the tree allows it: the four grandchildren of h are nodes 4h .. 4h + 3, their boxes 128 contiguous bytes —
+    // ONE dependent fetch instead of two or three, the same box tests or fewer (the children's own boxes are skipped: their union is h's,
+    // which is known to be reached). The grandchild most lanes are nearest to goes first, the other live ones are pushed, best on top.
+    if (2 * h < P) {
+      st_nodes++;
+      float4 b[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) b[u] = boxes[8 * (size_t)h + u];
+      float d[4]; bool ok[4];
+#pragma unroll
+      for (int c = 0; c < 4; c++) { d[c] = box_d2(b[2 * c], b[2 * c + 1], q); ok[c] = (d[c] <= bd) && (d[c] < INFINITY); }
+      // this lane's nearest live grandchild (ties: the lowest index)
+      int best = -1; float bestd = INFINITY;
+#pragma unroll
+      for (int c = 0; c < 4; c++) if (ok[c] && d[c] < bestd) { bestd = d[c]; best = c; }
+      int key[4];   // wave-uniform: votes * 4 + (3 - c) for a live grandchild, -1 for one no lane reaches
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        const unsigned long long m = __ballot(ok[c]);
+        const int votes = __popcll(__ballot(best == c));
+        key[c] = m != 0ull ? votes * 4 + (3 - c) : -1;
+      }
+      // sort the four keys descending (5 compare-exchanges on scalars)
+      auto cx = [](int& a, int& bb) { const int hi = max(a, bb), lo = min(a, bb); a = hi; bb = lo; };
+      cx(key[0], key[1]); cx(key[2], key[3]); cx(key[0], key[2]); cx(key[1], key[3]); cx(key[1], key[2]);
+      if (key[0] >= 0) {
+        // push the runners-up, worst first, so that the second best is popped first
+#pragma unroll
+        for (int r = 3; r >= 1; r--) if (key[r] >= 0 && sp < WALK_STACK) { stk[wv][sp] = 4 * h + (3 - (key[r] & 3)); sp++; KNN_STAT(st_push++;) }
+        h = 4 * h + (3 - (key[0] & 3));
+        continue;
+      }
+    } else
+#endif
     if (h < P) {
       st_nodes++;
       const float4 llo = boxes[4 * (size_t)h], lhi = boxes[4 * (size_t)h + 1], rlo = boxes[4 * (size_t)h + 2], rhi = boxes[4 * (size_t)h + 3];
