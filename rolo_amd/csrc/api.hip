@@ -126,6 +126,7 @@ struct rolo_ctx {
     int* bbox = nullptr; size_t bbox_cap = 0;
     int32_t* nbr = nullptr; size_t nbr_cap = 0;   // neighbour indices between the walk and the covariance kernel
     double* stage = nullptr; size_t stage_cap = 0;  // multi-GPU: covariance exchange buffer (sorted order, one segment per rank)
+    double* lower = nullptr; size_t lower_cap = 0;  // k_correspondences > 64: the key the next round of 64 starts above, per sorted position
   } ks[2];
   hipEvent_t ev_done = nullptr;    // end of the frame rolo_register_async enqueued (the stream may carry other contexts' frames behind it)
   hipStream_t stream2 = nullptr;   // second stream for the eager (uncaptured) path of rolo_batch_*. Created WITH the context on purpose: HIP deals streams
@@ -244,7 +245,7 @@ int upload_cloud(rolo_ctx* c, CloudDev& cl, size_t& xyz_cap, const float* pts, i
 // search structures of one cloud: geometry + allocations
 int prepare_cloud(rolo_ctx* c, CloudDev& cl, size_t& cov_cap, size_t& sorted_cap, size_t& boxes_cap, size_t& knn_cap, size_t& knnd_cap, KnnCloud& out, bool tree_only = false) {
   const int n = cl.n, k = tree_only ? 1 : c->P.k_correspondences;
-  if (k < 1 || k > 64) { g_err = "k_correspondences must be in [1,64]"; return ROLO_EUNSUPPORTED; }
+  if (k < 1) { g_err = "k_correspondences must be positive"; return ROLO_EINVAL; }
   if (n < k) { g_err = "cloud has fewer points than k_correspondences"; return ROLO_ETOOFEW; }
   cl.n_leaves = (n + KNN_LEAF - 1) / KNN_LEAF;
   int P = 2; while (P < cl.n_leaves) P <<= 1;
@@ -292,9 +293,15 @@ int build_clouds(rolo_ctx* c, bool do_src, bool do_tgt, hipStream_t stream, bool
   if ((rc = ensure(S.vals0, S.vals0_cap, n_total))) return rc;
   if ((rc = ensure(S.vals1, S.vals1_cap, n_total))) return rc;
   if ((rc = ensure(S.bbox, S.bbox_cap, knn_bbox_ints()))) return rc;
-  const size_t kslots = c->P.k_correspondences > 32 ? 64 : 32;   // slot-major neighbour lists: KMAX slots per sorted position
+  const int kc = tree_only ? 1 : c->P.k_correspondences;
+  const size_t kslots = kc > 64 ? 64 * (((size_t)kc + 63) / 64) : (kc > 32 ? 64 : 32);   // slot-major neighbour lists: KMAX slots per sorted position (k > 64: rounds of 64)
   if ((rc = ensure(S.nbr, S.nbr_cap, kslots * ((size_t)A.c[0].n_sorted + (nc > 1 ? (size_t)A.c[1].n_sorted : 0))))) return rc;
   A.c[0].nbr = S.nbr; if (nc > 1) A.c[1].nbr = S.nbr + kslots * (size_t)A.c[0].n_sorted;
+  for (int i = 0; i < 2; i++) { A.c[i].lower = nullptr; A.c[i].slot0 = 0; A.c[i].k_total = 0; }
+  if (kc > 64) {   // one key per sorted position: where the next round of 64 starts
+    if ((rc = ensure(S.lower, S.lower_cap, (size_t)A.c[0].n_sorted + (nc > 1 ? (size_t)A.c[1].n_sorted : 0)))) return rc;
+    A.c[0].lower = S.lower; if (nc > 1) A.c[1].lower = S.lower + A.c[0].n_sorted;
+  }
   const size_t tmp = knn_sort_temp_bytes((int)n_total);
   if ((rc = ensure(S.sort_tmp, S.sort_tmp_cap, tmp + 256))) return rc;
   // Multi-GPU ("K5 shards by query point with the full cloud replicated"): every rank sorts and builds the BVH of the whole
@@ -341,7 +348,7 @@ int build_clouds(rolo_ctx* c, bool do_src, bool do_tgt, hipStream_t stream, bool
     if (do_tgt) { c->tgt.have_sorted = true; c->tgt.have_cov = false; c->tgt.bbox6 = S.bbox + (do_src ? 6 : 0); }
     return ROLO_OK;
   }
-  const bool split_tail = !fused_tail_env();
+  const bool split_tail = !fused_tail_env() || kc > 64;
   { ProfScope ps(c, ROLO_PROF_KNN_WALK, stream); HIPCHK(launch_knn_walk(A, c->P.k_correspondences, split_tail ? -1 : c->P.regularization, vf, stream)); }
   if (split_tail) { ProfScope ps(c, ROLO_PROF_KNN_TAIL, stream); HIPCHK(launch_knn_tail(A, c->P.k_correspondences, c->P.regularization, vf, stream)); }
   if (sharded) {
@@ -678,7 +685,7 @@ void rolo_ctx_destroy(rolo_ctx* c) {
   if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
   void* bufs[] = {c->src.bbox_part, c->tgt.bbox_part, c->src.xyz, c->src.cov, c->src.sorted, c->src.boxes, c->src.knn_idx, c->src.knn_d2, c->tgt.xyz, c->tgt.cov, c->tgt.sorted,
                   c->tgt.boxes, c->tgt.knn_idx, c->tgt.knn_d2, c->ks[0].sort_tmp, c->ks[0].keys0, c->ks[0].keys1, c->ks[0].vals0, c->ks[0].vals1, c->ks[0].bbox,
-                  c->ks[1].sort_tmp, c->ks[1].keys0, c->ks[1].keys1, c->ks[1].vals0, c->ks[1].vals1, c->ks[1].bbox, c->ks[0].nbr, c->ks[1].nbr, c->ks[0].stage, c->ks[1].stage, c->tab.keys,
+                  c->ks[1].sort_tmp, c->ks[1].keys0, c->ks[1].keys1, c->ks[1].vals0, c->ks[1].vals1, c->ks[1].bbox, c->ks[0].nbr, c->ks[1].nbr, c->ks[0].stage, c->ks[1].stage, c->ks[0].lower, c->ks[1].lower, c->tab.keys,
                   c->tab.ids, c->tab.rec, c->tab.id_keys, c->tgt_keys, c->tgt_slot, c->counters, c->corr[0], c->corr[1], c->partials, c->sums,
                   c->state, c->trace, c->stage_in, c->stage_out, c->stage_d, c->stage_i};
   for (void* b : bufs) if (b) (void)hipFree(b);

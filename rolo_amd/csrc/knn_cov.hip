@@ -471,31 +471,11 @@ ROLO_DEV void inv3(const double (&A)[9], double (&o)[9]) {
   o[0] = c00 * inv; o[1] = c01 * inv; o[2] = c02 * inv; o[3] = c10 * inv; o[4] = c11 * inv; o[5] = c12 * inv; o[6] = c20 * inv; o[7] = c21 * inv; o[8] = c22 * inv;
 }
 
-// covariance of the neighbourhood + regularisation, one lane per query
-template <int KMAX>
-ROLO_DEV void knn_covariance_tail(const int (&ki)[KMAX], int kk, const float4* __restrict__ orig, int n, int qi, int reg,
-                                  double* __restrict__ cov, double (&c6)[6]) {
-  // ---- covariance of the neighbourhood (rot_vgicp_impl.hpp:438-455), fp64, centred two-pass ----
-  // the K neighbours are gathered once and stay in registers for both passes (this kernel is not occupancy-critical)
-  float px[KMAX], py[KMAX], pz[KMAX];
-#pragma unroll
-  for (int u = 0; u < KMAX; u++) {
-    const float4 p = (u < kk) ? orig[ki[u]] : make_float4(0.f, 0.f, 0.f, 0.f);
-    px[u] = p.x; py[u] = p.y; pz[u] = p.z;
-  }
-  double mx = 0, my = 0, mz = 0;
-#pragma unroll
-  for (int u = 0; u < KMAX; u++) if (u < kk) { mx += (double)px[u]; my += (double)py[u]; mz += (double)pz[u]; }
-  mx /= kk; my /= kk; mz /= kk;
-  double cxx = 0, cxy = 0, cxz = 0, cyy = 0, cyz = 0, czz = 0;
-#pragma unroll
-  for (int u = 0; u < KMAX; u++) if (u < kk) {
-    const double ax = (double)px[u] - mx, ay = (double)py[u] - my, az = (double)pz[u] - mz;
-    cxx += ax * ax; cxy += ax * ay; cxz += ax * az; cyy += ay * ay; cyz += ay * az; czz += az * az;
-  }
-  cxx /= kk; cxy /= kk; cxz /= kk; cyy /= kk; cyz /= kk; czz /= kk;
-
+// regularisation of the neighbourhood covariance (rot_vgicp_impl.hpp:457-490) and the store of its six unique entries
+ROLO_DEV void knn_covariance_finish(double cxx, double cxy, double cxz, double cyy, double cyz, double czz, int n, int qi, int reg,
+                                    double* __restrict__ cov, double (&c6)[6]) {
   double out[9];
+
   if (reg == ROLO_REG_NONE) {
     out[0] = cxx; out[1] = cxy; out[2] = cxz; out[3] = cxy; out[4] = cyy; out[5] = cyz; out[6] = cxz; out[7] = cyz; out[8] = czz;
   } else if (reg == ROLO_REG_FROBENIUS) {
@@ -527,6 +507,47 @@ ROLO_DEV void knn_covariance_tail(const int (&ki)[KMAX], int kk, const float4* _
   for (int d = 0; d < 6; d++) cov[d * pitch + qi] = c6[d];
 }
 
+// covariance of the neighbourhood + regularisation, one lane per query
+template <int KMAX>
+ROLO_DEV void knn_covariance_tail(const int (&ki)[KMAX], int kk, const float4* __restrict__ orig, int n, int qi, int reg,
+                                  double* __restrict__ cov, double (&c6)[6]) {
+  // ---- covariance of the neighbourhood (rot_vgicp_impl.hpp:438-455), fp64, centred two-pass ----
+  // the K neighbours are gathered once and stay in registers for both passes (this kernel is not occupancy-critical)
+  float px[KMAX], py[KMAX], pz[KMAX];
+#pragma unroll
+  for (int u = 0; u < KMAX; u++) {
+    const float4 p = (u < kk) ? orig[ki[u]] : make_float4(0.f, 0.f, 0.f, 0.f);
+    px[u] = p.x; py[u] = p.y; pz[u] = p.z;
+  }
+  double mx = 0, my = 0, mz = 0;
+#pragma unroll
+  for (int u = 0; u < KMAX; u++) if (u < kk) { mx += (double)px[u]; my += (double)py[u]; mz += (double)pz[u]; }
+  mx /= kk; my /= kk; mz /= kk;
+  double cxx = 0, cxy = 0, cxz = 0, cyy = 0, cyz = 0, czz = 0;
+#pragma unroll
+  for (int u = 0; u < KMAX; u++) if (u < kk) {
+    const double ax = (double)px[u] - mx, ay = (double)py[u] - my, az = (double)pz[u] - mz;
+    cxx += ax * ax; cxy += ax * ay; cxz += ax * az; cyy += ay * ay; cyz += ay * az; czz += az * az;
+  }
+  cxx /= kk; cxy /= kk; cxz /= kk; cyy /= kk; cyz /= kk; czz /= kk;
+  knn_covariance_finish(cxx, cxy, cxz, cyy, cyz, czz, n, qi, reg, cov, c6);
+}
+
+// the same for any number of neighbours (k_correspondences > 64): the neighbours are gathered twice, slot by slot, in the same order
+ROLO_DEV void knn_covariance_tail_loop(const int32_t* __restrict__ nbr, size_t n_sorted, int j, int kk, const float4* __restrict__ orig, int n, int qi, int reg,
+                                       double* __restrict__ cov, double (&c6)[6]) {
+  double mx = 0, my = 0, mz = 0;
+  for (int u = 0; u < kk; u++) { const float4 p = orig[nbr[(size_t)u * n_sorted + j]]; mx += (double)p.x; my += (double)p.y; mz += (double)p.z; }
+  mx /= kk; my /= kk; mz /= kk;
+  double cxx = 0, cxy = 0, cxz = 0, cyy = 0, cyz = 0, czz = 0;
+  for (int u = 0; u < kk; u++) {
+    const float4 p = orig[nbr[(size_t)u * n_sorted + j]];
+    const double ax = (double)p.x - mx, ay = (double)p.y - my, az = (double)p.z - mz;
+    cxx += ax * ax; cxy += ax * ay; cxz += ax * az; cyy += ay * ay; cyz += ay * az; czz += az * az;
+  }
+  cxx /= kk; cxy /= kk; cxz /= kk; cyy /= kk; cyz /= kk; czz /= kk;
+  knn_covariance_finish(cxx, cxy, cxz, cyy, cyz, czz, n, qi, reg, cov, c6);
+}
 }  // namespace
 }  // namespace rolo
 
@@ -617,6 +638,18 @@ hipError_t launch_knn_walk(const KnnPair& A, int k, int regularization_or_minus1
   if (g0 + g1 == 0) return hipSuccess;
   (void)vf;   // (insert workgroups appended to THIS launch made its wave-uniform leaf loads vector loads: a store anywhere in the kernel is a potential clobber)
   constexpr int pad = 0;   // (an LDS pad here limited the walk to 3 / 2 workgroups per CU: 0.216 / 0.259 ms against 0.196)
+  if (k > 64) {   // any k: rounds of 64 — round r searches the 64 (the last: k - 64 r) nearest ABOVE the previous round's last key (KnnCloud::lower).
+                  // ceil(k / 64) full walks: correct, as slow as it sounds; the reference accepts any k, its default is 20 and ROLO never changes it
+    if (regularization_or_minus1 >= 0) return hipErrorInvalidValue;   // the covariance tail is its own launch here
+    KnnPair R = A;
+    for (int r = 0; 64 * r < k; r++) {
+      const int kr = k - 64 * r < 64 ? k - 64 * r : 64;
+      for (int i = 0; i < R.n_clouds; i++) { R.c[i].slot0 = 64 * r; R.c[i].k_total = k; }
+      if (r == 0) knn_walk_kernel<64, false><<<g0 + g1, 256, pad, s>>>(R, g0, kr, -1);
+      else knn_walk_kernel<64, false, true><<<g0 + g1, 256, pad, s>>>(R, g0, kr, -1);
+    }
+    return hipGetLastError();
+  }
   if (k == 20) {
     if (regularization_or_minus1 >= 0) knn_walk_kernel<20, true><<<g0 + g1, 256, pad, s>>>(A, g0, k, regularization_or_minus1);
     else knn_walk_kernel<20, false><<<g0 + g1, 256, pad, s>>>(A, g0, k, -1);
@@ -644,7 +677,8 @@ hipError_t launch_knn_unstage(const KnnPair& A, bool own_slice_only, const Voxel
 hipError_t launch_knn_tail(const KnnPair& A, int k, int regularization, const VoxelFuse& vf, hipStream_t s) {
   const int g0 = slice_blocks(A.c[0]), g1 = A.n_clouds > 1 ? slice_blocks(A.c[1]) : 0;
   if (g0 + g1 == 0) return hipSuccess;
-  if (k == 20) knn_tail_kernel<20><<<g0 + g1, 256, 0, s>>>(A, g0, k, regularization, vf);
+  if (k > 64) knn_tail_loop_kernel<<<g0 + g1, 256, 0, s>>>(A, g0, k, regularization, vf);
+  else if (k == 20) knn_tail_kernel<20><<<g0 + g1, 256, 0, s>>>(A, g0, k, regularization, vf);
   else if (k <= 32) knn_tail_kernel<32><<<g0 + g1, 256, 0, s>>>(A, g0, k, regularization, vf);
   else knn_tail_kernel<64><<<g0 + g1, 256, 0, s>>>(A, g0, k, regularization, vf);
   return hipGetLastError();

@@ -66,9 +66,9 @@ ROLO_DEV int key_idx(double k) { return (int)(unsigned)((unsigned long long)__do
 ROLO_DEV double vmin_f64(double a, double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 ROLO_DEV double vmax_f64(double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 // score the KNN_LEAF (16) points of leaf g against this lane's query and insert the ones that beat its current k-th best
-template <int KMAX>
+template <int KMAX, bool LOWER = false>
 ROLO_DEV void knn_score_leaf(const float4* __restrict__ sorted, int g, const float4& q, double (&K)[KMAX], int kk, double& bkey, float& bd,
-                             unsigned& n_ins, unsigned& lane_acc, unsigned& rounds) {
+                             unsigned& n_ins, unsigned& lane_acc, unsigned& rounds, double lo = 0.0) {
   // fetch the whole leaf first: the address is wave-uniform, so these are KNN_LEAF scalar loads in flight behind ONE wait
   // (loading inside the loop serialised the scalar-cache round trips of a leaf behind the insert branch)
   float4 pts[KNN_LEAF];
@@ -80,7 +80,8 @@ ROLO_DEV void knn_score_leaf(const float4* __restrict__ sorted, int g, const flo
     const float4 c = pts[u];
     const float dx = q.x - c.x, dy = q.y - c.y, dz = q.z - c.z;
     const float cd = ((dx * dx) + (dy * dy)) + (dz * dz);  // file is compiled with -ffp-contract=off
-    const double ck = key_pack(cd, __float_as_int(c.w));
+    const double ck0 = key_pack(cd, __float_as_int(c.w));
+    const double ck = (LOWER && !(ck0 > lo)) ? key_pack(INFINITY, INT_MAX) : ck0;   // LOWER: a point of an earlier round's 64 is no candidate
     KNN_STAT(if (__any(ck < bkey)) { n_ins++; lane_acc += (unsigned)__popcll(__ballot(ck < bkey)); })
     KNN_STAT(if (ck < bkey0) my_acc++;)
     if (ck < bkey) {
@@ -177,8 +178,8 @@ ROLO_DEV void knn_score_leaf_queue(const float4* __restrict__ sorted, int g, con
 #ifndef ROLO_KNN_WALK_OCC
 #define ROLO_KNN_WALK_OCC 4   // 128 VGPRs allowed: the loop needs 61, the slack buys the compiler ~3 % (0.196 -> 0.188 ms); a 2 x 131 072-point pair fills 4 waves per SIMD
 #endif
-template <int KMAX, bool FUSE_TAIL>
-__global__ __launch_bounds__(256, ROLO_KNN_WALK_OCC) void knn_walk_kernel(KnnPair A, int split, int k, int reg) {
+template <int KMAX, bool FUSE_TAIL, bool LOWER = false>
+__global__ __launch_bounds__(256, KMAX > 32 ? 2 : ROLO_KNN_WALK_OCC) void knn_walk_kernel(KnnPair A, int split, int k, int reg) {   // 64 slots = 128 key registers: 256 VGPRs, 2 waves per SIMD
   __shared__ int stk[4][WALK_STACK];
   const int tid = threadIdx.x;
   const int wv = tid >> 6;
@@ -223,8 +224,12 @@ __global__ __launch_bounds__(256, ROLO_KNN_WALK_OCC) void knn_walk_kernel(KnnPai
 #ifdef ROLO_KNN_LANE_QUEUE
 #define KNN_SCORE(g) knn_score_leaf_queue<KMAX>(sorted, g, q, K, kk, bkey, bd, sentinel)
 #else
-#define KNN_SCORE(g) knn_score_leaf<KMAX>(sorted, g, q, K, kk, bkey, bd, st_ins, st_lane, st_rounds)
+#define KNN_SCORE(g) knn_score_leaf<KMAX, LOWER>(sorted, g, q, K, kk, bkey, bd, st_ins, st_lane, st_rounds, lo)
 #endif
+  // rounds of a search for more than 64 neighbours (LOWER): only keys above the previous round's last one count
+  double lo = 0.0;
+  if (LOWER && active) lo = A.c[which].lower[j];
+  (void)lo;
   for (int g = g_own0; g < g_own1; g++) { KNN_SCORE(g); st_leaves++; }
 
   // ---- packet walk ----
@@ -328,14 +333,17 @@ __global__ __launch_bounds__(256, ROLO_KNN_WALK_OCC) void knn_walk_kernel(KnnPai
   int ki[KMAX];
 #pragma unroll
   for (int u = 0; u < KMAX; u++) ki[u] = key_idx(K[u]);
+  const int slot0 = (KMAX == 64) ? A.c[which].slot0 : 0;                          // rounds exist for the 64-slot kernel only
+  const int ktot = (KMAX == 64 && A.c[which].k_total) ? A.c[which].k_total : kk;
   if (knn_idx) {
 #pragma unroll
-    for (int u = 0; u < KMAX; u++) if (u < kk) { knn_idx[(size_t)qi * kk + u] = ki[u]; knn_d2[(size_t)qi * kk + u] = key_d2(K[u]); }
+    for (int u = 0; u < KMAX; u++) if (u < kk) { knn_idx[(size_t)qi * ktot + slot0 + u] = ki[u]; knn_d2[(size_t)qi * ktot + slot0 + u] = key_d2(K[u]); }
   }
+  if (KMAX == 64 && A.c[which].lower) A.c[which].lower[j] = bkey;   // the next round starts above this round's last key
   if (!FUSE_TAIL) {   // neighbour indices only (slot-major, coalesced): knn_tail_kernel turns them into covariances
     int32_t* __restrict__ nbr = A.c[which].nbr;
 #pragma unroll
-    for (int u = 0; u < KMAX; u++) nbr[(size_t)u * n_sorted + j] = ki[u];
+    for (int u = 0; u < KMAX; u++) nbr[(size_t)(slot0 + u) * n_sorted + j] = ki[u];
     return;
   }
   // FUSE_TAIL (ROLO_KNN_FUSE_TAIL=1, an A/B): covariance + regularisation right here, so that the light wavefronts do theirs while the heavy
@@ -381,6 +389,34 @@ __global__ __launch_bounds__(256, ROLO_KNN_TAIL_OCC) void knn_tail_kernel(KnnPai
     }
   }
   if (fuse) {   // every lane of the wavefront takes part in the segmented fold
+    int id = -1;
+    if (act) { const int slot = vf.tgt_slot[qi]; if (slot >= 0) id = vf.tab.ids[slot]; }
+    accumulate_point(vf.tab, id, sp, c6, fix_scales(cl.n, vf.counters), true, const_cast<int*>(vf.counters) + 1);
+  }
+}
+
+// k_correspondences > 64: the same kernel with the neighbour slots walked in a loop (knn_covariance_tail_loop) — correct, not tuned
+__global__ __launch_bounds__(256) void knn_tail_loop_kernel(KnnPair A, int split, int k, int reg, VoxelFuse vf) {
+  const int blk = xcd_contiguous_block((int)blockIdx.x, (int)gridDim.x);
+  const int which = blk >= split ? 1 : 0;
+  const KnnCloud& cl = A.c[which];
+  const int j = cl.q_begin + (blk - (which ? split : 0)) * 256 + threadIdx.x;
+  const bool fuse = vf.enabled && which == vf.which && !cl.stage;
+  float4 sp = make_float4(0.f, 0.f, 0.f, 0.f);
+  int qi = INT_MAX;
+  if (j < cl.q_end) { sp = cl.sorted[j]; qi = __float_as_int(sp.w); }
+  const bool act = qi != INT_MAX;
+  if (!act && !fuse) return;
+  double c6[6] = {0, 0, 0, 0, 0, 0};
+  if (act) {
+    if (cl.stage) {
+      double* o = cl.stage + (size_t)(j / cl.chunk) * cl.seg + cl.stage_off + (size_t)(j % cl.chunk) * 6;
+      knn_covariance_tail_loop(cl.nbr, (size_t)cl.n_sorted, j, k, cl.xyz, 1, 0, reg, o, c6);
+    } else {
+      knn_covariance_tail_loop(cl.nbr, (size_t)cl.n_sorted, j, k, cl.xyz, cl.n, qi, reg, cl.cov, c6);
+    }
+  }
+  if (fuse) {
     int id = -1;
     if (act) { const int slot = vf.tgt_slot[qi]; if (slot >= 0) id = vf.tab.ids[slot]; }
     accumulate_point(vf.tab, id, sp, c6, fix_scales(cl.n, vf.counters), true, const_cast<int*>(vf.counters) + 1);

@@ -135,7 +135,10 @@ struct BatchSlot { PassArgs a; LmState* st; rolo_trace_rec* trace; int grid; int
 // position; position j lives in segment j / chunk at stage + (j / chunk) * seg + stage_off + (j % chunk) * 6) instead of cov[].
 struct KnnCloud { const float4* xyz; float4* sorted; float4* boxes; double* cov; int32_t* knn_idx; float* knn_d2; int32_t* nbr; int n, n_leaves, P, n_sorted;
                   int q_begin, q_end; double* stage; int chunk, stage_off; size_t seg;
-                  const int* bpart; int n_bpart; };   // partial bounding boxes to fold (the pack kernel's, or bbox_kernel's in the scratch buffer)
+                  const int* bpart; int n_bpart;      // partial bounding boxes to fold (the pack kernel's, or bbox_kernel's in the scratch buffer)
+                  // k_correspondences > 64: the lists are found 64 at a time — round r keeps the 64 smallest keys ABOVE lower[j], the last key of
+                  // round r - 1 (keys (d2, index) are unique per point), and writes slots [slot0, slot0 + 64) of the k_total per query
+                  double* lower; int slot0, k_total; };
 struct KnnPair { KnnCloud c[2]; int n_clouds; };
 // The target's voxel map built inside the search's launches (single GPU, covariances computed here and bounded): the table is cleared by
 // extra workgroups of the key kernel, the points are inserted by extra workgroups of the sort-scatter launches (a share each, on

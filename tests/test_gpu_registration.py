@@ -231,13 +231,15 @@ def test_fused_map_with_other_k_and_search_modes(k, overlap):
     g.close()
 
 
-def test_forty_eight_neighbours():
-    """k above 32 (the reference takes any k): the 64-slot kernels — neighbour lists bit-exact against the oracle, covariances and pose agree"""
+@pytest.mark.parametrize("k", [48, 64, 65, 100, 130])
+def test_many_neighbours(k):
+    """k above 32 (the reference takes any k): the 64-slot kernels, and above 64 the rounds of 64 (each round the 64 nearest beyond the previous
+    round's last key) — neighbour lists bit-exact against the oracle, covariances and pose agree"""
     src, tgt, cfg = make_pair("os64_uniform")
-    p = pyorc.default_params(polar_resolution=cfg["polar"], voxel_type=cfg["voxel_type"], voxel_resolution=cfg["leaf"], k_correspondences=48)
+    p = pyorc.default_params(polar_resolution=cfg["polar"], voxel_type=cfg["voxel_type"], voxel_resolution=cfg["leaf"], k_correspondences=k)
     o = pyorc.Reg(p); o.set_target(tgt); o.set_source(src)
-    g = RotVGICP(); g.setResolution(cfg["leaf"]); g.setCorrespondenceRandomness(48); g.setInputTarget(tgt); g.setInputSource(src)
-    idx_o, d2_o = pyorc.knn(src, 48)
+    g = RotVGICP(); g.setResolution(cfg["leaf"]); g.setCorrespondenceRandomness(k); g.setInputTarget(tgt); g.setInputSource(src)
+    idx_o, d2_o = pyorc.knn(src, k)
     idx_g, d2_g = g.knn(0)
     assert np.array_equal(idx_g, idx_o) and np.array_equal(d2_g, d2_o)
     assert o.compute_covariances() == 0
