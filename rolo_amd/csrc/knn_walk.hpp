@@ -88,7 +88,7 @@ ROLO_DEV void knn_score_leaf(const float4* __restrict__ sorted, int g, const flo
       // sorted insert, descending slot order so every step reads not-yet-overwritten neighbours — in four tiers: a slot whose lower
       // neighbour is already <= the candidate in EVERY lane keeps its value (min(ck, K[s]) = K[s] and K[s-1] <= K[s]), so the lower tiers
       // run only if some lane's candidate sorts below them. Late in the walk candidates barely beat the k-th best: most executions stop
-      // after the first tier (fp64 min / max issue at half the fp32 rate — the insert is two thirds of the walk's VALU cycles).
+      // after the first tier (the insert is two thirds of the walk's VALU instructions; v_min_f64 / v_max_f64 issue at the fp32 rate, profiles/tools/valu_rate.hip).
       // tier boundaries (slots [B1, KMAX) always, then [B2, B1), [B3, B2), [0, B3)); tunable for KMAX = 20 (-DROLO_KNN_B1/B2/B3)
 #ifndef ROLO_KNN_B1
 #define ROLO_KNN_B1 15
@@ -230,7 +230,14 @@ __global__ __launch_bounds__(256, KMAX > 32 ? 2 : ROLO_KNN_WALK_OCC) void knn_wa
   double lo = 0.0;
   if (LOWER && active) lo = A.c[which].lower[j];
   (void)lo;
-  for (int g = g_own0; g < g_own1; g++) { KNN_SCORE(g); st_leaves++; }
+  {  // the wavefront's own leaves first, then the extra ones: the own points are the nearer ones, so fewer keys are inserted only to be pushed out again
+     // (walk 0.1763 -> 0.1725 ms at 2 x 131 072 points, 0.1486 -> 0.1470 at 2 x 43 776)
+    const int n_own = min(g_mine0 + ROLO_KNN_PACKET / KNN_LEAF, n_leaves) - g_mine0, n_before = g_mine0 - g_own0;
+    for (int i = 0; i < g_own1 - g_own0; i++) {
+      const int g = i < n_own ? g_mine0 + i : (i - n_own < n_before ? g_own0 + (i - n_own) : g_mine0 + (i - n_before));
+      KNN_SCORE(g); st_leaves++;
+    }
+  }
 
   // ---- packet walk ----
   // (a stack in one vector register — slot i in lane i, v_writelane / v_readlane — measured the same as this LDS stack: 0.202 vs 0.200 ms;
