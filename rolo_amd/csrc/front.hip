@@ -32,8 +32,12 @@
 namespace rolo {
 
 constexpr int FRONT_GUARD = 8;       // guard cells in front of / behind the per-point arrays (reference reads index -1.. )
-constexpr int FRONT_MAX_H = 2048;    // Horizon_SCAN limit of this build (shipped configs: 1024, 1800, 2048)
-constexpr int SORT_CAP = 3072;       // LDS bitonic capacity (elements): 6 sector segments of <= 512, or one ring's surface scan (<= 2048)
+constexpr int FRONT_MAX_H = 2048;      // Horizon_SCAN up to here: one ring's working set lives in LDS (shipped configs: 1024, 1800, 2048)
+constexpr int FRONT_MAX_H_BIG = 4096;  // ... and up to here in a per-ring scratch area in HBM (the same kernel through global pointers: correct, several times slower;
+                                       // no sensor the reference accepts has that many columns — its params.yaml mentions a Livox Horizon at 4000)
+// bitonic capacity (elements) for a Horizon_SCAN limit of maxh: 6 sector segments of <= maxh / 4, which also holds one ring's surface scan (<= maxh)
+constexpr int front_sort_cap(int maxh) { return 6 * (maxh / 4); }
+constexpr size_t front_ring_bytes(int maxh) { return sizeof(unsigned long long) * (size_t)front_sort_cap(maxh) + sizeof(int) * (size_t)(maxh + 32) * 8 + sizeof(int) * (size_t)(maxh + 16); }
 constexpr int ST_OUT = 0, ST_UNDECIDED = 1, ST_PICKED = 2;
 
 namespace {
@@ -286,7 +290,8 @@ struct FeatArgs {
   const int* start_ring; const int* end_ring;
   const int* n_ptr; int n_scan; float edge_threshold, surf_threshold, leaf;
   float4* corner_stage; int* corner_cnt;  // [n_scan][6][20], [n_scan][6]
-  float4* surf_stage; int* surf_cnt;      // [n_scan][FRONT_MAX_H], [n_scan]
+  float4* surf_stage; int* surf_cnt;      // [n_scan][MAXH], [n_scan]
+  unsigned char* big;                     // Horizon_SCAN > 2048: front_ring_bytes(MAXH) of scratch per ring
 };
 
 // One workgroup of XT = 1024 threads per ring: 128 rings are only 128 workgroups, so the parallelism has to come from inside —
@@ -294,7 +299,7 @@ struct FeatArgs {
 #ifndef ROLO_XT
 #define ROLO_XT 1024
 #endif
-constexpr int XT = ROLO_XT, XW = XT / 64, UP = (512 + XT - 1) / XT;   // threads, wavefronts, sector positions per thread
+constexpr int XT = ROLO_XT, XW = XT / 64;   // threads, wavefronts
 #ifdef ROLO_XT_STATS
 __device__ unsigned long long g_xt[128][8];   // per ring: phase time stamps of extract_kernel (shader clock)
 #define XT_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 128) g_xt[blockIdx.x][k] = clock64(); } while (0)
@@ -305,17 +310,20 @@ extern "C" int rolo_debug_extract_times(unsigned long long* out /* 128 x 8 */) {
 #else
 #define XT_STAMP(k)
 #endif
+template <int MAXH, bool GLOBAL>
 __global__ __launch_bounds__(XT) void extract_kernel(FeatArgs A) {
-  extern __shared__ unsigned char smem_raw[];
-  // layout: keys[SORT_CAP] u64 | l_picked | l_col | l_label | l_curv (ring window) | list[FRONT_MAX_H+16] | l_brk | l_rank | l_stat | l_reach (window)
+  extern __shared__ unsigned char smem_lds[];
+  constexpr int SORT_CAP = front_sort_cap(MAXH), SEGMAX = MAXH / 4, UP = (SEGMAX + XT - 1) / XT;   // UP: sector positions per thread
+  unsigned char* smem_raw = GLOBAL ? A.big + (size_t)blockIdx.x * front_ring_bytes(MAXH) : smem_lds;
+  // layout: keys[SORT_CAP] u64 | l_picked | l_col | l_label | l_curv (ring window) | list[MAXH+16] | l_brk | l_rank | l_stat | l_reach (window)
   unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem_raw);
-  const int WIN = FRONT_MAX_H + 2 * 16;
+  const int WIN = MAXH + 2 * 16;
   int* l_picked = reinterpret_cast<int*>(keys + SORT_CAP);
   int* l_col = l_picked + WIN;
   int* l_label = l_col + WIN;
   float* l_curv = reinterpret_cast<float*>(l_label + WIN);
   int* list = reinterpret_cast<int*>(l_curv + WIN);
-  int* l_brk = list + (FRONT_MAX_H + 16);
+  int* l_brk = list + (MAXH + 16);
   int* l_rank = l_brk + WIN;
   int* l_stat = l_rank + WIN;
   int* l_reach = l_stat + WIN;   // how far a pick's suppression marks go from this cell: forward | backward << 4 (0..5 each)
@@ -332,7 +340,7 @@ __global__ __launch_bounds__(XT) void extract_kernel(FeatArgs A) {
   const int w0 = s - 16;
   int wlen = (e - s) + 32 + 1;
   if (wlen < 0) wlen = 0;
-  if (wlen > WIN) wlen = WIN;  // guarded by the host (ring population <= FRONT_MAX_H)
+  if (wlen > WIN) wlen = WIN;  // guarded by the host (ring population <= MAXH)
   for (int i = t; i < wlen; i += XT) {
     const int gi = w0 + i;
     const bool in = gi >= -FRONT_GUARD && gi < n + FRONT_GUARD;
@@ -364,7 +372,7 @@ __global__ __launch_bounds__(XT) void extract_kernel(FeatArgs A) {
       const int sp = (s * (6 - j) + e * j) / 6, ep = (s * (5 - j) + e * (j + 1)) / 6 - 1;
       maxlen = max(maxlen, ep - sp);
     }
-    while (seg < maxlen) seg <<= 1;  // <= 512: a sector holds at most Horizon_SCAN / 6 + 1 points
+    while (seg < maxlen) seg <<= 1;  // <= SEGMAX: a sector holds at most Horizon_SCAN / 6 + 1 points
   }
   for (int i = t; i < 6 * seg; i += XT) {
     const int j = i / seg, li = i - j * seg;
@@ -401,7 +409,7 @@ __global__ __launch_bounds__(XT) void extract_kernel(FeatArgs A) {
     const bool thr_ok = A.surf_threshold > 0.f && A.edge_threshold >= 0.f;
     const bool head_ok = !head_sp || (thr_ok && !tail_sp && ep >= 5 && w0 <= 0 && -w0 < wlen);
     const bool tail_ok = !tail_sp || (thr_ok && !head_sp && n >= 64 && A.start_ring[0] == 0 && A.end_ring[0] >= 30);
-    if (head_ok && tail_ok && len < 512) {
+    if (head_ok && tail_ok && len < SEGMAX) {
       // ---- parallel greedy picks ----
       // The reference walks the sector in curvature order and a pick marks its +-5 neighbours (up to a column break) as
       // taken. Equivalent fixed point: a candidate is picked iff no better-ranked candidate that reaches it is picked.
@@ -632,7 +640,7 @@ __global__ __launch_bounds__(XT) void extract_kernel(FeatArgs A) {
   }
   const float inv = 1.0f / A.leaf;
   const long long dx = (long long)((mx[0] - mn[0]) * inv) + 1, dy = (long long)((mx[1] - mn[1]) * inv) + 1, dz = (long long)((mx[2] - mn[2]) * inv) + 1;
-  float4* out = A.surf_stage + (size_t)ring * FRONT_MAX_H;
+  float4* out = A.surf_stage + (size_t)ring * MAXH;
   if (dx * dy * dz > (long long)INT_MAX) {  // PCL: warn and copy the input through
     for (int i = t; i < m; i += XT) out[i] = A.extracted[list[i]];
     if (t == 0) A.surf_cnt[ring] = m;
@@ -763,6 +771,7 @@ struct Front {
   float* curv = nullptr; int *picked = nullptr, *label = nullptr;
   float4 *corner_stage = nullptr, *surf_stage = nullptr, *corner_out = nullptr, *surf_out = nullptr;
   int *corner_cnt = nullptr, *surf_cnt = nullptr;
+  unsigned char* big = nullptr; int maxh = FRONT_MAX_H, cap_maxh = 0;   // Horizon_SCAN > 2048: per-ring scratch of the extract kernel, staging pitch
   int n_valid = 0; int n_scan = 0, H = 0;
   bool projected = false;
   bool extract_cleared = false;   // the projection's clear launch already zeroed curv / picked / label for the extraction that follows
@@ -787,7 +796,7 @@ bool dev_alloc(T*& p, size_t count) {
 
 void front_free(Front* f) {
   void* bufs[] = {f->raw, f->ring, f->owner, f->local_idx, f->ring_count, f->start_ring, f->end_ring, f->counters, f->extracted, f->col, f->range,
-                  f->range_mat, f->curv, f->picked, f->label, f->corner_stage, f->surf_stage, f->corner_out, f->surf_out, f->corner_cnt, f->surf_cnt, f->rel_time, f->msg_raw, f->msg_xyz, f->msg_ring, f->msg_time};
+                  f->range_mat, f->curv, f->picked, f->label, f->corner_stage, f->surf_stage, f->corner_out, f->surf_out, f->corner_cnt, f->surf_cnt, f->big, f->rel_time, f->msg_raw, f->msg_xyz, f->msg_ring, f->msg_time};
   for (void* b : bufs) if (b) (void)hipFree(b);
 }
 
@@ -806,7 +815,7 @@ namespace {
 // device buffers for frames of up to n_raw points / n_scan x horizon_scan pixels
 int front_prepare(rolo_ctx* c, const rolo_front_params* P, int n_raw, int stride, bool stage_raw, Front** out) {
   if (P->n_scan <= 0 || P->horizon_scan <= 0 || P->downsample_rate <= 0) { ctx_set_error("bad front params"); return ROLO_EINVAL; }
-  if (P->horizon_scan > FRONT_MAX_H) { ctx_set_error("Horizon_SCAN above the limit of this build (2048)"); return ROLO_EUNSUPPORTED; }
+  if (P->horizon_scan > FRONT_MAX_H_BIG) { ctx_set_error("Horizon_SCAN above the limit of this build (4096)"); return ROLO_EUNSUPPORTED; }
   FCHK(hipSetDevice(ctx_device(c)));
   void** slot = ctx_front_slot(c);
   if (!*slot) *slot = new Front();
@@ -832,12 +841,15 @@ int front_prepare(rolo_ctx* c, const rolo_front_params* P, int n_raw, int stride
          dev_alloc(f->surf_out, npix);
     f->cap_pix = npix;
   }
-  if ((size_t)NS > f->cap_scan || !f->ring_count) {
+  const int maxh = H > FRONT_MAX_H ? FRONT_MAX_H_BIG : FRONT_MAX_H;   // pitch of the per-ring staging rows, and which extract kernel runs
+  if ((size_t)NS > f->cap_scan || !f->ring_count || maxh > f->cap_maxh) {
     ok = ok && dev_alloc(f->ring_count, NS) && dev_alloc(f->start_ring, NS) && dev_alloc(f->end_ring, NS) && dev_alloc(f->counters, 8) &&
-         dev_alloc(f->corner_stage, (size_t)NS * 6 * 20) && dev_alloc(f->corner_cnt, (size_t)NS * 6) && dev_alloc(f->surf_stage, (size_t)NS * FRONT_MAX_H) &&
+         dev_alloc(f->corner_stage, (size_t)NS * 6 * 20) && dev_alloc(f->corner_cnt, (size_t)NS * 6) && dev_alloc(f->surf_stage, (size_t)NS * maxh) &&
          dev_alloc(f->surf_cnt, NS);
-    f->cap_scan = NS;
+    if (maxh > FRONT_MAX_H) ok = ok && dev_alloc(f->big, (size_t)NS * front_ring_bytes(FRONT_MAX_H_BIG));
+    f->cap_scan = ok ? NS : 0; f->cap_maxh = ok ? maxh : 0;
   }
+  f->maxh = maxh;
   if (!ok) { ctx_set_error("hipMalloc failed (front end)"); return ROLO_EHIP; }
   f->n_scan = NS; f->H = H; f->projected = false;
   *out = f;
@@ -901,17 +913,21 @@ int front_extract_enqueue(Front* f, const rolo_front_params* P, hipStream_t s, f
   A.label = f->label + FRONT_GUARD; A.start_ring = f->start_ring; A.end_ring = f->end_ring; A.n_ptr = f->counters; A.n_scan = NS;
   A.edge_threshold = P->edge_threshold; A.surf_threshold = P->surf_threshold; A.leaf = P->odometry_surf_leaf_size;
   A.corner_stage = f->corner_stage; A.corner_cnt = f->corner_cnt; A.surf_stage = f->surf_stage; A.surf_cnt = f->surf_cnt;
-  const size_t WIN = FRONT_MAX_H + 32;
-  const size_t lds = sizeof(unsigned long long) * SORT_CAP + sizeof(int) * WIN * 8 + sizeof(int) * (FRONT_MAX_H + 16);
-  static std::atomic<unsigned long long> attr_set{0};   // per device ordinal (bit d): the attribute belongs to the device's code object
-  const unsigned long long dev_bit = 1ull << (f->device & 63);
-  if (!(attr_set.load() & dev_bit)) { FCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(extract_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set.fetch_or(dev_bit); }
-  extract_kernel<<<NS, XT, lds, s>>>(A);
+  A.big = reinterpret_cast<unsigned char*>(f->big);
+  if (f->maxh > FRONT_MAX_H) {
+    extract_kernel<FRONT_MAX_H_BIG, true><<<NS, XT, 0, s>>>(A);   // the ring's working set in HBM scratch
+  } else {
+    constexpr size_t lds = front_ring_bytes(FRONT_MAX_H);
+    static std::atomic<unsigned long long> attr_set{0};   // per device ordinal (bit d): the attribute belongs to the device's code object
+    const unsigned long long dev_bit = 1ull << (f->device & 63);
+    if (!(attr_set.load() & dev_bit)) { FCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(extract_kernel<FRONT_MAX_H, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set.fetch_or(dev_bit); }
+    extract_kernel<FRONT_MAX_H, false><<<NS, XT, lds, s>>>(A);
+  }
   if (fused_out) {
-    feature_gather_kernel<<<NS * 7, 256, 0, s>>>(f->corner_stage, f->corner_cnt, NS * 6, f->surf_stage, f->surf_cnt, NS, FRONT_MAX_H, fused_out, f->counters, pub3);
+    feature_gather_kernel<<<NS * 7, 256, 0, s>>>(f->corner_stage, f->corner_cnt, NS * 6, f->surf_stage, f->surf_cnt, NS, f->maxh, fused_out, f->counters, pub3);
   } else {
     concat_kernel<<<NS * 6, 256, 0, s>>>(f->corner_stage, f->corner_cnt, NS * 6, 20, f->corner_out, f->counters + 1);
-    concat_kernel<<<NS, 256, 0, s>>>(f->surf_stage, f->surf_cnt, NS, FRONT_MAX_H, f->surf_out, f->counters + 2);
+    concat_kernel<<<NS, 256, 0, s>>>(f->surf_stage, f->surf_cnt, NS, f->maxh, f->surf_out, f->counters + 2);
   }
   FCHK(hipGetLastError());
   return ROLO_OK;

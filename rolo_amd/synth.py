@@ -22,6 +22,7 @@ SENSORS = {
     "os1-64": (64, 1024, -22.5, 22.5),
     "os1-128": (128, 1024, -22.5, 22.5),
     "os1-128x2048": (128, 2048, -22.5, 22.5),
+    "wide-32x4096": (32, 4096, -16.0, 16.0),   # no such sensor: Horizon_SCAN above 2048 (the front end's HBM-scratch path)
 }
 
 # fixed obstacle table: ("box", cx, cy, hx, hy, z0, z1) or ("cyl", cx, cy, radius, z0, z1)

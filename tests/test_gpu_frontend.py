@@ -11,7 +11,8 @@ from rolo_amd.rotvgicp import RotVGICP
 pytestmark = pytest.mark.gpu
 
 SENSORS = {"vlp16": dict(n_scan=16, horizon_scan=1800), "os1-64": dict(n_scan=64, horizon_scan=1024),
-           "os1-128": dict(n_scan=128, horizon_scan=1024), "os1-128x2048": dict(n_scan=128, horizon_scan=2048)}
+           "os1-128": dict(n_scan=128, horizon_scan=1024), "os1-128x2048": dict(n_scan=128, horizon_scan=2048),
+           "wide-32x4096": dict(n_scan=32, horizon_scan=4096)}
 
 
 def both(sensor, frame, **kw):
@@ -45,7 +46,7 @@ def check_features(fo, po, fe, pg):
     return eo, eg
 
 
-@pytest.mark.parametrize("sensor", ["vlp16", "os1-64", "os1-128", "os1-128x2048"])
+@pytest.mark.parametrize("sensor", ["vlp16", "os1-64", "os1-128", "os1-128x2048", "wide-32x4096"])
 def test_projection_and_features_match_oracle(sensor):
     f0, f1, _ = synth.make_pair(sensor)
     for fr in (f0, f1):
