@@ -251,9 +251,9 @@ def _peer_proc_main(rank, world, dirpath):
     g.close()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 4, 8])
 def test_ranks_in_processes_one_device_peer_exchange(tmp_path, world):
-    """W processes, hipIpc handles, one device: the whole N > 1 path — K5 by query slice + peer-written covariance exchange, passes by
+    """W processes (up to the 8 of a node: every slot of the mailbox layout), hipIpc handles, one device: the whole N > 1 path — K5 by query slice + peer-written covariance exchange, passes by
     source shard + mailbox all-reduce in the controller — against the unsharded registration."""
     import subprocess
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", ROLO_PEER_TIMEOUT_MS="20000")
