@@ -313,6 +313,51 @@ __global__ __launch_bounds__(SORT_T) void sort_hist_kernel(const uint32_t* __res
   if (tid < SORT_D) cnt[(size_t)pass * SORT_NB * SORT_D + blk * SORT_D + tid] = hist[tid];
 }
 
+#ifdef ROLO_KNN_KD_REFINE
+// 256 threads, one point each (padding: +inf coordinates, sorts last on every axis): returns the point of this thread's slot after the splits
+ROLO_DEV float4 kd_refine_block(float4 cur) {
+  __shared__ float4 pts[256];
+  __shared__ unsigned long long key[256];
+  __shared__ float w_lo[4][3], w_hi[4][3];
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  for (int seg = 256; seg >= 2 * KNN_LEAF; seg >>= 1) {
+    const bool pad = __float_as_int(cur.w) == INT_MAX;
+    float lo[3] = {pad ? INFINITY : cur.x, pad ? INFINITY : cur.y, pad ? INFINITY : cur.z};
+    float hi[3] = {pad ? -INFINITY : cur.x, pad ? -INFINITY : cur.y, pad ? -INFINITY : cur.z};
+    const int in_wave = seg < 64 ? seg : 64;
+#pragma unroll
+    for (int d = 0; d < 3; d++)
+      for (int m = 1; m < in_wave; m <<= 1) { lo[d] = fminf(lo[d], __shfl_xor(lo[d], m)); hi[d] = fmaxf(hi[d], __shfl_xor(hi[d], m)); }
+    if (seg > 64) {
+      if (lane == 0) for (int d = 0; d < 3; d++) { w_lo[wv][d] = lo[d]; w_hi[wv][d] = hi[d]; }
+      __syncthreads();
+      const int w0 = (t / seg) * (seg / 64);
+      for (int d = 0; d < 3; d++) { lo[d] = w_lo[w0][d]; hi[d] = w_hi[w0][d]; for (int w = 1; w < seg / 64; w++) { lo[d] = fminf(lo[d], w_lo[w0 + w][d]); hi[d] = fmaxf(hi[d], w_hi[w0 + w][d]); } }
+    }
+    const float ex = hi[0] - lo[0], ey = hi[1] - lo[1], ez = hi[2] - lo[2];
+    const int axis = (ey > ex && ey >= ez) ? 1 : ((ez > ex && ez > ey) ? 2 : 0);
+    const float c = axis == 0 ? cur.x : (axis == 1 ? cur.y : cur.z);
+    unsigned u = __float_as_uint(c); u ^= (u >> 31) ? 0xffffffffu : 0x80000000u;
+    pts[t] = cur;
+    key[t] = ((unsigned long long)u << 32) | (unsigned)t;
+    __syncthreads();
+    for (int k = 2; k <= seg; k <<= 1)
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        const int ixj = t ^ j;
+        if (ixj > t) {
+          const unsigned long long a = key[t], b = key[ixj];
+          const bool up = ((t & (seg - 1)) & k) == 0;
+          if ((a > b) == up) { key[t] = b; key[ixj] = a; }
+        }
+        __syncthreads();
+      }
+    cur = pts[(int)(unsigned)(key[t] & 0xffffffffull)];
+    __syncthreads();
+  }
+  return cur;
+}
+#endif
+
 // one thread per slot of the sorted copy: gather the point in curve order, write it + (first lane of a leaf) the leaf box
 __global__ __launch_bounds__(256) void leaf_kernel(KnnPair A, int split, const uint32_t* __restrict__ order) {
   // one thread per slot of the sorted copy (a thread per leaf gathered its 16 points one after the other: 13 us); the leaf box is a min / max
@@ -324,18 +369,23 @@ __global__ __launch_bounds__(256) void leaf_kernel(KnnPair A, int split, const u
   order += which ? A.c[0].n : 0;
   const int s = ((int)blockIdx.x - (which ? split : 0)) * blockDim.x + threadIdx.x;
   const int g = s / KNN_LEAF;
-  if (g >= P) return;   // whole leaves only: KNN_LEAF divides the block size
-  float lox = INFINITY, loy = INFINITY, loz = INFINITY, hix = -INFINITY, hiy = -INFINITY, hiz = -INFINITY;
-  if (g < n_leaves) {
-    float4 o = make_float4(INFINITY, INFINITY, INFINITY, __int_as_float(INT_MAX));
-    if (s < n) {
-      const uint32_t idx = order[s];
-      const float4 q = p[idx];
-      o = make_float4(q.x, q.y, q.z, __int_as_float((int)idx));
-      lox = hix = q.x; loy = hiy = q.y; loz = hiz = q.z;
-    }
-    sorted[s] = o;
+  float4 o = make_float4(INFINITY, INFINITY, INFINITY, __int_as_float(INT_MAX));   // padding: never a neighbour, never inside a box
+  if (g < P && s < n) {
+    const uint32_t idx = order[s];
+    const float4 q = p[idx];
+    o = make_float4(q.x, q.y, q.z, __int_as_float((int)idx));
   }
+#ifdef ROLO_KNN_KD_REFINE
+  // (experiment) the 256 curve-consecutive points of this workgroup re-ordered by four median splits on the widest axis (256 -> 16 x 16): the curve
+  // keeps the block together in space, the splits make its packets (64) and leaves (16) compact boxes instead of stretches of a curve that
+  // enters and leaves a surface. Padding sorts last at every level, so the real points stay a prefix of the block. (P >= 16: whole blocks.)
+  if (P >= 16) o = kd_refine_block(o);
+#endif
+  if (g >= P) return;   // whole leaves only: KNN_LEAF divides the block size
+  const bool real = __float_as_int(o.w) != INT_MAX;
+  float lox = real ? o.x : INFINITY, loy = real ? o.y : INFINITY, loz = real ? o.z : INFINITY;
+  float hix = real ? o.x : -INFINITY, hiy = real ? o.y : -INFINITY, hiz = real ? o.z : -INFINITY;
+  if (g < n_leaves) sorted[s] = o;
 #pragma unroll
   for (int m = 1; m < KNN_LEAF; m <<= 1) {
     lox = fminf(lox, __shfl_xor(lox, m)); loy = fminf(loy, __shfl_xor(loy, m)); loz = fminf(loz, __shfl_xor(loz, m));
