@@ -1589,6 +1589,10 @@ int rolo_peer_export(rolo_ctx* c, int world, int max_points, void* handle64) {
   }
   if (e != hipSuccess) { if (P.base) { (void)hipFree(P.base); P.base = nullptr; } return fail_hip(e, "hipIpcGetMemHandle (HSA_ENABLE_IPC_MODE_LEGACY=0 set?)"); }
   HIPCHK(hipMemsetAsync(P.base, 0, PEER_STAGE_OFFSET, c->stream));
+  {  // what the peers check before they push anything here (rolo_peer_connect)
+    const unsigned long long hdr[2] = {(unsigned long long)P.area_bytes, (unsigned long long)world};
+    HIPCHK(hipMemcpyAsync(static_cast<unsigned long long*>(P.base) + PEER_W_AREA_BYTES, hdr, sizeof(hdr), hipMemcpyHostToDevice, c->stream));
+  }
   if (!P.h_err) HIPCHK(hipHostMalloc((void**)&P.h_err, sizeof(int)));
   *P.h_err = 0;
   HIPCHK(hipStreamSynchronize(c->stream));
@@ -1626,6 +1630,19 @@ int rolo_peer_connect(rolo_ctx* c, const void* handles, int rank, int world) {
       hipError_t e = hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess);
       if (e != hipSuccess) { peer_disconnect_impl(c); return fail_hip(e, "hipIpcOpenMemHandle"); }
       P.mapped[r] = ptr; P.ipc_opened[r] = true;
+    }
+  }
+  // every rank pushes its covariance segments into every peer's exchange area and its LM sums into every peer's slots: a peer that exported a
+  // smaller mailbox (another max_points, another world) would be written out of bounds — refuse before the first frame
+  for (int r = 0; r < world; r++) {
+    if (r == rank) continue;
+    unsigned long long hdr[2] = {0, 0};
+    hipError_t e = hipMemcpy(hdr, static_cast<const unsigned long long*>(P.mapped[r]) + PEER_W_AREA_BYTES, sizeof(hdr), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) { peer_disconnect_impl(c); return fail_hip(e, "reading a peer's mailbox header"); }
+    if (hdr[0] != (unsigned long long)P.area_bytes || hdr[1] != (unsigned long long)world) {
+      peer_disconnect_impl(c);
+      g_err = "rolo_peer_connect: rank " + std::to_string(r) + " exported a mailbox for another max_points / world (every rank must call rolo_peer_export with the same arguments)";
+      return ROLO_EINVAL;
     }
   }
   P.args = PeerArgs{};

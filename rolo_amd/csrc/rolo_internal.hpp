@@ -115,6 +115,8 @@ constexpr int PEER_SLOT_WORDS = 2 * NV_MAX; // 64 words of 8 bytes per (parity, 
 constexpr int PEER_W_LM_EPOCH = 0;          // own counter of LM exchanges done (only the local controller touches it)
 constexpr int PEER_W_COV_EPOCH = 1;         // own counter of covariance exchanges done
 constexpr int PEER_W_TICKET = 2;            // arrival ticket of the covariance push kernel
+constexpr int PEER_W_AREA_BYTES = 3;        // bytes of ONE exchange area of this mailbox (written at export, read by the peers at connect: every rank pushes whole segments here)
+constexpr int PEER_W_WORLD = 4;             // the world size this mailbox was exported for
 constexpr int PEER_W_COV_FLAG = 8;          // [PEER_MAX] flag of rank r: epoch of the last covariance segment r pushed here
 constexpr int PEER_W_SLOTS = 64;            // [2][PEER_MAX][PEER_SLOT_WORDS]
 constexpr size_t PEER_STAGE_OFFSET = 16384; // bytes: covariance exchange area behind the header (2 * 8 * 512 B of slots end at 8704)

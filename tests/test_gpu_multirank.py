@@ -272,6 +272,21 @@ def test_ranks_in_processes_one_device_peer_exchange(tmp_path, world):
     _check_against_unsharded(res, 4)
 
 
+def test_peer_connect_refuses_a_mailbox_of_another_size():
+    """Every rank pushes whole segments into every peer's exchange area: a peer that exported for fewer points must be refused at connect"""
+    from rolo_amd.rotvgicp import RotVGICP
+    from rolo_amd._lib import RoloError
+    a, b = RotVGICP(0), RotVGICP(0)
+    ha, hb = a.peer_export(2, 100000), b.peer_export(2, 20000)
+    with pytest.raises(RoloError) as ei:
+        a.peer_connect([ha, hb], 0, 2)
+    assert ei.value.code == -1 and "max_points" in str(ei.value)
+    hb = b.peer_export(2, 100000)   # exported again with matching arguments: fine
+    a.peer_connect([ha, hb], 0, 2); b.peer_connect([ha, hb], 1, 2)
+    assert a.peer_info()[:2] == (0, 2) and b.peer_info()[:2] == (1, 2)
+    a.close(); b.close()
+
+
 def test_peer_timeout_is_an_error_not_a_hang(monkeypatch):
     """A rank whose peer never shows up gives up after ROLO_PEER_TIMEOUT_MS with ROLO_ECOMM (-9)."""
     import time
