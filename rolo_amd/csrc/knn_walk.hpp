@@ -75,6 +75,9 @@ ROLO_DEV void knn_score_leaf(const float4* __restrict__ sorted, int g, const flo
 #pragma unroll
   for (int u = 0; u < KNN_LEAF; u++) pts[u] = sorted[KNN_LEAF * (size_t)g + u];
   KNN_STAT(const double bkey0 = bkey; unsigned my_acc = 0;)   // accepted against the bound at leaf entry: what a per-lane queue would hold
+#ifdef ROLO_KNN_STATS2
+  unsigned my_cur = 0;
+#endif
 #pragma unroll
   for (int u = 0; u < KNN_LEAF; u++) {
     const float4 c = pts[u];
@@ -84,6 +87,9 @@ ROLO_DEV void knn_score_leaf(const float4* __restrict__ sorted, int g, const flo
     const double ck = (LOWER && !(ck0 > lo)) ? key_pack(INFINITY, INT_MAX) : ck0;   // LOWER: a point of an earlier round's 64 is no candidate
     KNN_STAT(if (__any(ck < bkey)) { n_ins++; lane_acc += (unsigned)__popcll(__ballot(ck < bkey)); })
     KNN_STAT(if (ck < bkey0) my_acc++;)
+#ifdef ROLO_KNN_STATS2
+    if (ck < bkey) my_cur++;   // accepted against the CURRENT bound: this lane's own inserts
+#endif
     if (ck < bkey) {
       // sorted insert, descending slot order so every step reads not-yet-overwritten neighbours — in four tiers: a slot whose lower
       // neighbour is already <= the candidate in EVERY lane keeps its value (min(ck, K[s]) = K[s] and K[s-1] <= K[s]), so the lower tiers
@@ -117,9 +123,14 @@ ROLO_DEV void knn_score_leaf(const float4* __restrict__ sorted, int g, const flo
     }
   }
 #ifdef ROLO_KNN_STATS
+#ifdef ROLO_KNN_STATS2
+  rounds += my_cur;   // per LANE (record [7] becomes the wave maximum of a lane's inserts over the whole walk: what a cross-leaf queue would execute at least)
+  (void)my_acc;
+#else
   { unsigned m = my_acc;   // wave maximum: the drain iterations of a per-lane queue for this leaf
     for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off, 64));
     rounds += m; }
+#endif
 #endif
 }
 
@@ -327,10 +338,14 @@ __global__ __launch_bounds__(256, KMAX > 32 ? 2 : ROLO_KNN_WALK_OCC) void knn_wa
   }
 #ifdef ROLO_KNN_STATS
   { unsigned long long wt1; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(wt1));
+    unsigned st_rounds_rec = st_rounds;
+#ifdef ROLO_KNN_STATS2
+    for (int off = 32; off > 0; off >>= 1) st_rounds_rec = max(st_rounds_rec, (unsigned)__shfl_xor((int)st_rounds_rec, off, 64));
+#endif
     const unsigned wid = blockIdx.x * 4 + (threadIdx.x >> 6);
     if ((threadIdx.x & 63) == 0 && wid < 16384) {
       g_knn_wave_rec[wid][0] = st_nodes; g_knn_wave_rec[wid][1] = st_leaves; g_knn_wave_rec[wid][2] = st_ins; g_knn_wave_rec[wid][3] = st_push;
-      g_knn_wave_rec[wid][4] = (unsigned)wt0; g_knn_wave_rec[wid][5] = (unsigned)wt1; g_knn_wave_rec[wid][6] = st_lane; g_knn_wave_rec[wid][7] = st_rounds;
+      g_knn_wave_rec[wid][4] = (unsigned)wt0; g_knn_wave_rec[wid][5] = (unsigned)wt1; g_knn_wave_rec[wid][6] = st_lane; g_knn_wave_rec[wid][7] = st_rounds_rec;
     } }
 #endif
   (void)st_nodes; (void)st_leaves; (void)st_ins; (void)st_lane; (void)st_rounds;
