@@ -65,6 +65,13 @@ ROLO_DEV int key_idx(double k) { return (int)(unsigned)((unsigned long long)__do
 // quieting) — our operands are never NaN by construction. Pure VALU, no memory: safe as inline asm.
 ROLO_DEV double vmin_f64(double a, double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 ROLO_DEV double vmax_f64(double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+// one slot of the sorted insert, K[s] = max(K[s-1], min(c, K[s])), as ONE asm statement: between two statements the compiler puts an s_nop for the
+// read-after-write it cannot see into (20 per full insert); inside one statement the hardware interlock does the same job without the slot
+#ifndef ROLO_KNN_SPLIT_MINMAX
+ROLO_DEV void insert_slot(double& ks, double ksm1, double c) { asm("v_min_f64 %0, %1, %0\n\tv_max_f64 %0, %2, %0" : "+v"(ks) : "v"(c), "v"(ksm1)); }
+#else
+ROLO_DEV void insert_slot(double& ks, double ksm1, double c) { ks = vmax_f64(ksm1, vmin_f64(c, ks)); }
+#endif
 // score the KNN_LEAF (16) points of leaf g against this lane's query and insert the ones that beat its current k-th best
 template <int KMAX, bool LOWER = false>
 ROLO_DEV void knn_score_leaf(const float4* __restrict__ sorted, int g, const float4& q, double (&K)[KMAX], int kk, double& bkey, float& bd,
@@ -103,16 +110,16 @@ ROLO_DEV void knn_score_leaf(const float4* __restrict__ sorted, int g, const flo
 #endif
       constexpr int B1 = KMAX == 20 ? ROLO_KNN_B1 : 3 * (KMAX / 4), B2 = KMAX == 20 ? ROLO_KNN_B2 : 2 * (KMAX / 4), B3 = KMAX == 20 ? ROLO_KNN_B3 : KMAX / 4;
 #pragma unroll
-      for (int s = KMAX - 1; s >= B1; s--) K[s] = vmax_f64(K[s - 1], vmin_f64(ck, K[s]));
+      for (int s = KMAX - 1; s >= B1; s--) insert_slot(K[s], K[s - 1], ck);
       if (__any(ck < K[B1 - 1])) {
 #pragma unroll
-        for (int s = B1 - 1; s >= B2; s--) K[s] = vmax_f64(K[s - 1], vmin_f64(ck, K[s]));
+        for (int s = B1 - 1; s >= B2; s--) insert_slot(K[s], K[s - 1], ck);
         if (__any(ck < K[B2 - 1])) {
 #pragma unroll
-          for (int s = B2 - 1; s >= B3; s--) K[s] = vmax_f64(K[s - 1], vmin_f64(ck, K[s]));
+          for (int s = B2 - 1; s >= B3; s--) insert_slot(K[s], K[s - 1], ck);
           if (__any(ck < K[B3 - 1])) {
 #pragma unroll
-            for (int s = B3 - 1; s >= 1; s--) K[s] = vmax_f64(K[s - 1], vmin_f64(ck, K[s]));
+            for (int s = B3 - 1; s >= 1; s--) insert_slot(K[s], K[s - 1], ck);
             K[0] = vmin_f64(ck, K[0]);
           }
         }
