@@ -659,7 +659,9 @@ def test_cpp_operator_constructed_per_frame_uses_the_context_pool(tmp_path):
     per_frame_obj, persistent, create_destroy, same_a, same_b = r.stdout.split()
     print("ms per frame: object per frame %s, persistent object %s; an unpooled rolo_ctx_create + destroy alone: %s" % (per_frame_obj, persistent, create_destroy))
     assert same_a == "1" and same_b == "1"                      # every frame of both loops reproduces the first frame's result exactly
-    assert float(per_frame_obj) <= 1.15 * float(persistent) + 0.05   # the verdict's bar is 5 %; the assertion leaves room for a noisy box
+    # the measured figure (bench.py `cpp_operator_per_frame`: 0.706 against 0.705 ms) is not this test's business — a shared box can stretch either
+    # loop; what it must catch is a context created and destroyed per frame (+8 ms, ten times the frame)
+    assert float(per_frame_obj) <= 2.0 * float(persistent) + 0.5 and float(per_frame_obj) < 0.5 * float(create_destroy)
 
 
 def test_context_pool_hands_out_fresh_objects():
