@@ -393,6 +393,178 @@ __global__ __launch_bounds__(XT) void extract_kernel(FeatArgs A) {
   bitonic_sort_lds_seg<XT>(keys, 6 * seg, seg);   // std::sort(begin+sp, begin+ep) with the (value, ind) tie order
   XT_STAMP(2);
 
+  // ---- all twelve pick stages of the ring as ONE fixed point (rings away from the cloud's two ends, at most 20 corners per sector) ----
+  // The reference walks sector 0 corners, sector 0 surfaces, sector 1 corners, ... (featureExtraction.cpp:168-252); a pick marks its +-5
+  // neighbours (up to a column break) and later candidates that are marked are skipped. Order every candidate of the ring by (sector, pass,
+  // rank in its walk): a candidate is picked iff no candidate EARLIER in that order that reaches it is picked — the stage-by-stage rule
+  // below with the order extended across stages, so the chains of twelve stages resolve together (a stage costs ~4 us of barriers with
+  // a third of the threads busy). Not covered here and left to the staged code: sectors at the cloud's ends (stale smoothness entries),
+  // thresholds that let a cell be corner AND surface candidate, and the cap — the corner walk stops after its 20th pick
+  // (largestPickedNum, :186-193), so a sector with more corner picks than that is redone stage by stage (checked before anything is applied).
+  bool global_done = false;
+#ifndef ROLO_XT_STAGED
+  {
+    constexpr int UPG = (6 * SEGMAX + XT - 1) / XT;   // entries (sector, position) per thread
+    __shared__ int s_gpk[UPG][XW], s_gep[6], s_gbad;
+    bool eligible = A.surf_threshold > 0.f && A.edge_threshold >= A.surf_threshold && seg >= 64 && e - s >= 12;
+    int sps[6], eps[6];
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+      sps[j] = (s * (6 - j) + e * j) / 6; eps[j] = (s * (5 - j) + e * (j + 1)) / 6 - 1;
+      eligible = eligible && eps[j] > sps[j] && eps[j] - sps[j] < SEGMAX;
+    }
+    // the cloud's ends (as in the staged code below): the head ring's stale {0, 0} entries name point 0 — inside this ring's window,
+    // an ordinary surface candidate of curvature 0; a tail ring's name point 0 too, which the first ring marked long ago: out of the window, skipped
+    const bool head = s < 5, tail = eps[5] >= n - 5;
+    if (head) eligible = eligible && !tail && eps[0] >= 5 && w0 <= 0 && -w0 < wlen;
+    if (tail) eligible = eligible && !head && n >= 64 && A.start_ring[0] == 4 && A.end_ring[0] >= 30;
+    if (eligible) {   // uniform
+      if (t < 6) s_gep[t] = 0;
+      if (t == 0) s_gbad = 0;
+      int my_li[UPG], my_rank[UPG];
+#pragma unroll
+      for (int u = 0; u < UPG; u++) {
+        const int i = t + XT * u, j = i / SEGMAX, p = i - j * SEGMAX;
+        my_li[u] = -1; my_rank[u] = INT_MAX;
+        if (j < 6) {
+          int sp = sps[0], ep = eps[0];
+#pragma unroll
+          for (int jj = 1; jj < 6; jj++) if (j == jj) { sp = sps[jj]; ep = eps[jj]; }
+          const int len = ep - sp;
+          if (p <= len) {
+            const int k = sp + p;
+            const int ind = (k == ep) ? ((ep >= 5 && ep < n - 5) ? ep : 0) : (int)(unsigned)(keys[j * seg + p] & 0xffffffffull);   // smooth[ep] is outside the sorted range
+            const int li = ind - w0;
+            const bool in_win = li >= 0 && li < wlen;   // a stale entry of a tail ring names point 0, far outside this ring's window: a no-op
+            const float cv = (ind == 0 || !in_win) ? 0.f : l_curv[li];   // stale entry: curvature 0 whatever the window holds
+            const bool corner = cv > A.edge_threshold, surf = cv < A.surf_threshold;   // never both: edge_threshold >= surf_threshold
+            if (in_win && (corner || surf)) {
+              const int rank = corner ? ((k == ep) ? 0 : ep - k) : p;   // corners walk k = ep .. sp, surfaces k = sp .. ep
+              my_li[u] = li; my_rank[u] = ((2 * j + (corner ? 0 : 1)) << 12) | rank;
+              l_rank[li] = my_rank[u];
+              l_stat[li] = l_picked[li] == 0 ? ST_UNDECIDED : ST_OUT;
+            }
+          }
+        }
+      }
+      __syncthreads();
+      unsigned my_nb[UPG];
+#pragma unroll
+      for (int u = 0; u < UPG; u++) {
+        my_nb[u] = 0u;
+        const int li = my_li[u];
+        if (li < 0) continue;
+        const int rc = l_reach[li], fr = rc & 15, br = rc >> 4;
+#pragma unroll
+        for (int d = 1; d <= 5; d++) {
+          const int rf = l_rank[li + d], rb = l_rank[li - d];
+          if (d <= fr && rf < my_rank[u]) my_nb[u] |= 1u << (d - 1);
+          if (d <= br && rb < my_rank[u]) my_nb[u] |= 1u << (4 + d);
+        }
+      }
+      while (true) {
+        int undecided = 0;
+#pragma unroll
+        for (int u = 0; u < UPG; u++) {
+          const int li = my_li[u];
+          if (li < 0 || l_stat[li] != ST_UNDECIDED) continue;
+          bool any_sel = false, any_und = false;
+#pragma unroll
+          for (int d = 1; d <= 5; d++) {
+            const int sf = l_stat[li + d], sb = l_stat[li - d];
+            if (my_nb[u] & (1u << (d - 1))) { any_sel |= sf == ST_PICKED; any_und |= sf == ST_UNDECIDED; }
+            if (my_nb[u] & (1u << (4 + d))) { any_sel |= sb == ST_PICKED; any_und |= sb == ST_UNDECIDED; }
+          }
+          if (any_sel) l_stat[li] = ST_OUT;
+          else if (!any_und) l_stat[li] = ST_PICKED;
+          else undecided = 1;
+        }
+        if (!__syncthreads_or(undecided)) break;
+      }
+      // corner picks per (entry slot, wavefront); the k == ep entry of a sector leads its walk
+      bool pk[UPG];
+#pragma unroll
+      for (int u = 0; u < UPG; u++) {
+        const int i = t + XT * u, j = i / SEGMAX, p = i - j * SEGMAX;
+        const bool is_corner = my_li[u] >= 0 && ((my_rank[u] >> 12) & 1) == 0;
+        pk[u] = is_corner && l_stat[my_li[u]] == ST_PICKED;
+        bool is_ep = false;
+        if (j < 6 && is_corner) { int len = eps[0] - sps[0];
+#pragma unroll
+          for (int jj = 1; jj < 6; jj++) if (j == jj) len = eps[jj] - sps[jj];
+          is_ep = p == len; }
+        if (is_ep && pk[u]) s_gep[j] = 1;
+        const unsigned long long bal = __ballot(pk[u] && !is_ep);
+        if (lane == 0) s_gpk[u][wv] = __popcll(bal);
+        // ordinal inside the slot: picks at higher positions of this wavefront's 64
+        my_rank[u] = (my_rank[u] & ~0xfff) | (is_ep ? 0xfff : __popcll(bal & ~((2ull << lane) - 1ull)));   // rank no longer needed: low 12 bits = picks above in the wave (0xfff: the ep entry)
+      }
+      __syncthreads();
+      // a sector's total and, per entry, the picks at higher positions in other wavefront slots of the same sector
+      int higher[UPG];
+#pragma unroll
+      for (int u = 0; u < UPG; u++) {
+        higher[u] = 0;
+        const int i0 = wv * 64 + XT * u, j = i0 / SEGMAX;
+        int total = j < 6 ? s_gep[min(j, 5)] : 0;
+#pragma unroll
+        for (int u2 = 0; u2 < UPG; u2++)
+#pragma unroll
+          for (int w2 = 0; w2 < XW; w2++) {
+            const int i2 = w2 * 64 + XT * u2;
+            if (i2 / SEGMAX == j) { const int c = s_gpk[u2][w2]; total += c; if (i2 > i0) higher[u] += c; }
+          }
+        if (j < 6 && total > 20) s_gbad = 1;
+        if (j < 6 && lane == 0 && (i0 - j * SEGMAX) == 0) A.corner_cnt[ring * 6 + j] = total;   // (rewritten by the staged code if the cap strikes)
+      }
+      __syncthreads();
+      if (s_gbad == 0) {
+#pragma unroll
+        for (int u = 0; u < UPG; u++) {
+          const int li = my_li[u];
+          if (li < 0 || l_stat[li] != ST_PICKED) continue;
+          const int j = (t + XT * u) / SEGMAX;
+          if (((my_rank[u] >> 12) & 1) == 0) {
+            const int within = my_rank[u] & 0xfff;
+            const int ordinal = within == 0xfff ? 0 : s_gep[j] + higher[u] + within;
+            l_label[li] = 1;
+            A.corner_stage[(ring * 6 + j) * 20 + ordinal] = A.extracted[li + w0];
+          } else {
+            l_label[li] = -1;
+          }
+          l_picked[li] = 1;
+          const int rc = l_reach[li], fr = rc & 15, br = rc >> 4;
+#pragma unroll
+          for (int d = 1; d <= 5; d++) { if (d <= fr) l_picked[li + d] = 1; if (d <= br) l_picked[li - d] = 1; }
+        }
+        __syncthreads();
+        // every k of a sector with label <= 0 joins the ring's surface scan, in k order (:240-252); the sectors tile [s, e - 1]
+        const int e_last = eps[5];
+        for (int base = s; base <= e_last; base += XT) {
+          const int k = base + t;
+          const bool v = k <= e_last && l_label[k - w0] <= 0;
+          const unsigned long long bal = __ballot(v);
+          if (lane == 0) s_cw[par][wv] = __popcll(bal);
+          __syncthreads();
+          int woff = 0, tot = 0;
+#pragma unroll
+          for (int w = 0; w < XW; w++) { const int c = s_cw[par][w]; tot += c; if (w < wv) woff += c; }
+          if (v) list[scan_cnt + woff + __popcll(bal & ((1ull << lane) - 1ull))] = k;
+          scan_cnt += tot;
+          par ^= 1;
+        }
+        global_done = true;
+      } else {
+        // the cap strikes somewhere on this ring: nothing has been applied; neutral rank / state cells for the staged code
+#pragma unroll
+        for (int u = 0; u < UPG; u++) if (my_li[u] >= 0) { l_rank[my_li[u]] = INT_MAX; l_stat[my_li[u]] = ST_OUT; }
+        __syncthreads();
+      }
+    }
+  }
+#endif
+
+  if (!global_done)
   for (int j = 0; j < 6; j++) {
     const int sp = (s * (6 - j) + e * j) / 6;
     const int ep = (s * (5 - j) + e * (j + 1)) / 6 - 1;
@@ -408,7 +580,7 @@ __global__ __launch_bounds__(XT) void extract_kernel(FeatArgs A) {
     const bool head_sp = sp < 5, tail_sp = ep >= n - 5;
     const bool thr_ok = A.surf_threshold > 0.f && A.edge_threshold >= 0.f;
     const bool head_ok = !head_sp || (thr_ok && !tail_sp && ep >= 5 && w0 <= 0 && -w0 < wlen);
-    const bool tail_ok = !tail_sp || (thr_ok && !head_sp && n >= 64 && A.start_ring[0] == 0 && A.end_ring[0] >= 30);
+    const bool tail_ok = !tail_sp || (thr_ok && !head_sp && n >= 64 && A.start_ring[0] == 4 && A.end_ring[0] >= 30);   // ring 0 starts at 0 - 1 + 5 and its stale entry marked point 0
     if (head_ok && tail_ok && len < SEGMAX) {
       // ---- parallel greedy picks ----
       // The reference walks the sector in curvature order and a pick marks its +-5 neighbours (up to a column break) as

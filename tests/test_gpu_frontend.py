@@ -89,11 +89,17 @@ def test_sparse_and_tiny_inputs():
     check_features(fo, po, fe, pg)
 
 
-def test_thresholds_change_the_selection():
+@pytest.mark.parametrize("edge,surf", [(0.1, 0.02), (0.02, 0.02), (0.003, 0.002), (0.05, 0.1)])
+def test_thresholds_change_the_selection(edge, surf):
+    """other thresholds, chosen to leave the fast path of the pick stages (one fixed point over the whole ring): many corner candidates — sectors
+    with more than the 20 corner picks the reference's walk stops at are redone stage by stage — and an edge threshold BELOW the surface one
+    (a cell can be both kinds of candidate: staged from the start)"""
     f0, _, _ = synth.make_pair("os1-64")
-    fo, po, fe, pg = both("os1-64", f0, edge_threshold=0.1, surf_threshold=0.02, odometry_surf_leaf_size=0.2)
+    fo, po, fe, pg = both("os1-64", f0, edge_threshold=edge, surf_threshold=surf, odometry_surf_leaf_size=0.2)
     check_projection(po, pg)
-    check_features(fo, po, fe, pg)
+    eo, eg = check_features(fo, po, fe, pg)
+    if edge <= 0.02:
+        assert eo["corner"].shape[0] >= 64 * 6 * 10   # the cap is what bounds the corner count here
 
 
 def test_deskew_matches_oracle():
