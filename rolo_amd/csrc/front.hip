@@ -207,36 +207,7 @@ __global__ __launch_bounds__(256) void ring_scatter_kernel(const float* __restri
   }
 }
 
-// ---- K3 ----
-__global__ __launch_bounds__(256) void smoothness_kernel(const float* __restrict__ range, const int* __restrict__ n_ptr, float* __restrict__ curv,
-                                                        int* __restrict__ picked, int* __restrict__ label) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int n = *n_ptr;  // N of this frame stays on the device: no host round trip between projection and features
-  if (i >= n) return;
-  float c = 0.f;
-  if (i >= 5 && i < n - 5) {  // featureExtraction.cpp:91-99, float sum in the written order
-    const float diffRange = range[i - 5] + range[i - 4] + range[i - 3] + range[i - 2] + range[i - 1] - range[i] * 10
-                          + range[i + 1] + range[i + 2] + range[i + 3] + range[i + 4] + range[i + 5];
-    c = diffRange * diffRange;
-  }
-  curv[i] = c; picked[i] = 0; label[i] = 0;
-}
-
-__global__ __launch_bounds__(256) void occlusion_kernel(const float* __restrict__ range, const int* __restrict__ col, const int* __restrict__ n_ptr,
-                                                       int* __restrict__ picked) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int n = *n_ptr;
-  if (i < 5 || i >= n - 6) return;  // featureExtraction.cpp:116
-  const float depth1 = range[i], depth2 = range[i + 1];
-  const int columnDiff = abs(col[i + 1] - col[i]);
-  if (columnDiff < 10) {
-    if (depth1 - depth2 > 0.3) { for (int k = 0; k <= 5; k++) picked[i - k] = 1; }
-    else if (depth2 - depth1 > 0.3) { for (int k = 1; k <= 6; k++) picked[i + k] = 1; }
-  }
-  const float diff1 = fabsf(float(range[i - 1] - range[i]));
-  const float diff2 = fabsf(float(range[i + 1] - range[i]));
-  if (diff1 > 0.02 * range[i] && diff2 > 0.02 * range[i]) picked[i] = 1;
-}
+// ---- K3 (calculateSmoothness, markOccludedPoints) lives in the window load of extract_kernel below ----
 
 // ---- K4 ----
 // Ascending bitonic sort of every aligned `seg`-element segment of key[0, total) in LDS (seg a power of two, total a
@@ -286,7 +257,7 @@ template <int NT>
 ROLO_DEV void bitonic_sort_lds(unsigned long long* key, int n_pow2) { bitonic_sort_lds_seg<NT>(key, n_pow2, n_pow2); }
 
 struct FeatArgs {
-  const float4* extracted; const int* col; const float* curv; int* picked; int* label;  // global, guard-offset pointers
+  const float4* extracted; const int* col; const float* range; float* curv; int* picked; int* label;  // global, guard-offset pointers
   const int* start_ring; const int* end_ring;
   const int* n_ptr; int n_scan; float edge_threshold, surf_threshold, leaf;
   float4* corner_stage; int* corner_cnt;  // [n_scan][6][20], [n_scan][6]
@@ -341,13 +312,51 @@ __global__ __launch_bounds__(XT) void extract_kernel(FeatArgs A) {
   int wlen = (e - s) + 32 + 1;
   if (wlen < 0) wlen = 0;
   if (wlen > WIN) wlen = WIN;  // guarded by the host (ring population <= MAXH)
-  for (int i = t; i < wlen; i += XT) {
-    const int gi = w0 + i;
-    const bool in = gi >= -FRONT_GUARD && gi < n + FRONT_GUARD;
-    l_picked[i] = in ? A.picked[gi] : 0;
-    l_col[i] = in ? A.col[gi] : 0;
-    l_label[i] = in ? A.label[gi] : 0;
-    l_curv[i] = in ? A.curv[gi] : 0.f;
+  // K3 inside this kernel (was: smoothness_kernel + occlusion_kernel, two launches on the frame's critical path): curvature
+  // (calculateSmoothness, featureExtraction.cpp:87-110) and the occlusion / parallel-beam marks (markOccludedPoints, :112-149) of the window's
+  // cells straight from range / col. The reference SCATTERS the marks (point j marks j-5..j or j+1..j+6); here every cell GATHERS the three
+  // conditions of the points that could mark it — the same set, no write shared between workgroups.
+  {
+    int* l_flag = reinterpret_cast<int*>(keys);   // scratch (the sector sort fills keys later): conditions of the points [w0 - 6, w0 + wlen + 6)
+    for (int i = t; i < wlen + 12; i += XT) {
+      const int j = w0 - 6 + i;
+      int fl = 0;
+      if (j >= 5 && j < n - 6) {   // :116
+        const float depth1 = A.range[j], depth2 = A.range[j + 1];
+        const int columnDiff = abs(A.col[j + 1] - A.col[j]);
+        if (columnDiff < 10) {
+          if (depth1 - depth2 > 0.3) fl |= 1;        // marks j-5 .. j
+          else if (depth2 - depth1 > 0.3) fl |= 2;   // marks j+1 .. j+6
+        }
+        const float diff1 = fabsf(float(A.range[j - 1] - A.range[j]));
+        const float diff2 = fabsf(float(A.range[j + 1] - A.range[j]));
+        if (diff1 > 0.02 * A.range[j] && diff2 > 0.02 * A.range[j]) fl |= 4;   // marks j
+      }
+      l_flag[i] = fl;
+    }
+    __syncthreads();
+    for (int i = t; i < wlen; i += XT) {
+      const int gi = w0 + i;
+      const bool in = gi >= -FRONT_GUARD && gi < n + FRONT_GUARD;
+      float c = 0.f;
+      if (gi >= 5 && gi < n - 5) {  // :91-99, float sum in the written order
+        const float* range = A.range;
+        const float diffRange = range[gi - 5] + range[gi - 4] + range[gi - 3] + range[gi - 2] + range[gi - 1] - range[gi] * 10
+                              + range[gi + 1] + range[gi + 2] + range[gi + 3] + range[gi + 4] + range[gi + 5];
+        c = diffRange * diffRange;
+      }
+      int pk = (l_flag[i + 6] >> 2) & 1;
+#pragma unroll
+      for (int k = 0; k <= 5; k++) pk |= l_flag[i + 6 + k] & 1;
+#pragma unroll
+      for (int k = 1; k <= 6; k++) pk |= (l_flag[i + 6 - k] >> 1) & 1;
+      l_picked[i] = pk;
+      l_col[i] = in ? A.col[gi] : 0;
+      l_label[i] = 0;
+      l_curv[i] = c;
+      if (gi >= s - 4 && gi <= e + 5 && gi >= 0 && gi < n) A.curv[gi] = c;   // the ring's own cells (rings tile [0, n)): cloudCurvature as the reference leaves it
+    }
+    __syncthreads();   // keys is scratch no longer
   }
   int scan_cnt = 0, par = 0;  // surface-scan length so far (every thread keeps the same count)
   // brk[i]: the suppression marks of a pick stop between window cells i and i + 1 (|columnDiff| > 10, :199-210)
@@ -1077,11 +1086,9 @@ int front_extract_enqueue(Front* f, const rolo_front_params* P, hipStream_t s, f
     FCHK(hipMemsetAsync(f->label, 0, sizeof(int) * np, s));
   }
   f->extract_cleared = false;
-  const int grid = (int)(((size_t)NS * f->H + 255) / 256);  // N <= n_scan * Horizon_SCAN is only known on the device
-  smoothness_kernel<<<grid, 256, 0, s>>>(f->range + FRONT_GUARD, f->counters, f->curv + FRONT_GUARD, f->picked + FRONT_GUARD, f->label + FRONT_GUARD);
-  occlusion_kernel<<<grid, 256, 0, s>>>(f->range + FRONT_GUARD, f->col + FRONT_GUARD, f->counters, f->picked + FRONT_GUARD);
+  // (K3 — calculateSmoothness + markOccludedPoints — runs inside extract_kernel; curv / picked / label are zero at this point)
   FeatArgs A;
-  A.extracted = f->extracted + FRONT_GUARD; A.col = f->col + FRONT_GUARD; A.curv = f->curv + FRONT_GUARD; A.picked = f->picked + FRONT_GUARD;
+  A.extracted = f->extracted + FRONT_GUARD; A.col = f->col + FRONT_GUARD; A.range = f->range + FRONT_GUARD; A.curv = f->curv + FRONT_GUARD; A.picked = f->picked + FRONT_GUARD;
   A.label = f->label + FRONT_GUARD; A.start_ring = f->start_ring; A.end_ring = f->end_ring; A.n_ptr = f->counters; A.n_scan = NS;
   A.edge_threshold = P->edge_threshold; A.surf_threshold = P->surf_threshold; A.leaf = P->odometry_surf_leaf_size;
   A.corner_stage = f->corner_stage; A.corner_cnt = f->corner_cnt; A.surf_stage = f->surf_stage; A.surf_cnt = f->surf_cnt;
