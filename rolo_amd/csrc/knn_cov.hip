@@ -395,6 +395,32 @@ __global__ __launch_bounds__(256) void leaf_kernel(KnnPair A, int split, const u
     boxes[2 * (size_t)(P + g)] = make_float4(lox, loy, loz, 0.f);
     boxes[2 * (size_t)(P + g) + 1] = make_float4(hix, hiy, hiz, 0.f);
   }
+  // the levels above this workgroup's 256 / KNN_LEAF leaves, up to their common ancestor: one launch of tree_reduce_kernel less per frame
+  // (whole blocks only: P >= LPB leaves, which makes the block's leaves an aligned subtree)
+  constexpr int LPB = 256 / KNN_LEAF;
+  if (P >= LPB) {   // uniform
+    __shared__ float4 nlo[LPB], nhi[LPB];
+    const int lt = threadIdx.x / KNN_LEAF;   // leaf of this thread inside the block
+    if ((s & (KNN_LEAF - 1)) == 0) { nlo[lt] = make_float4(lox, loy, loz, 0.f); nhi[lt] = make_float4(hix, hiy, hiz, 0.f); }
+    __syncthreads();
+    const size_t g0 = (size_t)P + (size_t)(g - lt);   // heap index of the block's first leaf (all threads: g - lt is the same leaf)
+    int m = LPB; size_t first = g0;
+    while (m > 1) {   // LPB = 16: four levels, a handful of lanes each
+      const int half = m >> 1;
+      first >>= 1;
+      float4 a, b;
+      const int u = threadIdx.x;
+      if (u < half) {
+        const float4 l0 = nlo[2 * u], l1 = nlo[2 * u + 1], h0 = nhi[2 * u], h1 = nhi[2 * u + 1];
+        a = make_float4(fminf(l0.x, l1.x), fminf(l0.y, l1.y), fminf(l0.z, l1.z), 0.f);
+        b = make_float4(fmaxf(h0.x, h1.x), fmaxf(h0.y, h1.y), fmaxf(h0.z, h1.z), 0.f);
+      }
+      __syncthreads();
+      if (u < half) { nlo[u] = a; nhi[u] = b; boxes[2 * (first + u)] = a; boxes[2 * (first + u) + 1] = b; }
+      __syncthreads();
+      m = half;
+    }
+  }
 }
 
 // Builds log2(chunk) levels of the implicit BVH in LDS: inputs are the `count_in` nodes at heap indices
@@ -662,7 +688,9 @@ hipError_t launch_knn_build(const KnnPair& A_in, void* sort_tmp, size_t sort_tmp
   static_assert(256 % KNN_LEAF == 0 && (KNN_LEAF & (KNN_LEAF - 1)) == 0, "leaf_kernel reduces a leaf inside a wavefront");
   const int l0 = (A.c[0].P * KNN_LEAF + 255) / 256, l1 = nc > 1 ? (A.c[1].P * KNN_LEAF + 255) / 256 : 0;
   leaf_kernel<<<l0 + l1, 256, 0, s>>>(A, l0, order);
-  int count0 = A.c[0].P, count1 = nc > 1 ? A.c[1].P : 1;
+  // leaf_kernel leaves the 4 levels above its 16 leaves behind: the reduction starts at P / 16 nodes (one launch up to 8192 leaves)
+  constexpr int LPB = 256 / KNN_LEAF;
+  int count0 = A.c[0].P >= LPB ? A.c[0].P / LPB : A.c[0].P, count1 = nc > 1 ? (A.c[1].P >= LPB ? A.c[1].P / LPB : A.c[1].P) : 1;
   while (count0 > 1 || count1 > 1) {
     const int chunk0 = count0 < 512 ? count0 : 512, chunk1 = count1 < 512 ? count1 : 512;
     const int b0 = count0 > 1 ? count0 / chunk0 : 0, b1 = count1 > 1 ? count1 / chunk1 : 0;
