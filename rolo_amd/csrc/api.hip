@@ -595,6 +595,23 @@ hipStream_t ctx_stream(rolo_ctx* c) { return c->stream; }
 int ctx_device(rolo_ctx* c) { return c->device; }
 void ctx_set_error(const char* msg) { g_err = msg ? msg : ""; }
 void ctx_set_fused_lm(rolo_ctx* c, int on) { c->P.fused_lm = on ? 1 : 0; }
+// rolo_set_source_device(T * src) + rolo_set_target_device(tgt) as ONE launch (the odometry driver's per-frame hand-over; both clouds on the device)
+int ctx_set_pair_device(rolo_ctx* c, const float* d_src, int n_src, int stride_src, const float* T16_host_or_null, const float* d_tgt, int n_tgt, int stride_tgt) {
+  if (!c) return ROLO_EINVAL;
+  if (n_src <= 0 || n_tgt <= 0 || stride_src < 3 || stride_tgt < 3 || !d_src || !d_tgt) { g_err = "bad cloud arguments"; return ROLO_EINVAL; }
+  int rc = set_device(c); if (rc) return rc;
+  CloudDev* cl[2] = {&c->src, &c->tgt};
+  size_t* cap[2] = {&c->src_xyz_cap, &c->tgt_xyz_cap};
+  const int n[2] = {n_src, n_tgt};
+  for (int i = 0; i < 2; i++) {
+    if ((rc = ensure(cl[i]->xyz, *cap[i], (size_t)n[i]))) return rc;
+    if ((rc = ensure(cl[i]->bbox_part, cl[i]->bbox_part_cap, (size_t)((n[i] + 255) / 256) * 6))) return rc;
+  }
+  HIPCHK(launch_pack_pair(d_src, stride_src, c->src.xyz, n_src, c->src.bbox_part, T16_host_or_null, d_tgt, stride_tgt, c->tgt.xyz, n_tgt, c->tgt.bbox_part, c->stream));
+  for (int i = 0; i < 2; i++) { cl[i]->n_bbox_part = (n[i] + 255) / 256; cl[i]->n = n[i]; cl[i]->have_cov = false; cl[i]->have_sorted = false; cl[i]->bbox6 = nullptr; }
+  c->have_map = false; c->have_corr = false;
+  return ROLO_OK;
+}
 // scan2map.hip: the two sub-map clouds (corner, surface) as the context's source / target with their search trees built
 int ctx_build_map_trees(rolo_ctx* c, const float* corner, int nc, const float* surf, int ns, int stride, KnnPair* out) {
   int rc = set_device(c); if (rc) return rc;

@@ -17,6 +17,7 @@ void ctx_set_error(const char* msg);
 int ctx_device(rolo_ctx* c);
 void ctx_set_fused_lm(rolo_ctx* c, int on);
 int ctx_create_high_priority(int device, rolo_ctx** out);
+int ctx_set_pair_device(rolo_ctx* c, const float* d_src, int n_src, int stride_src, const float* T16_host_or_null, const float* d_tgt, int n_tgt, int stride_tgt);
 }
 
 namespace {
@@ -334,7 +335,11 @@ int rolo_odom_collect(rolo_odom* o, float* pose6, double* rot9, double* trans3, 
     hipStream_t s = (hipStream_t)rolo_ctx_stream(o->ctx);
     const bool early = o->early_src && o->early_stamp == o->cloudTimeCur && memcmp(o->early_T.m, o->transformation_interpolated.m, sizeof(o->early_T.m)) == 0;
     o->early_src = false;
-    if (!early) {   // (early: the propagated source is in d_prop already and its covariances are on their way)
+    const bool pair_pack = !early && !(o->reuse_cov && o->cov_chain) && o->nOld > 0 && nNew > 0;
+    if (pair_pack) {   // *Propagated_cloud = T * featureOld (:459) and both setInput* as ONE launch: the transform rides on the pack
+      if ((rc = rolo::ctx_set_pair_device(o->ctx, reinterpret_cast<const float*>(d_featOld), o->nOld, 4, o->transformation_interpolated.m,
+                                          reinterpret_cast<const float*>(d_featNew), nNew, 4))) return rc;
+    } else if (!early) {   // (early: the propagated source is in d_prop already and its covariances are on their way)
       if (o->nOld > 0 && rolo::launch_transform_cloud(reinterpret_cast<const float*>(d_featOld), reinterpret_cast<float*>(o->d_prop), o->nOld, 4, nullptr,
                                                       o->transformation_interpolated.m, s) != hipSuccess) {
         rolo::ctx_set_error("transform kernel launch failed"); return ROLO_EHIP;
@@ -342,7 +347,7 @@ int rolo_odom_collect(rolo_odom* o, float* pose6, double* rot9, double* trans3, 
       if ((rc = rolo_set_source_device(o->ctx, reinterpret_cast<const float*>(o->d_prop), o->nOld, 4))) return rc;
       if (o->reuse_cov && o->cov_chain) { if ((rc = rolo_adopt_target_covariances(o->ctx))) return rc; }
     }
-    if ((rc = rolo_set_target_device(o->ctx, reinterpret_cast<const float*>(d_featNew), nNew, 4))) return rc;
+    if (!pair_pack && (rc = rolo_set_target_device(o->ctx, reinterpret_cast<const float*>(d_featNew), nNew, 4))) return rc;
     double guess_t[3];
     for (int i = 0; i < 3; i++) guess_t[i] = (double)o->transformation_interpolated.m[i * 4 + 3];
     const double zero3[3] = {0, 0, 0};

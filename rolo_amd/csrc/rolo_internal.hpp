@@ -212,6 +212,9 @@ hipError_t launch_transform_cloud(const float* in, float* out, int n, int stride
                                   const float* T16_host, hipStream_t s);
 // bbox_part != nullptr: one partial bounding box (6 order-preserving ints) per workgroup of 256 points goes there
 hipError_t launch_pack_xyz(const float* in, int stride, float4* out, int n, hipStream_t s, int* bbox_part = nullptr);
+// source (moved by the row-major 4x4 float transform T16 on the way, or nullptr) and target packed by one launch, partial boxes as launch_pack_xyz leaves them
+hipError_t launch_pack_pair(const float* in0, int stride0, float4* out0, int n0, int* bbox0, const float* T16_host_or_null,
+                            const float* in1, int stride1, float4* out1, int n1, int* bbox1, hipStream_t s);
 hipError_t launch_cov_unpack(const double* soa, int n, double* m16, hipStream_t s);   // 6 SoA -> n x 16
 hipError_t launch_cov_pack(const double* m16, int n, double* soa, hipStream_t s);     // n x 16 -> 6 SoA
 
