@@ -1109,12 +1109,12 @@ static int enqueue_frame(rolo_ctx* c) {
     c->vf.enabled = 0;
     if (rc) return rc;
     STAMP(1);
-    { ProfScope ps(c, ROLO_PROF_VOXEL_BUILD); HIPCHK(launch_voxel_build(c->tgt, c->tab, c->tgt_keys, c->tgt_slot, c->counters, voxel_morton_order(c), voxel_fixed_cov(c), c->tgt.bbox6, c->vf_done, c->stream, c->h_counters)); }   // the finalize kernel leaves the counters in pinned memory
+    { ProfScope ps(c, ROLO_PROF_VOXEL_BUILD); HIPCHK(launch_voxel_build(c->tgt, c->tab, c->tgt_keys, c->tgt_slot, c->counters, voxel_morton_order(c), voxel_fixed_cov(c), c->tgt.bbox6, c->vf_done, c->stream, c->h_counters, c->state, c->h_args)); }   // the finalize kernel leaves the counters in pinned memory and starts the frame's LM state from c->h_args (pinned)
     c->vf_done = false;
   }
   PassArgs a; int grid;
   if ((rc = prepare_pass(c, a, grid))) return rc;
-  HIPCHK(launch_frame_begin(c->state, c->h_args, c->stream));   // read straight from pinned host memory (one 64-thread kernel; a copy launch before)
+  // (the LM state of the frame was started by the voxel map's finalize kernel above: frame_begin_kernel was a launch of its own until round 3)
   STAMP(2);
   int nrot, ntrans; frame_chunks(c, nrot, ntrans);
   if (lm_fused(c)) {

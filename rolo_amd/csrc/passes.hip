@@ -18,6 +18,7 @@
 // are predicated on the device-side state, so a fixed schedule of launches can be enqueued (or graph-captured)
 // without knowing how many trials the data will need.
 #include "rolo_internal.hpp"
+#include "lm_begin.hpp"
 #include "dev_math.hpp"
 #include "voxel_dev.hpp"
 #include "peer_dev.hpp"
@@ -993,24 +994,6 @@ __global__ __launch_bounds__(THREADS) void lm_kernel(PassArgs a, const LmState* 
   }
 }
 
-ROLO_DEV void rot_begin_dev(LmState* st, const RotBegin& a) {
-  for (int i = 0; i < 9; i++) { st->xt_R[i] = a.R[i]; st->x0_R[i] = a.R[i]; st->tr_R[i] = a.R[i]; }
-  for (int i = 0; i < 3; i++) { st->xt_t[i] = a.t[i]; st->x0_t[i] = a.t[i]; }
-  for (int i = 0; i < 36; i++) { st->H[i] = 0; st->final_H[i] = (i % 7 == 0) ? 1.0 : 0.0; }
-  for (int i = 0; i < 6; i++) { st->b[i] = 0; st->d[i] = 0; }
-  for (int i = 0; i < 9; i++) st->delta_R[i] = (i % 4 == 0) ? 1.0 : 0.0;
-  for (int i = 0; i < 3; i++) st->delta_t[i] = 0;
-  st->y0 = 0; st->lambda = -1.0; st->nu = 2.0;
-  st->stage = 1; st->phase = 0; st->outer = 0; st->trial = 0; st->cur = 0; st->tr_cur = 0; st->n_corr = 0; st->tr_n_corr = 0;
-  st->run_trans = a.run_trans;
-  st->rot_done = 0; st->rot_converged = 0; st->rot_failed = 0; st->rot_outer = 0; st->rot_passes = 0; st->rot_ncorr = 0;
-  st->trans_done = 0; st->trans_failed = 0; st->trans_outer = 0; st->trans_passes = 0;
-  st->trace_count = 0; st->error = 0; st->pending = 0;
-  st->optimizer = a.optimizer; st->max_iterations = a.max_iterations; st->fixed_iterations = a.fixed_iterations;
-  st->lm_max = a.lm_max; st->q2_intended = a.q2_intended; st->rot_eps = a.rot_eps; st->trans_eps = a.trans_eps; st->lm_init = a.lm_init;
-  st->inv_rot_eps = 1.0 / a.rot_eps; st->inv_trans_eps = 1.0 / a.trans_eps;
-}
-
 __global__ void rot_begin_kernel(LmState* st, RotBegin a) {
   if (threadIdx.x != 0) return;
   rot_begin_dev(st, a);
@@ -1025,11 +1008,7 @@ __global__ void trans_begin_kernel(LmState* st, TransBegin a) {
 
 __global__ void frame_begin_kernel(LmState* st, const FrameArgs* a) {
   if (threadIdx.x != 0) return;
-  const RotBegin r = a->rot;
-  const TransBegin t = a->trans;
-  rot_begin_dev(st, r);
-  for (int i = 0; i < 3; i++) { st->t0[i] = t.t0[i]; st->g[i] = t.g[i]; st->l[i] = t.l[i]; }
-  st->dtn = t.dtn; st->dtn1 = t.dtn1; st->ct_lambda = t.ct_lambda;
+  frame_begin_dev(st, a);
 }
 
 __global__ void frame_begin_batch_kernel(const BatchSlot* __restrict__ slots, const FrameArgs* __restrict__ args, int n) {

@@ -170,7 +170,8 @@ hipError_t launch_knn_unstage(const KnnPair& A, bool own_slice_only, const Voxel
 // bbox6: the target's bounding box as the neighbour search leaves it on the device (6 order-preserving ints), or nullptr
 // prefused: clear / insert / accumulate already ran inside the search's launches (VoxelFuse): finalize only
 hipError_t launch_voxel_build(const CloudDev& tgt, VoxelTable tab, unsigned long long* tgt_keys, int* tgt_slot, int* counters, bool morton_order, bool fixed_cov,
-                              const int* bbox6, bool prefused, hipStream_t s, int* pub_counters = nullptr /* pinned host copy of the 4 counters, written by the finalize kernel */);
+                              const int* bbox6, bool prefused, hipStream_t s, int* pub_counters = nullptr /* pinned host copy of the 4 counters, written by the finalize kernel */,
+                              struct LmState* lm_state = nullptr, const struct FrameArgs* lm_args = nullptr /* the finalize kernel also starts the frame's LM state (lm_begin.hpp) */);
 hipError_t launch_stamp(unsigned long long* buf, int slot, hipStream_t s);   // debug timeline
 hipError_t launch_voxel_keys(const float4* pts, int n, VoxelTable tab, int32_t* keys3, hipStream_t s);
 

@@ -16,6 +16,7 @@
 // Voxel coordinates are evaluated in fp64 with true divisions, exactly the reference's expressions, so the
 // integer keys are bit-identical to the CPU path (up to libm ulps of atan2/acos at bin edges).
 #include "rolo_internal.hpp"
+#include "lm_begin.hpp"
 #include "dev_math.hpp"
 #include "voxel_dev.hpp"
 #include <climits>
@@ -137,8 +138,9 @@ __global__ __launch_bounds__(256) void voxel_accum_sorted_kernel(const float4* _
   accumulate_point(tab, id, p, c, fix_scales(n, counters), fixed_cov != 0, counters + 1);
 }
 
-__global__ __launch_bounds__(256) void voxel_finalize_kernel(VoxelTable tab, const int* counters, int n_pts, int fixed_cov, int* pub_counters) {
+__global__ __launch_bounds__(256) void voxel_finalize_kernel(VoxelTable tab, const int* counters, int n_pts, int fixed_cov, int* pub_counters, LmState* lm_state, const FrameArgs* lm_args) {
   const int id = blockIdx.x * blockDim.x + threadIdx.x;
+  if (lm_state && blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) frame_begin_dev(lm_state, lm_args);   // the frame's LM state (was: frame_begin_kernel, its own launch); a lane of the last, mostly idle workgroup
   if (pub_counters && id < 4) pub_counters[id] = counters[id];   // the counters are final before this launch
   if (id >= counters[0]) return;
   double* r = tab.rec + (size_t)id * REC_DOUBLES;
@@ -168,11 +170,11 @@ __global__ __launch_bounds__(256) void voxel_keys_kernel(const float4* __restric
 }  // namespace
 
 hipError_t launch_voxel_build(const CloudDev& tgt, VoxelTable tab, unsigned long long* tgt_keys, int* tgt_slot, int* counters, bool morton_order, bool fixed_cov,
-                              const int* bbox6, bool prefused, hipStream_t s, int* pub_counters) {
+                              const int* bbox6, bool prefused, hipStream_t s, int* pub_counters, LmState* lm_state, const FrameArgs* lm_args) {
   static_assert(KEY_EMPTY == ~0ull, "voxel_clear_kernel and the 0xFF memsets elsewhere agree on the empty key");
   const int grid = (tgt.n + 255) / 256;
   if (prefused) {
-    voxel_finalize_kernel<<<grid, 256, 0, s>>>(tab, counters, tgt.n, 1, pub_counters);
+    voxel_finalize_kernel<<<grid, 256, 0, s>>>(tab, counters, tgt.n, 1, pub_counters, lm_state, lm_args);
     return hipGetLastError();
   }
   voxel_clear_kernel<<<256, 256, 0, s>>>(tab.keys, (size_t)tab.mask + 1, bbox6, counters);
@@ -185,7 +187,7 @@ hipError_t launch_voxel_build(const CloudDev& tgt, VoxelTable tab, unsigned long
     voxel_insert_kernel<<<grid, 256, 0, s>>>(tgt.xyz, tgt.n, tab, tgt_keys, tgt_slot, counters);
     voxel_accum_kernel<<<grid, 256, 0, s>>>(tgt.xyz, tgt.cov, tgt.n, tab, tgt_slot, counters, fixed_cov ? 1 : 0);
   }
-  voxel_finalize_kernel<<<grid, 256, 0, s>>>(tab, counters, tgt.n, fixed_cov ? 1 : 0, pub_counters);
+  voxel_finalize_kernel<<<grid, 256, 0, s>>>(tab, counters, tgt.n, fixed_cov ? 1 : 0, pub_counters, lm_state, lm_args);
   return hipGetLastError();
 }
 
