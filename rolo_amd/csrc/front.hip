@@ -956,6 +956,7 @@ struct Front {
   int n_valid = 0; int n_scan = 0, H = 0;
   bool projected = false;
   bool extract_cleared = false;   // the projection's clear launch already zeroed curv / picked / label for the extraction that follows
+  size_t precleared_np = 0;       // fused frames: the per-point arrays (np elements) were cleared BEHIND the previous frame's features, off the next frame's critical path (0: not)
   // rolo_front_set_deskew: armed for the next projection only
   bool deskew_armed = false;
   int deskew_n = 0;   // length of the armed per-point time array
@@ -1020,7 +1021,7 @@ int front_prepare(rolo_ctx* c, const rolo_front_params* P, int n_raw, int stride
     ok = ok && dev_alloc(f->owner, npix) && dev_alloc(f->local_idx, npix) && dev_alloc(f->extracted, np) && dev_alloc(f->col, np) && dev_alloc(f->range, np) &&
          dev_alloc(f->range_mat, npix) && dev_alloc(f->curv, np) && dev_alloc(f->picked, np) && dev_alloc(f->label, np) && dev_alloc(f->corner_out, npix) &&
          dev_alloc(f->surf_out, npix);
-    f->cap_pix = npix;
+    f->cap_pix = npix; f->precleared_np = 0;   // fresh buffers: not cleared
   }
   const int maxh = H > FRONT_MAX_H ? FRONT_MAX_H_BIG : FRONT_MAX_H;   // pitch of the per-ring staging rows, and which extract kernel runs
   if ((size_t)NS > f->cap_scan || !f->ring_count || maxh > f->cap_maxh) {
@@ -1062,7 +1063,9 @@ int front_project_enqueue(Front* f, const rolo_front_params* P, const float* d_p
     return ROLO_EINVAL;
   }
   // guard cells of the per-point arrays are zero; the three arrays of the extraction stage are cleared in the same launch
-  front_clear_kernel<<<512, 256, 0, s>>>(f->owner, npix, f->col, f->range, f->curv, f->picked, f->label, npix + 2 * FRONT_GUARD);
+  if (f->precleared_np != npix + 2 * FRONT_GUARD)   // (a fused frame leaves the arrays cleared for its successor)
+    front_clear_kernel<<<512, 256, 0, s>>>(f->owner, npix, f->col, f->range, f->curv, f->picked, f->label, npix + 2 * FRONT_GUARD);
+  f->precleared_np = 0;
   f->extract_cleared = true;
   if (n_raw > 0) project_kernel<<<(n_raw + 255) / 256, 256, 0, s>>>(d_pts, stride, d_ring, n_raw, *P, f->owner);
   ring_scan_kernel<<<NS, 256, 0, s>>>(f->owner, H, f->local_idx, f->ring_count);
@@ -1136,6 +1139,14 @@ int front_frame_features_enqueue(rolo_ctx* c, const rolo_front_params* P, const 
   if ((rc = front_extract_enqueue(f, P, s, d_feat, h_counts3))) return rc;   // h_counts3 is pinned: the gather kernel writes the counts there itself
   FCHK(hipGetLastError());
   if (done) FCHK(hipEventRecord(done, s));
+  // the next frame's clear, behind this frame's features: nobody reads the per-point arrays of a fused frame any more (its outputs are d_feat
+  // and the three counts), and the front-end stream is idle until the next frame arrives — 3.6 us and a kernel boundary off its critical path
+  {
+    const size_t npix = f->cap_pix;
+    front_clear_kernel<<<512, 256, 0, s>>>(f->owner, npix, f->col, f->range, f->curv, f->picked, f->label, npix + 2 * FRONT_GUARD);
+    FCHK(hipGetLastError());
+    f->precleared_np = npix + 2 * FRONT_GUARD;
+  }
   f->projected = false;  // the staged rolo_extract_features must not run on top of a fused frame
   return ROLO_OK;
 }
@@ -1289,7 +1300,7 @@ int rolo_front_load_projection(rolo_ctx* c, const rolo_front_params* P, const fl
   FCHK(hipStreamSynchronize(s));   // n_valid is a stack variable; pageable copies are staged anyway
   f->n_valid = n_valid;
   f->projected = true;
-  f->extract_cleared = false;
+  f->extract_cleared = false; f->precleared_np = 0;   // the arrays hold this projection now
   return ROLO_OK;
 }
 
