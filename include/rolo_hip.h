@@ -30,8 +30,10 @@ extern "C" {
 #define ROLO_EALIAS (-8)        /* reference: std::invalid_argument, rot_vgicp_impl.hpp:150-152 */
 #define ROLO_ECOMM (-9)         /* RCCL error */
 #define ROLO_EKEYRANGE (-10)    /* voxel coordinate outside +-2^20 (packed 3x21-bit key) */
-#define ROLO_ENONFINITE (-11)   /* a non-finite point / covariance (degenerate neighbourhood) reached the voxel map's fixed-point sums; the
-                                   reference would carry the NaN into the voxel and on into H */
+#define ROLO_ENONFINITE (-11)   /* a non-finite point / covariance (degenerate neighbourhood) reached the voxel map's fixed-point sums. DEVIATION from the
+                                   reference, on purpose: vmp_voxel.hpp:169-196 carries the NaN into that ONE voxel and on into H (a degraded or NaN pose, no
+                                   error); this library fails the frame with this code instead of returning a finite but wrong pose. When a frame holds
+                                   both this and ROLO_EKEYRANGE, this (more negative) code is reported. */
 
 /* enum orders follow include/rot_gicp/gicp/gicp_settings.hpp:6-13 and lsq_registration.hpp:13 */
 enum { ROLO_REG_NONE = 0, ROLO_REG_MIN_EIG, ROLO_REG_NORMALIZED_MIN_EIG, ROLO_REG_PLANE, ROLO_REG_FROBENIUS, ROLO_REG_PLANE_S };
@@ -228,6 +230,12 @@ int rolo_comm_info(rolo_ctx* ctx, int* rank, int* world);
 int rolo_peer_export(rolo_ctx* ctx, int world, int max_points, void* handle64);
 int rolo_peer_connect(rolo_ctx* ctx, const void* handles /* world x 64 bytes, rank order */, int rank, int world);
 int rolo_peer_disconnect(rolo_ctx* ctx);
+/* Collective self-test of a connected group, to be run by EVERY rank (same reps) before the first frame: `reps` all-reduces of 32 known fp64
+ * through the LM mailboxes and one covariance-segment push of known words into every peer's exchange area, verified on every rank. us_out[0] =
+ * mean microseconds of one LM exchange launch (first one excluded), us_out[1] = microseconds of the covariance exchange (push + flags + wait).
+ * ROLO_ECOMM with a message naming the rank and the words that were wrong or missing — the first crossing of a new transport (hipIpc mapping,
+ * peer access, fine-grained memory over xGMI) fails here and not as a wrong pose inside a frame. */
+int rolo_peer_selftest(rolo_ctx* ctx, int reps, double* us_out /* [2], optional */);
 /* rank / world of the connection (world 0: none); mem_kind16 (optional, 16 chars): "finegrained" | "coarse" */
 int rolo_peer_info(rolo_ctx* ctx, int* rank, int* world, char* mem_kind16);
 

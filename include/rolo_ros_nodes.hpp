@@ -360,7 +360,9 @@ public:
     if (ftime && P.sensor == LidarType::OUSTER && ftime->datatype == wire::PointField::UINT32) { L.off_time = (int)ftime->offset; L.time_kind = 2; }
     const wire::Time stamp = m.header.stamp;
     // deskewCloudInfo :266-366 on the odometry this node published itself (ImageProjection listens to odomTopic + "_incremental")
-    if (P.deskewEnabled && odomQueue.size() >= 2 && n > 0) {
+    // odomAvailable is STICKY in the reference (imageProjection.cpp:150-155: set once two messages have arrived, never cleared), also after the gate loop
+    // below has popped the queue under two entries — e.g. across a pause in the stamps; ImageProjectionNode keeps the same flag
+    if (P.deskewEnabled && odomAvailable && n > 0) {
       const double timeScanCur = stamp.toSec(), gate = L.time_kind == 0 ? 0.25 : 0.3;
       while (!odomQueue.empty()) { if (std::fabs(timeScanCur - odomQueue.front().header.stamp.toSec()) > gate) odomQueue.pop_front(); else break; }
       if (!odomQueue.empty()) {
@@ -395,12 +397,14 @@ public:
     out.odometry_cloud.initialGuessRoll = Lp[3]; out.odometry_cloud.initialGuessPitch = Lp[4]; out.odometry_cloud.initialGuessYaw = Lp[5];
     out.odometry_cloud.odomAvailable = 1;
     odomQueue.push_back(out.laser_odom_incremental);
+    if (odomQueue.size() >= 2) odomAvailable = true;   // ImageProjection::odometryHandler :150-155
     return Status::Published;
   }
   LidarOdometry& core() { return core_; }
   NodeParams P;
   std::deque<wire::PointCloud2> cloudQueue;
   std::deque<wire::Odometry> odomQueue;
+  bool odomAvailable = false;
 private:
   static void odom2pose(const wire::Odometry& o, float pose6[6]) {
     double r, p, y; wire::getRPY(o.pose.orientation, r, p, y);

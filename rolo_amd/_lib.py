@@ -154,6 +154,7 @@ SYMBOLS = {
     "rolo_peer_export": (C.c_int, [vp, C.c_int, C.c_int, vp]),
     "rolo_peer_connect": (C.c_int, [vp, vp, C.c_int, C.c_int]),
     "rolo_peer_disconnect": (C.c_int, [vp]),
+    "rolo_peer_selftest": (C.c_int, [vp, C.c_int, C.POINTER(C.c_double)]),
     "rolo_peer_info": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p]),
     "rolo_ctx_counters": (C.c_int, [vp, C.POINTER(C.c_longlong), C.c_int]),
     "rolo_prof_enable": (C.c_int, [vp, C.c_int]),

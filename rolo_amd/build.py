@@ -23,7 +23,9 @@ FLAGS = os.environ.get("ROLO_EXTRA_FLAGS", "").split() + ["--offload-arch=gfx950
 # float32 paths whose results must be bit-identical to the CPU statement (kNN distances and their pruning bounds,
 # pcl::transformPointCloud, range-image projection, curvature): no FMA contraction (HIP's __fmul_rn/__fadd_rn are
 # plain operators that the compiler is otherwise free to fuse)
-EXTRA = {"knn_cov.hip": ["-ffp-contract=off"], "scan2map.hip": ["-ffp-contract=off"], "misc.hip": ["-ffp-contract=off"], "front.hip": ["-ffp-contract=off", "-O2"]}  # -O2: hipcc 7.2 -O3 hits "Illegal instruction detected" in the backend on this file
+EXTRA = {"knn_cov.hip": ["-ffp-contract=off"], "scan2map.hip": ["-ffp-contract=off"], "misc.hip": ["-ffp-contract=off"], "front.hip": ["-ffp-contract=off"]}
+# (front.hip was built at -O2 through round 3: hipcc 7.2 -O3 died in the backend — "Illegal instruction detected: Operand has incorrect register class" — on the
+# round-1 form of extract_kernel's serial greedy walk; that function was rewritten in rounds 2-3 and the file has compiled at -O3 since: profiles/tools/README.md)
 
 
 def _stale(out, deps):

@@ -103,7 +103,6 @@ struct rolo_peer_state {
   void* mapped[PEER_MAX] = {};   // every rank's mailbox as mapped here
   bool ipc_opened[PEER_MAX] = {};
   PeerArgs args{};
-  unsigned long long cov_count = 0;   // covariance exchanges enqueued (eagerly): the exchange area alternates
   int* h_err = nullptr;          // pinned: ROLO_ECOMM written by a kernel whose poll timed out
   const char* mem_kind = "";
 };
@@ -261,7 +260,7 @@ int prepare_cloud(rolo_ctx* c, CloudDev& cl, size_t& cov_cap, size_t& sorted_cap
   out.xyz = cl.xyz; out.sorted = cl.sorted; out.boxes = cl.boxes; out.cov = cl.cov;
   out.knn_idx = c->want_knn_lists ? cl.knn_idx : nullptr; out.knn_d2 = c->want_knn_lists ? cl.knn_d2 : nullptr;
   out.n = n; out.n_leaves = cl.n_leaves; out.P = P; out.n_sorted = KNN_LEAF * cl.n_leaves;
-  out.q_begin = 0; out.q_end = out.n_sorted; out.stage = nullptr; out.chunk = out.n_sorted; out.stage_off = 0; out.seg = 0;
+  out.q_begin = 0; out.q_end = out.n_sorted; out.stage = nullptr; out.chunk = out.n_sorted; out.stage_off = 0; out.seg = 0; out.stage_epoch = nullptr; out.stage_alt = 0;
   out.bpart = cl.n_bbox_part > 0 ? cl.bbox_part : nullptr; out.n_bpart = cl.n_bbox_part;
   return ROLO_OK;
 }
@@ -308,7 +307,6 @@ int build_clouds(rolo_ctx* c, bool do_src, bool do_tgt, hipStream_t stream, bool
   // cloud (cheap, identical on all ranks), searches only its slice of the Morton-sorted queries — whole 256-query workgroups, equal
   // slices — and the 48-byte covariances are all-gathered once per frame in sorted order, then scattered to cov[] by original index.
   const bool sharded = c->comm != nullptr || peers(c) || (c->world > 1 && c->shard_knn);
-  size_t peer_area_off = 0;
   if (sharded) {
     size_t seg = 0;
     for (int i = 0; i < nc; i++) {
@@ -321,15 +319,18 @@ int build_clouds(rolo_ctx* c, bool do_src, bool do_tgt, hipStream_t stream, bool
       seg += (size_t)K.chunk * 6;
     }
     double* stage;
-    if (peers(c)) {   // the exchange area the peers write into: inside the exported mailbox allocation, two areas alternating
+    const unsigned long long* stage_epoch = nullptr; size_t stage_alt = 0;
+    if (peers(c)) {   // the exchange area the peers write into: inside the exported mailbox allocation, two areas alternating by the parity of the
+                      // exchange's number — which the kernels read from the mailbox's epoch word ON THE DEVICE: a frame replayed from its hipGraph, an eager
+                      // frame and a frame of a rank that captured earlier or later all agree (a host-side counter baked into a capture did not)
       if (seg * (size_t)c->world * sizeof(double) > c->peer.area_bytes) { g_err = "peer exchange area too small for this frame: rolo_peer_export with a larger max_points"; return ROLO_EINVAL; }
-      peer_area_off = PEER_STAGE_OFFSET + (size_t)(c->peer.cov_count & 1ull) * c->peer.area_bytes;
-      stage = reinterpret_cast<double*>(static_cast<char*>(c->peer.base) + peer_area_off);
+      stage = reinterpret_cast<double*>(static_cast<char*>(c->peer.base) + PEER_STAGE_OFFSET);
+      stage_epoch = static_cast<const unsigned long long*>(c->peer.base) + PEER_W_COV_EPOCH; stage_alt = c->peer.area_bytes / sizeof(double);
     } else {
       if ((rc = ensure(S.stage, S.stage_cap, seg * (size_t)c->world))) return rc;
       stage = S.stage;
     }
-    for (int i = 0; i < nc; i++) { A.c[i].seg = seg; A.c[i].stage = stage; }
+    for (int i = 0; i < nc; i++) { A.c[i].seg = seg; A.c[i].stage = stage; A.c[i].stage_epoch = stage_epoch; A.c[i].stage_alt = stage_alt; }
   }
   // the build overwrites this scratch set's bounding boxes: whoever still pointed at them (a cloud searched earlier) loses them
   if (c->src.bbox6 >= S.bbox && c->src.bbox6 < S.bbox + 12) c->src.bbox6 = nullptr;
@@ -354,8 +355,7 @@ int build_clouds(rolo_ctx* c, bool do_src, bool do_tgt, hipStream_t stream, bool
   if (sharded) {
     const size_t seg = A.c[0].seg;
     if (peers(c)) {   // every rank pushes its segment into every peer's area, flags, and waits for the others' flags (peer.hip)
-      HIPCHK(launch_peer_cov_exchange(c->peer.args, peer_area_off, seg, c->peer.h_err, stream));
-      c->peer.cov_count++;
+      HIPCHK(launch_peer_cov_exchange(c->peer.args, c->peer.area_bytes, seg, c->peer.h_err, stream));
     } else if (c->comm) {
       int e = g_rccl.AllGather(S.stage + (size_t)c->rank * seg, S.stage, seg, NCCL_FLOAT64, c->comm, stream);
       if (e != 0) { g_err = std::string("ncclAllGather: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "?"); return ROLO_ECOMM; }
@@ -691,6 +691,9 @@ static int ctx_create_impl(int device, bool high_priority, rolo_ctx** out) {
 
 void rolo_front_destroy(rolo_ctx* c);  // front.hip
 void rolo_s2m_destroy(rolo_ctx* c);    // scan2map.hip
+}
+namespace rolo { void front_reset_object_state(rolo_ctx* c); }   // front.hip
+extern "C" {
 
 void rolo_ctx_destroy(rolo_ctx* c) {
   if (!c) return;
@@ -737,7 +740,11 @@ void reset_to_fresh(rolo_ctx* c) {
   c->have_map = false; c->have_corr = false; c->n_voxels = 0; c->n_edge = 0;
   c->want_knn_lists = false; c->prof_on = false; c->shard_knn = false;
   c->rank = 0; c->world = 1;
-  // (schedule hints and the captured graph stay: they are keyed on sizes, buffers and parameters, not on the object's identity)
+  front_reset_object_state(c);   // no projection, armed de-skew or pre-cleared arrays of the previous owner
+  c->n_frames = c->n_replays = c->n_captures = c->n_eager = c->n_topup_frames = c->n_topup_chunks = 0;   // rolo_ctx_counters counts per object
+  // (schedule hints, their windows and the captured graph stay on purpose: they are keyed on sizes, buffers and parameters, not on the object's
+  // identity — a frame loop that constructs its operator per frame, src/lidarOdometry.cpp:460, keeps replaying its graph. Drivers created on the
+  // context, rolo_odom_create, must be destroyed before the context is released: the pool does not track them.)
 }
 }  // namespace
 
@@ -761,7 +768,7 @@ void rolo_ctx_release(rolo_ctx* c) {
   if (c->comm || c->peer.base || c->async_pending || !c->prof.empty()) { rolo_ctx_destroy(c); return; }
   {
     std::lock_guard<std::mutex> lk(g_pool_mu);
-    if (g_pool.size() < POOL_MAX) { reset_to_fresh(c); g_pool.push_back(c); return; }
+    if (g_pool.size() < POOL_MAX) { (void)hipSetDevice(c->device); if (c->stream) (void)hipStreamSynchronize(c->stream); reset_to_fresh(c); g_pool.push_back(c); return; }
   }
   rolo_ctx_destroy(c);
 }
@@ -1670,9 +1677,62 @@ int rolo_peer_connect(rolo_ctx* c, const void* handles, int rank, int world) {
   const char* tm = getenv("ROLO_PEER_TIMEOUT_MS");
   const double ms = tm ? atof(tm) : 10000.0;
   P.args.timeout_ticks = (unsigned long long)(std::max(ms, 1.0) * (double)khz);
-  P.connected = true; P.cov_count = 0;
+  P.connected = true;
   c->rank = rank; c->world = world;
   c->have_corr = false; c->src.have_cov = false; c->tgt.have_cov = false; c->have_map = false;
+  return ROLO_OK;
+}
+
+// Collective self-test of a connected group, meant to run before the first frame (bench.py's sharded leg, a deployment's start-up): the two
+// exchanges of the sharded path with KNOWN words — `reps` all-reduces of 32 fp64 through the LM mailboxes (peer_allreduce_kernel: the block the
+// controller runs per trial) and one covariance-segment push into every peer's exchange area — verified on every rank. The first time the
+// ranks' mailboxes are written across devices (hipIpc mapping, peer access, fine-grained memory over xGMI) fails HERE, with a named error,
+// instead of as a wrong pose or a time-out inside a frame. Every rank must call it with the same reps (it advances both exchange epochs).
+int rolo_peer_selftest(rolo_ctx* c, int reps, double* us2) {
+  if (!c || reps < 1 || reps > 1000) return ROLO_EINVAL;
+  if (!peers(c)) { g_err = "rolo_peer_selftest: context is not connected to peers"; return ROLO_ESTATE; }
+  if (c->async_pending) { g_err = "a registration is in flight on this context"; return ROLO_ESTATE; }
+  int rc = set_device(c); if (rc) return rc;
+  const int W = c->peer.args.world, rank = c->peer.args.rank;
+  hipEvent_t ea = nullptr, eb = nullptr;
+  HIPCHK(hipEventCreate(&ea)); HIPCHK(hipEventCreate(&eb));
+  struct EvGuard { hipEvent_t a, b; ~EvGuard() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); } } guard{ea, eb};
+  // (1) the LM exchange: rank r contributes (r + 1)(i + 1) + rep in value i; every rank must read W (W + 1) / 2 (i + 1) + W rep
+  double lm_us = 0.0; int timed = 0;
+  for (int rep = 0; rep < reps; rep++) {
+    for (int i = 0; i < NV_MAX; i++) c->h_sums[i] = (double)(rank + 1) * (i + 1) + rep;
+    HIPCHK(hipMemcpyAsync(c->sums, c->h_sums, sizeof(double) * NV_MAX, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipEventRecord(ea, c->stream));
+    HIPCHK(launch_peer_allreduce(c->sums, c->peer.args, c->peer.h_err, c->stream));
+    HIPCHK(hipEventRecord(eb, c->stream));
+    HIPCHK(hipMemcpyAsync(c->h_sums, c->sums, sizeof(double) * NV_MAX, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (*c->peer.h_err != 0) { g_err = "rolo_peer_selftest: LM exchange " + std::to_string(rep) + " timed out on rank " + std::to_string(rank) + " (a peer's words never arrived in this rank's mailbox)"; return ROLO_ECOMM; }
+    for (int i = 0; i < NV_MAX; i++) {
+      const double want = 0.5 * W * (W + 1) * (i + 1) + (double)W * rep;
+      if (c->h_sums[i] != want) { g_err = "rolo_peer_selftest: LM exchange " + std::to_string(rep) + " on rank " + std::to_string(rank) + ": value " + std::to_string(i) + " = " + std::to_string(c->h_sums[i]) + ", expected " + std::to_string(want); return ROLO_ECOMM; }
+    }
+    if (rep > 0 || reps == 1) { float ms = 0.f; (void)hipEventElapsedTime(&ms, ea, eb); lm_us += 1e3 * ms; timed++; }   // the first one carries every rank's start-up skew
+  }
+  // (2) the covariance exchange: 4 workgroups' worth of words per rank
+  const size_t seg = (size_t)6 * 256 * 4;
+  if (seg * (size_t)W * sizeof(double) > c->peer.area_bytes) { g_err = "rolo_peer_selftest: exchange area smaller than the test segment"; return ROLO_EINVAL; }
+  unsigned* bad = reinterpret_cast<unsigned*>(c->sums);   // NV_MAX doubles of scratch: PEER_MAX counters fit
+  static_assert(PEER_MAX * sizeof(unsigned) <= NV_MAX * sizeof(double), "selftest counters");
+  HIPCHK(hipMemsetAsync(bad, 0, PEER_MAX * sizeof(unsigned), c->stream));
+  HIPCHK(launch_peer_selftest_fill(c->peer.args, c->peer.area_bytes, seg, c->stream));
+  HIPCHK(hipEventRecord(ea, c->stream));
+  HIPCHK(launch_peer_cov_exchange(c->peer.args, c->peer.area_bytes, seg, c->peer.h_err, c->stream));
+  HIPCHK(hipEventRecord(eb, c->stream));
+  HIPCHK(launch_peer_selftest_check(c->peer.args, c->peer.area_bytes, seg, bad, c->stream));
+  unsigned h_bad[PEER_MAX] = {};
+  HIPCHK(hipMemcpyAsync(h_bad, bad, sizeof(h_bad), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (*c->peer.h_err != 0) { g_err = "rolo_peer_selftest: covariance exchange timed out on rank " + std::to_string(rank) + " (a peer's flag never arrived)"; return ROLO_ECOMM; }
+  for (int r = 0; r < W; r++)
+    if (h_bad[r]) { g_err = "rolo_peer_selftest: rank " + std::to_string(rank) + " read " + std::to_string(h_bad[r]) + " wrong words in the segment rank " + std::to_string(r) + " pushed"; return ROLO_ECOMM; }
+  float ms = 0.f; (void)hipEventElapsedTime(&ms, ea, eb);
+  if (us2) { us2[0] = timed ? lm_us / timed : 0.0; us2[1] = 1e3 * ms; }
   return ROLO_OK;
 }
 

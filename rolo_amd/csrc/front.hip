@@ -1188,6 +1188,19 @@ int front_frame_features_from_msg(rolo_ctx* c, const rolo_front_params* P, const
 
 using namespace rolo;
 
+namespace rolo {
+// rolo_ctx_release: a recycled context is a fresh object — a projection, an armed de-skew or cleared arrays of its previous owner must not carry over
+// (a staged rolo_extract_features on a recycled context returns ROLO_ESTATE until its new owner has projected a frame)
+void front_reset_object_state(rolo_ctx* c) {
+  void** slot = ctx_front_slot(c);
+  if (!*slot) return;
+  Front* f = static_cast<Front*>(*slot);
+  f->projected = false; f->extract_cleared = false; f->precleared_np = 0;
+  f->deskew_armed = false; f->deskew_from_msg = false; f->deskew_n = 0;
+  f->n_valid = 0;
+}
+}  // namespace rolo
+
 extern "C" {
 
 void rolo_front_destroy(rolo_ctx* c) {

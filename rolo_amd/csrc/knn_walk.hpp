@@ -21,6 +21,18 @@ namespace {
 
 constexpr int WALK_STACK = 48;
 
+// Sharded K5 with peers (rolo_peer_*): the exchange buffer alternates between two areas of the rank's mailbox. WHICH one a frame uses is the parity
+// of the exchange's number, read on the device from the own mailbox's epoch word (peer.hip bumps it once per exchange, in stream order) — a captured
+// hipGraph replays the same launches frame after frame, so the host cannot bake the area in. add = 1 before the exchange of this frame (tail), 0 after it (unstage).
+ROLO_DEV double* stage_area(const KnnCloud& cl, unsigned add) {
+  double* s = cl.stage;
+  if (cl.stage_epoch) {
+    const unsigned long long e = __hip_atomic_load(cl.stage_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) + add;
+    if (e & 1ull) s += cl.stage_alt;
+  }
+  return s;
+}
+
 // Workgroup b of a launch runs on XCD b % 8 (round-robin dispatch), each XCD with its own 4 MB L2. Neighbouring packets of the
 // Hilbert-sorted cloud read the same leaves and boxes, so give every XCD a CONTIGUOUS eighth of the packets: what one wavefront
 // pulled in from HBM (1-2 us per cold fetch — the walk's real bound on the ~48k-point feature clouds) the next ones find in L2.
@@ -380,7 +392,7 @@ __global__ __launch_bounds__(256, KMAX > 32 ? 2 : ROLO_KNN_WALK_OCC) void knn_wa
   // and the 4-context throughput falls from 2750 to 2490 scans/s — the tails' fp64 work competes with the walking wavefronts for issue slots.
   const KnnCloud& cl = A.c[which];
   if (cl.stage) {   // multi-GPU: into the exchange buffer, sorted order
-    double* o = cl.stage + (size_t)(j / cl.chunk) * cl.seg + cl.stage_off + (size_t)(j % cl.chunk) * 6;
+    double* o = stage_area(cl, 1) + (size_t)(j / cl.chunk) * cl.seg + cl.stage_off + (size_t)(j % cl.chunk) * 6;
     double c6[6]; knn_covariance_tail<KMAX>(ki, kk, cl.xyz, 1, 0, reg, o, c6);
   } else {
     double c6[6]; knn_covariance_tail<KMAX>(ki, kk, cl.xyz, cl.n, qi, reg, cl.cov, c6);
@@ -411,7 +423,7 @@ __global__ __launch_bounds__(256, ROLO_KNN_TAIL_OCC) void knn_tail_kernel(KnnPai
 #pragma unroll
     for (int u = 0; u < KMAX; u++) ki[u] = nbr[(size_t)u * n_sorted + j];
     if (cl.stage) {   // multi-GPU: into the exchange buffer, sorted order
-      double* o = cl.stage + (size_t)(j / cl.chunk) * cl.seg + cl.stage_off + (size_t)(j % cl.chunk) * 6;
+      double* o = stage_area(cl, 1) + (size_t)(j / cl.chunk) * cl.seg + cl.stage_off + (size_t)(j % cl.chunk) * 6;
       knn_covariance_tail<KMAX>(ki, (KMAX == 20) ? 20 : k, cl.xyz, 1, 0, reg, o, c6);   // pitch 1, index 0: six consecutive doubles
     } else {
       knn_covariance_tail<KMAX>(ki, (KMAX == 20) ? 20 : k, cl.xyz, cl.n, qi, reg, cl.cov, c6);
@@ -439,7 +451,7 @@ __global__ __launch_bounds__(256) void knn_tail_loop_kernel(KnnPair A, int split
   double c6[6] = {0, 0, 0, 0, 0, 0};
   if (act) {
     if (cl.stage) {
-      double* o = cl.stage + (size_t)(j / cl.chunk) * cl.seg + cl.stage_off + (size_t)(j % cl.chunk) * 6;
+      double* o = stage_area(cl, 1) + (size_t)(j / cl.chunk) * cl.seg + cl.stage_off + (size_t)(j % cl.chunk) * 6;
       knn_covariance_tail_loop(cl.nbr, (size_t)cl.n_sorted, j, k, cl.xyz, 1, 0, reg, o, c6);
     } else {
       knn_covariance_tail_loop(cl.nbr, (size_t)cl.n_sorted, j, k, cl.xyz, cl.n, qi, reg, cl.cov, c6);
@@ -468,7 +480,7 @@ __global__ __launch_bounds__(256) void knn_unstage_kernel(KnnPair A, int split, 
   if (!act && !fuse) return;
   double c6[6] = {0, 0, 0, 0, 0, 0};
   if (act) {
-    const double* __restrict__ o = cl.stage + (size_t)(j / cl.chunk) * cl.seg + cl.stage_off + (size_t)(j % cl.chunk) * 6;
+    const double* __restrict__ o = stage_area(cl, 0) + (size_t)(j / cl.chunk) * cl.seg + cl.stage_off + (size_t)(j % cl.chunk) * 6;
     const size_t pitch = (size_t)cl.n;
 #pragma unroll
     for (int v = 0; v < 6; v++) { c6[v] = o[v]; cl.cov[v * pitch + qi] = c6[v]; }

@@ -8,6 +8,11 @@
 // rotation; singular values made positive, sorted descending with the column swaps) so that the HIP path takes the same value as the
 // reference would, not a neighbour of it. Eigen's sources are not in /root/reference; restated from its published algorithm
 // (Eigen/src/SVD/JacobiSVD.h, Eigen/src/Jacobi/Jacobi.h, Eigen/src/Geometry/Transform.h).
+// EIGEN VERSION ASSUMED: 3.4 (computeRotationScaling as above: x = sign of det, U.col(2) *= x). Eigen 3.3.x — the stock version of ROS1 Noetic /
+// Ubuntu 20.04, which the reference's README floor ("Eigen >= 3.3.7") admits — uses x = det(U V^T) itself (about +-1, not exactly) and
+// m.col(0) /= x: with 3.3 the Rotation at lidarOdometry.cpp:474 / :130 differs from this restatement in the last float ulps (far inside the
+// 1e-5 rad bar; the oracle shares this restatement, so only a dump of the real reference built with the target Eigen —
+// tools/dump_reference_golden.cpp — can tell the two apart).
 #pragma once
 #include <cfloat>
 #include <cmath>

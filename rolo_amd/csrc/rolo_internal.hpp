@@ -137,6 +137,7 @@ struct BatchSlot { PassArgs a; LmState* st; rolo_trace_rec* trace; int grid; int
 // position; position j lives in segment j / chunk at stage + (j / chunk) * seg + stage_off + (j % chunk) * 6) instead of cov[].
 struct KnnCloud { const float4* xyz; float4* sorted; float4* boxes; double* cov; int32_t* knn_idx; float* knn_d2; int32_t* nbr; int n, n_leaves, P, n_sorted;
                   int q_begin, q_end; double* stage; int chunk, stage_off; size_t seg;
+                  const unsigned long long* stage_epoch; size_t stage_alt;   // peers: stage = area 0; the area of a frame = stage + (exchange number & 1) * stage_alt doubles (knn_walk.hpp stage_area)
                   const int* bpart; int n_bpart;      // partial bounding boxes to fold (the pack kernel's, or bbox_kernel's in the scratch buffer)
                   // k_correspondences > 64: the lists are found 64 at a time — round r keeps the 64 smallest keys ABOVE lower[j], the last key of
                   // round r - 1 (keys (d2, index) are unique per point), and writes slots [slot0, slot0 + 64) of the k_total per query
@@ -190,10 +191,14 @@ hipError_t launch_ctrl(LmState* st, const double* partials, int nblocks, const d
                        const PeerArgs* peer = nullptr, int dof = 0);
 // peer.hip: sums[NV_MAX] (device) <- sum over the ranks, in rank order (stage-level evaluations); *err_flag (device int) is set on a timeout
 hipError_t launch_peer_allreduce(double* sums, const PeerArgs& peer, int* err_flag, hipStream_t s);
-// peer.hip: covariance exchange of one frame — push the own segment [rank * seg_doubles, +seg_doubles) of the local exchange area (area_off
-// bytes behind the mailbox base; two areas alternate) into every peer's area and raise the own flag there (last workgroup), then wait
-// (one wavefront) for every rank's flag of this epoch
-hipError_t launch_peer_cov_exchange(const PeerArgs& peer, size_t area_off, size_t seg_doubles, int* err_flag, hipStream_t s);
+// peer.hip: covariance exchange of one frame — push the own segment [rank * seg_doubles, +seg_doubles) of the local exchange area into every
+// peer's area and raise the own flag there (last workgroup), then wait (one wavefront) for every rank's flag of this epoch. Two areas of
+// area_bytes each alternate behind PEER_STAGE_OFFSET; the kernels pick the area from the exchange's number (own epoch word + 1) on the device
+hipError_t launch_peer_cov_exchange(const PeerArgs& peer, size_t area_bytes, size_t seg_doubles, int* err_flag, hipStream_t s);
+
+// rolo_peer_selftest: fill the own segment of the next exchange's area with known words / count the wrong words per rank after the exchange (bad: PEER_MAX device counters, zeroed by the caller)
+hipError_t launch_peer_selftest_fill(const PeerArgs& peer, size_t area_bytes, size_t seg_doubles, hipStream_t s);
+hipError_t launch_peer_selftest_check(const PeerArgs& peer, size_t area_bytes, size_t seg_doubles, unsigned* bad, hipStream_t s);
 
 struct RotBegin { double R[9], t[3]; int optimizer, max_iterations, fixed_iterations, lm_max, q2_intended; double rot_eps, trans_eps, lm_init; int run_trans; };
 struct TransBegin { double t0[3], g[3], l[3], dtn, dtn1; float ct_lambda; int direct; /* 1: start now (rotation already done) */ };

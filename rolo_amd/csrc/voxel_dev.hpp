@@ -107,7 +107,7 @@ ROLO_DEV void accumulate_point(const VoxelTable& tab, int id, const float4& p, c
 #pragma unroll
       for (int d = 0; d < 6; d++) ok = ok && (fabs(c[d]) <= 1.0 + 1e-9);
     }
-    if (!ok) *err = ROLO_ENONFINITE;
+    if (!ok) atomicMin(err, ROLO_ENONFINITE);   // the more negative code wins deterministically when a frame also holds a key out of range (ROLO_EKEYRANGE)
   }
   long long q[10];
   double cv[6];
@@ -170,7 +170,7 @@ ROLO_DEV void voxel_insert_point(const VoxelTable& tab, const float4* __restrict
   note_point(i < n, near_edge, counters);
   if (i >= n) return;
   unsigned long long key;
-  if (!pack_key(kx, ky, kz, key)) { atomicExch(&counters[1], ROLO_EKEYRANGE); tgt_slot[i] = -1; tgt_keys[i] = KEY_EMPTY; return; }
+  if (!pack_key(kx, ky, kz, key)) { atomicMin(&counters[1], ROLO_EKEYRANGE); tgt_slot[i] = -1; tgt_keys[i] = KEY_EMPTY; return; }
   unsigned h = hash_key(key) & tab.mask;
   while (true) {
     unsigned long long prev = atomicCAS(&tab.keys[h], KEY_EMPTY, key);

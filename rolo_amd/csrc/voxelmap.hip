@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void voxel_insert_sorted_kernel(const float4* 
     note_point(real, near_edge, counters);
     if (real) {
       if (pack_key(kx, ky, kz, key)) valid = true;
-      else { atomicExch(&counters[1], ROLO_EKEYRANGE); key = KEY_EMPTY; }
+      else { atomicMin(&counters[1], ROLO_EKEYRANGE); key = KEY_EMPTY; }
     }
   }
   const unsigned long long prev_key = ((unsigned long long)(unsigned)__shfl_up((int)(key >> 32), 1, 64) << 32) | (unsigned)__shfl_up((int)(key & 0xffffffffull), 1, 64);

@@ -34,6 +34,9 @@ def rank_main(rank, world, d, sensor, frames, leaf, device=0):
         os.replace(os.path.join(d, f"h{rank}.tmp"), os.path.join(d, f"h{rank}.bin"))
         file_barrier(d, "exported", rank, world)
         g.peer_connect([open(os.path.join(d, f"h{q}.bin"), "rb").read() for q in range(world)], rank, world)
+        # both exchanges with known words BEFORE any frame: the first crossing of the link (hipIpc mapping, peer access, fine-grained memory over xGMI)
+        # fails here with a named error (rolo_peer_selftest) instead of as a wrong pose or a time-out inside a frame
+        selftest = g.peer_selftest(16)
 
     # inputs resident in HBM, through the HIP runtime directly (no torch in the rank processes: torch's own streams / queues on top of W
     # processes oversubscribe the one device's hardware queues and every kernel then pays a queue switch — measured: 61 us per 12 us pass)
@@ -64,6 +67,8 @@ def rank_main(rank, world, d, sensor, frames, leaf, device=0):
     res = {"rank": rank, "ms_per_frame": 1e3 * dt / frames, "passes": g.last_stats.n_passes + g.last_translation_stats.n_passes, "counters": g.counters(),
            "pose_head": Td.reshape(-1)[:4].tolist(), "mailbox": g.peer_info()[2] if world > 1 else ""}
     res["device"] = device
+    if world > 1:
+        res["selftest"] = {"ok": True, "lm_exchange_us": selftest[0], "cov_exchange_us": selftest[1]}
     # per-launch event times (eager launches while profiling)
     acc = profile.kernel_times(g, frame, reps=3)
     rot, tr = g.last_stats.n_passes, g.last_translation_stats.n_passes

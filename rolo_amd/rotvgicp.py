@@ -369,6 +369,12 @@ class RotVGICP:
     def peer_disconnect(self):
         check(lib().rolo_peer_disconnect(self._h), "rolo_peer_disconnect")
 
+    def peer_selftest(self, reps: int = 8):
+        """collective (every rank, same reps): known words through both exchanges, verified; returns (us per LM exchange, us of the covariance exchange)"""
+        us = (C.c_double * 2)()
+        check(lib().rolo_peer_selftest(self._h, int(reps), us), "rolo_peer_selftest")
+        return float(us[0]), float(us[1])
+
     def peer_info(self):
         """(rank, world, memory kind of the mailbox); world 0 = not connected"""
         r, w = C.c_int(), C.c_int(); k = C.create_string_buffer(16)

@@ -210,6 +210,7 @@ int main(int argc, char** argv) {
           spit(outdir + "/pose_" + std::to_string(processed) + ".bin", wire::serialize(o.laser_pose));
           spit(outdir + "/odom_cloud_" + std::to_string(processed) + ".bin", wire::serialize(o.odometry_cloud));
           TF.lidarOdometryHandler(o.laser_odom_incremental);   // odomTopic + "_incremental" loops back into the same process
+          A.odometryHandler(o.laser_odom_incremental);         // ... and into ImageProjection (imageProjection.cpp:92, :149-155): the de-skew's odometry
         }
         std::printf("msg %d cloud %d lidarOdometry %d frame %d\n", idx, processed, (int)sc, (int)o.frame);
         processed++;

@@ -5,7 +5,7 @@ import pytest
 
 from oracle import pyorc
 from rolo_amd import synth
-from rolo_amd.frontend import FrontEnd, front_params
+from rolo_amd.frontend import FrontEnd, front_params, deskew_params
 from rolo_amd.rotvgicp import RotVGICP
 
 pytestmark = pytest.mark.gpu
@@ -225,3 +225,35 @@ def test_load_projection_refuses_indices_that_would_leave_the_arrays():
     bad = col.copy(); bad[0] = -1
     assert call(start, end, bad) == -1
     g.close()
+
+
+def test_recycled_context_forgets_its_previous_owners_projection():
+    """rolo_ctx_release -> rolo_ctx_acquire hands the SAME context back as a fresh object: the previous owner's projection must not be there for a staged
+    rolo_extract_features to run on, its armed de-skew must not fire on the new owner's first frame, and the per-object counters start at zero"""
+    import ctypes as C
+    from rolo_amd._lib import lib, RoloError
+    from rolo_amd.rotvgicp import RotVGICP
+    L = lib()
+    L.rolo_ctx_pool_clear()
+    h = C.c_void_p(); assert L.rolo_ctx_acquire(0, C.byref(h)) == 0
+    first = h.value
+    fr = synth.make_frame("vlp16", np.eye(3), np.zeros(3), synth.SEED)
+    cfg = dict(n_scan=16, horizon_scan=1800)
+    a = RotVGICP(0, _borrowed=h.value)
+    fe = FrontEnd(a, front_params(**cfg))
+    pg = fe.project(fr.xyz, fr.ring)                     # projected, never extracted
+    fe.setDeskewFromCloud(deskew_params((0.01, 0.02, 0.03)))   # ... and a de-skew armed for a frame that never comes
+    L.rolo_ctx_release(h)
+    h2 = C.c_void_p(); assert L.rolo_ctx_acquire(0, C.byref(h2)) == 0
+    assert h2.value == first
+    b = RotVGICP(0, _borrowed=h2.value)
+    fe2 = FrontEnd(b, front_params(**cfg))
+    with pytest.raises(RoloError) as ei:
+        fe2.extract(pg["n"])
+    assert ei.value.code == -5                           # ROLO_ESTATE: this object has not projected anything
+    assert b.counters()["frames"] == 0
+    p2 = fe2.project(fr.xyz, fr.ring); e2 = fe2.extract(p2["n"])
+    fo = pyorc.front_params(**cfg)
+    eo = pyorc.extract_features(fo, pyorc.project(fo, fr.xyz, fr.ring))   # NO de-skew: the previous owner's armed one is gone
+    assert np.array_equal(p2["extracted"], pg["extracted"]) and np.array_equal(e2["corner"], eo["corner"]) and np.array_equal(e2["surface"], eo["surface"])
+    L.rolo_ctx_release(h2); L.rolo_ctx_pool_clear()

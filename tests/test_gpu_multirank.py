@@ -141,6 +141,8 @@ def _peer_rank_body(g, rank, world, exchange_handles, frames):
     handles = exchange_handles(rank, h)
     g.peer_connect(handles, rank, world)
     assert g.peer_info()[:2] == (rank, world)
+    us = g.peer_selftest(4)   # known words through both exchanges before the first frame (collective: every rank calls it)
+    assert us[0] > 0 and us[1] > 0
     out = []
     for _ in range(frames):   # frames 1 and 2 eager (the schedule length settles), frame 3 captured, frame 4 replayed from the hipGraph
         g.setInputTarget(tgt.copy()); g.setInputSource(src.copy())   # a new array object: setInput* really uploads, K5 runs every frame
@@ -307,3 +309,181 @@ def test_peer_timeout_is_an_error_not_a_hang(monkeypatch):
     assert time.time() - t0 < 20
     assert ei.value.code == -9
     a.close(); b.close()
+
+
+# ---- BASELINE configs[3] at its own size: the 262 144-point frame (128 x 2048), leaf 0.5 m, 20 iterations, sharded over W rank processes ---------
+def _digest(a):
+    import hashlib
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def _config3_rank_main(rank, world, dirpath):
+    """one rank of the sharded 262k-point frame: loads the pair the parent generated, runs 4 frames (eager, eager, captured, replayed),
+    leaves pose / translation / pass counts per frame and digests of the exchanged covariances"""
+    import json
+    import time
+    from rolo_amd.rotvgicp import RotVGICP
+    src = np.load(os.path.join(dirpath, "src.npy")); tgt = np.load(os.path.join(dirpath, "tgt.npy"))
+
+    def exchange(r, h):
+        with open(os.path.join(dirpath, f"h{r}.tmp"), "wb") as f:
+            f.write(h)
+        os.replace(os.path.join(dirpath, f"h{r}.tmp"), os.path.join(dirpath, f"h{r}.bin"))
+        hs = []
+        for q in range(world):
+            p = os.path.join(dirpath, f"h{q}.bin"); t0 = time.time()
+            while not os.path.exists(p):
+                if time.time() - t0 > 180:
+                    raise SystemExit(3)
+                time.sleep(0.02)
+            hs.append(open(p, "rb").read())
+        return hs
+
+    g = RotVGICP(0); g.setResolution(0.5); g.setFixedIterations(20)
+    g.peer_connect(exchange(rank, g.peer_export(world, src.shape[0] + tgt.shape[0])), rank, world)
+    st = g.peer_selftest(4)
+    frames = []
+    for _ in range(4):
+        g.setInputTarget(tgt.copy()); g.setInputSource(src.copy())
+        g.register_async(None, np.zeros(3), G, L0)
+        Tf, Td, t = g.register_wait()
+        frames.append(dict(Td=Td.reshape(-1).tolist(), t=t.tolist(), rot_outer=g.last_stats.n_outer, passes=[g.last_stats.n_passes, g.last_translation_stats.n_passes]))
+    res = dict(rank=rank, frames=frames, counters=g.counters(), selftest_us=list(st), mailbox=g.peer_info()[2],
+               cov_src=_digest(g.getSourceCovariances()), cov_tgt=_digest(g.getTargetCovariances()))
+    json.dump(res, open(os.path.join(dirpath, f"res{rank}.json"), "w"))
+    open(os.path.join(dirpath, f"done{rank}"), "w").close()
+    t0 = time.time()   # keep the mailbox alive until every rank is done
+    while not all(os.path.exists(os.path.join(dirpath, f"done{q}")) for q in range(world)) and time.time() - t0 < 180:
+        time.sleep(0.02)
+    g.close()
+
+
+def _rot_angle(Ra, Rb):
+    c = (np.trace(Ra.T @ Rb) - 1.0) / 2.0
+    return float(np.arccos(np.clip(c, -1.0, 1.0))) if c < 1.0 - 1e-12 else float(np.sqrt(max(0.0, 2.0 * (1.0 - c))))
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_sharded_262k_frame_matches_oracle(tmp_path, world):
+    """BASELINE configs[3] ("OS1-128 262k pts point-sharded across 8 x MI355X") at its workload: W rank processes over hipIpc handles (one device here,
+    one GPU each on a node), K5 by query slice + peer-written covariance exchange, passes by source shard + mailbox all-reduce in the controller,
+    hipGraph replayed — every rank's pose against the ORACLE (<= 1e-5 rad / <= 1e-4 m, the north-star bar), exchanged covariances bit-identical to the
+    unsharded ones, all ranks bit-identical to each other. Reference loop that is split: rot_vgicp_impl.hpp:313-382."""
+    import json
+    import subprocess
+    from oracle import pyorc
+    from rolo_amd.rotvgicp import RotVGICP
+    src, tgt, _ = synth.dense_pair("os1-128x2048")
+    assert src.shape[0] == 262144 and tgt.shape[0] == 262144
+    np.save(tmp_path / "src.npy", src); np.save(tmp_path / "tgt.npy", tgt)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", ROLO_PEER_TIMEOUT_MS="60000")
+    code = "import sys; sys.path.insert(0, %r); from tests.test_gpu_multirank import _config3_rank_main; _config3_rank_main(int(sys.argv[1]), %d, %r)" % (ROOT, world, str(tmp_path))
+    procs = [subprocess.Popen([sys.executable, "-c", code, str(r)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+    # while the ranks run: the oracle on the same frame (CPU), then the unsharded HIP run once they are done
+    o = pyorc.Reg(pyorc.default_params(voxel_type=1, voxel_resolution=0.5, fixed_iterations=20)); o.set_target(tgt); o.set_source(src)
+    rc, _, Td_o, _, _ = o.align(); assert rc == 0
+    rc, t_o, _ = o.compute_translation(np.zeros(3), G, L0); assert rc == 0
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=420)[0].decode(errors="replace"))
+    except subprocess.TimeoutExpired:
+        for p in procs:
+            p.kill()
+        pytest.fail("sharded ranks did not finish within 420 s")
+    assert all(p.returncode == 0 for p in procs), " | ".join(o_[-600:] for o_ in outs)
+    res = [json.load(open(tmp_path / f"res{r}.json")) for r in range(world)]
+    ref = RotVGICP(); ref.setResolution(0.5); ref.setFixedIterations(20)
+    ref.setInputTarget(tgt); ref.setInputSource(src)
+    ref.register_async(None, np.zeros(3), G, L0); _, Td_u, t_u = ref.register_wait()
+    cs, ct = _digest(ref.getSourceCovariances()), _digest(ref.getTargetCovariances())
+    ref.close()
+    for r in res:
+        assert r["cov_src"] == cs and r["cov_tgt"] == ct                       # exchanged covariances = the unsharded ones, bit for bit
+        assert r["counters"]["frames"] == 4 and r["counters"]["graph_replays"] >= 1 and r["counters"]["topup_frames"] == 0, r["counters"]
+        for f in r["frames"]:
+            Td = np.array(f["Td"]).reshape(4, 4); t = np.array(f["t"])
+            assert f["rot_outer"] == 20
+            assert _rot_angle(Td[:3, :3], Td_o[:3, :3]) <= 1e-5 and np.abs(t - t_o).max() <= 1e-4      # vs the ORACLE
+            assert np.abs(Td - Td_u).max() < 1e-9 and np.abs(t - t_u).max() < 1e-9                      # vs the unsharded HIP run (order of additions)
+        assert r["frames"] == res[0]["frames"]                                  # every rank, every frame: bit-identical decisions
+
+
+def _distinct_rank_main(rank, world, dirpath):
+    """a DIFFERENT pair of equal size every frame; rank 1 never uses the hipGraph (use_graph = 0), rank 0 captures on its third frame — the ranks' captures
+    are out of step, which a host-side choice of the exchange area baked into a capture did not survive (round 3's advisor finding)"""
+    import time
+    from rolo_amd.rotvgicp import RotVGICP
+    pairs = [synth.dense_pair("os1-64", col_stride=4, origin=synth.pool_origin(i)) for i in range(3)]
+
+    def exchange(r, h):
+        with open(os.path.join(dirpath, f"h{r}.tmp"), "wb") as f:
+            f.write(h)
+        os.replace(os.path.join(dirpath, f"h{r}.tmp"), os.path.join(dirpath, f"h{r}.bin"))
+        hs = []
+        for q in range(world):
+            p = os.path.join(dirpath, f"h{q}.bin"); t0 = time.time()
+            while not os.path.exists(p):
+                if time.time() - t0 > 120:
+                    raise SystemExit(3)
+                time.sleep(0.02)
+            hs.append(open(p, "rb").read())
+        return hs
+
+    g = RotVGICP(0); g.setResolution(1.0)
+    if rank == 1:
+        g.setUseGraph(False)
+    n = pairs[0][0].shape[0] + pairs[0][1].shape[0]
+    g.peer_connect(exchange(rank, g.peer_export(world, n)), rank, world)
+    out = []
+    for k in range(7):
+        src, tgt, _ = pairs[k % 3]
+        g.setInputTarget(tgt.copy()); g.setInputSource(src.copy())
+        g.register_async(None, np.zeros(3), G, L0)
+        Tf, Td, t = g.register_wait()
+        cov = np.concatenate([g.getSourceCovariances().reshape(-1), g.getTargetCovariances().reshape(-1)])
+        out.append(np.concatenate([Td.reshape(-1), t, [float(int(_digest(cov)[:12], 16))]]))
+    cnt = g.counters()
+    np.save(os.path.join(dirpath, f"vec{rank}.npy"), np.concatenate(out + [np.array([cnt["graph_replays"], cnt["eager_frames"]], float)]))
+    open(os.path.join(dirpath, f"done{rank}"), "w").close()
+    t0 = time.time()
+    while not all(os.path.exists(os.path.join(dirpath, f"done{q}")) for q in range(world)) and time.time() - t0 < 120:
+        time.sleep(0.02)
+    g.close()
+
+
+def test_peer_exchange_distinct_frames_with_captures_out_of_step(tmp_path):
+    import subprocess
+    from rolo_amd.rotvgicp import RotVGICP
+    world = 2
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", ROLO_PEER_TIMEOUT_MS="20000")
+    code = "import sys; sys.path.insert(0, %r); from tests.test_gpu_multirank import _distinct_rank_main; _distinct_rank_main(int(sys.argv[1]), %d, %r)" % (ROOT, world, str(tmp_path))
+    procs = [subprocess.Popen([sys.executable, "-c", code, str(r)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=240)[0].decode(errors="replace"))
+    except subprocess.TimeoutExpired:
+        for p in procs:
+            p.kill()
+        pytest.fail("peer ranks did not finish within 240 s")
+    assert all(p.returncode == 0 for p in procs), " | ".join(o[-600:] for o in outs)
+    res = [np.load(tmp_path / f"vec{r}.npy") for r in range(world)]
+    assert res[0][-2] >= 1 and res[1][-2] == 0 and res[1][-1] == 7     # rank 0 replayed its graph, rank 1 ran every frame eagerly
+    pairs = [synth.dense_pair("os1-64", col_stride=4, origin=synth.pool_origin(i)) for i in range(3)]
+    assert len({p[0].shape[0] for p in pairs}) == 1 and not np.array_equal(pairs[0][0], pairs[1][0])
+    want = []
+    ref = RotVGICP(); ref.setResolution(1.0)
+    for k in range(7):
+        src, tgt, _ = pairs[k % 3]
+        ref.setInputTarget(tgt.copy()); ref.setInputSource(src.copy())
+        ref.register_async(None, np.zeros(3), G, L0); _, Td, t = ref.register_wait()
+        cov = np.concatenate([ref.getSourceCovariances().reshape(-1), ref.getTargetCovariances().reshape(-1)])
+        want.append(np.concatenate([Td.reshape(-1), t, [float(int(_digest(cov)[:12], 16))]]))
+    ref.close()
+    want = np.concatenate(want)
+    for r in res:
+        got = r[:-2].reshape(7, 20); w = want.reshape(7, 20)
+        assert np.array_equal(got[:, 19], w[:, 19])                     # every frame's exchanged covariances are THAT frame's, bit for bit
+        assert np.abs(got[:, :19] - w[:, :19]).max() < 1e-9
+    assert np.array_equal(res[0][:-2], res[1][:-2])

@@ -159,3 +159,39 @@ def test_fused_front_end_node_publishes_what_the_three_node_chain_publishes(demo
         assert np.array_equal(W.xyzi_of(ca["extracted_corner"]), W.xyzi_of(cb["extracted_corner"]))
         assert np.array_equal(W.xyzi_of(ca["extracted_surface"]), W.xyzi_of(cb["extracted_surface"]))
         assert cb["odomAvailable"] == 1 and np.abs(ca["initialGuess"] - cb["initialGuess"]).max() <= 2e-6
+
+
+def test_fused_front_end_node_deskews_like_the_chain_across_a_stamp_gap(demo, tmp_path):
+    """rolo/deskewEnabled on, the nodes' own odometry fed back (odomTopic + "_incremental" -> ImageProjection::odometryHandler), and a pause in the stamps
+    that lets the 0.3 s gate of deskewCloudInfo (imageProjection.cpp:266-366) empty the odometry queue: odomAvailable is sticky in the reference
+    (:150-155) — the fused node must de-skew exactly the frames the three-node chain de-skews, before and after the gap."""
+    poses = trajectory(11)
+    frames = [synth.make_frame("vlp16", R, t, synth.SEED + k) for k, (R, t) in enumerate(poses)]
+    stamps = [100.0 + 0.1 * k + (1.0 if k >= 7 else 0.0) for k in range(len(frames))]   # one second of silence before message 7
+    paths = []
+    for k, fr in enumerate(frames):
+        p = tmp_path / f"msg{k}.bin"; p.write_bytes(W.pack_pc2(W.velodyne_msg(fr, stamps[k], seq=k))); paths.append(str(p))
+    outs = {}
+    for mode in ("chain", "fused"):
+        out = tmp_path / mode; out.mkdir()
+        r = subprocess.run([demo, mode, "velodyne", "16", "1800", "1", "4", str(out)] + paths, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        outs[mode] = (out, [l for l in r.stdout.strip().splitlines() if l.startswith("msg")])
+    n_out = len(frames) - 2
+    assert [int(l.split()[-1]) for l in outs["fused"][1][2:]] == [int(l.split()[-1]) for l in outs["chain"][1][2:2 + n_out]]
+    moved = 0
+    for k in range(1, n_out):
+        a = W.parse_odometry((outs["chain"][0] / f"odom_{k}.bin").read_bytes()); b = W.parse_odometry((outs["fused"][0] / f"odom_{k}.bin").read_bytes())
+        assert a["header"] == b["header"]
+        assert np.abs(a["position"] - b["position"]).max() <= 2e-6 and np.abs(a["orientation"] - b["orientation"]).max() <= 2e-6
+        ca = W.parse_cloud_info((outs["chain"][0] / f"odom_cloud_{k}.bin").read_bytes()); cb = W.parse_cloud_info((outs["fused"][0] / f"odom_cloud_{k}.bin").read_bytes())
+        assert np.array_equal(W.xyzi_of(ca["extracted_corner"]), W.xyzi_of(cb["extracted_corner"]))     # the same de-skewed points, bit for bit
+        assert np.array_equal(W.xyzi_of(ca["extracted_surface"]), W.xyzi_of(cb["extracted_surface"]))
+    # and the de-skew did act on some frame: the chain's projected cloud differs from the raw projection there
+    fo = pyorc.front_params(n_scan=16, horizon_scan=1800)
+    for k in range(n_out):
+        ci = W.parse_cloud_info((outs["chain"][0] / f"cloud_info_{k}.bin").read_bytes())
+        po = pyorc.project(fo, frames[k].xyz, frames[k].ring)
+        if not np.array_equal(W.xyzi_of(ci["cloud_projected"])[:, :3], po["extracted"][:, :3]):
+            moved += 1
+    assert moved >= 2
