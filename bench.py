@@ -60,6 +60,7 @@ def parse():
     ap.add_argument("--no-pipeline", action="store_true", help="skip the raw-frame -> pose pipeline leg")
     ap.add_argument("--pipeline-only", action="store_true", help="run only the pipeline leg and print its dict (profiling runs)")
     ap.add_argument("--no-config5", action="store_true", help="skip the 512-pair OS1-64 leg (BASELINE configs[4])")
+    ap.add_argument("--no-layout-check", action="store_true", help="skip the re-measurement with contexts re-created after foreign streams")
     ap.add_argument("--config5-pairs", type=int, default=512)
     ap.add_argument("--single-round", action="store_true", help="one timed round only (profiling runs)")
     ap.add_argument("--pool", type=int, default=8,
@@ -624,6 +625,24 @@ def main():
         out["config"]["schedule"] = {k_: int(sum(c_[k_] for c_ in cnt)) for k_ in ("frames", "graph_replays", "graph_captures", "eager_frames", "topup_frames")}
         passes = int(round(float(np.median(tot))))
         out["config"]["passes_per_frame"] = passes
+
+    # ---- layout check: throughput must not depend on WHEN the contexts are created relative to other streams of the process ----------------
+    # (HIP deals streams to its four hardware queues in creation order; rounds 1-3 depended on it: 2140 vs 2940 scans/s for the same four contexts.
+    # The library now takes its streams from a per-device bank created in bursts — rolo_ctx_create / api.hip — so contexts closed and re-created
+    # after FOREIGN streams appeared must measure the same.)
+    if world == 1 and args.mode == "replicas" and B == 1 and not args.no_layout_check:
+        try:
+            foreign = [torch.cuda.Stream() for _ in range(3)]   # three streams the library did not create: every non-trivial shift of a 4-queue deal
+            for c_ in ctxs:
+                c_.close()
+            ctxs = [new_ctx() for _ in range(len(ctxs))]
+            g = ctxs[0]
+            dt2, rounds2 = timed(ctxs, args.steps, args.warmup, data)
+            v2 = args.steps * len(ctxs) / dt2
+            out["layout_check"] = {"scans_per_s_contexts_recreated_after_foreign_streams": v2, "ratio": v2 / value, "foreign_streams": len(foreign),
+                                   "what": "the headline's contexts closed, three foreign HIP streams created, the same number of contexts created again, the same timed rounds"}
+        except Exception as e:  # pragma: no cover
+            out["layout_check"] = {"error": repr(e)}
 
     # ---- frame-level HBM figures of BASELINE.json's metric ("scans/sec ...; achieved HBM GB/s") -------------------------------------
     # algorithmic: SURVEY.md 8d's bytes of one frame — 360 B/pt covariances for both clouds, 136 B/pt + 96 B/voxel map build, and

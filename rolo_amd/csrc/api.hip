@@ -128,11 +128,12 @@ struct rolo_ctx {
     double* lower = nullptr; size_t lower_cap = 0;  // k_correspondences > 64: the key the next round of 64 starts above, per sorted position
   } ks[2];
   hipEvent_t ev_done = nullptr;    // end of the frame rolo_register_async enqueued (the stream may carry other contexts' frames behind it)
-  hipStream_t stream2 = nullptr;   // second stream for the eager (uncaptured) path of rolo_batch_*. Created WITH the context on purpose: HIP deals streams
-                                   // to its 4 hardware queues in creation order, so the main streams of four contexts land on two queues, two streams each
-                                   // — measured the best layout for frames of several contexts in flight on MI355X (2930 scans/s; one
-                                   // queue per context 2140, three contexts on three queues 2620, GPU_MAX_HW_QUEUES=8 1310)
+  hipStream_t stream2 = nullptr;   // second stream for the eager (uncaptured) path of rolo_batch_*; stream and stream2 are a PAIR of the device's stream bank
+                                   // (below): main streams on every other stream of a burst = two hardware queues, alternating — measured the best layout for
+                                   // frames of several contexts in flight on MI355X (2930 scans/s; one queue per context 2140, three
+                                   // contexts on three queues 2620, GPU_MAX_HW_QUEUES=8 1310)
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  int bank_slot = -1;              // >= 0: stream / stream2 belong to the device's stream bank (given back, not destroyed)
   // voxel map
   VoxelTable tab{};
   size_t tab_keys_cap = 0, tab_ids_cap = 0, tab_rec_cap = 0, tab_idk_cap = 0;
@@ -272,6 +273,14 @@ static bool fused_tail_env() {
   static const bool v = [] { const char* e = getenv("ROLO_KNN_FUSE_TAIL"); return e && atoi(e) != 0; }();
   return v;
 }
+// ROLO_KNN_BUDGET=<leaves>: the cooperative walk (knn_walk.hpp) — after that many leaves a packet starts handing sub-trees to the idle wavefronts of its workgroup.
+// Default 0 = the plain walk: measured in round 4, the cooperative form is exact (all list tests pass with it) but no faster (0.224 against 0.223 ms over the
+// pool at 24 leaves): what thieves can take are the far sub-trees at the bottom of a stack, which prune to nothing, and the kernel is bound by the spread of the
+// work over the CUs (x 1.21 - 1.34 between the busiest CU and the mean), which nothing inside a workgroup can move.
+static int knn_budget_env() {
+  static const int v = [] { const char* e = getenv("ROLO_KNN_BUDGET"); const int b = e ? atoi(e) : 0; return b < 0 ? 0 : b; }();
+  return v;
+}
 // ROLO_VOXEL_FUSE=0: the voxel map as its own launches after the search (the A/B of VoxelFuse)
 static bool voxel_fuse_env() {
   static const bool v = [] { const char* e = getenv("ROLO_VOXEL_FUSE"); return !(e && atoi(e) == 0); }();
@@ -350,7 +359,7 @@ int build_clouds(rolo_ctx* c, bool do_src, bool do_tgt, hipStream_t stream, bool
     return ROLO_OK;
   }
   const bool split_tail = !fused_tail_env() || kc > 64;
-  { ProfScope ps(c, ROLO_PROF_KNN_WALK, stream); HIPCHK(launch_knn_walk(A, c->P.k_correspondences, split_tail ? -1 : c->P.regularization, vf, stream)); }
+  { ProfScope ps(c, ROLO_PROF_KNN_WALK, stream); HIPCHK(launch_knn_walk(A, c->P.k_correspondences, split_tail ? -1 : c->P.regularization, vf, stream, (kc == 20 && split_tail) ? knn_budget_env() : 0)); }
   if (split_tail) { ProfScope ps(c, ROLO_PROF_KNN_TAIL, stream); HIPCHK(launch_knn_tail(A, c->P.k_correspondences, c->P.regularization, vf, stream)); }
   if (sharded) {
     const size_t seg = A.c[0].seg;
@@ -661,6 +670,60 @@ namespace rolo {
 int ctx_create_high_priority(int device, rolo_ctx** out) { return ctx_create_impl(device, true, out); }
 }  // namespace rolo
 extern "C" {
+// ROLO_CU_PARTITION=<groups> (2 | 4 | 8; default 0 = off): the main stream of the k-th context created in this process is confined to XCD group k % groups
+// (hipExtStreamCreateWithCUMask; mask bit i = CU i, which sits on XCD i % 8 on this part) — every context its own XCDs and L2s, so that one frame's kernel
+// boundaries cannot write back / invalidate the L2 under another frame's kernels. An experiment switch (round 3's verdict, item 4); the measurement is in DESIGN.md.
+static int cu_partition_env() {
+  static const int v = [] { const char* e = getenv("ROLO_CU_PARTITION"); const int g = e ? atoi(e) : 0; return (g == 2 || g == 4 || g == 8) ? g : 0; }();
+  return v;
+}
+static std::atomic<int> g_ctx_serial{0};
+
+// ---- stream bank: the placement of the contexts' streams on HIP's hardware queues belongs to the library ------------------------------------------
+// HIP deals a process's streams to its 4 hardware queues in CREATION order, and throughput with several frames in flight depends on the result:
+// four contexts whose main streams sit two by two on two queues register 2940 scans/s, each on a queue of its own 2140. Rounds
+// 1-3 got the good layout by creating an idle second stream with every context — which held only while contexts were created back to back in a fresh
+// process: four more contexts next to four idle ones (bench.py's config5 leg, round 3), or a caller that creates one stream of its own between two
+// contexts, landed in a bad layout and lost 27 % with nothing to detect it. Now every device has a BANK of streams created back to back, eight at a
+// time, on first use; a context takes the lowest free PAIR (main stream + the eager fork of rolo_batch_*) and gives it back when it is destroyed.
+// The pairs' positions relative to each other — main streams on every other stream of a burst: two hardware queues, alternating — no longer depend
+// on when contexts come and go or on what else the process creates in between. bench.py's `layout_check` re-measures after foreign streams.
+struct StreamBank { std::vector<hipStream_t> s; std::vector<char> used; };
+static std::mutex g_bank_mu;
+static std::map<int, StreamBank> g_banks;
+static int bank_acquire_pair(int device, hipStream_t* main, hipStream_t* second, int* slot) {
+  std::lock_guard<std::mutex> lk(g_bank_mu);
+  StreamBank& B = g_banks[device];
+  size_t i = 0;
+  for (; i + 1 < B.s.size(); i += 2) if (!B.used[i]) break;
+  if (i + 1 >= B.s.size()) {   // another burst of eight, back to back
+    i = B.s.size();
+    for (int k = 0; k < 8; k++) {
+      hipStream_t st = nullptr;
+      if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return ROLO_EHIP;
+      B.s.push_back(st); B.used.push_back(0);
+    }
+  }
+  B.used[i] = B.used[i + 1] = 1;
+  *main = B.s[i]; *second = B.s[i + 1]; *slot = (int)i;
+  return ROLO_OK;
+}
+static void bank_release_pair(int device, int slot) {
+  std::lock_guard<std::mutex> lk(g_bank_mu);
+  auto it = g_banks.find(device);
+  if (it == g_banks.end() || slot < 0 || (size_t)slot + 1 >= it->second.s.size()) return;
+  it->second.used[(size_t)slot] = it->second.used[(size_t)slot + 1] = 0;
+}
+static hipError_t create_masked_stream(hipStream_t* st, int device, int group, int groups) {
+  hipDeviceProp_t prop;
+  hipError_t e = hipGetDeviceProperties(&prop, device);
+  if (e != hipSuccess) return e;
+  const int ncu = prop.multiProcessorCount, words = (ncu + 31) / 32, per = 8 / groups;
+  std::vector<uint32_t> mask((size_t)words, 0u);
+  for (int i = 0; i < ncu; i++) { const int xcd = i % 8; if (xcd / per == group) mask[(size_t)i / 32] |= 1u << (i % 32); }
+  return hipExtStreamCreateWithCUMask(st, (uint32_t)words, mask.data());
+}
+
 static int ctx_create_impl(int device, bool high_priority, rolo_ctx** out) {
   if (!out) return ROLO_EINVAL;
   int n = 0;
@@ -672,12 +735,17 @@ static int ctx_create_impl(int device, bool high_priority, rolo_ctx** out) {
   rolo_default_params(&c->P);
   int prio_lo = 0, prio_hi = 0;   // (numerically lower = higher priority)
   if (high_priority && (hipSetDevice(device) != hipSuccess || hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) != hipSuccess)) { prio_lo = prio_hi = 0; (void)hipGetLastError(); }
-  if (hipSetDevice(device) != hipSuccess ||
-      (high_priority && prio_hi != prio_lo ? hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_hi) : hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
-      hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming) != hipSuccess) { delete c; g_err = "hipStreamCreate failed"; return ROLO_EHIP; }
+  const int groups = high_priority ? 0 : cu_partition_env();
+  bool ok = hipSetDevice(device) == hipSuccess;
+  if (ok && (groups || high_priority)) {   // experiment / front-end contexts: streams of their own
+    ok = (groups ? create_masked_stream(&c->stream, device, g_ctx_serial.fetch_add(1) % groups, groups)
+                 : (prio_hi != prio_lo ? hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_hi) : hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking))) == hipSuccess &&
+         hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) == hipSuccess;
+  } else if (ok) ok = bank_acquire_pair(device, &c->stream, &c->stream2, &c->bank_slot) == ROLO_OK;
+  if (!ok || hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming) != hipSuccess) { rolo_ctx_destroy(c); g_err = "hipStreamCreate failed"; return ROLO_EHIP; }
   if (hipHostMalloc((void**)&c->h_state, sizeof(LmState)) != hipSuccess || hipHostMalloc((void**)&c->h_sums, sizeof(double) * NV_MAX) != hipSuccess ||
-      hipHostMalloc((void**)&c->h_counters, sizeof(int) * 4) != hipSuccess || hipHostMalloc((void**)&c->h_args, sizeof(FrameArgs)) != hipSuccess) { delete c; g_err = "hipHostMalloc failed"; return ROLO_EHIP; }
+      hipHostMalloc((void**)&c->h_counters, sizeof(int) * 4) != hipSuccess || hipHostMalloc((void**)&c->h_args, sizeof(FrameArgs)) != hipSuccess) { rolo_ctx_destroy(c); g_err = "hipHostMalloc failed"; return ROLO_EHIP; }
   memset(c->h_state, 0, sizeof(LmState));
   int rc = ensure(c->state, c->state_cap, 2);   // [0] the state every entry point sees; [1] the other half of the fused launches' double buffer
   if (!rc) rc = ensure(c->sums, c->sums_cap, NV_MAX);
@@ -716,11 +784,12 @@ void rolo_ctx_destroy(rolo_ctx* c) {
   if (c->h_state) (void)hipHostFree(c->h_state);
   if (c->h_sums) (void)hipHostFree(c->h_sums);
   if (c->h_counters) (void)hipHostFree(c->h_counters);
-  if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
+  if (c->stream2) { (void)hipStreamSynchronize(c->stream2); if (c->bank_slot < 0) (void)hipStreamDestroy(c->stream2); }
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   if (c->ev_done) (void)hipEventDestroy(c->ev_done);
-  if (c->stream) (void)hipStreamDestroy(c->stream);
+  if (c->stream && c->bank_slot < 0) (void)hipStreamDestroy(c->stream);
+  if (c->bank_slot >= 0) bank_release_pair(c->device, c->bank_slot);
   delete c;
 }
 

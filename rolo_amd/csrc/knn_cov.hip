@@ -710,9 +710,10 @@ extern "C" int rolo_debug_wave_records(unsigned* out /* 16384 x 8 */) {
 
 static inline int slice_blocks(const KnnCloud& c) { return (c.q_end - c.q_begin + 255) / 256; }
 
-hipError_t launch_knn_walk(const KnnPair& A, int k, int regularization_or_minus1, const VoxelFuse& vf, hipStream_t s) {
-  constexpr int QPB = 4 * ROLO_KNN_PACKET;   // queries per workgroup of the walk
-  const int g0 = (A.c[0].q_end - A.c[0].q_begin + QPB - 1) / QPB, g1 = A.n_clouds > 1 ? (A.c[1].q_end - A.c[1].q_begin + QPB - 1) / QPB : 0;
+hipError_t launch_knn_walk(const KnnPair& A, int k, int regularization_or_minus1, const VoxelFuse& vf, hipStream_t s, int coop_budget) {
+  constexpr int QPB = 256;   // queries per workgroup of the plain walk: four wavefronts of 64
+  const int n0 = A.c[0].q_end - A.c[0].q_begin, n1 = A.n_clouds > 1 ? A.c[1].q_end - A.c[1].q_begin : 0;
+  const int g0 = (n0 + QPB - 1) / QPB, g1 = (n1 + QPB - 1) / QPB;
   if (g0 + g1 == 0) return hipSuccess;
   (void)vf;   // (insert workgroups appended to THIS launch made its wave-uniform leaf loads vector loads: a store anywhere in the kernel is a potential clobber)
   constexpr int pad = 0;   // (an LDS pad here limited the walk to 3 / 2 workgroups per CU: 0.216 / 0.259 ms against 0.196)
@@ -730,6 +731,17 @@ hipError_t launch_knn_walk(const KnnPair& A, int k, int regularization_or_minus1
   }
   if (k == 20) {
     if (regularization_or_minus1 >= 0) knn_walk_kernel<20, true><<<g0 + g1, 256, pad, s>>>(A, g0, k, regularization_or_minus1);
+    else if (coop_budget > 0) {
+      // the cooperative walk (knn_walk.hpp): NW packets per workgroup, a heavy packet's remaining sub-trees go to the workgroup's idle wavefronts.
+      // NW follows the launch size — a workgroup per CU at least: 4 for the pipeline's ~48 k-point feature clouds, 16 for the 2 x 131 072-point frame
+      const int packets = (n0 + 63) / 64 + (n1 + 63) / 64;
+      static const int force_nw = [] { const char* e = getenv("ROLO_KNN_COOP_NW"); return e ? atoi(e) : 0; }();
+      const int nw = force_nw ? force_nw : (packets >= 16 * 256 ? 16 : (packets >= 8 * 256 ? 8 : 4));
+      const int G4 = g0 + g1, G = (G4 + nw / 4 - 1) / (nw / 4);   // a workgroup = nw / 4 runs of four consecutive packets (the plain walk's blocks), strided by G
+      if (nw == 16) knn_walk_coop_kernel<16><<<G, 1024, 0, s>>>(A, g0, G4, coop_budget);
+      else if (nw == 8) knn_walk_coop_kernel<8><<<G, 512, 0, s>>>(A, g0, G4, coop_budget);
+      else knn_walk_coop_kernel<4><<<G, 256, 0, s>>>(A, g0, G4, coop_budget);
+    }
     else knn_walk_kernel<20, false><<<g0 + g1, 256, pad, s>>>(A, g0, k, -1);
   }
   else {

@@ -19,7 +19,7 @@
 namespace rolo {
 namespace {
 
-constexpr int WALK_STACK = 48;
+constexpr int WALK_STACK = KNN_WALK_STACK;
 
 // Sharded K5 with peers (rolo_peer_*): the exchange buffer alternates between two areas of the rank's mailbox. WHICH one a frame uses is the parity
 // of the exchange's number, read on the device from the own mailbox's epoch word (peer.hip bumps it once per exchange, in stream order) — a captured
@@ -40,15 +40,16 @@ ROLO_DEV double* stage_area(const KnnCloud& cl, unsigned add) {
 // pure latency) give each XCD ONE contiguous eighth (pipeline frame latency 0.787 -> 0.731 ms, 1552 -> 1769 frames/s); big launches deal
 // runs of 64 blocks round-robin instead, because the work per packet varies along the curve and whole eighths balance worse
 // (2 x 131 072 points: 0.226 ms contiguous, 0.199 ms in runs, 0.207 ms unmapped). Both are bijections on [0, G).
-ROLO_DEV int xcd_contiguous_block(int b, int G) {
+// wpb = wavefronts (packets) per block: the thresholds are in packets, whatever the workgroup size
+ROLO_DEV int xcd_contiguous_block(int b, int G, int wpb = 4) {
 #ifdef ROLO_KNN_NO_XCD_REMAP
   return b;
 #else
-  if (G <= 512) {
+  if (G * wpb <= 2048) {
     const int x = b & 7, k = b >> 3, q = G >> 3, r = G & 7;   // XCD x owns G / 8 (+1 for x < G % 8) consecutive blocks
     return x * q + min(x, r) + k;
   }
-  constexpr int RUN = 64, GROUP = 8 * RUN;
+  const int RUN = 256 / wpb, GROUP = 8 * RUN;                  // runs of 256 packets
   if (b >= G / GROUP * GROUP) return b;                       // the whole groups are permuted, the remainder stays put
   const int grp = b / GROUP, o = b - grp * GROUP;             // o = k * 8 + x : the k-th block this group sends to XCD x
   return grp * GROUP + (o & 7) * RUN + (o >> 3);
@@ -84,15 +85,76 @@ ROLO_DEV void insert_slot(double& ks, double ksm1, double c) { asm("v_min_f64 %0
 #else
 ROLO_DEV void insert_slot(double& ks, double ksm1, double c) { ks = vmax_f64(ksm1, vmin_f64(c, ks)); }
 #endif
+// ---- wave-uniform fetches as EXPLICIT scalar loads ----------------------------------------------------------------------------------------
+// Node boxes and leaf points are fetched through wave-uniform addresses: one s_load per 64 bytes per WAVE instead of a vector load per lane. Rounds
+// 1-3 left that to the compiler, which emits scalar loads only while it can prove that nothing in the kernel may have written memory before them
+// — a store, an atomic, a fence, a clock builtin or a volatile asm ahead of the loop (or on any path that reaches it again) turned the leaf's 64
+// floats into vector loads: 64 more VGPRs, spills, a 5-10 x slower walk ("the clobber rule"). That rule forbade every form of
+// work sharing between wavefronts. The loads are inline asm now (s_load_dwordx16 + the wait, outputs in SGPR tuples): scalar by construction,
+// whatever else the kernel does. The data they read (sorted points, boxes) is written by EARLIER launches only, so a non-volatile asm is exact.
+typedef float sgpr16 __attribute__((ext_vector_type(16)));
+#ifndef ROLO_KNN_ASM_LOADS
+#define ROLO_KNN_ASM_LOADS 0   // the PLAIN walk kernels (no store, atomic or fence ahead of their loops: the compiler's own scalar loads, as measured in rounds 1-3; 1 = the asm loads there too, an A/B: +2-3 %);
+#endif                         // the cooperative kernel, which fences and stores between walks, always takes the asm loads
+constexpr bool KNN_PLAIN_ASM = ROLO_KNN_ASM_LOADS != 0;
+// (the "s" constraint does not make a pointer uniform by itself: one the compiler believes divergent — e.g. picked through a value read from LDS — would be
+// substituted as a VGPR pair, which the instruction does not take)
+ROLO_DEV const float4* uniform_ptr(const float4* p) {
+  const unsigned long long v = (unsigned long long)p;
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+  return (const float4*)(((unsigned long long)hi << 32) | lo);
+}
+template <bool ASM>
+ROLO_DEV void sload_leaf(const float4* __restrict__ p_, float4 (&pts)[KNN_LEAF]) {
+  if (!ASM) {
+#pragma unroll
+    for (int u = 0; u < KNN_LEAF; u++) pts[u] = p_[u];
+    return;
+  }
+  const float4* p = uniform_ptr(p_);
+#if 1
+  static_assert(KNN_LEAF == 16 || KNN_LEAF == 8, "leaf size");
+  sgpr16 a, b;
+  if (KNN_LEAF == 16) {
+    sgpr16 c, d;
+    asm("s_load_dwordx16 %0, %4, 0x0\n\ts_load_dwordx16 %1, %4, 0x40\n\ts_load_dwordx16 %2, %4, 0x80\n\ts_load_dwordx16 %3, %4, 0xc0\n\ts_waitcnt lgkmcnt(0)"
+        : "=&s"(a), "=&s"(b), "=&s"(c), "=&s"(d) : "s"(p));
+#pragma unroll
+    for (int u = 0; u < 4; u++) { pts[8 + u] = make_float4(c[4 * u], c[4 * u + 1], c[4 * u + 2], c[4 * u + 3]); pts[12 + u] = make_float4(d[4 * u], d[4 * u + 1], d[4 * u + 2], d[4 * u + 3]); }
+  } else {
+    asm("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %2, 0x40\n\ts_waitcnt lgkmcnt(0)" : "=&s"(a), "=&s"(b) : "s"(p));
+  }
+#pragma unroll
+  for (int u = 0; u < 4; u++) { pts[u] = make_float4(a[4 * u], a[4 * u + 1], a[4 * u + 2], a[4 * u + 3]); pts[4 + u] = make_float4(b[4 * u], b[4 * u + 1], b[4 * u + 2], b[4 * u + 3]); }
+#else
+#pragma unroll
+  for (int u = 0; u < KNN_LEAF; u++) pts[u] = p[u];
+#endif
+}
+// the two child boxes of node h: boxes[4h .. 4h + 3] = left lo, left hi, right lo, right hi (64 bytes)
+template <bool ASM>
+ROLO_DEV void sload_node(const float4* __restrict__ p_, float4& llo, float4& lhi, float4& rlo, float4& rhi) {
+  if (!ASM) { llo = p_[0]; lhi = p_[1]; rlo = p_[2]; rhi = p_[3]; return; }
+  const float4* p = uniform_ptr(p_);
+#if 1
+  sgpr16 a;
+  asm("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(a) : "s"(p));
+  llo = make_float4(a[0], a[1], a[2], a[3]); lhi = make_float4(a[4], a[5], a[6], a[7]); rlo = make_float4(a[8], a[9], a[10], a[11]); rhi = make_float4(a[12], a[13], a[14], a[15]);
+#else
+  llo = p[0]; lhi = p[1]; rlo = p[2]; rhi = p[3];
+#endif
+}
+
 // score the KNN_LEAF (16) points of leaf g against this lane's query and insert the ones that beat its current k-th best
-template <int KMAX, bool LOWER = false>
+// CAP (continuation of a budgeted walk, below): the lane's list starts EMPTY but its bound does not — bkey never rises above bcap, the k-th best
+// of the list the first part of the walk left behind
+template <int KMAX, bool LOWER = false, bool CAP = false, bool ASM = false>
 ROLO_DEV void knn_score_leaf(const float4* __restrict__ sorted, int g, const float4& q, double (&K)[KMAX], int kk, double& bkey, float& bd,
-                             unsigned& n_ins, unsigned& lane_acc, unsigned& rounds, double lo = 0.0) {
+                             unsigned& n_ins, unsigned& lane_acc, unsigned& rounds, double lo = 0.0, double bcap = 0.0) {
   // fetch the whole leaf first: the address is wave-uniform, so these are KNN_LEAF scalar loads in flight behind ONE wait
   // (loading inside the loop serialised the scalar-cache round trips of a leaf behind the insert branch)
   float4 pts[KNN_LEAF];
-#pragma unroll
-  for (int u = 0; u < KNN_LEAF; u++) pts[u] = sorted[KNN_LEAF * (size_t)g + u];
+  sload_leaf<ASM>(sorted + KNN_LEAF * (size_t)g, pts);
   KNN_STAT(const double bkey0 = bkey; unsigned my_acc = 0;)   // accepted against the bound at leaf entry: what a per-lane queue would hold
 #ifdef ROLO_KNN_STATS2
   unsigned my_cur = 0;
@@ -138,6 +200,7 @@ ROLO_DEV void knn_score_leaf(const float4* __restrict__ sorted, int g, const flo
       }
 #pragma unroll
       for (int s = 0; s < KMAX; s++) if (s == kk - 1) bkey = K[s];
+      if (CAP) bkey = vmin_f64(bkey, bcap);
       bd = key_d2(bkey);
     }
   }
@@ -153,54 +216,106 @@ ROLO_DEV void knn_score_leaf(const float4* __restrict__ sorted, int g, const flo
 #endif
 }
 
-// The same leaf scored through a per-lane LDS queue (-DROLO_KNN_LANE_QUEUE, an A/B): every lane first appends the candidates that beat its
-// bound AT LEAF ENTRY to its own queue (16 predicated ds_write_b64), then the wavefront drains the queues together — one sorted insert per
-// iteration with ALL lanes live, max-over-lanes iterations instead of one partial-exec insert per point ANY lane accepts (the union over
-// lanes). A queued key that no longer beats the (tighter) bound when it is popped is a no-op in the min / max network, so the neighbour
-// lists are unchanged.
-template <int KMAX>
-ROLO_DEV void knn_score_leaf_queue(const float4* __restrict__ sorted, int g, const float4& q, double (&K)[KMAX], int kk, double& bkey, float& bd, double sentinel) {
-  // declared HERE, not passed in: through a (generic) pointer parameter the compiler no longer knows the stores go to LDS, every later
-  // wave-uniform leaf load becomes a potential clobber victim and turns into a vector load (128 VGPRs + 209 spilled: the clobber rule of DESIGN.md section 4)
-  __shared__ double qbuf_all[4][KNN_LEAF * 64];
-  double* qbuf = qbuf_all[threadIdx.x >> 6];
-  float4 pts[KNN_LEAF];
-#pragma unroll
-  for (int u = 0; u < KNN_LEAF; u++) pts[u] = sorted[KNN_LEAF * (size_t)g + u];
-  const int lane = threadIdx.x & 63;
-  int cnt = 0;
-#pragma unroll
-  for (int u = 0; u < KNN_LEAF; u++) {
-    const float4 c = pts[u];
-    const float dx = q.x - c.x, dy = q.y - c.y, dz = q.z - c.z;
-    float cd = ((dx * dx) + (dy * dy)) + (dz * dz);
-    asm("" : "+v"(cd), "+v"(cnt));   // one candidate at a time: without this ordering the 16 keys are formed up front (32 more VGPRs, 209 spills)
-    const double ck = key_pack(cd, __float_as_int(c.w));
-    if (ck < bkey) { qbuf[cnt * 64 + lane] = ck; cnt++; }
-  }
-  while (__any(cnt > 0)) {
-    double ck = sentinel;
-    if (cnt > 0) { cnt--; ck = qbuf[cnt * 64 + lane]; }
-    constexpr int T = KMAX / 4;
-#pragma unroll
-    for (int s = KMAX - 1; s >= 3 * T; s--) K[s] = vmax_f64(K[s - 1], vmin_f64(ck, K[s]));
-    if (__any(ck < K[3 * T - 1])) {
-#pragma unroll
-      for (int s = 3 * T - 1; s >= 2 * T; s--) K[s] = vmax_f64(K[s - 1], vmin_f64(ck, K[s]));
-      if (__any(ck < K[2 * T - 1])) {
-#pragma unroll
-        for (int s = 2 * T - 1; s >= T; s--) K[s] = vmax_f64(K[s - 1], vmin_f64(ck, K[s]));
-        if (__any(ck < K[T - 1])) {
-#pragma unroll
-          for (int s = T - 1; s >= 1; s--) K[s] = vmax_f64(K[s - 1], vmin_f64(ck, K[s]));
-          K[0] = vmin_f64(ck, K[0]);
-        }
+// ---- the packet walk proper --------------------------------------------------------------------------------------------------------------
+// One wavefront, 64 queries, from node h down; the far children wait on a small per-wave stack in LDS. Every control decision is wave-uniform.
+// PUBLISH (knn_walk_coop_kernel): once the walk has scored `budget` leaves, whenever everything it published before has been taken it moves the
+// BOTTOM entries of its stack — the oldest, i.e. the largest sub-trees — into a small ring in LDS where the idle wavefronts of its workgroup
+// steal them (work stealing: the owner works at the top of its stack, thieves take from the bottom).
+typedef __attribute__((address_space(3))) int lds_int;
+typedef __attribute__((address_space(3))) double lds_double;
+constexpr int COOP_RING = 16;
+struct CoopPub { lds_int* ring; lds_int* head; lds_int* tail; lds_double* cap; int budget; };   // head: entries published so far, tail: entries taken so far
+
+template <int KMAX, bool LOWER, bool CAP, bool PUBLISH, bool ASM>
+ROLO_DEV void packet_walk(const float4* __restrict__ sorted, const float4* __restrict__ boxes, int P, int g_own0, int g_own1, const float4& q, double (&K)[KMAX], int kk,
+                          double& bkey, float& bd, double lo, double bcap, lds_int* stk, int& sp, int h, const CoopPub& pub, int& n_scored, int& n_published,
+                          unsigned& st_nodes, unsigned& st_leaves, unsigned& st_ins, unsigned& st_lane, unsigned& st_rounds, unsigned& st_push) {
+  (void)st_push; (void)pub; (void)n_scored; (void)n_published;
+  while (true) {
+    h = __builtin_amdgcn_readfirstlane(h);
+    if (h < P) {
+      st_nodes++;
+      float4 llo, lhi, rlo, rhi;
+      sload_node<ASM>(boxes + 4 * (size_t)h, llo, lhi, rlo, rhi);
+      const float bl = box_d2(llo, lhi, q), br = box_d2(rlo, rhi, q);
+      const bool okl = (bl <= bd) && (bl < INFINITY), okr = (br <= bd) && (br < INFINITY);
+      const unsigned long long ml = __ballot(okl), mr = __ballot(okr);
+      if (ml != 0ull && mr != 0ull) {
+        // nearer child first, by majority vote of the lanes that reach either child (a "lane with the largest
+        // radius decides" rule needed a 6-step cross-lane max per node and did not reduce the nodes visited)
+        const unsigned long long pref = __ballot((okl || okr) && (bl <= br));
+        const bool left_first = 2 * __popcll(pref) >= __popcll(ml | mr);
+        if (sp < WALK_STACK) { stk[sp] = left_first ? 2 * h + 1 : 2 * h; sp++; KNN_STAT(st_push++;) }
+        h = left_first ? 2 * h : 2 * h + 1;
+        continue;
+      }
+      if (ml != 0ull) { h = 2 * h; continue; }
+      if (mr != 0ull) { h = 2 * h + 1; continue; }
+    } else {
+      const int g = h - P;
+      if (g < g_own0 || g >= g_own1) {   // (the wavefront's own leaves and their neighbours along the curve were scored as seeds)
+        knn_score_leaf<KMAX, LOWER, CAP, ASM>(sorted, g, q, K, kk, bkey, bd, st_ins, st_lane, st_rounds, lo, bcap);
+        st_leaves++;
+        if (PUBLISH) n_scored++;
       }
     }
+    if (sp == 0) return;
+    if (PUBLISH && n_scored >= pub.budget && sp >= 2) {
+      const int lane = threadIdx.x & 63;
+      const int hd = __builtin_amdgcn_readfirstlane(*pub.head);
+      const int tl = __builtin_amdgcn_readfirstlane(__hip_atomic_load((int*)pub.tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+      if (hd == tl) {   // the ring is empty: hand out the bottom half of the stack (at most 4 entries), and the bound the thieves may prune with
+        const int m = min(sp >> 1, 4);
+        if (lane < m) pub.ring[(hd + lane) % COOP_RING] = stk[lane];
+        pub.cap[lane] = bkey;
+        const int keep = sp - m;
+        const int e = lane < keep ? stk[m + lane] : 0;
+        if (lane < keep) stk[lane] = e;
+        sp = keep;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) __hip_atomic_store((int*)pub.head, hd + m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        n_published += m;
+      }
+    }
+    sp--;
+    h = stk[sp];
   }
+}
+
+// a thief's (or the owner's own) take from the bottom ring of wavefront d: the oldest published sub-tree, or -1. Lane 0 acts for the wavefront.
+// The entry is read BEFORE the compare-and-swap on `tail`: slot t is only rewritten by its owner once tail has moved past t, so a successful swap proves the read was of entry t.
+ROLO_DEV int coop_steal(lds_int* ring, lds_int* head, lds_int* tail) {
+  int e = -1;
+  if ((threadIdx.x & 63) == 0) {
+    while (true) {
+      const int t = __hip_atomic_load((int*)tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      const int hd = __hip_atomic_load((int*)head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (t >= hd) break;
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      const int v = ring[t % COOP_RING];
+      int expect = t;
+      if (__hip_atomic_compare_exchange_strong((int*)tail, &expect, t + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) { e = v; break; }
+    }
+  }
+  return __builtin_amdgcn_readfirstlane(e);
+}
+
+// neighbour lists of one finished packet -> the debug lists (rolo_get_knn), the next round's lower bound (k > 64), the slot-major index array for knn_tail_kernel
+template <int KMAX>
+ROLO_DEV void walk_write_lists(const KnnCloud& cl, const double (&K)[KMAX], int kk, double bkey, int qi, int j) {
+  int ki[KMAX];
 #pragma unroll
-  for (int s = 0; s < KMAX; s++) if (s == kk - 1) bkey = K[s];
-  bd = key_d2(bkey);
+  for (int u = 0; u < KMAX; u++) ki[u] = key_idx(K[u]);
+  const int slot0 = (KMAX == 64) ? cl.slot0 : 0;                          // rounds exist for the 64-slot kernel only
+  const int ktot = (KMAX == 64 && cl.k_total) ? cl.k_total : kk;
+  if (cl.knn_idx) {
+#pragma unroll
+    for (int u = 0; u < KMAX; u++) if (u < kk) { cl.knn_idx[(size_t)qi * ktot + slot0 + u] = ki[u]; cl.knn_d2[(size_t)qi * ktot + slot0 + u] = key_d2(K[u]); }
+  }
+  if (KMAX == 64 && cl.lower) cl.lower[j] = bkey;   // the next round starts above this round's last key
+  int32_t* __restrict__ nbr = cl.nbr;
+#pragma unroll
+  for (int u = 0; u < KMAX; u++) nbr[(size_t)(slot0 + u) * cl.n_sorted + j] = ki[u];
 }
 
 // The walk keeps only the 20 packed keys and the query live (58 VGPRs): cut for 8 wavefronts per SIMD. Neighbour indices
@@ -208,31 +323,48 @@ ROLO_DEV void knn_score_leaf_queue(const float4* __restrict__ sorted, int g, con
 #ifndef ROLO_KNN_WALK_OCC
 #define ROLO_KNN_WALK_OCC 4   // 128 VGPRs allowed: the loop needs 61, the slack buys the compiler ~3 % (0.196 -> 0.188 ms); a 2 x 131 072-point pair fills 4 waves per SIMD
 #endif
+#ifndef ROLO_KNN_PACKET
+#define ROLO_KNN_PACKET 64   // queries per wavefront (32- and 16-query packets were measured and lost: DESIGN.md section 9)
+#endif
+#ifndef ROLO_KNN_SEED_EXTRA
+#define ROLO_KNN_SEED_EXTRA 1   // leaves on either side of the wavefront's own ones (along the curve) scored before the tree walk starts: curve neighbours are space neighbours,
+                                // so every lane enters the walk with a tighter bound (0 / 1 / 2 / 4: walk 0.188 / 0.177 / 0.178 / 0.187 ms at 2 x 131 072 points, 0.147 / 0.136 / 0.138 / 0.138 at 2 x 65 536)
+#endif
+static_assert(ROLO_KNN_PACKET == 64, "one query per lane");
+
+// the seeds of a packet: its own 64 / KNN_LEAF leaves first, then ROLO_KNN_SEED_EXTRA leaves on either side (the own points are the nearer ones, so
+// fewer keys are inserted only to be pushed out again: walk 0.1763 -> 0.1725 ms at 2 x 131 072 points, 0.1486 -> 0.1470 at 2 x 43 776)
+template <int KMAX, bool LOWER, bool ASM>
+ROLO_DEV void walk_seeds(const float4* __restrict__ sorted, int g_mine0, int g_own0, int g_own1, int n_leaves, const float4& q, double (&K)[KMAX], int kk, double& bkey, float& bd, double lo,
+                         unsigned& st_leaves, unsigned& st_ins, unsigned& st_lane, unsigned& st_rounds) {
+  const int n_own = min(g_mine0 + 64 / KNN_LEAF, n_leaves) - g_mine0, n_before = g_mine0 - g_own0;
+  for (int i = 0; i < g_own1 - g_own0; i++) {
+    const int g = i < n_own ? g_mine0 + i : (i - n_own < n_before ? g_own0 + (i - n_own) : g_mine0 + (i - n_before));
+    knn_score_leaf<KMAX, LOWER, false, ASM>(sorted, g, q, K, kk, bkey, bd, st_ins, st_lane, st_rounds, lo);
+    st_leaves++;
+  }
+}
+
 template <int KMAX, bool FUSE_TAIL, bool LOWER = false>
 __global__ __launch_bounds__(256, KMAX > 32 ? 2 : ROLO_KNN_WALK_OCC) void knn_walk_kernel(KnnPair A, int split, int k, int reg) {   // 64 slots = 128 key registers: 256 VGPRs, 2 waves per SIMD
   __shared__ int stk[4][WALK_STACK];
   const int tid = threadIdx.x;
   const int wv = tid >> 6;
   // which cloud of the pair this workgroup searches (wave-uniform: everything below stays in scalar registers)
-  const int blk = xcd_contiguous_block((int)blockIdx.x, (int)gridDim.x);
+  const int blk = xcd_contiguous_block((int)blockIdx.x, (int)gridDim.x, 4);
   const int which = blk >= split ? 1 : 0;
   const float4* __restrict__ sorted = A.c[which].sorted;
   const float4* __restrict__ boxes = A.c[which].boxes;
-  int32_t* knn_idx = A.c[which].knn_idx;
-  float* knn_d2 = A.c[which].knn_d2;
   const int n_sorted = A.c[which].n_sorted, P = A.c[which].P;
-#ifndef ROLO_KNN_PACKET
-#define ROLO_KNN_PACKET 64   // queries per wavefront (experiment: 32 / 16 leave the upper lanes idle — shorter dependent chain per wave, more waves)
-#endif
   const int lane_ = tid & 63;
-  const int j = A.c[which].q_begin + (blk - (which ? split : 0)) * (4 * ROLO_KNN_PACKET) + wv * ROLO_KNN_PACKET + lane_;
+  const int j = A.c[which].q_begin + (blk - (which ? split : 0)) * 256 + wv * 64 + lane_;
   float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
   int qi = INT_MAX;
-  if (lane_ < ROLO_KNN_PACKET && j < A.c[which].q_end) { q = sorted[j]; qi = __float_as_int(q.w); }
+  if (j < A.c[which].q_end) { q = sorted[j]; qi = __float_as_int(q.w); }
   const bool active = qi != INT_MAX;  // not padding
   const int kk = (KMAX == 20) ? 20 : k;
   const int n_leaves = n_sorted / KNN_LEAF;
-  unsigned st_nodes = 0, st_leaves = 0, st_ins = 0, st_lane = 0, st_rounds = 0;
+  unsigned st_nodes = 0, st_leaves = 0, st_ins = 0, st_lane = 0, st_rounds = 0, st_push = 0;
 
   // K[0..KMAX) ascending; sentinel = (inf, INT_MAX)
   const double sentinel = key_pack(INFINITY, INT_MAX);
@@ -244,30 +376,14 @@ __global__ __launch_bounds__(256, KMAX > 32 ? 2 : ROLO_KNN_WALK_OCC) void knn_wa
   double bkey = active ? sentinel : key_pack(0.f, 0);
 
   // ---- seed: the wavefront's own 64 / KNN_LEAF leaves ----
-#ifndef ROLO_KNN_SEED_EXTRA
-#define ROLO_KNN_SEED_EXTRA 1   // leaves on either side of the wavefront's own ones (along the curve) scored before the tree walk starts: curve neighbours are space neighbours,
-                                // so every lane enters the walk with a tighter bound (0 / 1 / 2 / 4: walk 0.188 / 0.177 / 0.178 / 0.187 ms at 2 x 131 072 points, 0.147 / 0.136 / 0.138 / 0.138 at 2 x 65 536)
-#endif
   const int g_mine0 = __builtin_amdgcn_readfirstlane(j / KNN_LEAF);  // lane 0 of the wave: j is a multiple of 64
   const int g_own0 = max(g_mine0 - ROLO_KNN_SEED_EXTRA, 0);
-  const int g_own1 = min(g_mine0 + ROLO_KNN_PACKET / KNN_LEAF + ROLO_KNN_SEED_EXTRA, n_leaves);
-#ifdef ROLO_KNN_LANE_QUEUE
-#define KNN_SCORE(g) knn_score_leaf_queue<KMAX>(sorted, g, q, K, kk, bkey, bd, sentinel)
-#else
-#define KNN_SCORE(g) knn_score_leaf<KMAX, LOWER>(sorted, g, q, K, kk, bkey, bd, st_ins, st_lane, st_rounds, lo)
-#endif
+  const int g_own1 = min(g_mine0 + 64 / KNN_LEAF + ROLO_KNN_SEED_EXTRA, n_leaves);
   // rounds of a search for more than 64 neighbours (LOWER): only keys above the previous round's last one count
   double lo = 0.0;
   if (LOWER && active) lo = A.c[which].lower[j];
   (void)lo;
-  {  // the wavefront's own leaves first, then the extra ones: the own points are the nearer ones, so fewer keys are inserted only to be pushed out again
-     // (walk 0.1763 -> 0.1725 ms at 2 x 131 072 points, 0.1486 -> 0.1470 at 2 x 43 776)
-    const int n_own = min(g_mine0 + ROLO_KNN_PACKET / KNN_LEAF, n_leaves) - g_mine0, n_before = g_mine0 - g_own0;
-    for (int i = 0; i < g_own1 - g_own0; i++) {
-      const int g = i < n_own ? g_mine0 + i : (i - n_own < n_before ? g_own0 + (i - n_own) : g_mine0 + (i - n_before));
-      KNN_SCORE(g); st_leaves++;
-    }
-  }
+  walk_seeds<KMAX, LOWER, KNN_PLAIN_ASM>(sorted, g_mine0, g_own0, g_own1, n_leaves, q, K, kk, bkey, bd, lo, st_leaves, st_ins, st_lane, st_rounds);
 
   // ---- packet walk ----
   // (a stack in one vector register — slot i in lane i, v_writelane / v_readlane — measured the same as this LDS stack: 0.202 vs 0.200 ms;
@@ -277,84 +393,9 @@ __global__ __launch_bounds__(256, KMAX > 32 ? 2 : ROLO_KNN_WALK_OCC) void knn_wa
 #ifdef ROLO_KNN_STATS
   unsigned long long wt0;
   asm("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)\n\ts_mov_b32 %1, 1" : "=s"(wt0), "=s"(h));
-  unsigned st_push = 0;
 #endif
-#if defined(ROLO_KNN_PRIO)
-  int it = 0;   // s_setprio below is a plain asm tied to this counter: the builtin (and any volatile asm) counts as a memory clobber, after which
-                // the wave-uniform leaf loads are no longer provably unclobbered and become vector loads (64 more VGPRs, spills)
-#endif
-  while (true) {
-    h = __builtin_amdgcn_readfirstlane(h);
-#if defined(ROLO_KNN_PRIO) && ROLO_KNN_PRIO == 1   // rotate the issue priority among the waves of a SIMD
-    it++;
-    if ((it & 7) == 0) { switch (((it >> 3) + (int)blockIdx.x) & 3) { case 0: asm("s_setprio 0" : "+s"(it)); break; case 1: asm("s_setprio 1" : "+s"(it)); break; case 2: asm("s_setprio 2" : "+s"(it)); break; default: asm("s_setprio 3" : "+s"(it)); } }
-#elif defined(ROLO_KNN_PRIO) && ROLO_KNN_PRIO == 2   // the further a wave has come, the higher its priority
-    it++;
-    if (it == 48) asm("s_setprio 1" : "+s"(it)); else if (it == 96) asm("s_setprio 2" : "+s"(it)); else if (it == 144) asm("s_setprio 3" : "+s"(it));
-#elif defined(ROLO_KNN_PRIO) && ROLO_KNN_PRIO == 3   // the less a wave has done, the higher its priority (fair share)
-    it++;
-    if (it == 1) asm("s_setprio 3" : "+s"(it)); else if (it == 32) asm("s_setprio 2" : "+s"(it)); else if (it == 64) asm("s_setprio 1" : "+s"(it)); else if (it == 96) asm("s_setprio 0" : "+s"(it));
-#endif
-#ifdef ROLO_KNN_WIDE
-    // Two levels per step where the tree allows it: the four grandchildren of h are nodes 4h .. 4h + 3, their boxes 128 contiguous bytes —
-    // ONE dependent fetch instead of two or three, the same box tests or fewer (the children's own boxes are skipped: their union is h's,
-    // which is known to be reached). The grandchild most lanes are nearest to goes first, the other live ones are pushed, best on top.
-    if (2 * h < P) {
-      st_nodes++;
-      float4 b[8];
-#pragma unroll
-      for (int u = 0; u < 8; u++) b[u] = boxes[8 * (size_t)h + u];
-      float d[4]; bool ok[4];
-#pragma unroll
-      for (int c = 0; c < 4; c++) { d[c] = box_d2(b[2 * c], b[2 * c + 1], q); ok[c] = (d[c] <= bd) && (d[c] < INFINITY); }
-      // this lane's nearest live grandchild (ties: the lowest index)
-      int best = -1; float bestd = INFINITY;
-#pragma unroll
-      for (int c = 0; c < 4; c++) if (ok[c] && d[c] < bestd) { bestd = d[c]; best = c; }
-      int key[4];   // wave-uniform: votes * 4 + (3 - c) for a live grandchild, -1 for one no lane reaches
-#pragma unroll
-      for (int c = 0; c < 4; c++) {
-        const unsigned long long m = __ballot(ok[c]);
-        const int votes = __popcll(__ballot(best == c));
-        key[c] = m != 0ull ? votes * 4 + (3 - c) : -1;
-      }
-      // sort the four keys descending (5 compare-exchanges on scalars)
-      auto cx = [](int& a, int& bb) { const int hi = max(a, bb), lo = min(a, bb); a = hi; bb = lo; };
-      cx(key[0], key[1]); cx(key[2], key[3]); cx(key[0], key[2]); cx(key[1], key[3]); cx(key[1], key[2]);
-      if (key[0] >= 0) {
-        // push the runners-up, worst first, so that the second best is popped first
-#pragma unroll
-        for (int r = 3; r >= 1; r--) if (key[r] >= 0 && sp < WALK_STACK) { stk[wv][sp] = 4 * h + (3 - (key[r] & 3)); sp++; KNN_STAT(st_push++;) }
-        h = 4 * h + (3 - (key[0] & 3));
-        continue;
-      }
-    } else
-#endif
-    if (h < P) {
-      st_nodes++;
-      const float4 llo = boxes[4 * (size_t)h], lhi = boxes[4 * (size_t)h + 1], rlo = boxes[4 * (size_t)h + 2], rhi = boxes[4 * (size_t)h + 3];
-      const float bl = box_d2(llo, lhi, q), br = box_d2(rlo, rhi, q);
-      const bool okl = (bl <= bd) && (bl < INFINITY), okr = (br <= bd) && (br < INFINITY);
-      const unsigned long long ml = __ballot(okl), mr = __ballot(okr);
-      if (ml != 0ull && mr != 0ull) {
-        // nearer child first, by majority vote of the lanes that reach either child (a "lane with the largest
-        // radius decides" rule needed a 6-step cross-lane max per node and did not reduce the nodes visited)
-        const unsigned long long pref = __ballot((okl || okr) && (bl <= br));
-        const bool left_first = 2 * __popcll(pref) >= __popcll(ml | mr);
-        if (sp < WALK_STACK) { stk[wv][sp] = left_first ? 2 * h + 1 : 2 * h; sp++; KNN_STAT(st_push++;) }
-        h = left_first ? 2 * h : 2 * h + 1;
-        continue;
-      }
-      if (ml != 0ull) { h = 2 * h; continue; }
-      if (mr != 0ull) { h = 2 * h + 1; continue; }
-    } else {
-      const int g = h - P;
-      if (g < g_own0 || g >= g_own1) { KNN_SCORE(g); st_leaves++; }
-    }
-    if (sp == 0) break;
-    sp--;
-    h = stk[wv][sp];
-  }
+  { const CoopPub none{}; int n_scored = 0, n_pub = 0;
+    packet_walk<KMAX, LOWER, false, false, KNN_PLAIN_ASM>(sorted, boxes, P, g_own0, g_own1, q, K, kk, bkey, bd, lo, 0.0, (lds_int*)&stk[wv][0], sp, h, none, n_scored, n_pub, st_nodes, st_leaves, st_ins, st_lane, st_rounds, st_push); }
 #ifdef ROLO_KNN_STATS
   { unsigned long long wt1; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(wt1));
     unsigned st_rounds_rec = st_rounds;
@@ -367,36 +408,204 @@ __global__ __launch_bounds__(256, KMAX > 32 ? 2 : ROLO_KNN_WALK_OCC) void knn_wa
       g_knn_wave_rec[wid][4] = (unsigned)wt0; g_knn_wave_rec[wid][5] = (unsigned)wt1; g_knn_wave_rec[wid][6] = st_lane; g_knn_wave_rec[wid][7] = st_rounds_rec;
     } }
 #endif
-  (void)st_nodes; (void)st_leaves; (void)st_ins; (void)st_lane; (void)st_rounds;
+  (void)st_nodes; (void)st_leaves; (void)st_ins; (void)st_lane; (void)st_rounds; (void)st_push;
 
   if (!active) return;
 
-  int ki[KMAX];
-#pragma unroll
-  for (int u = 0; u < KMAX; u++) ki[u] = key_idx(K[u]);
-  const int slot0 = (KMAX == 64) ? A.c[which].slot0 : 0;                          // rounds exist for the 64-slot kernel only
-  const int ktot = (KMAX == 64 && A.c[which].k_total) ? A.c[which].k_total : kk;
-  if (knn_idx) {
-#pragma unroll
-    for (int u = 0; u < KMAX; u++) if (u < kk) { knn_idx[(size_t)qi * ktot + slot0 + u] = ki[u]; knn_d2[(size_t)qi * ktot + slot0 + u] = key_d2(K[u]); }
-  }
-  if (KMAX == 64 && A.c[which].lower) A.c[which].lower[j] = bkey;   // the next round starts above this round's last key
   if (!FUSE_TAIL) {   // neighbour indices only (slot-major, coalesced): knn_tail_kernel turns them into covariances
-    int32_t* __restrict__ nbr = A.c[which].nbr;
-#pragma unroll
-    for (int u = 0; u < KMAX; u++) nbr[(size_t)(slot0 + u) * n_sorted + j] = ki[u];
+    walk_write_lists<KMAX>(A.c[which], K, kk, bkey, qi, j);
     return;
   }
   // FUSE_TAIL (ROLO_KNN_FUSE_TAIL=1, an A/B): covariance + regularisation right here, so that the light wavefronts do theirs while the heavy
   // ones are still walking and the 42 MB of index traffic disappear. Measured: 0.2335 ms against 0.1884 + 0.0394 ms for walk + tail launch,
   // and the 4-context throughput falls from 2750 to 2490 scans/s — the tails' fp64 work competes with the walking wavefronts for issue slots.
   const KnnCloud& cl = A.c[which];
+  int ki[KMAX];
+#pragma unroll
+  for (int u = 0; u < KMAX; u++) ki[u] = key_idx(K[u]);
+  if (cl.knn_idx) {
+#pragma unroll
+    for (int u = 0; u < KMAX; u++) if (u < kk) { cl.knn_idx[(size_t)qi * kk + u] = ki[u]; cl.knn_d2[(size_t)qi * kk + u] = key_d2(K[u]); }
+  }
   if (cl.stage) {   // multi-GPU: into the exchange buffer, sorted order
     double* o = stage_area(cl, 1) + (size_t)(j / cl.chunk) * cl.seg + cl.stage_off + (size_t)(j % cl.chunk) * 6;
     double c6[6]; knn_covariance_tail<KMAX>(ki, kk, cl.xyz, 1, 0, reg, o, c6);
   } else {
     double c6[6]; knn_covariance_tail<KMAX>(ki, kk, cl.xyz, cl.n, qi, reg, cl.cov, c6);
   }
+}
+
+// ---- the cooperative walk: a heavy packet's sub-trees are stolen by the idle wavefronts of its workgroup ------------------------------------------
+// The plain walk lasts as long as its heaviest packets: mean wavefront 78 us, p99 134 us, max 214 us of a 168 us kernel — packets whose 64
+// curve-adjacent queries lie on scattered fragments pay the SUM of what every lane needs, and no static quantity predicts them (DESIGN.md
+// sections 4, 9). Here a workgroup is NW wavefronts = NW packets (NW / 4 runs of four consecutive packets from distant stretches of the curve, the
+// mix a CU gets from the dispatcher under the plain kernel), and work moves between them through LDS:
+//   * every wavefront walks its own packet. Once it has scored `budget` leaves it is a donor: whenever the small ring it publishes to is empty it
+//     moves the bottom entries of its stack (the largest sub-trees) and its lanes' current bounds there, and goes on at the top of its stack;
+//   * a wavefront whose packet is done writes its lists and turns thief: it picks a donor of its workgroup, steals entries from that ring and walks
+//     them WITH THE DONOR'S 64 queries into a fresh, empty list whose bound is capped by the donor's published bound (CAP) — so it collects exactly
+//     the points of those sub-trees that beat that bound — until the donor is done, and leaves the list in an LDS result slot;
+//   * after a workgroup barrier every donor merges the result lists addressed to it into its own with the same min / max network and writes.
+// Exactness: stolen sub-trees are disjoint from each other and from everything the donor scores itself, every point of the final k beats every
+// bound ever published (bounds only tighten), so the k smallest of (donor's list + result lists) are the k smallest of the whole cloud: lists and
+// float distances stay bit-identical to the oracle's. LDS traffic is a few words per hand-over; nothing crosses workgroups (device-scope
+// atomics would: the XCDs' L2s are not coherent with each other without write-back / invalidate).
+// Measured and not kept: (1) TWO launches — budgeted walk + a continuation launch with eight wavefronts per unfinished packet: slower than the
+// plain walk at every budget (0.266 against 0.220 ms at 28 leaves; the second launch starts with cold L2s and thousands of empty workgroups);
+// (2) publishing the stack ONCE at the budget and popping from it: the donor itself walks the big entries it pops, the ring is empty by the
+// time anybody is free to help (0.217 against 0.223 ms).
+template <int NW> struct CoopCfg { static constexpr int NSLOT = NW == 16 ? 14 : (NW == 8 ? 7 : 3); };   // result slots of 10 KB: the workgroup's LDS share (160 KB per CU at 4 waves per SIMD)
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW, ROLO_KNN_WALK_OCC) void knn_walk_coop_kernel(KnnPair A, int split4 /* first 4-packet block of cloud 1 */, int G4 /* 4-packet blocks */, int budget) {
+  constexpr int KMAX = 20, kk = 20, NSLOT = CoopCfg<NW>::NSLOT;
+  __shared__ int pstk[NW][WALK_STACK];     // private stacks
+  __shared__ int ring[NW][COOP_RING];      // published sub-trees
+  __shared__ double d_cap[NW][64];         // published bounds (the donor's k-th key per lane)
+  __shared__ double res[NSLOT][KMAX][64];  // result lists of thieves
+  __shared__ int r_head[NW], r_tail[NW], r_done[NW], d_j0[NW], d_which[NW];
+  __shared__ int res_owner[NSLOT];         // the donor a result list belongs to (-1: none)
+  __shared__ int n_res, n_p1;              // result slots handed out; wavefronts done with their own packet
+  const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane_ = tid & 63;   // (w in a scalar register: everything derived from it — cloud, tree, first query — stays wave-uniform for the compiler)
+  // this wavefront's packet: run k = w / 4 of the workgroup is 4-packet block (blockIdx.x + gridDim.x * k) of the plain walk's launch geometry
+  const int vb = (int)blockIdx.x + (int)gridDim.x * (w >> 2);
+  const int blk4 = vb < G4 ? xcd_contiguous_block(vb, G4, 4) : G4;
+  const int which = (blk4 >= split4 && A.n_clouds > 1) ? 1 : 0;
+  const KnnCloud& cl = A.c[which];
+  const int j0 = blk4 < G4 ? cl.q_begin + (blk4 - (which ? split4 : 0)) * 256 + (w & 3) * 64 : cl.q_end;
+  if (lane_ == 0) { r_head[w] = 0; r_tail[w] = 0; r_done[w] = 0; d_j0[w] = j0; d_which[w] = which; }
+  if (tid < NSLOT) res_owner[tid] = -1;
+  if (tid == 0) { n_res = 0; n_p1 = 0; }
+  __syncthreads();
+  const int j = j0 + lane_;
+  float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+  int qi = INT_MAX;
+  if (j < cl.q_end) { q = cl.sorted[j]; qi = __float_as_int(q.w); }
+  const bool active = qi != INT_MAX;
+  unsigned st_nodes = 0, st_leaves = 0, st_ins = 0, st_lane = 0, st_rounds = 0, st_push = 0;
+  const double sentinel = key_pack(INFINITY, INT_MAX);
+  double K[KMAX];
+#pragma unroll
+  for (int u = 0; u < KMAX; u++) K[u] = sentinel;
+  float bd = active ? INFINITY : -1.0f;
+  double bkey = active ? sentinel : key_pack(0.f, 0);
+#ifdef ROLO_KNN_STATS
+  unsigned long long ct0, ct1 = 0, ct2 = 0; unsigned c_sessions = 0, c_p1_leaves = 0, c_full = 0;
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ct0));
+#endif
+
+  // ---- the own packet ----
+  int n_published = 0;
+  {
+    const float4* __restrict__ sorted = cl.sorted;
+    const float4* __restrict__ boxes = cl.boxes;
+    const int P = cl.P, n_leaves = cl.n_sorted / KNN_LEAF;
+    const int g_mine0 = __builtin_amdgcn_readfirstlane(j0 / KNN_LEAF);
+    const int g_own0 = max(g_mine0 - ROLO_KNN_SEED_EXTRA, 0);
+    const int g_own1 = min(g_mine0 + 64 / KNN_LEAF + ROLO_KNN_SEED_EXTRA, n_leaves);
+    walk_seeds<KMAX, false, true>(sorted, g_mine0, g_own0, g_own1, n_leaves, q, K, kk, bkey, bd, 0.0, st_leaves, st_ins, st_lane, st_rounds);
+    const CoopPub pub{(lds_int*)&ring[w][0], (lds_int*)&r_head[w], (lds_int*)&r_tail[w], (lds_double*)&d_cap[w][0], budget};
+    int sp = 0, n_scored = 0, h = 1;
+    while (h >= 0) {   // the tree from the root, then whatever of the own published sub-trees nobody took
+      packet_walk<KMAX, false, false, true, true>(sorted, boxes, P, g_own0, g_own1, q, K, kk, bkey, bd, 0.0, 0.0, (lds_int*)&pstk[w][0], sp, h, pub, n_scored, n_published,
+                                            st_nodes, st_leaves, st_ins, st_lane, st_rounds, st_push);
+      h = n_published ? coop_steal(pub.ring, pub.head, pub.tail) : -1;
+    }
+    if (lane_ == 0) {
+      __hip_atomic_store(&r_done[w], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_fetch_add(&n_p1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    KNN_STAT(c_p1_leaves = st_leaves; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ct1));)
+  }
+  const bool donor = n_published > 0;
+  // a packet nobody helped with is final: its lists go out now, so that no list is live in registers while the wavefront helps
+  // (global stores before further walks are harmless: the tree fetches are explicit scalar loads)
+  if (!donor && active) walk_write_lists<KMAX>(cl, K, kk, bkey, qi, j);
+
+  // ---- thief: ONE donor per wavefront (its result list needs an LDS slot until the barrier); donors wait at the barrier, their lists stay in registers ----
+  while (!donor) {
+    int d = -1;
+    for (int o = 1; o < NW; o++) {
+      const int c = (w + o) % NW;
+      if (__hip_atomic_load(&r_head[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) > __hip_atomic_load(&r_tail[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) { d = c; break; }
+    }
+    d = __builtin_amdgcn_readfirstlane(d);
+    if (d < 0) {
+      if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&n_p1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) >= NW) break;   // nobody is left who could publish
+      __builtin_amdgcn_s_sleep(8);
+      continue;
+    }
+    int slot = 0;
+    if (lane_ == 0) slot = __hip_atomic_fetch_add(&n_res, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    slot = __builtin_amdgcn_readfirstlane(slot);
+    if (slot >= NSLOT) { KNN_STAT(c_full = 1;) break; }   // no room for another result list: the donors finish on their own
+    KNN_STAT(c_sessions++;)
+    // the donor's packet
+    const KnnCloud& dc = A.c[__builtin_amdgcn_readfirstlane(d_which[d])];
+    const float4* __restrict__ sorted = dc.sorted;
+    const float4* __restrict__ boxes = dc.boxes;
+    const int P = dc.P, n_leaves = dc.n_sorted / KNN_LEAF;
+    const int jd0 = __builtin_amdgcn_readfirstlane(d_j0[d]), jd = jd0 + lane_;
+    float4 qd = make_float4(0.f, 0.f, 0.f, 0.f);
+    bool act_d = false;
+    if (jd < dc.q_end) { qd = sorted[jd]; act_d = __float_as_int(qd.w) != INT_MAX; }
+    const int gd0 = __builtin_amdgcn_readfirstlane(jd0 / KNN_LEAF);
+    const int gd_own0 = max(gd0 - ROLO_KNN_SEED_EXTRA, 0), gd_own1 = min(gd0 + 64 / KNN_LEAF + ROLO_KNN_SEED_EXTRA, n_leaves);
+    double L[KMAX];
+#pragma unroll
+    for (int u = 0; u < KMAX; u++) L[u] = sentinel;
+    double bk = act_d ? sentinel : key_pack(0.f, 0);
+    float bdd = -1.0f;
+    const CoopPub none{};
+    while (true) {
+      const int e = coop_steal((lds_int*)&ring[d][0], (lds_int*)&r_head[d], (lds_int*)&r_tail[d]);
+      if (e < 0) {
+        if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&r_done[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))) break;
+        __builtin_amdgcn_s_sleep(4);
+        continue;
+      }
+      const double cap = act_d ? d_cap[d][lane_] : key_pack(0.f, 0);   // the donor's bound as of its last hand-over: it only tightens
+      bk = vmin_f64(bk, cap);
+      bdd = act_d ? key_d2(bk) : -1.0f;
+      int sp = 0, ns = 0, np = 0;
+      packet_walk<KMAX, false, true, false, true>(sorted, boxes, P, gd_own0, gd_own1, qd, L, kk, bk, bdd, 0.0, cap, (lds_int*)&pstk[w][0], sp, e, none, ns, np,
+                                            st_nodes, st_leaves, st_ins, st_lane, st_rounds, st_push);
+    }
+#pragma unroll
+    for (int u = 0; u < KMAX; u++) res[slot][u][lane_] = L[u];
+    if (lane_ == 0) res_owner[slot] = d;
+    break;
+  }
+#ifdef ROLO_KNN_STATS
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ct2));
+  { const unsigned wid = blockIdx.x * NW + w;   // [0] nodes [1] leaves of the own packet [2] leaves scored as a thief [3] donor | entries published << 8 | sessions << 16 | slots full << 31
+    if (lane_ == 0 && wid < 16384) {            // [4] start [5] own packet done [6] stealing done (100 MHz) [7] -
+      g_knn_wave_rec[wid][0] = st_nodes; g_knn_wave_rec[wid][1] = c_p1_leaves; g_knn_wave_rec[wid][2] = st_leaves - c_p1_leaves;
+      g_knn_wave_rec[wid][3] = (donor ? 1u : 0u) | ((unsigned)min(n_published, 255) << 8) | (c_sessions << 16) | (c_full << 31);
+      g_knn_wave_rec[wid][4] = (unsigned)ct0; g_knn_wave_rec[wid][5] = (unsigned)ct1; g_knn_wave_rec[wid][6] = (unsigned)ct2; g_knn_wave_rec[wid][7] = 0;
+    } }
+#endif
+  (void)st_nodes; (void)st_leaves; (void)st_ins; (void)st_lane; (void)st_rounds; (void)st_push;
+  __syncthreads();
+
+  // ---- donors merge what the thieves found and write ----
+  if (!donor) return;
+  const int nr = min(n_res, NSLOT);
+  for (int s = 0; s < nr; s++) {
+    if (res_owner[s] != w) continue;
+    for (int u = 0; u < KMAX; u++) {   // ascending: once no lane's key beats its bound, none of the list's later keys will
+      const double ck = res[s][u][lane_];
+      if (!__any(ck < bkey)) break;
+      if (ck < bkey) {
+#pragma unroll
+        for (int t = KMAX - 1; t >= 1; t--) insert_slot(K[t], K[t - 1], ck);
+        K[0] = vmin_f64(ck, K[0]);
+        bkey = K[kk - 1];
+      }
+    }
+  }
+  if (!active) return;
+  walk_write_lists<KMAX>(cl, K, kk, bkey, qi, j);
 }
 
 #ifndef ROLO_KNN_TAIL_OCC
