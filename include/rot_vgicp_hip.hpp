@@ -94,10 +94,14 @@ public:
   // The reference constructs this object once per frame (src/lidarOdometry.cpp:460): construction / destruction go through the library's
   // context pool (rolo_ctx_acquire / _release) — a released context keeps its streams and device buffers and comes back reset to a fresh
   // object's state, so the per-frame object costs no hipMalloc / hipFree.
+  // This object registers ONE frame at a time (align, then computeTranslation, on the caller's thread): it asks for the latency form of the LM chain —
+  // one launch per trial (rolo_params.fused_lm; the library default is the throughput form, which pays off only with several contexts in flight).
   explicit RotVGICP(int device = 0) {
     if (rolo_ctx_acquire(device, &ctx_) != ROLO_OK) throw std::runtime_error(std::string("RotVGICP(HIP): ") + rolo_last_error());
     rolo_default_params(&p_);
+    p_.fused_lm = 1;
     for (int i = 0; i < 16; i++) final_[i] = (i % 5 == 0) ? 1.f : 0.f;
+    push();
   }
   ~RotVGICP() { rolo_ctx_release(ctx_); }
   RotVGICP(const RotVGICP&) = delete;
@@ -208,10 +212,22 @@ public:
 private:
   void push() { check(rolo_set_params(ctx_, &p_)); }
   static void check(int rc) { if (rc != ROLO_OK) throw std::runtime_error(std::string("RotVGICP(HIP): ") + rolo_last_error()); }
+  // pcl::transformPointCloud(*input_, output, T) (lsq_registration_impl.hpp:78, :178) ON THE HOST, as the reference does it: the whole cloud copied (header,
+  // width / height, every field), then x, y, z replaced by the scalar path's  c0 x + c1 y + c2 z + c3  (left to right) and w by 1. Until round 4 this went
+  // through rolo_transform_cloud — the source uploaded a second time, a kernel, a 1 MB download and a host wait, twice per frame (~0.2 of the 0.74 ms a
+  // VLP-16 frame took through this class) — for a cloud the reference caller never reads (src/lidarOdometry.cpp:468, :491: `aligned` is cleared and dropped).
   void transform_into(PointCloudSource& output, const float* T) {
-    output.points.resize(src_->points.size());
-    check(rolo_transform_cloud(ctx_, reinterpret_cast<const float*>(src_->points.data()), reinterpret_cast<float*>(output.points.data()),
-                               (int)src_->points.size(), (int)(sizeof(PointSource) / sizeof(float)), T));
+    output = *src_;
+    constexpr size_t stride = sizeof(PointSource) / sizeof(float);
+    float* p = output.points.empty() ? nullptr : reinterpret_cast<float*>(output.points.data());
+    const size_t n = output.points.size();
+    for (size_t i = 0; i < n; i++, p += stride) {
+      const float x = p[0], y = p[1], z = p[2];
+      p[0] = T[0] * x + T[1] * y + T[2] * z + T[3];
+      p[1] = T[4] * x + T[5] * y + T[6] * z + T[7];
+      p[2] = T[8] * x + T[9] * y + T[10] * z + T[11];
+      p[3] = 1.0f;
+    }
   }
   void fetch_covs(bool source) {
     const size_t n = source ? (src_ ? src_->points.size() : 0) : (tgt_ ? tgt_->points.size() : 0);

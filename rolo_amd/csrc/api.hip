@@ -405,6 +405,8 @@ bool voxel_fixed_cov(const rolo_ctx* c) {
 }
 
 void fill_table_params(rolo_ctx* c) {
+  static const int polar_exact = [] { const char* e = getenv("ROLO_POLAR_EXACT"); return (e && atoi(e) == 0) ? 0 : 1; }();
+  c->tab.polar_exact = polar_exact;
   c->tab.voxel_type = c->P.voxel_type;
   c->tab.voxel_resolution = c->P.voxel_resolution;
   for (int i = 0; i < 3; i++) c->tab.polar_res[i] = c->P.polar_resolution[i];
@@ -1115,19 +1117,35 @@ int rolo_compute_t_error(rolo_ctx* c, const double* t3, const double* g3, const 
 }
 
 // ---- drivers ------------------------------------------------------------------------------------------------
+static int enqueue_frame(rolo_ctx* c, bool with_trans);
+// One enqueue, one wait (round 4; until then: covariances + voxel map with a host round trip for its counters, then the LM chunks): the frame path of
+// rolo_register_async with the rotation stage alone — the voxel map rides inside the search's launches (VoxelFuse), its finalize kernel starts the LM
+// state from pinned arguments, the first schedule of predicated trials follows the last frames' need, and the host waits once.
 int rolo_align(rolo_ctx* c, const float* guess16, float* Tf, double* Td, rolo_stats* stats) {
   if (!c) return ROLO_EINVAL;
+  if (c->async_pending) { g_err = "a registration is in flight on this context"; return ROLO_ESTATE; }
   int rc = set_device(c); if (rc) return rc;
+  if (c->src.n <= 0 || c->tgt.n <= 0) { g_err = "source/target not set"; return ROLO_ESTATE; }
   c->have_map = false;  // computeTransformation: voxelmap_.reset() (rot_vgicp_impl.hpp:147)
-  if ((rc = ensure_map(c))) return rc;
-  PassArgs a; int grid;
-  if ((rc = prepare_pass(c, a, grid))) return rc;
   double R[9], t[3]; guess_to_Rt(guess16, R, t);
-  HIPCHK(launch_rot_begin(c->state, make_rot_begin(c, R, t, 0), c->stream));
-  if ((rc = run_stage(c, a, grid, 1, rot_first_chunk(c)))) return rc;
+  c->h_args->rot = make_rot_begin(c, R, t, 0);
+  c->h_args->trans = TransBegin{};
+  if ((rc = enqueue_frame(c, false))) return rc;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if ((rc = peer_check(c))) return rc;
+  if (c->h_counters[1] != 0) { g_err = c->h_counters[1] == ROLO_ENONFINITE ? "non-finite point or covariance in the voxel map build" : "voxel coordinate outside the packed key range"; return c->h_counters[1]; }
+  c->n_voxels = c->h_counters[0];
+  c->n_edge = c->h_counters[2];
+  c->have_map = true;
+  if (!c->h_state->rot_done) {   // the first schedule was too short: keep feeding predicated trials
+    PassArgs a; int grid;
+    if ((rc = prepare_pass(c, a, grid))) return rc;
+    if ((rc = run_stage(c, a, grid, 1, 8))) return rc;
+  }
   c->have_corr = true;
+  if (!c->h_state->error) update_hint(c->hint_rot, c->win_rot, c->h_state->rot_passes);
   fill_rot_outputs(c->h_state, Tf, Td, stats);
-  if (c->h_state->error) { g_err = "device-side error during align"; return c->h_state->error; }
+  if (c->h_state->error) { g_err = c->h_state->error == ROLO_ENOCORR ? "no correspondences" : "device-side error during align"; return c->h_state->error; }
   return ROLO_OK;
 }
 
@@ -1153,7 +1171,7 @@ int rolo_compute_translation(rolo_ctx* c, double* trans, const double* g3, const
 static bool stamp_env() { static const bool v = [] { const char* e = getenv("ROLO_STAMP"); return e && atoi(e) != 0; }(); return v; }
 #define STAMP(slot) do { if (stamp_env()) HIPCHK(launch_stamp(c->stamps, slot, c->stream)); } while (0)
 
-static int enqueue_frame(rolo_ctx* c) {
+static int enqueue_frame(rolo_ctx* c, bool with_trans) {   // with_trans = false: the rotation stage alone (rolo_align as one enqueue)
   int rc;
   if (c->src.n <= 0 || c->tgt.n <= 0) { g_err = "source/target not set"; return ROLO_ESTATE; }
   if (stamp_env()) {
@@ -1193,6 +1211,7 @@ static int enqueue_frame(rolo_ctx* c) {
   // (the LM state of the frame was started by the voxel map's finalize kernel above: frame_begin_kernel was a launch of its own until round 3)
   STAMP(2);
   int nrot, ntrans; frame_chunks(c, nrot, ntrans);
+  if (!with_trans) ntrans = 0;
   if (lm_fused(c)) {
     // both stages are the same launches (the device decides which pass a launch evaluates); each hint carries one spare
     if ((rc = enqueue_lm_chunk(c, a, std::max(nrot + ntrans - 1, 2), true))) return rc;   // the closing launch leaves the state in pinned memory
@@ -1247,7 +1266,7 @@ static int register_async_impl(rolo_ctx* c, const float* guess16, const double* 
       if (c->graph_exec) { (void)hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
       if (c->graph) { (void)hipGraphDestroy(c->graph); c->graph = nullptr; }
       HIPCHK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-      rc = enqueue_frame(c);
+      rc = enqueue_frame(c, true);
       hipGraph_t gph = nullptr;
       hipError_t e = hipStreamEndCapture(c->stream, &gph);
       const bool epoch_moved = key.epoch != g_alloc_epoch;  // an allocation inside the capture would be a bug; fall back
@@ -1267,7 +1286,7 @@ static int register_async_impl(rolo_ctx* c, const float* guess16, const double* 
       c->gseen = key; c->gseen_valid = true;
     }
   }
-  if ((rc = enqueue_frame(c))) return rc;
+  if ((rc = enqueue_frame(c, true))) return rc;
   if (graphable) c->gseen.epoch = g_alloc_epoch;  // the eager frame did the allocations the capture must not do
   c->n_eager++;
   c->async_pending = true;

@@ -39,6 +39,7 @@ struct VoxelTable {
   int voxel_type;
   double voxel_resolution;
   double polar_res[3];
+  int polar_exact;           // 1 (default): POLAR keys of target points near a bin edge through the correctly rounded atan2 / acos (polar_exact.hpp); 0: counted only (ROLO_POLAR_EXACT=0, the A/B)
 };
 
 struct CloudDev {          // one point cloud resident in HBM

@@ -2,6 +2,7 @@
 #pragma once
 #include "rolo_internal.hpp"
 #include "dev_math.hpp"
+#include "polar_exact.hpp"
 
 namespace rolo {
 
@@ -19,18 +20,25 @@ ROLO_DEV void voxel_coord_dev(const VoxelTable& tab, double x, double y, double 
   }
 }
 
-// The same, also telling whether a POLAR coordinate lies within 1e-12 (in bins) of a bin edge: device atan2 / acos differ from glibc's by
-// ulps, so only there could the integer key differ from the CPU path's (SURVEY §7 "hard parts"); counted by the map build, asserted 0 by
-// the tests. UNIFORM keys are a division and a floor — correctly rounded on both sides, no hazard, nothing counted.
+// The same for the TARGET's keys (map build, rolo_get_target_voxel_keys), where the integer key must be the reference's, bit for bit: device atan2 / acos
+// differ from a host libm by ulps, which can move a key only for a point whose quotient lies within ~1e-14 of an integer. Such points (within 1e-12 bins of
+// an edge: near_edge, counted in rolo_num_edge_points) are RE-KEYED with the correctly rounded atan2 / acos of polar_exact.hpp — the value a correctly
+// rounded libm returns by definition — followed by the reference's own fp64 sum, quotient and floor ("flag ... and resolve those (few)";
+// round 3 only counted them). exact = false keeps the fast key (ROLO_POLAR_EXACT=0: the A/B that shows which planted points would differ).
+// UNIFORM keys are a division and a floor — correctly rounded on both sides, no hazard, nothing counted.
 ROLO_DEV void voxel_coord_dev_edge(const VoxelTable& tab, double x, double y, double z, int& kx, int& ky, int& kz, bool& near_edge) {
   near_edge = false;
+  const bool exact = tab.polar_exact != 0;
   if (tab.voxel_type == ROLO_VOXEL_POLAR) {
     const double r = sqrt((x * x + y * y) + z * z);
     const double a = (atan2(y, x) + 3.14159265358979323846) / tab.polar_res[0], b = acos(z / r) / tab.polar_res[1], c = r / tab.polar_res[2];
     const double fa = floor(a), fb = floor(b), fc = floor(c);
     kx = (int)fa; ky = (int)fb; kz = (int)fc;
     const double lo = 1e-12, hi = 1.0 - 1e-12;
-    near_edge = (a - fa) < lo || (a - fa) > hi || (b - fb) < lo || (b - fb) > hi || (c - fc) < lo || (c - fc) > hi;
+    const bool ea = (a - fa) < lo || (a - fa) > hi, eb = (b - fb) < lo || (b - fb) > hi;
+    near_edge = ea || eb || (c - fc) < lo || (c - fc) > hi;
+    if (exact && ea) kx = (int)floor((ddx::atan2_cr(y, x) + 3.14159265358979323846) / tab.polar_res[0]);
+    if (exact && eb) ky = (int)floor(ddx::acos_cr(z / r) / tab.polar_res[1]);
   } else {
     kx = (int)floor(x / tab.voxel_resolution - 0.5);
     ky = (int)floor(y / tab.voxel_resolution - 0.5);

@@ -162,8 +162,8 @@ __global__ __launch_bounds__(256) void voxel_keys_kernel(const float4* __restric
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const float4 p = pts[i];
-  int kx, ky, kz;
-  voxel_coord_dev(tab, (double)p.x, (double)p.y, (double)p.z, kx, ky, kz);
+  int kx, ky, kz; bool near_edge;
+  voxel_coord_dev_edge(tab, (double)p.x, (double)p.y, (double)p.z, kx, ky, kz, near_edge);   // the keys the map build files the target under
   keys3[3 * (size_t)i] = kx; keys3[3 * (size_t)i + 1] = ky; keys3[3 * (size_t)i + 2] = kz;
 }
 

@@ -88,7 +88,16 @@ int main(int argc, char** argv) {
   std::array<double, 3> reg_t{0, 0, 0}, guess{-0.28, -0.04, -0.02}, last{-0.28, -0.04, -0.02};
   rot_vgicp.computeTranslation(aligned, reg_t, guess, last, 0.1, 0.1, 0.3f);
   for (int i = 0; i < 16; i++) std::printf("%.9g ", T[i]);
-  std::printf("%.17g %.17g %.17g %d %zu\n", reg_t[0], reg_t[1], reg_t[2], rot_vgicp.hasConverged() ? 1 : 0, aligned.size());
+  // `aligned` after computeTranslation = pcl::transformPointCloud(*input_, output, translation) (lsq_registration_impl.hpp:75-78): the class computes it on the host;
+  // rolo_transform_cloud is the same restatement on the device (bit-exact against the oracle's) — the two must agree bit for bit, all 8 floats of every record
+  int aligned_same = 0;
+  {
+    std::vector<rolo::PointXYZI> ref(source->points.size());
+    const float Tt[16] = {1, 0, 0, (float)reg_t[0], 0, 1, 0, (float)reg_t[1], 0, 0, 1, (float)reg_t[2], 0, 0, 0, 1};
+    if (rolo_transform_cloud(rot_vgicp.handle(), reinterpret_cast<const float*>(source->points.data()), reinterpret_cast<float*>(ref.data()), (int)ref.size(), 8, Tt) == ROLO_OK)
+      aligned_same = aligned.points.size() == ref.size() && std::memcmp(aligned.points.data(), ref.data(), sizeof(rolo::PointXYZI) * ref.size()) == 0;
+  }
+  std::printf("%.17g %.17g %.17g %d %zu %d\n", reg_t[0], reg_t[1], reg_t[2], rot_vgicp.hasConverged() ? 1 : 0, aligned.size(), aligned_same);
   // covariance accessors, getFinalHessian, evaluateCost (rot_vgicp.hpp:89-97, lsq_registration.hpp:55-57): a second operator fed with the
   // first one's covariances must reproduce its rotation; line 3 = max |dT|, cost at identity, trace(H), |b|, final Hessian (0,0), n_covs
   {

@@ -633,6 +633,7 @@ def test_cpp_shim_end_to_end(tmp_path):
     rc2, t_o, _ = o.compute_translation(np.zeros(3), g3, g3)
     assert np.abs(T - Tf_o).max() < 1e-6 and np.abs(t - t_o).max() <= 1e-4
     assert int(vals[19]) == int(cv) and int(vals[20]) == src.shape[0]
+    assert int(vals[21]) == 1   # `aligned` (host-side pcl::transformPointCloud of the class) = rolo_transform_cloud, bit for bit
     # setSource/TargetCovariances, getSource/TargetCovariances, evaluateCost, getFinalHessian (rot_vgicp.hpp:89-97, lsq_registration.hpp:55-57):
     # an operator fed with the first one's covariances reproduces its rotation; evaluateCost is the oracle's 6-dof linearisation
     v2 = [float(v) for v in lines[1].split()]
@@ -960,3 +961,43 @@ def test_cooperative_walk_lists_bit_exact(budget):
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "COOP" in r.stdout
+
+
+def _edge_keys_main():
+    """body of the fast-path leg of test_polar_keys_at_planted_bin_edges (own process: ROLO_POLAR_EXACT is read once per process)"""
+    import os
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "polar_edge_points.npz"))
+    g = RotVGICP(); g.setPolarResolution(0.175, 0.175, 2.0)
+    g.setInputTarget(d["points"]); g.setInputSource(d["points"])
+    print("EDGEDIFF", int((g.targetVoxelKeys() != d["keys"]).any(axis=1).sum()))
+
+
+def test_polar_keys_at_planted_bin_edges():
+    """VERDICT r03 item 6 / SURVEY section 7: 1166 float32 points planted within 5e-13 bins of a theta / phi / r bin edge of the production POLAR grid
+    (tests/golden/make_golden_edges.py) — where a libm a few ulp off files a point under the neighbouring key. The map build re-keys such points with the
+    correctly rounded atan2 / acos (polar_exact.hpp): keys bit-identical to the oracle's (glibc), through rolo_get_target_voxel_keys AND through the map
+    itself (same voxels, same counts). The leg with ROLO_POLAR_EXACT=0 reports how many keys the fast device functions alone get wrong."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = np.load(os.path.join(root, "tests", "golden", "polar_edge_points.npz"))
+    pts = d["points"]
+    assert pts.shape[0] >= 1000
+    src, tgt, cfg = make_pair("vlp16_polar")
+    cloud = np.concatenate([pts, tgt[:6000]]).astype(np.float32)   # the planted points inside an ordinary scan
+    g = RotVGICP(); g.setPolarResolution(*cfg["polar"])
+    g.setInputTarget(cloud); g.setInputSource(src)
+    k_o = pyorc.voxel_keys(cloud, 0, polar_res=cfg["polar"])
+    assert np.array_equal(k_o[:pts.shape[0]], d["keys"])            # the fixture's keys (authoring container) = this box's oracle
+    assert np.array_equal(g.targetVoxelKeys(), k_o)                  # every key, planted or not, bit for bit
+    g.buildVoxelMap()
+    assert g.numEdgePoints() >= pts.shape[0]                         # all of them were seen as edge points (the statistic stays)
+    kg, cg, _, _ = g.voxels()
+    o = pyorc.Reg(pyorc.default_params(polar_resolution=cfg["polar"])); o.set_target(cloud); o.set_source(src)
+    assert o.compute_covariances() == 0 and o.build_voxelmap() == 0
+    ko, co, _, _ = o.voxels()
+    og, oo = np.lexsort(kg.T[::-1]), np.lexsort(ko.T[::-1])
+    assert np.array_equal(kg[og], ko[oo]) and np.array_equal(cg[og], co[oo])   # the same voxels with the same point counts
+    r = subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, %r); from tests.test_gpu_registration import _edge_keys_main; _edge_keys_main()" % root],
+                       env=dict(os.environ, ROLO_POLAR_EXACT="0"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-1500:]
+    print("keys the fast device atan2 / acos alone get wrong among the planted points:", r.stdout.strip().split("EDGEDIFF")[-1].strip())
