@@ -367,6 +367,10 @@ int rolo_odom_set_deskew(rolo_odom* o, const rolo_deskew* d, const float* rel_ti
  * transformUpdate()'s clamps (:1060-1068; tolerances FLT_MAX in every shipped config) are left to the caller.
  * selected_out[n_corner + n_surf] / coeff_out[(n_corner + n_surf) * 4] (optional): laserCloudOri*Flag and coeffSel of the LAST iteration. */
 typedef struct rolo_scan2map_stats { int skipped, iterations, converged, degenerate, n_selected; } rolo_scan2map_stats;
+/* kdtreeCornerFromMap / kdtreeSurfFromMap ->setInputCloud (:690-691) as a call of its own: uploads the sub-map and builds its two search trees once; they stay
+ * resident in the context until the next call. rolo_scan2map_optimize with map_corner = map_surf = NULL then registers against the resident sub-map (the
+ * surrounding key-frame set changes every few scans, not every scan). */
+int rolo_scan2map_set_submap(rolo_ctx* ctx, const float* map_corner, int m_corner, const float* map_surf, int m_surf);
 int rolo_scan2map_optimize(rolo_ctx* ctx, const float* corner, int n_corner, const float* surf, int n_surf, const float* map_corner, int m_corner,
                            const float* map_surf, int m_surf, float* transformTobeMapped6, int edge_min, int surf_min, rolo_scan2map_stats* stats,
                            unsigned char* selected_out, float* coeff_out);

@@ -15,8 +15,8 @@ _LIB_PATH = os.path.join(_HERE, "librolo_oracle.so")
 
 
 def build(force: bool = False) -> str:
-    srcs = [os.path.join(_HERE, f) for f in ("rolo_oracle.cpp", "rolo_oracle_front.cpp", "rolo_oracle.h",
-                                             "rolo_oracle_front.h", "orc_linalg.hpp", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("rolo_oracle.cpp", "rolo_oracle_front.cpp", "rolo_oracle_backend.cpp", "rolo_oracle.h", "rolo_oracle_front.h",
+                                             "rolo_oracle_backend.h", "orc_linalg.hpp", "orc_kdtree.hpp", "Makefile")]
     stale = (not os.path.exists(_LIB_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs)
     if force or stale:
         subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "librolo_oracle.so"])
@@ -409,3 +409,20 @@ class Odom:
         rc = lib().orc_odom_cloud(self.h, stamp, _f(corner), corner.shape[0], _f(surface), surface.shape[0],
                                   _f(pose), _d(R), _d(t))
         return rc, pose, R, t
+
+
+def scan2map(corner, surf, map_corner, map_surf, tf6, edge_min=10, surf_min=100, threads=0):
+    """orc_scan2map (src/backMapping.cpp:681-1058). Returns (transformTobeMapped, stats dict, selected flags, coeffs of the last iteration)."""
+    L = lib()
+    fp = C.POINTER(C.c_float)
+    L.orc_scan2map.restype = C.c_int
+    L.orc_scan2map.argtypes = [fp, C.c_int, fp, C.c_int, fp, C.c_int, fp, C.c_int, fp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_ubyte), fp]
+    a = [np.ascontiguousarray(x, np.float32) for x in (corner, surf, map_corner, map_surf)]
+    assert all(x.ndim == 2 and x.shape[1] == 4 for x in a)
+    tf = np.ascontiguousarray(tf6, np.float32).copy()
+    n = a[0].shape[0] + a[1].shape[0]
+    st = (C.c_int * 5)(); sel = np.zeros(n, np.uint8); co = np.zeros((n, 4), np.float32)
+    rc = L.orc_scan2map(_f(a[0]), a[0].shape[0], _f(a[1]), a[1].shape[0], _f(a[2]), a[2].shape[0], _f(a[3]), a[3].shape[0], _f(tf), edge_min, surf_min, threads,
+                        st, sel.ctypes.data_as(C.POINTER(C.c_ubyte)), _f(co))
+    assert rc == 0
+    return tf, dict(zip(("skipped", "iterations", "converged", "degenerate", "n_selected"), [int(v) for v in st])), sel.astype(bool), co

@@ -121,6 +121,7 @@ SYMBOLS = {
     "rolo_build_voxelmap": (C.c_int, [vp]),
     "rolo_scan2map_optimize": (C.c_int, [vp, fp, C.c_int, fp, C.c_int, fp, C.c_int, fp, C.c_int, fp, C.c_int, C.c_int, C.POINTER(Scan2MapStats),
                                           C.POINTER(C.c_ubyte), fp]),
+    "rolo_scan2map_set_submap": (C.c_int, [vp, fp, C.c_int, fp, C.c_int]),
     "rolo_num_voxels": (C.c_int, [vp]),
     "rolo_num_edge_points": (C.c_int, [vp]),
     "rolo_get_voxels": (C.c_int, [vp, ip, ip, dp, dp]),

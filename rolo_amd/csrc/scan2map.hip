@@ -10,8 +10,10 @@
 // no packet to share) and reduces J^T J (21 values), J^T r (6) and the number of selected points per workgroup; a second tiny kernel sums the
 // rows in a fixed order. The 6 x 6 solve, the degeneracy projection and the convergence test run on the host in float, as the reference's
 // cv::solve / cv::eigen do (one 232-byte read-back per iteration; the back end runs at <= 1 / 0.15 s).
-// Third-party numerics restated, not copied (OpenCV / Eigen are not in the reference tree): cv::eigen of a symmetric float matrix = Jacobi
-// rotations, eigenvalues descending, eigenvectors as rows; colPivHouseholderQr().solve of the 5 x 3 plane system = its least-squares solution.
+// Third-party numerics restated, not copied (OpenCV / Eigen are not in the reference tree), in FLOAT with the operation order of their published
+// algorithms: cv::eigen of a symmetric float matrix = OpenCV's largest-pivot Jacobi scheme, eigenvalues descending, eigenvectors as rows;
+// colPivHouseholderQr().solve of the 5 x 3 plane system = Eigen's column-pivoted Householder QR. The C++ oracle (oracle/rolo_oracle_backend.cpp)
+// restates the same algorithms independently: selection flags bit-identical, coefficients to float rounding (tests/test_gpu_backend.py).
 #include "rolo_internal.hpp"
 #include "dev_math.hpp"
 #include <cfloat>
@@ -100,66 +102,141 @@ ROLO_DEV void knn5(const KnnCloud& M, float qx, float qy, float qz, int* stk /* 
   }
 }
 
-// eigen-decomposition of a symmetric 3 x 3 float matrix by cyclic Jacobi rotations: eigenvalues descending, eigenvectors as rows (cv::eigen)
-ROLO_DEV void eigen_sym3f(float a11, float a12, float a13, float a22, float a23, float a33, float (&D)[3], float (&V)[9]) {
-  float A[9] = {a11, a12, a13, a12, a22, a23, a13, a23, a33};
-#pragma unroll
-  for (int i = 0; i < 9; i++) V[i] = (i % 4 == 0) ? 1.f : 0.f;
-  for (int sweep = 0; sweep < 30; sweep++) {
-    const float off = fabsf(A[1]) + fabsf(A[2]) + fabsf(A[5]);
-    if (off < FLT_MIN * 16) break;
-#pragma unroll
-    for (int pq = 0; pq < 3; pq++) {
-      const int p = pq == 2 ? 1 : 0, q = pq == 0 ? 1 : 2;
-      const float apq = A[p * 3 + q];
-      if (fabsf(apq) < FLT_MIN) continue;
-      const float app = A[p * 4], aqq = A[q * 4];
-      const float theta = (aqq - app) / (2.f * apq);
-      const float t = (theta >= 0.f ? 1.f : -1.f) / (fabsf(theta) + sqrtf(theta * theta + 1.f));
-      const float c = 1.f / sqrtf(t * t + 1.f), s = t * c;
-#pragma unroll
-      for (int k = 0; k < 3; k++) {   // A <- A J (columns p, q)
-        const float akp = A[k * 3 + p], akq = A[k * 3 + q];
-        A[k * 3 + p] = c * akp - s * akq; A[k * 3 + q] = s * akp + c * akq;
-      }
-#pragma unroll
-      for (int k = 0; k < 3; k++) {   // A <- J^T A (rows p, q)
-        const float apk = A[p * 3 + k], aqk = A[q * 3 + k];
-        A[p * 3 + k] = c * apk - s * aqk; A[q * 3 + k] = s * apk + c * aqk;
-      }
-#pragma unroll
-      for (int k = 0; k < 3; k++) {   // V rows = eigenvectors: V <- J^T V
-        const float vpk = V[p * 3 + k], vqk = V[q * 3 + k];
-        V[p * 3 + k] = c * vpk - s * vqk; V[q * 3 + k] = s * vpk + c * vqk;
-      }
-    }
-  }
-  D[0] = A[0]; D[1] = A[4]; D[2] = A[8];
-  // sort descending with the rows of V
-#pragma unroll
-  for (int i = 0; i < 2; i++)
-#pragma unroll
-    for (int j = 0; j < 2 - i; j++)
-      if (D[j] < D[j + 1]) {
-        const float td = D[j]; D[j] = D[j + 1]; D[j + 1] = td;
-#pragma unroll
-        for (int k = 0; k < 3; k++) { const float tv = V[j * 3 + k]; V[j * 3 + k] = V[(j + 1) * 3 + k]; V[(j + 1) * 3 + k] = tv; }
-      }
+// OpenCV's own hypot (scaled; only + * / sqrt: the same bits on host and device)
+__host__ __device__ inline float cv_hypotf(float a, float b) {
+  a = fabsf(a); b = fabsf(b);
+  if (a > b) { b /= a; return a * sqrtf(1 + b * b); }
+  if (b > 0) { a /= b; return b * sqrtf(1 + a * a); }
+  return 0;
 }
 
-// least-squares solution of the 5 x 3 system A x = -1 (matA0.colPivHouseholderQr().solve(matB0), :845-861): normal equations in double
-// (well conditioned: 5 points within 1 m of each other, coordinates O(100 m)), result narrowed to float
-ROLO_DEV bool plane_lsq(const float (&px)[5], const float (&py)[5], const float (&pz)[5], float& pa, float& pb, float& pc) {
-  double sxx = 0, sxy = 0, sxz = 0, syy = 0, syz = 0, szz = 0, bx = 0, by = 0, bz = 0;
-#pragma unroll
-  for (int j = 0; j < 5; j++) {
-    const double x = px[j], y = py[j], z = pz[j];
-    sxx += x * x; sxy += x * y; sxz += x * z; syy += y * y; syz += y * z; szz += z * z; bx -= x; by -= y; bz -= z;
+// cv::eigen of a symmetric N x N float matrix (backMapping.cpp:771 N = 3 on the device, :1009 N = 6 on the host), restated from OpenCV's published Jacobi
+// scheme (not in the reference tree): only the upper triangle is kept; each step annihilates the off-diagonal element of largest magnitude (per-row and
+// per-column maxima in index arrays, strict comparisons: the first of equals wins), rotation from y = (w_l - w_k) / 2, t = |y| + hypot(p, y),
+// s = hypot(p, t), c = t / s, s = p / s, t = (p / t) p; at most 30 N^2 steps, stop when |p| <= FLT_EPSILON; eigenvalues descending, eigenvectors as rows.
+// The float operation order is the parity target (oracle/rolo_oracle_backend.cpp restates the same scheme independently).
+template <int N>
+__host__ __device__ inline void cv_eigen_sym(float* A /* N x N, destroyed */, float* W, float* V) {
+  int indR[N], indC[N];
+  for (int i = 0; i < N; i++) { for (int j = 0; j < N; j++) V[i * N + j] = 0.f; V[i * N + i] = 1.f; }
+  auto row_max = [&](int k) { int m = k + 1; float mv = fabsf(A[k * N + m]); for (int i = k + 2; i < N; i++) { const float v = fabsf(A[k * N + i]); if (mv < v) { mv = v; m = i; } } return m; };
+  auto col_max = [&](int k) { int m = 0; float mv = fabsf(A[k]); for (int i = 1; i < k; i++) { const float v = fabsf(A[i * N + k]); if (mv < v) { mv = v; m = i; } } return m; };
+  for (int k = 0; k < N; k++) {
+    W[k] = A[k * N + k];
+    if (k < N - 1) indR[k] = row_max(k);
+    if (k > 0) indC[k] = col_max(k);
   }
-  const Sym3 Minv = sym3_inverse(Sym3{sxx, sxy, sxz, syy, syz, szz});
-  const Vec3 x = sym3_mulv(Minv, Vec3{bx, by, bz});
-  pa = (float)x.x; pb = (float)x.y; pc = (float)x.z;
-  return isfinite(pa) && isfinite(pb) && isfinite(pc);
+  for (int it = 0; it < N * N * 30; it++) {
+    int k = 0; float mv = fabsf(A[indR[0]]);
+    for (int i = 1; i < N - 1; i++) { const float v = fabsf(A[i * N + indR[i]]); if (mv < v) { mv = v; k = i; } }
+    int l = indR[k];
+    for (int i = 1; i < N; i++) { const float v = fabsf(A[indC[i] * N + i]); if (mv < v) { mv = v; k = indC[i]; l = i; } }
+    const float p = A[k * N + l];
+    if (fabsf(p) <= FLT_EPSILON) break;
+    const float y = (W[l] - W[k]) * 0.5f;
+    float t = fabsf(y) + cv_hypotf(p, y);
+    float s = cv_hypotf(p, t);
+    const float c = t / s;
+    s = p / s; t = (p / t) * p;
+    if (y < 0) { s = -s; t = -t; }
+    A[k * N + l] = 0;
+    W[k] -= t; W[l] += t;
+    for (int i = 0; i < k; i++) { const float a0 = A[i * N + k], b0 = A[i * N + l]; A[i * N + k] = a0 * c - b0 * s; A[i * N + l] = a0 * s + b0 * c; }
+    for (int i = k + 1; i < l; i++) { const float a0 = A[k * N + i], b0 = A[i * N + l]; A[k * N + i] = a0 * c - b0 * s; A[i * N + l] = a0 * s + b0 * c; }
+    for (int i = l + 1; i < N; i++) { const float a0 = A[k * N + i], b0 = A[l * N + i]; A[k * N + i] = a0 * c - b0 * s; A[l * N + i] = a0 * s + b0 * c; }
+    for (int i = 0; i < N; i++) { const float a0 = V[k * N + i], b0 = V[l * N + i]; V[k * N + i] = a0 * c - b0 * s; V[l * N + i] = a0 * s + b0 * c; }
+    for (int j = 0; j < 2; j++) {
+      const int idx = j == 0 ? k : l;
+      if (idx < N - 1) indR[idx] = row_max(idx);
+      if (idx > 0) indC[idx] = col_max(idx);
+    }
+  }
+  for (int k = 0; k < N - 1; k++) {
+    int m = k;
+    for (int i = k + 1; i < N; i++) if (W[m] < W[i]) m = i;
+    if (k != m) { const float tw = W[m]; W[m] = W[k]; W[k] = tw; for (int i = 0; i < N; i++) { const float tv = V[m * N + i]; V[m * N + i] = V[k * N + i]; V[k * N + i] = tv; } }
+  }
+}
+
+// matX0 = matA0.colPivHouseholderQr().solve(matB0) for the 5 x 3 plane system A x = -1 (:845-861), restated from Eigen's published algorithm in FLOAT as the
+// reference runs it: column-pivoted Householder QR — the column of largest remaining norm first, norms down-dated as in LAPACK working note 176, rank decided
+// against eps * (largest column norm) / rows —, Q^T applied to the right-hand side, back substitution on the non-zero pivots, permutation undone.
+// Columns are swapped with static indices (three cases) so that everything stays in registers.
+ROLO_DEV void plane_colpiv_qr(const float (&px)[5], const float (&py)[5], const float (&pz)[5], float& xa, float& xb, float& xc) {
+  float q0[5], q1[5], q2[5];
+#pragma unroll
+  for (int i = 0; i < 5; i++) { q0[i] = px[i]; q1[i] = py[i]; q2[i] = pz[i]; }
+  auto sq = [](const float (&c)[5], int from) { float s = 0; for (int i = from; i < 5; i++) s += c[i] * c[i]; return s; };
+  auto swapc = [](float (&a)[5], float (&b)[5]) {
+#pragma unroll
+    for (int i = 0; i < 5; i++) { const float t = a[i]; a[i] = b[i]; b[i] = t; } };
+  float nU0 = sqrtf(sq(q0, 0)), nU1 = sqrtf(sq(q1, 0)), nU2 = sqrtf(sq(q2, 0)), nD0 = nU0, nD1 = nU1, nD2 = nU2;
+  const float th0 = fmaxf(nU0, fmaxf(nU1, nU2)) * FLT_EPSILON / 5.0f, threshold_helper = th0 * th0, downdate = sqrtf(FLT_EPSILON);
+  int nonzero = 3, t0, t1;
+  float h0, h1, h2;
+  auto householder = [](float (&c)[5], int k, float& tau) {   // makeHouseholderInPlace on c[k..4]: essential part left in c[k+1..4], beta in c[k]
+    float tail = 0; for (int i = k + 1; i < 5; i++) tail += c[i] * c[i];
+    const float c0 = c[k];
+    if (tail <= FLT_MIN) { tau = 0; for (int i = k + 1; i < 5; i++) c[i] = 0; return; }
+    float beta = sqrtf(c0 * c0 + tail);
+    if (c0 >= 0) beta = -beta;
+    for (int i = k + 1; i < 5; i++) c[i] = c[i] / (c0 - beta);
+    tau = (beta - c0) / beta;
+    c[k] = beta;
+  };
+  auto apply = [](const float (&v)[5], int k, float tau, float (&c)[5]) {   // applyHouseholderOnTheLeft on column c, rows k..4
+    float tmp = 0; for (int i = k + 1; i < 5; i++) tmp += v[i] * c[i];
+    tmp += c[k];
+    c[k] -= tau * tmp;
+    for (int i = k + 1; i < 5; i++) c[i] -= tau * v[i] * tmp;
+  };
+  auto downdate_norm = [&](const float (&c)[5], int k, float& nU, float& nD) {
+    if (nU != 0.f) {
+      float temp = fabsf(c[k]) / nU;
+      temp = (1.f + temp) * (1.f - temp);
+      temp = temp < 0.f ? 0.f : temp;
+      const float q = nU / nD, temp2 = temp * (q * q);
+      if (temp2 <= downdate) { nD = sqrtf(sq(c, k + 1)); nU = nD; }
+      else nU *= sqrtf(temp);
+    }
+  };
+  // k = 0
+  { int big = 0; float bn = nU0; if (nU1 > bn) { bn = nU1; big = 1; } if (nU2 > bn) { bn = nU2; big = 2; }
+    if (bn * bn < threshold_helper * 5.0f) nonzero = 0;
+    t0 = big;
+    if (big == 1) { swapc(q0, q1); float t = nU0; nU0 = nU1; nU1 = t; t = nD0; nD0 = nD1; nD1 = t; }
+    else if (big == 2) { swapc(q0, q2); float t = nU0; nU0 = nU2; nU2 = t; t = nD0; nD0 = nD2; nD2 = t; }
+    householder(q0, 0, h0);
+    apply(q0, 0, h0, q1); apply(q0, 0, h0, q2);
+    downdate_norm(q1, 0, nU1, nD1); downdate_norm(q2, 0, nU2, nD2); }
+  // k = 1
+  { int big = 1; float bn = nU1; if (nU2 > bn) { bn = nU2; big = 2; }
+    if (nonzero == 3 && bn * bn < threshold_helper * 4.0f) nonzero = 1;
+    t1 = big;
+    if (big == 2) { swapc(q1, q2); float t = nU1; nU1 = nU2; nU2 = t; t = nD1; nD1 = nD2; nD2 = t; }
+    householder(q1, 1, h1);
+    apply(q1, 1, h1, q2);
+    downdate_norm(q2, 1, nU2, nD2); }
+  // k = 2
+  { if (nonzero == 3 && nU2 * nU2 < threshold_helper * 3.0f) nonzero = 2;
+    householder(q2, 2, h2); }
+  // permutation: identity with the transpositions (0, t0), (1, t1) applied on the right, in that order
+  int p0 = 0, p1 = 1, p2 = 2;
+  if (t0 == 1) { const int t = p0; p0 = p1; p1 = t; } else if (t0 == 2) { const int t = p0; p0 = p2; p2 = t; }
+  if (t1 == 2) { const int t = p1; p1 = p2; p2 = t; }
+  float c[5] = {-1.f, -1.f, -1.f, -1.f, -1.f};
+  if (nonzero > 0) apply(q0, 0, h0, c);
+  if (nonzero > 1) apply(q1, 1, h1, c);
+  if (nonzero > 2) apply(q2, 2, h2, c);
+  // R = [q0[0] q1[0] q2[0]; 0 q1[1] q2[1]; 0 0 q2[2]]: back substitution on the leading nonzero x nonzero block
+  if (nonzero > 2) { c[2] /= q2[2]; c[0] -= q2[0] * c[2]; c[1] -= q2[1] * c[2]; }
+  if (nonzero > 1) { c[1] /= q1[1]; c[0] -= q1[0] * c[1]; }
+  if (nonzero > 0) { c[0] /= q0[0]; }
+  float x[3] = {0.f, 0.f, 0.f};
+  if (nonzero > 0) { if (p0 == 0) x[0] = c[0]; else if (p0 == 1) x[1] = c[0]; else x[2] = c[0]; }
+  if (nonzero > 1) { if (p1 == 0) x[0] = c[1]; else if (p1 == 1) x[1] = c[1]; else x[2] = c[1]; }
+  if (nonzero > 2) { if (p2 == 0) x[0] = c[2]; else if (p2 == 1) x[1] = c[2]; else x[2] = c[2]; }
+  xa = x[0]; xb = x[1]; xc = x[2];
 }
 
 __global__ __launch_bounds__(S2M_THREADS) void s2m_kernel(S2mArgs A) {
@@ -199,12 +276,13 @@ __global__ __launch_bounds__(S2M_THREADS) void s2m_kernel(S2mArgs A) {
           a11 += ax * ax; a12 += ax * ay; a13 += ax * az; a22 += ay * ay; a23 += ay * az; a33 += az * az;
         }
         a11 /= 5; a12 /= 5; a13 /= 5; a22 /= 5; a23 /= 5; a33 /= 5;
-        float D[3], V[9];
-        eigen_sym3f(a11, a12, a13, a22, a23, a33, D, V);
+        float A1[9] = {a11, a12, a13, a12, a22, a23, a13, a23, a33}, D[3], V[9];
+        cv_eigen_sym<3>(A1, D, V);
         if (D[0] > 3 * D[1]) {
           const float x0 = sx, y0 = sy, z0 = sz;
-          const float x1 = cx + 0.1f * V[0], y1 = cy + 0.1f * V[1], z1 = cz + 0.1f * V[2];
-          const float x2 = cx - 0.1f * V[0], y2 = cy - 0.1f * V[1], z2 = cz - 0.1f * V[2];
+          // "float x1 = cx + 0.1 * matV1.at<float>(0, 0)" (:782-788): the literal is a double — the sum is formed in double and narrowed on assignment
+          const float x1 = (float)((double)cx + 0.1 * (double)V[0]), y1 = (float)((double)cy + 0.1 * (double)V[1]), z1 = (float)((double)cz + 0.1 * (double)V[2]);
+          const float x2 = (float)((double)cx - 0.1 * (double)V[0]), y2 = (float)((double)cy - 0.1 * (double)V[1]), z2 = (float)((double)cz - 0.1 * (double)V[2]);
           const float m1 = (x0 - x1) * (y0 - y2) - (x0 - x2) * (y0 - y1), m2 = (x0 - x1) * (z0 - z2) - (x0 - x2) * (z0 - z1), m3 = (y0 - y1) * (z0 - z2) - (y0 - y2) * (z0 - z1);
           const float a012 = sqrtf(m1 * m1 + m2 * m2 + m3 * m3);
           const float l12 = sqrtf((x1 - x2) * (x1 - x2) + (y1 - y2) * (y1 - y2) + (z1 - z2) * (z1 - z2));
@@ -212,23 +290,25 @@ __global__ __launch_bounds__(S2M_THREADS) void s2m_kernel(S2mArgs A) {
           const float lb = -((x1 - x2) * m1 - (z1 - z2) * m3) / a012 / l12;
           const float lc = -((x1 - x2) * m2 + (y1 - y2) * m3) / a012 / l12;
           const float ld2 = a012 / l12;
-          const float s = 1 - 0.9f * fabsf(ld2);
+          const float s = (float)(1.0 - 0.9 * (double)fabsf(ld2));   // "float s = 1 - 0.9 * fabs(ld2)": double literals, narrowed on assignment
           coeff = make_float4(s * la, s * lb, s * lc, s * ld2);
-          sel = s > 0.1f;
+          sel = (double)s > 0.1;                                       // "if (s > 0.1)": compared as doubles
         }
       } else {        // surfOptimization :845-897
         float pa, pb, pc, pd = 1.f;
-        if (plane_lsq(px, py, pz, pa, pb, pc)) {
+        plane_colpiv_qr(px, py, pz, pa, pb, pc);
+        {
           const float ps = sqrtf(pa * pa + pb * pb + pc * pc);
           pa /= ps; pb /= ps; pc /= ps; pd /= ps;
           bool planeValid = true;
 #pragma unroll
-          for (int j = 0; j < 5; j++) if (fabsf(pa * px[j] + pb * py[j] + pc * pz[j] + pd) > 0.2f) planeValid = false;
+          for (int j = 0; j < 5; j++) if ((double)fabsf(pa * px[j] + pb * py[j] + pc * pz[j] + pd) > 0.2) planeValid = false;   // "> 0.2": compared as doubles (a NaN plane is valid here and dies at s > 0.1, as in the reference)
           if (planeValid) {
             const float pd2 = pa * sx + pb * sy + pc * sz + pd;
-            const float s = 1 - 0.9f * fabsf(pd2) / sqrtf(sqrtf(po.x * po.x + po.y * po.y + po.z * po.z));
+            // "float s = 1 - 0.9 * fabs(pd2) / sqrt(sqrt(...))": the square roots in float, the rest in double, narrowed on assignment
+            const float s = (float)(1.0 - 0.9 * (double)fabsf(pd2) / (double)sqrtf(sqrtf(po.x * po.x + po.y * po.y + po.z * po.z)));
             coeff = make_float4(s * pa, s * pb, s * pc, s * pd2);
-            sel = s > 0.1f;
+            sel = (double)s > 0.1;
           }
         }
       }
@@ -310,30 +390,6 @@ bool solve_qr6f(const float* Ain, const float* bin, float* x) {
   }
   return true;
 }
-// cv::eigen of a symmetric 6 x 6 float matrix: Jacobi, eigenvalues descending, eigenvectors as rows
-void eigen_sym6f(const float* Ain, float* E, float* V) {
-  float A[36]; std::memcpy(A, Ain, sizeof(A));
-  for (int i = 0; i < 36; i++) V[i] = (i % 7 == 0) ? 1.f : 0.f;
-  for (int sweep = 0; sweep < 60; sweep++) {
-    float off = 0; for (int p = 0; p < 6; p++) for (int q = p + 1; q < 6; q++) off += std::fabs(A[p * 6 + q]);
-    if (off < 1e-30f) break;
-    for (int p = 0; p < 6; p++) for (int q = p + 1; q < 6; q++) {
-      const float apq = A[p * 6 + q];
-      if (std::fabs(apq) < FLT_MIN) continue;
-      const float theta = (A[q * 7] - A[p * 7]) / (2.f * apq);
-      const float t = (theta >= 0.f ? 1.f : -1.f) / (std::fabs(theta) + std::sqrt(theta * theta + 1.f));
-      const float c = 1.f / std::sqrt(t * t + 1.f), s = t * c;
-      for (int k = 0; k < 6; k++) { const float akp = A[k * 6 + p], akq = A[k * 6 + q]; A[k * 6 + p] = c * akp - s * akq; A[k * 6 + q] = s * akp + c * akq; }
-      for (int k = 0; k < 6; k++) { const float apk = A[p * 6 + k], aqk = A[q * 6 + k]; A[p * 6 + k] = c * apk - s * aqk; A[q * 6 + k] = s * apk + c * aqk; }
-      for (int k = 0; k < 6; k++) { const float vpk = V[p * 6 + k], vqk = V[q * 6 + k]; V[p * 6 + k] = c * vpk - s * vqk; V[q * 6 + k] = s * vpk + c * vqk; }
-    }
-  }
-  for (int i = 0; i < 6; i++) E[i] = A[i * 7];
-  for (int i = 0; i < 5; i++) for (int j = 0; j < 5 - i; j++) if (E[j] < E[j + 1]) {
-    std::swap(E[j], E[j + 1]);
-    for (int k = 0; k < 6; k++) std::swap(V[j * 6 + k], V[(j + 1) * 6 + k]);
-  }
-}
 bool invert6f(const float* Ain, float* inv) {   // matV.inv() (LU with partial pivoting)
   float a[36]; std::memcpy(a, Ain, sizeof(a));
   for (int i = 0; i < 36; i++) inv[i] = (i % 7 == 0) ? 1.f : 0.f;
@@ -359,13 +415,30 @@ using namespace rolo;
 namespace rolo {
 void** ctx_s2m_slot(rolo_ctx* c);   // api.hip
 struct S2mScratch { float4* feat = nullptr; double *part = nullptr, *sum = nullptr; unsigned char* sel = nullptr; float4* coeff = nullptr;
-                    size_t feat_cap = 0, part_cap = 0, sum_cap = 0, sel_cap = 0, coeff_cap = 0; };
+                    size_t feat_cap = 0, part_cap = 0, sum_cap = 0, sel_cap = 0, coeff_cap = 0;
+                    KnnPair maps{}; int m_corner = 0, m_surf = 0; bool have_maps = false; };   // the resident sub-map (rolo_scan2map_set_submap): trees of the context's two clouds
 }  // namespace rolo
 extern "C" void rolo_s2m_destroy(rolo_ctx* c) {   // called by rolo_ctx_destroy
   S2mScratch* W = static_cast<S2mScratch*>(*ctx_s2m_slot(c));
   if (!W) return;
   for (void* p : {(void*)W->feat, (void*)W->part, (void*)W->sum, (void*)W->sel, (void*)W->coeff}) if (p) (void)hipFree(p);
   delete W; *ctx_s2m_slot(c) = nullptr;
+}
+
+// kdtreeCornerFromMap->setInputCloud(laserCloudCornerFromMapDS) / kdtreeSurfFromMap->setInputCloud(laserCloudSurfFromMapDS) (:690-691) as a call of its own: the
+// sub-map is uploaded and its two search trees are built ONCE and stay in the context (its source / target clouds) until the next call — the surrounding
+// key-frame set changes every few scans, not every scan (extractSurroundingKeyFrames), so rolo_scan2map_optimize(..., NULL, 0, NULL, 0, ...) then costs one
+// upload of the scan's features and the Gauss-Newton iterations.
+extern "C" int rolo_scan2map_set_submap(rolo_ctx* c, const float* map_corner, int m_corner, const float* map_surf, int m_surf) {
+  if (!c || m_corner < 0 || m_surf < 0 || (m_corner && !map_corner) || (m_surf && !map_surf)) return ROLO_EINVAL;
+  S2mScratch* W = static_cast<S2mScratch*>(*ctx_s2m_slot(c));
+  if (!W) { W = new S2mScratch(); *ctx_s2m_slot(c) = W; }
+  W->have_maps = false; W->m_corner = m_corner; W->m_surf = m_surf;
+  if (m_corner < 5 || m_surf < 5) return ROLO_OK;   // nothing a 5-NN query could be answered from: rolo_scan2map_optimize reports skipped = 2
+  const int rc = ctx_build_map_trees(c, map_corner, m_corner, map_surf, m_surf, 4, &W->maps);
+  if (rc) return rc;
+  W->have_maps = true;
+  return ROLO_OK;
 }
 
 extern "C" int rolo_scan2map_optimize(rolo_ctx* c, const float* corner, int n_corner, const float* surf, int n_surf, const float* map_corner, int m_corner,
@@ -376,14 +449,19 @@ extern "C" int rolo_scan2map_optimize(rolo_ctx* c, const float* corner, int n_co
     return ROLO_EINVAL;
   rolo_scan2map_stats st{};
   if (stats) *stats = st;
+  const bool resident = !map_corner && !map_surf;   // the sub-map of the last rolo_scan2map_set_submap
+  if (resident) {
+    S2mScratch* W0 = static_cast<S2mScratch*>(*ctx_s2m_slot(c));
+    if (!W0 || (W0->m_corner == 0 && W0->m_surf == 0 && !W0->have_maps)) { ctx_set_error("rolo_scan2map_optimize without a sub-map: call rolo_scan2map_set_submap first"); return ROLO_ESTATE; }
+    m_corner = W0->m_corner; m_surf = W0->m_surf;
+  }
   // :689 — "if (laserCloudCornerLastDSNum > edgeFeatureMinValidNum && laserCloudSurfLastDSNum > surfFeatureMinValidNum)"
   if (!(n_corner > edge_min && n_surf > surf_min)) { st.skipped = 1; if (stats) *stats = st; return ROLO_OK; }
   // a sub-map without five points cannot answer a 5-NN query: the reference's association then selects nothing from it (and reads
   // pointSearchSqDis[4] of a shorter result, :745 / :852) — nothing to optimise against; report it as skipped instead of an error
   if (m_corner < 5 || m_surf < 5) { st.skipped = 2; if (stats) *stats = st; return ROLO_OK; }
-  KnnPair maps{};
-  int rc = ctx_build_map_trees(c, map_corner, m_corner, map_surf, m_surf, 4, &maps);
-  if (rc) return rc;
+  if (!resident) { const int rc = rolo_scan2map_set_submap(c, map_corner, m_corner, map_surf, m_surf); if (rc) return rc; }
+  const KnnPair maps = static_cast<S2mScratch*>(*ctx_s2m_slot(c))->maps;
   hipStream_t s = ctx_stream(c);
   const int n = n_corner + n_surf;
   const int grid = (n + S2M_THREADS - 1) / S2M_THREADS;
@@ -433,8 +511,9 @@ extern "C" int rolo_scan2map_optimize(rolo_ctx* c, const float* corner, int n_co
     for (int r = 0; r < 6; r++) AtB[r] = (float)h_sum[21 + r];
     if (!solve_qr6f(AtA, AtB, X)) { for (int r = 0; r < 6; r++) X[r] = 0.f; }
     if (iterCount == 0) {   // degeneracy of the first linearisation :1004-1026
-      float E[6], V[36], V2[36], Vi[36];
-      eigen_sym6f(AtA, E, V);
+      float Acp[36], E[6], V[36], V2[36], Vi[36];
+      std::memcpy(Acp, AtA, sizeof(Acp));
+      cv_eigen_sym<6>(Acp, E, V);
       std::memcpy(V2, V, sizeof(V2));
       isDegenerate = false;
       for (int i = 5; i >= 0; i--) {
@@ -444,9 +523,10 @@ extern "C" int rolo_scan2map_optimize(rolo_ctx* c, const float* corner, int n_co
     }
     if (isDegenerate) { float X2[6]; std::memcpy(X2, X, sizeof(X2)); for (int r = 0; r < 6; r++) { float a = 0; for (int k = 0; k < 6; k++) a += matP[r * 6 + k] * X2[k]; X[r] = a; } }
     for (int r = 0; r < 6; r++) tf[r] += X[r];
-    const float r2d = 180.0f / (float)M_PI;
-    const float deltaR = std::sqrt(std::pow(X[0] * r2d, 2.f) + std::pow(X[1] * r2d, 2.f) + std::pow(X[2] * r2d, 2.f));
-    const float deltaT = std::sqrt(std::pow(X[3] * 100, 2.f) + std::pow(X[4] * 100, 2.f) + std::pow(X[5] * 100, 2.f));
+    const float r2d = 57.29578f;   // pcl::rad2deg(float)
+    // "float deltaR = sqrt(pow(pcl::rad2deg(x), 2) + ...)" (:1041-1048): rad2deg in float, pow(float, int) and the sum in double, narrowed on assignment
+    const float deltaR = (float)std::sqrt(std::pow((double)(X[0] * r2d), 2) + std::pow((double)(X[1] * r2d), 2) + std::pow((double)(X[2] * r2d), 2));
+    const float deltaT = (float)std::sqrt(std::pow((double)(X[3] * 100), 2) + std::pow((double)(X[4] * 100), 2) + std::pow((double)(X[5] * 100), 2));
     if (deltaR < 0.05f && deltaT < 0.05f) { st.converged = 1; break; }
   }
   st.degenerate = isDegenerate ? 1 : 0;

@@ -1,7 +1,8 @@
-"""GPU: SURVEY 8f.4 — the back end's scan-to-submap optimisation (rolo_scan2map_optimize) against the independent numpy twin
-(oracle/twin_backend.py) on feature clouds the oracle's front end extracts from synthetic frames: which points are selected, their
-point-to-line / point-to-plane coefficients, the number of Gauss-Newton iterations and the optimised pose (<= 1e-4 m, <= 1e-5 rad
-vs the twin), and the pose error against the ground truth of the synthetic trajectory."""
+"""GPU: SURVEY 8f.4 — the back end's scan-to-submap optimisation (rolo_scan2map_optimize) against the C++ oracle (oracle/rolo_oracle_backend.cpp: the
+reference's loops with cv::eigen / colPivHouseholderQr restated in float — the same algorithms the kernel restates, written independently) on feature clouds
+the oracle's front end extracts from synthetic frames: the selection flags of the last iteration BIT-IDENTICAL, their point-to-line / point-to-plane
+coefficients to float rounding, the same iterations and the optimised pose; plus the independent numpy twin (oracle/twin_backend.py, library eigh / lstsq:
+pose <= 1e-4 m, <= 1e-5 rad) and the ground truth of the synthetic trajectory."""
 import numpy as np
 import pytest
 from scipy.spatial.transform import Rotation
@@ -45,6 +46,13 @@ def test_scan2map_matches_twin_and_recovers_the_pose(sensor, cfg):
     tf_g, sel_g, co_g = g.scan2MapOptimization(corner, surf, mc, ms, guess, want_debug=True)
     tf_t, st_t, sel_t, co_t = twin_backend.scan2map(corner, surf, mc, ms, guess)
     st = g.last_stats
+    # ---- the C++ oracle: the standard of the other rows ----
+    tf_o, st_o, sel_o, co_o = pyorc.scan2map(corner, surf, mc, ms, guess)
+    assert (st.skipped, st.iterations, st.converged, st.degenerate, st.n_selected) == tuple(st_o[k] for k in ("skipped", "iterations", "converged", "degenerate", "n_selected"))
+    assert np.array_equal(sel_g, sel_o)                               # laserCloudOri*Flag of the last iteration: bit-identical
+    assert np.abs(co_g - co_o).max() <= 1e-6                          # coeffSel: float rounding (the J^T J rows are summed in another order: the poses differ in the last float bits)
+    assert np.abs(tf_g - tf_o).max() <= 2e-6
+    # ---- the independent twin ----
     assert st.skipped == 0 and st_t["skipped"] == 0
     assert st.converged == st_t["converged"] == 1 and st.degenerate == st_t["degenerate"]
     assert abs(st.iterations - st_t["iterations"]) <= 1
@@ -61,6 +69,11 @@ def test_scan2map_matches_twin_and_recovers_the_pose(sensor, cfg):
     assert np.abs(tf_g[3:] - truth[3:]).max() < 0.03 and np.abs(tf_g[:3] - truth[:3]).max() < 3e-3
     assert np.abs(guess[3:] - truth[3:]).max() > 0.05
 
+    # the sub-map resident in the context (rolo_scan2map_set_submap): the same bits as the one-call form
+    g.setSubmap(mc, ms)
+    for _ in range(2):
+        tf_r, sel_r, co_r = g.scan2MapOptimization(corner, surf, None, None, guess, want_debug=True)
+        assert np.array_equal(tf_r, tf_g) and np.array_equal(sel_r, sel_g) and np.array_equal(co_r, co_g)
     # too few features: nothing happens (backMapping.cpp:689, 708)
     tf_s = g.scan2MapOptimization(corner[:5], surf, mc, ms, guess)
     assert g.last_stats.skipped == 1 and np.array_equal(tf_s, guess)
