@@ -455,13 +455,6 @@ __global__ __launch_bounds__(256) void tree_reduce_kernel(float4* boxes0, int co
   }
 }
 
-ROLO_DEV float box_d2(const float4& lo, const float4& hi, const float4& q) {
-  float dx = fmaxf(fmaxf(__fsub_rn(lo.x, q.x), __fsub_rn(q.x, hi.x)), 0.f);
-  float dy = fmaxf(fmaxf(__fsub_rn(lo.y, q.y), __fsub_rn(q.y, hi.y)), 0.f);
-  float dz = fmaxf(fmaxf(__fsub_rn(lo.z, q.z), __fsub_rn(q.z, hi.z)), 0.f);
-  return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
-}
-
 // ---- Eigen::JacobiSVD<Matrix3d> restated for one thread (rot_vgicp_impl.hpp:468) ---------------------------
 struct Rot2 { double c, s; };
 

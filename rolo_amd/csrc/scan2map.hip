@@ -16,6 +16,7 @@
 // restates the same algorithms independently: selection flags bit-identical, coefficients to float rounding (tests/test_gpu_backend.py).
 #include "rolo_internal.hpp"
 #include "dev_math.hpp"
+#include "knn_packet.hpp"
 #include <cfloat>
 #include <climits>
 #include <cmath>
@@ -24,6 +25,8 @@
 
 namespace rolo {
 int ctx_build_map_trees(rolo_ctx* c, const float* corner, int nc, const float* surf, int ns, int stride, KnnPair* out);
+extern "C" int rolo_ctx_acquire(int device, rolo_ctx** out);
+extern "C" void rolo_ctx_release(rolo_ctx* c);
 hipStream_t ctx_stream(rolo_ctx* c);
 int ctx_device(rolo_ctx* c);
 void ctx_set_error(const char* msg);
@@ -37,6 +40,7 @@ constexpr int S2M_NV = 28;   // 21 (lower triangle of A^T A) + 6 (A^T b) + 1 (se
 struct S2mArgs {
   const float4* feat;      // n_corner corner points, then n_surf surface points (x, y, z, intensity)
   int n_corner, n_surf;
+  KnnCloud qry[2];         // the same features in CURVE order (sorted: x, y, z, bits(index in its cloud); padded to whole leaves): 64 consecutive ones form a packet
   KnnCloud map[2];         // corner / surface sub-map trees
   float T[12];             // transPointAssociateToMap rows (float Affine3f of pcl::getTransformation)
   float srx, crx, sry, cry, srz, crz;   // LMOptimization :942-947
@@ -239,6 +243,83 @@ ROLO_DEV void plane_colpiv_qr(const float (&px)[5], const float (&py)[5], const 
   xa = x[0]; xb = x[1]; xc = x[2];
 }
 
+// cornerOptimization :740-820 / surfOptimization :845-897 for one feature: (sx, sy, sz) = pointSel, po = pointOri, px / py / pz = its five nearest sub-map
+// points in (d2, index) order. Float arithmetic in the reference's operation order (double where its literals make it double).
+ROLO_DEV void s2m_fit(bool corner, float sx, float sy, float sz, const float4& po, const float (&px)[5], const float (&py)[5], const float (&pz)[5], bool& sel, float4& coeff) {
+  if (corner) {   // cornerOptimization :740-820
+    float cx = 0, cy = 0, cz = 0;
+#pragma unroll
+    for (int j = 0; j < 5; j++) { cx += px[j]; cy += py[j]; cz += pz[j]; }
+    cx /= 5; cy /= 5; cz /= 5;
+    float a11 = 0, a12 = 0, a13 = 0, a22 = 0, a23 = 0, a33 = 0;
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+      const float ax = px[j] - cx, ay = py[j] - cy, az = pz[j] - cz;
+      a11 += ax * ax; a12 += ax * ay; a13 += ax * az; a22 += ay * ay; a23 += ay * az; a33 += az * az;
+    }
+    a11 /= 5; a12 /= 5; a13 /= 5; a22 /= 5; a23 /= 5; a33 /= 5;
+    float A1[9] = {a11, a12, a13, a12, a22, a23, a13, a23, a33}, D[3], V[9];
+    cv_eigen_sym<3>(A1, D, V);
+    if (D[0] > 3 * D[1]) {
+      const float x0 = sx, y0 = sy, z0 = sz;
+      // "float x1 = cx + 0.1 * matV1.at<float>(0, 0)" (:782-788): the literal is a double — the sum is formed in double and narrowed on assignment
+      const float x1 = (float)((double)cx + 0.1 * (double)V[0]), y1 = (float)((double)cy + 0.1 * (double)V[1]), z1 = (float)((double)cz + 0.1 * (double)V[2]);
+      const float x2 = (float)((double)cx - 0.1 * (double)V[0]), y2 = (float)((double)cy - 0.1 * (double)V[1]), z2 = (float)((double)cz - 0.1 * (double)V[2]);
+      const float m1 = (x0 - x1) * (y0 - y2) - (x0 - x2) * (y0 - y1), m2 = (x0 - x1) * (z0 - z2) - (x0 - x2) * (z0 - z1), m3 = (y0 - y1) * (z0 - z2) - (y0 - y2) * (z0 - z1);
+      const float a012 = sqrtf(m1 * m1 + m2 * m2 + m3 * m3);
+      const float l12 = sqrtf((x1 - x2) * (x1 - x2) + (y1 - y2) * (y1 - y2) + (z1 - z2) * (z1 - z2));
+      const float la = ((y1 - y2) * m1 + (z1 - z2) * m2) / a012 / l12;
+      const float lb = -((x1 - x2) * m1 - (z1 - z2) * m3) / a012 / l12;
+      const float lc = -((x1 - x2) * m2 + (y1 - y2) * m3) / a012 / l12;
+      const float ld2 = a012 / l12;
+      const float s = (float)(1.0 - 0.9 * (double)fabsf(ld2));   // "float s = 1 - 0.9 * fabs(ld2)": double literals, narrowed on assignment
+      coeff = make_float4(s * la, s * lb, s * lc, s * ld2);
+      sel = (double)s > 0.1;                                       // "if (s > 0.1)": compared as doubles
+    }
+  } else {        // surfOptimization :845-897
+    float pa, pb, pc, pd = 1.f;
+    plane_colpiv_qr(px, py, pz, pa, pb, pc);
+    {
+      const float ps = sqrtf(pa * pa + pb * pb + pc * pc);
+      pa /= ps; pb /= ps; pc /= ps; pd /= ps;
+      bool planeValid = true;
+#pragma unroll
+      for (int j = 0; j < 5; j++) if ((double)fabsf(pa * px[j] + pb * py[j] + pc * pz[j] + pd) > 0.2) planeValid = false;   // "> 0.2": compared as doubles (a NaN plane is valid here and dies at s > 0.1, as in the reference)
+      if (planeValid) {
+        const float pd2 = pa * sx + pb * sy + pc * sz + pd;
+        // "float s = 1 - 0.9 * fabs(pd2) / sqrt(sqrt(...))": the square roots in float, the rest in double, narrowed on assignment
+        const float s = (float)(1.0 - 0.9 * (double)fabsf(pd2) / (double)sqrtf(sqrtf(po.x * po.x + po.y * po.y + po.z * po.z)));
+        coeff = make_float4(s * pa, s * pb, s * pc, s * pd2);
+        sel = (double)s > 0.1;
+      }
+    }
+  }
+}
+
+// one row of matA / matB (:960-989) of a selected feature, accumulated into the 21 + 6 + 1 sums
+ROLO_DEV void s2m_row(const S2mArgs& A, const float4& po, const float4& coeff, double (&acc)[S2M_NV]) {
+  const float ox = po.y, oy = po.z, oz = po.x;
+  const float kx = coeff.y, ky = coeff.z, kz = coeff.x;
+  const float srx = A.srx, crx = A.crx, sry = A.sry, cry = A.cry, srz = A.srz, crz = A.crz;
+  const float arx = (crx * sry * srz * ox + crx * crz * sry * oy - srx * sry * oz) * kx + (-srx * srz * ox - crz * srx * oy - crx * oz) * ky +
+                    (crx * cry * srz * ox + crx * cry * crz * oy - cry * srx * oz) * kz;
+  const float ary = ((cry * srx * srz - crz * sry) * ox + (sry * srz + cry * crz * srx) * oy + crx * cry * oz) * kx +
+                    ((-cry * crz - srx * sry * srz) * ox + (cry * srz - crz * srx * sry) * oy - crx * sry * oz) * kz;
+  const float arz = ((crz * srx * sry - cry * srz) * ox + (-cry * crz - srx * sry * srz) * oy) * kx + (crx * crz * ox - crx * srz * oy) * ky +
+                    ((sry * srz + cry * crz * srx) * ox + (crz * sry - cry * srx * srz) * oy) * kz;
+  const double row[6] = {arz, arx, ary, kz, kx, ky};
+  const double b = -(double)coeff.w;
+  int t = 0;
+#pragma unroll
+  for (int r = 0; r < 6; r++) {
+#pragma unroll
+    for (int c = 0; c <= r; c++) acc[t++] = row[r] * row[c];
+  }
+#pragma unroll
+  for (int r = 0; r < 6; r++) acc[21 + r] = row[r] * b;
+  acc[27] = 1.0;
+}
+
 __global__ __launch_bounds__(S2M_THREADS) void s2m_kernel(S2mArgs A) {
   __shared__ int stk[S2M_STACK * S2M_THREADS];
   __shared__ double red[S2M_THREADS / 64][S2M_NV];
@@ -264,79 +345,11 @@ __global__ __launch_bounds__(S2M_THREADS) void s2m_kernel(S2mArgs A) {
       float px[5], py[5], pz[5];
 #pragma unroll
       for (int j = 0; j < 5; j++) { const float4 p = M.xyz[bi[j]]; px[j] = p.x; py[j] = p.y; pz[j] = p.z; }
-      if (corner) {   // cornerOptimization :740-820
-        float cx = 0, cy = 0, cz = 0;
-#pragma unroll
-        for (int j = 0; j < 5; j++) { cx += px[j]; cy += py[j]; cz += pz[j]; }
-        cx /= 5; cy /= 5; cz /= 5;
-        float a11 = 0, a12 = 0, a13 = 0, a22 = 0, a23 = 0, a33 = 0;
-#pragma unroll
-        for (int j = 0; j < 5; j++) {
-          const float ax = px[j] - cx, ay = py[j] - cy, az = pz[j] - cz;
-          a11 += ax * ax; a12 += ax * ay; a13 += ax * az; a22 += ay * ay; a23 += ay * az; a33 += az * az;
-        }
-        a11 /= 5; a12 /= 5; a13 /= 5; a22 /= 5; a23 /= 5; a33 /= 5;
-        float A1[9] = {a11, a12, a13, a12, a22, a23, a13, a23, a33}, D[3], V[9];
-        cv_eigen_sym<3>(A1, D, V);
-        if (D[0] > 3 * D[1]) {
-          const float x0 = sx, y0 = sy, z0 = sz;
-          // "float x1 = cx + 0.1 * matV1.at<float>(0, 0)" (:782-788): the literal is a double — the sum is formed in double and narrowed on assignment
-          const float x1 = (float)((double)cx + 0.1 * (double)V[0]), y1 = (float)((double)cy + 0.1 * (double)V[1]), z1 = (float)((double)cz + 0.1 * (double)V[2]);
-          const float x2 = (float)((double)cx - 0.1 * (double)V[0]), y2 = (float)((double)cy - 0.1 * (double)V[1]), z2 = (float)((double)cz - 0.1 * (double)V[2]);
-          const float m1 = (x0 - x1) * (y0 - y2) - (x0 - x2) * (y0 - y1), m2 = (x0 - x1) * (z0 - z2) - (x0 - x2) * (z0 - z1), m3 = (y0 - y1) * (z0 - z2) - (y0 - y2) * (z0 - z1);
-          const float a012 = sqrtf(m1 * m1 + m2 * m2 + m3 * m3);
-          const float l12 = sqrtf((x1 - x2) * (x1 - x2) + (y1 - y2) * (y1 - y2) + (z1 - z2) * (z1 - z2));
-          const float la = ((y1 - y2) * m1 + (z1 - z2) * m2) / a012 / l12;
-          const float lb = -((x1 - x2) * m1 - (z1 - z2) * m3) / a012 / l12;
-          const float lc = -((x1 - x2) * m2 + (y1 - y2) * m3) / a012 / l12;
-          const float ld2 = a012 / l12;
-          const float s = (float)(1.0 - 0.9 * (double)fabsf(ld2));   // "float s = 1 - 0.9 * fabs(ld2)": double literals, narrowed on assignment
-          coeff = make_float4(s * la, s * lb, s * lc, s * ld2);
-          sel = (double)s > 0.1;                                       // "if (s > 0.1)": compared as doubles
-        }
-      } else {        // surfOptimization :845-897
-        float pa, pb, pc, pd = 1.f;
-        plane_colpiv_qr(px, py, pz, pa, pb, pc);
-        {
-          const float ps = sqrtf(pa * pa + pb * pb + pc * pc);
-          pa /= ps; pb /= ps; pc /= ps; pd /= ps;
-          bool planeValid = true;
-#pragma unroll
-          for (int j = 0; j < 5; j++) if ((double)fabsf(pa * px[j] + pb * py[j] + pc * pz[j] + pd) > 0.2) planeValid = false;   // "> 0.2": compared as doubles (a NaN plane is valid here and dies at s > 0.1, as in the reference)
-          if (planeValid) {
-            const float pd2 = pa * sx + pb * sy + pc * sz + pd;
-            // "float s = 1 - 0.9 * fabs(pd2) / sqrt(sqrt(...))": the square roots in float, the rest in double, narrowed on assignment
-            const float s = (float)(1.0 - 0.9 * (double)fabsf(pd2) / (double)sqrtf(sqrtf(po.x * po.x + po.y * po.y + po.z * po.z)));
-            coeff = make_float4(s * pa, s * pb, s * pc, s * pd2);
-            sel = (double)s > 0.1;
-          }
-        }
-      }
+      s2m_fit(corner, sx, sy, sz, po, px, py, pz, sel, coeff);
     }
     if (A.selected) A.selected[i] = sel ? 1 : 0;
     if (A.coeff) A.coeff[i] = sel ? coeff : make_float4(0.f, 0.f, 0.f, 0.f);
-    if (sel) {   // one row of matA / matB (:960-989): lidar -> camera axes
-      const float ox = po.y, oy = po.z, oz = po.x;
-      const float kx = coeff.y, ky = coeff.z, kz = coeff.x;
-      const float srx = A.srx, crx = A.crx, sry = A.sry, cry = A.cry, srz = A.srz, crz = A.crz;
-      const float arx = (crx * sry * srz * ox + crx * crz * sry * oy - srx * sry * oz) * kx + (-srx * srz * ox - crz * srx * oy - crx * oz) * ky +
-                        (crx * cry * srz * ox + crx * cry * crz * oy - cry * srx * oz) * kz;
-      const float ary = ((cry * srx * srz - crz * sry) * ox + (sry * srz + cry * crz * srx) * oy + crx * cry * oz) * kx +
-                        ((-cry * crz - srx * sry * srz) * ox + (cry * srz - crz * srx * sry) * oy - crx * sry * oz) * kz;
-      const float arz = ((crz * srx * sry - cry * srz) * ox + (-cry * crz - srx * sry * srz) * oy) * kx + (crx * crz * ox - crx * srz * oy) * ky +
-                        ((sry * srz + cry * crz * srx) * ox + (crz * sry - cry * srx * srz) * oy) * kz;
-      const double row[6] = {arz, arx, ary, kz, kx, ky};
-      const double b = -(double)coeff.w;
-      int t = 0;
-#pragma unroll
-      for (int r = 0; r < 6; r++) {
-#pragma unroll
-        for (int c = 0; c <= r; c++) acc[t++] = row[r] * row[c];
-      }
-#pragma unroll
-      for (int r = 0; r < 6; r++) acc[21 + r] = row[r] * b;
-      acc[27] = 1.0;
-    }
+    if (sel) s2m_row(A, po, coeff, acc);
   }
   // workgroup sum, fixed order
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -356,12 +369,101 @@ __global__ __launch_bounds__(S2M_THREADS) void s2m_kernel(S2mArgs A) {
   }
 }
 
-__global__ __launch_bounds__(64) void s2m_sum_kernel(const double* __restrict__ partials, int nblocks, double* __restrict__ out) {
-  const int v = threadIdx.x;
-  if (v >= S2M_NV) return;
+// ---- the same with PACKETS (round 4) ------------------------------------------------------------------------------------------------------------
+// The per-lane walk above takes ~1 ms for 48.7 k features against a 252 k-point sub-map: every lane descends the tree on its own, the wavefront executes
+// the union of 64 divergent walks. But the features are a point cloud too: sorted along the same Hilbert curve (a rigid motion keeps neighbours
+// neighbours, so they are sorted once per call, before the first pose), 64 consecutive ones are one blob — one wavefront walks the sub-map's tree ONCE
+// for its 64 queries with the packet walk of the K5 search (knn_packet.hpp: ballot-driven descent, leaves fetched once per wave, packed-key min / max
+// insert, k = 5). Same neighbours in the same (d2, index) order, so everything downstream — fits, flags, rows — is the same floats.
+__global__ __launch_bounds__(256) void s2m_packet_kernel(S2mArgs A, int split /* first block of the surface features */) {
+  __shared__ int stk[4][WALK_STACK];
+  __shared__ double red[4][S2M_NV];
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const bool corner = (int)blockIdx.x < split;   // workgroup-uniform
+  const KnnCloud& Q = A.qry[corner ? 0 : 1];
+  const KnnCloud& M = A.map[corner ? 0 : 1];
+  const int j = ((int)blockIdx.x - (corner ? 0 : split)) * 256 + wv * 64 + lane;
+  double acc[S2M_NV];
+#pragma unroll
+  for (int v = 0; v < S2M_NV; v++) acc[v] = 0.0;
+  float4 qs = make_float4(0.f, 0.f, 0.f, __int_as_float(INT_MAX));
+  if (j < Q.n_sorted) qs = Q.sorted[j];
+  const int qidx = __float_as_int(qs.w);
+  const bool active = qidx != INT_MAX;
+  const float* T = A.T;
+  // pointAssociateToMap :293-299 (float, left to right)
+  const float sx = T[0] * qs.x + T[1] * qs.y + T[2] * qs.z + T[3];
+  const float sy = T[4] * qs.x + T[5] * qs.y + T[6] * qs.z + T[7];
+  const float sz = T[8] * qs.x + T[9] * qs.y + T[10] * qs.z + T[11];
+  const float4 q = make_float4(active ? sx : 0.f, active ? sy : 0.f, active ? sz : 0.f, 0.f);
+  const double sentinel = key_pack(INFINITY, INT_MAX);
+  double K[5] = {sentinel, sentinel, sentinel, sentinel, sentinel};
+  float bd = active ? INFINITY : -1.0f;
+  double bkey = active ? sentinel : key_pack(0.f, 0);
+  {
+    unsigned s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0;
+    int sp = 0, ns = 0, np = 0;
+    const CoopPub none{};
+    packet_walk<5, false, false, false, false>(M.sorted, M.boxes, M.P, 0, 0, q, K, 5, bkey, bd, 0.0, 0.0, (lds_int*)&stk[wv][0], sp, 1, none, ns, np, s0, s1, s2, s3, s4, s5);
+  }
+  bool sel = false;
+  float4 coeff = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int gi = (corner ? 0 : A.n_corner) + qidx;   // position in the caller's order
+  if (active) {
+    float bdv[5]; int bi[5];
+#pragma unroll
+    for (int u = 0; u < 5; u++) { bdv[u] = key_d2(K[u]); bi[u] = key_idx(K[u]); }
+    const float4 po = qs;
+    if (bi[4] != INT_MAX && bdv[4] < 1.0f) {
+      float px[5], py[5], pz[5];
+#pragma unroll
+      for (int u = 0; u < 5; u++) { const float4 p = M.xyz[bi[u]]; px[u] = p.x; py[u] = p.y; pz[u] = p.z; }
+      s2m_fit(corner, sx, sy, sz, po, px, py, pz, sel, coeff);
+    }
+    if (A.selected) A.selected[gi] = sel ? 1 : 0;
+    if (A.coeff) A.coeff[gi] = sel ? coeff : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (sel) s2m_row(A, po, coeff, acc);
+  }
+  // workgroup sum, fixed order
+#pragma unroll
+  for (int v = 0; v < S2M_NV; v++) {
+    double x = acc[v];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
+    if (lane == 0) red[wv][v] = x;
+  }
+  __syncthreads();
+  if (threadIdx.x < S2M_NV) {
+    double s = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) s += red[w][threadIdx.x];
+    A.partials[(size_t)blockIdx.x * S2M_NV + threadIdx.x] = s;
+  }
+}
+
+// the rows of the workgroups summed in a fixed order (deterministic for a given grid): 8 strided groups of 32 lanes with eight loads in flight each, then
+// the groups in order; the 28 sums go straight to pinned host memory (one wait per iteration, no copy launch)
+__global__ __launch_bounds__(256) void s2m_sum_kernel(const double* __restrict__ partials, int nblocks, double* __restrict__ out) {
+  __shared__ double part[8][32];
+  const int v = threadIdx.x & 31, q = threadIdx.x >> 5;
   double s = 0;
-  for (int b = 0; b < nblocks; b++) s += partials[(size_t)b * S2M_NV + v];
-  out[v] = s;
+  if (v < S2M_NV) {
+    for (int b0 = q; b0 < nblocks; b0 += 64) {
+      double r[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) { const int b = b0 + 8 * u; const double x = partials[(size_t)min(b, nblocks - 1) * S2M_NV + v]; r[u] = b < nblocks ? x : 0.0; }
+#pragma unroll
+      for (int u = 0; u < 8; u++) s += r[u];
+    }
+  }
+  part[q][v] = s;
+  __syncthreads();
+  if (threadIdx.x < S2M_NV) {
+    double t = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) t += part[k][threadIdx.x];
+    out[threadIdx.x] = t;
+  }
 }
 
 // ---- host side: float linear algebra of LMOptimization ------------------------------------------------------------------------
@@ -416,13 +518,19 @@ namespace rolo {
 void** ctx_s2m_slot(rolo_ctx* c);   // api.hip
 struct S2mScratch { float4* feat = nullptr; double *part = nullptr, *sum = nullptr; unsigned char* sel = nullptr; float4* coeff = nullptr;
                     size_t feat_cap = 0, part_cap = 0, sum_cap = 0, sel_cap = 0, coeff_cap = 0;
-                    KnnPair maps{}; int m_corner = 0, m_surf = 0; bool have_maps = false; };   // the resident sub-map (rolo_scan2map_set_submap): trees of the context's two clouds
+                    KnnPair maps{}; int m_corner = 0, m_surf = 0; bool have_maps = false;   // the resident sub-map (rolo_scan2map_set_submap): trees of the context's two clouds
+                    rolo_ctx* qctx = nullptr; hipEvent_t qev = nullptr;
+                    double* h_sum = nullptr; };   // pinned: the 28 sums of an iteration, written by s2m_sum_kernel itself   // helper context (from the pool): the scan's features sorted along the curve, its two clouds
 }  // namespace rolo
 extern "C" void rolo_s2m_destroy(rolo_ctx* c) {   // called by rolo_ctx_destroy
   S2mScratch* W = static_cast<S2mScratch*>(*ctx_s2m_slot(c));
   if (!W) return;
   for (void* p : {(void*)W->feat, (void*)W->part, (void*)W->sum, (void*)W->sel, (void*)W->coeff}) if (p) (void)hipFree(p);
+  if (W->qev) (void)hipEventDestroy(W->qev);
+  if (W->h_sum) (void)hipHostFree(W->h_sum);
+  rolo_ctx* q = W->qctx;
   delete W; *ctx_s2m_slot(c) = nullptr;
+  if (q) rolo_ctx_release(q);
 }
 
 // kdtreeCornerFromMap->setInputCloud(laserCloudCornerFromMapDS) / kdtreeSurfFromMap->setInputCloud(laserCloudSurfFromMapDS) (:690-691) as a call of its own: the
@@ -464,7 +572,21 @@ extern "C" int rolo_scan2map_optimize(rolo_ctx* c, const float* corner, int n_co
   const KnnPair maps = static_cast<S2mScratch*>(*ctx_s2m_slot(c))->maps;
   hipStream_t s = ctx_stream(c);
   const int n = n_corner + n_surf;
-  const int grid = (n + S2M_THREADS - 1) / S2M_THREADS;
+  // ROLO_S2M_PACKETS=0: one tree walk per lane in the caller's order (rounds 2-3, the A/B); default: the features sorted along the curve once per call,
+  // 64 consecutive ones walk the sub-map's tree as one packet (s2m_packet_kernel)
+  static const bool use_packets = [] { const char* e = getenv("ROLO_S2M_PACKETS"); return !(e && atoi(e) == 0); }();
+  KnnPair qp{};
+  int grid = (n + S2M_THREADS - 1) / S2M_THREADS, split = 0;
+  if (use_packets) {
+    S2mScratch* Wq = static_cast<S2mScratch*>(*ctx_s2m_slot(c));
+    if (!Wq->qctx) { if (rolo_ctx_acquire(ctx_device(c), &Wq->qctx) != ROLO_OK) return ROLO_EHIP; SCHK(hipEventCreateWithFlags(&Wq->qev, hipEventDisableTiming)); }
+    const int rq = ctx_build_map_trees(Wq->qctx, corner, n_corner, surf, n_surf, 4, &qp);   // upload + Hilbert sort (+ a tree nobody walks) on the helper's stream
+    if (rq) return rq;
+    SCHK(hipEventRecord(Wq->qev, ctx_stream(Wq->qctx)));
+    SCHK(hipStreamWaitEvent(s, Wq->qev, 0));
+    split = (qp.c[0].n_sorted + 255) / 256;
+    grid = split + (qp.c[1].n_sorted + 255) / 256;
+  }
   // scratch lives with the context and only grows: hipFree is a device-wide synchronisation that would stall the frames other contexts have in flight
   S2mScratch* W = static_cast<S2mScratch*>(*ctx_s2m_slot(c));
   if (!W) { W = new S2mScratch(); *ctx_s2m_slot(c) = W; }
@@ -478,16 +600,19 @@ extern "C" int rolo_scan2map_optimize(rolo_ctx* c, const float* corner, int n_co
   if (!grow((void**)&W->feat, W->feat_cap, sizeof(float4) * (size_t)n) || !grow((void**)&W->part, W->part_cap, sizeof(double) * S2M_NV * (size_t)grid) ||
       !grow((void**)&W->sum, W->sum_cap, sizeof(double) * S2M_NV) || (selected_out && !grow((void**)&W->sel, W->sel_cap, (size_t)n)) ||
       (coeff_out && !grow((void**)&W->coeff, W->coeff_cap, sizeof(float4) * (size_t)n))) { ctx_set_error("hipMalloc failed (scan2map)"); return ROLO_EHIP; }
-  float4* d_feat = W->feat; double *d_part = W->part, *d_sum = W->sum; unsigned char* d_sel = selected_out ? W->sel : nullptr; float4* d_coeff = coeff_out ? W->coeff : nullptr;
+  float4* d_feat = W->feat; double* d_part = W->part; unsigned char* d_sel = selected_out ? W->sel : nullptr; float4* d_coeff = coeff_out ? W->coeff : nullptr;
   auto cleanup = [&]() {};
-  if (hipMemcpyAsync(d_feat, corner, sizeof(float4) * (size_t)n_corner, hipMemcpyHostToDevice, s) != hipSuccess ||
-      hipMemcpyAsync(d_feat + n_corner, surf, sizeof(float4) * (size_t)n_surf, hipMemcpyHostToDevice, s) != hipSuccess) { cleanup(); ctx_set_error("upload failed (scan2map)"); return ROLO_EHIP; }
+  if (!use_packets &&   // (the packet kernel reads the features from the helper context's sorted clouds)
+      (hipMemcpyAsync(d_feat, corner, sizeof(float4) * (size_t)n_corner, hipMemcpyHostToDevice, s) != hipSuccess ||
+       hipMemcpyAsync(d_feat + n_corner, surf, sizeof(float4) * (size_t)n_surf, hipMemcpyHostToDevice, s) != hipSuccess)) { cleanup(); ctx_set_error("upload failed (scan2map)"); return ROLO_EHIP; }
   S2mArgs A{};
   A.feat = d_feat; A.n_corner = n_corner; A.n_surf = n_surf; A.map[0] = maps.c[0]; A.map[1] = maps.c[1]; A.partials = d_part; A.selected = d_sel; A.coeff = d_coeff;
+  A.qry[0] = qp.c[0]; A.qry[1] = qp.c[1];
   float* tf = transformTobeMapped;
   bool isDegenerate = false;
   float matP[36]; for (int i = 0; i < 36; i++) matP[i] = (i % 7 == 0) ? 1.f : 0.f;
-  double h_sum[S2M_NV];
+  if (!W->h_sum) SCHK(hipHostMalloc((void**)&W->h_sum, sizeof(double) * S2M_NV));
+  double* h_sum = W->h_sum;
   for (int iterCount = 0; iterCount < 30; iterCount++) {
     // trans2Affine3f :339-342 = pcl::getTransformation(x, y, z, roll, pitch, yaw), float
     {
@@ -498,11 +623,12 @@ extern "C" int rolo_scan2map_optimize(rolo_ctx* c, const float* corner, int n_co
       A.T[8] = -Dx; A.T[9] = Cx * Fx; A.T[10] = Cx * Ex; A.T[11] = tf[5];
     }
     A.srx = std::sin(tf[1]); A.crx = std::cos(tf[1]); A.sry = std::sin(tf[2]); A.cry = std::cos(tf[2]); A.srz = std::sin(tf[0]); A.crz = std::cos(tf[0]);
-    s2m_kernel<<<grid, S2M_THREADS, 0, s>>>(A);
+    if (use_packets) s2m_packet_kernel<<<grid, 256, 0, s>>>(A, split);
+    else s2m_kernel<<<grid, S2M_THREADS, 0, s>>>(A);
     SCHK(hipGetLastError());
-    s2m_sum_kernel<<<1, 64, 0, s>>>(d_part, grid, d_sum);
+    s2m_sum_kernel<<<1, 256, 0, s>>>(d_part, grid, h_sum);
     SCHK(hipGetLastError());
-    if (hipMemcpyAsync(h_sum, d_sum, sizeof(h_sum), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { cleanup(); ctx_set_error("scan2map iteration failed"); return ROLO_EHIP; }
+    if (hipStreamSynchronize(s) != hipSuccess) { cleanup(); ctx_set_error("scan2map iteration failed"); return ROLO_EHIP; }
     st.iterations = iterCount + 1;
     st.n_selected = (int)(h_sum[27] + 0.5);
     if (st.n_selected < 50) break;   // LMOptimization returns false without touching the pose: the remaining iterations would repeat this one
