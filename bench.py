@@ -658,22 +658,23 @@ def main():
     # 104 B/pt per FUSED pass launch (a launch evaluates the trial cost and the next linearisation in one sweep over the same
     # records, so it is priced once, as DESIGN.md §4 and `roofline` do) x scans/s.
     # measured: the PMC-summed fabric traffic of one frame ((2 FETCH_SIZE + WRITE_SIZE) KB over every kernel of a single-context
-    # eager frame, profiles/pmc_traffic.json) x scans/s — "rocprof-reported achieved HBM GB/s".
+    # eager frame, the newest profiles/rNN/pmc_traffic.json) x scans/s — "rocprof-reported achieved HBM GB/s".
     try:
         from rolo_amd._lib import lib as _rl
         V = max(int(_rl().rolo_num_voxels(g._h)), 0)
         frame_bytes = 360.0 * 2 * n + 136.0 * n + 96.0 * V + 104.0 * n * passes
         fh = {"algorithmic_bytes_per_frame": frame_bytes, "achieved": frame_bytes * value / 1e9, "peak": HBM_PEAK_GBS * world,
               "unit": "GB/s", "frac": frame_bytes * value / 1e9 / (HBM_PEAK_GBS * world), "voxels": V, "fused_pass_launches": passes}
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc) and args.sensor == "os1-128":
+        from rolo_amd.profile import pmc_traffic_file
+        pmc, pmc_desc = pmc_traffic_file()
+        if pmc and os.path.exists(pmc) and args.sensor == "os1-128":
             tr = json.load(open(pmc))
             nfr = max(tr.get("knn_walk_kernel", {}).get("launches", 0), 1)
             # (the 1 GiB device-to-device copies of this script's own HBM copy test show up as __amd_rocclr_copyBuffer: not part of a frame)
             fabric = sum(v["hbm_bytes_per_launch"] * v["launches"] for k, v in tr.items()
                          if isinstance(v, dict) and "launches" in v and not k.startswith("__amd_rocclr_copyBuffer")) / nfr
             fh.update({"fabric_bytes_per_frame": fabric, "achieved_fabric_GBps": fabric * value / 1e9, "frac_fabric": fabric * value / 1e9 / (HBM_PEAK_GBS * world),
-                       "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of a single-context eager run, not this run)"})
+                       "traffic_source": pmc_desc})
         out["frame_hbm"] = fh
     except Exception as e:  # pragma: no cover
         out["frame_hbm"] = {"error": repr(e)}

@@ -26,6 +26,22 @@ BYTES_PER_POINT = {"knn_walk": 336.0, "knn_tail": 24.0, "knn_build": 32.0, "voxe
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def pmc_traffic_file():
+    """(path, description) of the newest committed PMC summary, profiles/rNN/pmc_traffic.json — the file the `traffic` figures are cited from; it carries the
+    commit it was collected at. (Until round 3 this was a root profiles/pmc_traffic.json that went stale.)"""
+    import glob
+    c = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]", "pmc_traffic.json")))
+    if not c:
+        return None, None
+    path = c[-1]
+    try:
+        meta = json.load(open(path)).get("_collected", {})
+    except Exception:
+        meta = {}
+    rel = os.path.relpath(path, ROOT)
+    return path, f"{rel} (collected at commit {meta.get('commit', '?')}: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of a single-context eager run, (2 FETCH + WRITE) KB; not measured in this run)"
+
+
 def read_slot(g, name, cap=4096):
     buf = (C.c_float * cap)()
     n = check(lib().rolo_prof_read(g._h, SLOTS[name], buf, cap), "rolo_prof_read")
@@ -91,8 +107,8 @@ def roofline(g, run_one_step, n_src, n_tgt, passes_per_frame, hbm_peak_gbs, reps
     algo_bytes = BYTES_PER_POINT[dom] * npts
     achieved = algo_bytes / (avg_ms[dom] * 1e-3) / 1e9 if avg_ms[dom] > 0 else 0.0
     traffic = None
-    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(pmc):
+    pmc, pmc_desc = pmc_traffic_file()
+    if pmc and os.path.exists(pmc):
         try:
             traffic = json.load(open(pmc)).get(dom + "_kernel", {}).get("hbm_bytes_per_launch")
         except Exception:
@@ -101,5 +117,5 @@ def roofline(g, run_one_step, n_src, n_tgt, passes_per_frame, hbm_peak_gbs, reps
     per_step_ms = [float(r.mean()) for r in real_runs.get(dom, []) if len(r)]
     return {"bound": "hbm", "kernel": dom + "_kernel", "achieved": achieved, "peak": hbm_peak_gbs, "unit": "GB/s",
             "frac": achieved / hbm_peak_gbs, "traffic": traffic, "avg_launch_ms_per_profiled_step": per_step_ms,
-            "traffic_source": "profiles/pmc_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, (2 FETCH + WRITE) KB; not measured in this run)",
+            "traffic_source": pmc_desc,
             "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": avg_ms[dom], "top3": top3, "per_frame_ms": per_frame_ms, "avg_ms": avg_ms}

@@ -10,6 +10,7 @@
 #include <mutex>
 
 #include <nav_msgs/Path.h>
+#include <std_msgs/Float64MultiArray.h>
 #include <tf/transform_broadcaster.h>
 
 #include "rolo_ros_convert.hpp"
@@ -25,6 +26,7 @@ public:
     pubLidarPose = nh.advertise<geometry_msgs::PoseStamped>(P.odomTopic + "_incremental/pose", 2000);
     pubLaserPath = nh.advertise<nav_msgs::Path>(P.odomTopic + "_incremental/path", 2000);
     pubRegScan = nh.advertise<sensor_msgs::PointCloud2>(P.odomTopic + "/registration_scan", 10);
+    pubPlotData = nh.advertise<std_msgs::Float64MultiArray>("rolo/data_test", 10);   // :405: advertised, never published by the reference either — part of the node's graph
   }
   void odometryHandler(const nav_msgs::OdometryConstPtr& mappedOdom) {
     std::lock_guard<std::mutex> lock(mtx);
@@ -66,7 +68,7 @@ private:
   std::mutex mtx;
   nav_msgs::Path laser_odom_path;
   ros::Subscriber subOdometryMapped, subCloudInfo;
-  ros::Publisher pubFrontCloudInfo, pubLidarOdometry, pubLidarPose, pubLaserPath, pubRegScan;
+  ros::Publisher pubFrontCloudInfo, pubLidarOdometry, pubLidarPose, pubLaserPath, pubRegScan, pubPlotData;
 };
 
 int main(int argc, char** argv) {

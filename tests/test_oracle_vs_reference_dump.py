@@ -70,3 +70,26 @@ def test_oracle_matches_the_reference_stage_by_stage(case):
     assert np.arccos(np.clip((np.trace(dR) - 1) / 2, -1, 1)) <= 1e-5
     rc2, t, _ = o2.compute_translation(np.zeros(3), z["t_guess"], z["t_last"])
     assert rc2 == 0 and np.abs(t - r["trans_final"]).max() <= 1e-4
+
+
+def test_dump_tool_io_half_round_trips(tmp_path):
+    """tools/dump_reference_golden.cpp cannot be built here (it includes the reference's own headers, which need Eigen + PCL), but the half of it that needs
+    nothing of the reference can: the raw-array reader, the parameter file and the .npy writer (-DDUMP_IO_SELFTEST). The inputs come from the recipe's own
+    exporter (tools/export_golden_inputs.py), numpy reads back what the tool wrote."""
+    import subprocess
+    import sys
+    exe = str(tmp_path / "dump_io_selftest")
+    r = subprocess.run(["g++", "-std=c++14", "-O1", "-Wall", "-Werror", "-DDUMP_IO_SELFTEST", os.path.join(ROOT, "tools", "dump_reference_golden.cpp"), "-o", exe],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    case = "vlp16_polar"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "export_golden_inputs.py"), case, "--out", str(tmp_path / "inputs")], capture_output=True, text=True, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    ind = tmp_path / "inputs" / case
+    r = subprocess.run([exe, str(ind)], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.startswith("ok"), r.stdout + r.stderr
+    z = np.load(os.path.join(ROOT, "tests", "golden", case + ".npz"))
+    assert np.array_equal(np.load(ind / "echo_source.npy"), np.asarray(z["source"], np.float32).reshape(-1, 4))
+    T = np.load(ind / "echo_T.npy")
+    assert T.shape == (4, 4) and T.dtype == np.float64 and np.array_equal(T, np.fromfile(ind / "T_probe.f64", np.float64).reshape(4, 4))
+    assert np.load(ind / "echo_ints.npy").tolist()[1:] == [7, -3] and np.load(ind / "echo_scalar.npy").shape == (1,)

@@ -19,7 +19,7 @@
 //   align_T(_f), align_iters, align_converged     pcl::Registration::align -> computeTransformation (lsq_registration_impl.hpp:152-179)
 //   trans_final                 computeTranslation               :55-80
 //
-//   g++ -O3 -DNDEBUG -std=c++14 -fopenmp -I<ROLO>/include $(pkg-config --cflags eigen3 pcl_registration-1.10) \
+//   g++ -O3 -DNDEBUG -std=c++14 -fopenmp -I<ROLO>/include $(pkg-config --cflags eigen3 pcl_registration-1.10) [line continues]
 //       tools/dump_reference_golden.cpp <ROLO>/src/rot_gicp/gicp/*.cpp -o dump_reference_golden $(pkg-config --libs pcl_registration-1.10 pcl_search-1.10 pcl_kdtree-1.10) -lflann_cpp
 //   ./dump_reference_golden <inputs_dir> <outputs_dir>
 #include <cstdint>
@@ -31,6 +31,10 @@
 #include <string>
 #include <vector>
 
+// -DDUMP_IO_SELFTEST: only the half that needs nothing of the reference — the raw-array reader, the .npy writer, the parameter file — with a main that
+// round-trips them (tests/test_oracle_vs_reference_dump.py builds and runs it in this repository's image, numpy reads the files back: a typo or a broken
+// .npy header there would otherwise greet the first maintainer who runs the recipe). The other half cannot be compiled without Eigen / PCL.
+#ifndef DUMP_IO_SELFTEST
 #include <pcl/point_cloud.h>
 #include <pcl/point_types.h>
 
@@ -40,6 +44,7 @@
 
 using PointT = pcl::PointXYZI;
 using Base = fast_gicp::RotVGICP<PointT, PointT>;
+#endif
 
 // ---- minimal I/O: raw arrays in, .npy (format 1.0) out ----------------------------------------------------------------------------------
 template <typename T> static std::vector<T> read_raw(const std::string& path) {
@@ -75,6 +80,21 @@ static std::map<std::string, double> read_params(const std::string& path) {
   while (f >> k >> v) m[k] = v;
   return m;
 }
+#ifdef DUMP_IO_SELFTEST
+int main(int argc, char** argv) {
+  if (argc != 2) { std::fprintf(stderr, "usage: dump_io_selftest <dir>\n"); return 1; }
+  const std::string d = std::string(argv[1]) + "/";
+  auto P = read_params(d + "params.txt");
+  const std::vector<float> a = read_raw<float>(d + "source.f32");
+  const std::vector<double> t = read_raw<double>(d + "T_probe.f64");
+  write_npy(d + "echo_source.npy", a, {a.size() / 4, 4});
+  write_npy(d + "echo_T.npy", t, {4, 4});
+  write_npy(d + "echo_scalar.npy", std::vector<double>{P["ct_lambda"] + P["leaf"]}, {1});
+  write_npy(d + "echo_ints.npy", std::vector<int32_t>{(int32_t)P["voxel_type"], 7, -3}, {3});
+  std::printf("ok %zu %zu\n", a.size(), t.size());
+  return 0;
+}
+#else
 static pcl::PointCloud<PointT>::Ptr to_cloud(const std::vector<float>& a) {
   pcl::PointCloud<PointT>::Ptr c(new pcl::PointCloud<PointT>);
   c->resize(a.size() / 4);
@@ -185,3 +205,4 @@ int main(int argc, char** argv) {
   std::printf("wrote the reference's per-stage fields for %zu + %zu points to %s\n", ns, nt, out.c_str());
   return 0;
 }
+#endif   // DUMP_IO_SELFTEST
