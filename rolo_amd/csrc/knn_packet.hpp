@@ -119,7 +119,7 @@ ROLO_DEV void knn_score_leaf(const float4* __restrict__ sorted, int g, const flo
   for (int u = 0; u < KNN_LEAF; u++) {
     const float4 c = pts[u];
     const float dx = q.x - c.x, dy = q.y - c.y, dz = q.z - c.z;
-    const float cd = ((dx * dx) + (dy * dy)) + (dz * dz);  // file is compiled with -ffp-contract=off
+    const float cd = ((dx * dx) + (dy * dy)) + (dz * dz);  // file is compiled with -ffp-contract=off (the compiler already pairs x and y into v_pk_add_f32 / v_pk_mul_f32)
     const double ck0 = key_pack(cd, __float_as_int(c.w));
     const double ck = (LOWER && !(ck0 > lo)) ? key_pack(INFINITY, INT_MAX) : ck0;   // LOWER: a point of an earlier round's 64 is no candidate
     KNN_STAT(if (__any(ck < bkey)) { n_ins++; lane_acc += (unsigned)__popcll(__ballot(ck < bkey)); })

@@ -6,21 +6,7 @@
 
 namespace rolo {
 
-// vmp_voxel.hpp:199-201 (UNIFORM) and :208-211 (POLAR), fp64, true divisions as written in the reference.
-ROLO_DEV void voxel_coord_dev(const VoxelTable& tab, double x, double y, double z, int& kx, int& ky, int& kz) {
-  if (tab.voxel_type == ROLO_VOXEL_POLAR) {
-    const double r = sqrt((x * x + y * y) + z * z);
-    kx = (int)floor((atan2(y, x) + 3.14159265358979323846) / tab.polar_res[0]);
-    ky = (int)floor(acos(z / r) / tab.polar_res[1]);
-    kz = (int)floor(r / tab.polar_res[2]);
-  } else {
-    kx = (int)floor(x / tab.voxel_resolution - 0.5);
-    ky = (int)floor(y / tab.voxel_resolution - 0.5);
-    kz = (int)floor(z / tab.voxel_resolution - 0.5);
-  }
-}
-
-// The same for the TARGET's keys (map build, rolo_get_target_voxel_keys), where the integer key must be the reference's, bit for bit: device atan2 / acos
+// vmp_voxel.hpp:199-201 (UNIFORM) and :208-211 (POLAR), fp64, true divisions as written in the reference. The integer key must be the reference's, bit for bit: device atan2 / acos
 // differ from a host libm by ulps, which can move a key only for a point whose quotient lies within ~1e-14 of an integer. Such points (within 1e-12 bins of
 // an edge: near_edge, counted in rolo_num_edge_points) are RE-KEYED with the correctly rounded atan2 / acos of polar_exact.hpp — the value a correctly
 // rounded libm returns by definition — followed by the reference's own fp64 sum, quotient and floor ("flag ... and resolve those (few)";
@@ -30,7 +16,7 @@ ROLO_DEV void voxel_coord_dev_edge(const VoxelTable& tab, double x, double y, do
   near_edge = false;
   const bool exact = tab.polar_exact != 0;
   if (tab.voxel_type == ROLO_VOXEL_POLAR) {
-    const double r = sqrt((x * x + y * y) + z * z);
+    const double r = sqrt(__dadd_rn(__dadd_rn(__dmul_rn(x, x), __dmul_rn(y, y)), __dmul_rn(z, z)));   // x.head<3>().norm(): no FMA contraction (the pass kernels hand in transformed, non-float coordinates)
     const double a = (atan2(y, x) + 3.14159265358979323846) / tab.polar_res[0], b = acos(z / r) / tab.polar_res[1], c = r / tab.polar_res[2];
     const double fa = floor(a), fb = floor(b), fc = floor(c);
     kx = (int)fa; ky = (int)fb; kz = (int)fc;
@@ -44,6 +30,13 @@ ROLO_DEV void voxel_coord_dev_edge(const VoxelTable& tab, double x, double y, do
     ky = (int)floor(y / tab.voxel_resolution - 0.5);
     kz = (int)floor(z / tab.voxel_resolution - 0.5);
   }
+}
+
+// vmp_voxel.hpp:199-201 (UNIFORM) and :208-211 (POLAR) for the pass kernels' correspondence lookup of a transformed source point (rot_vgicp_impl.hpp:184-186): the same
+// keys as the map build's, edge points through the correctly rounded functions too (round 4; a rare divergent branch: rot_pass_kernel stays at its register budget)
+ROLO_DEV void voxel_coord_dev(const VoxelTable& tab, double x, double y, double z, int& kx, int& ky, int& kz) {
+  bool near_edge;
+  voxel_coord_dev_edge(tab, x, y, z, kx, ky, kz, near_edge);
 }
 
 ROLO_DEV bool pack_key(int kx, int ky, int kz, unsigned long long& key) {

@@ -78,3 +78,22 @@ def test_scan2map_matches_twin_and_recovers_the_pose(sensor, cfg):
     tf_s = g.scan2MapOptimization(corner[:5], surf, mc, ms, guess)
     assert g.last_stats.skipped == 1 and np.array_equal(tf_s, guess)
     g.close()
+
+
+def test_resident_submap_call_order():
+    """rolo_scan2map_optimize(..., NULL, 0, NULL, 0, ...) needs a preceding rolo_scan2map_set_submap (ROLO_ESTATE otherwise); a sub-map without five points in one
+    of its clouds cannot answer a 5-NN query: skipped = 2, the pose untouched"""
+    from rolo_amd._lib import RoloError
+    corner, surf = features("vlp16", dict(n_scan=16, horizon_scan=1800), np.eye(3), np.zeros(3), synth.SEED)
+    guess = np.zeros(6, np.float32)
+    g = Scan2Map()
+    with pytest.raises(RoloError) as ei:
+        g.scan2MapOptimization(corner, surf, None, None, guess)
+    assert ei.value.code == -5
+    g.setSubmap(corner[:3], surf)
+    tf = g.scan2MapOptimization(corner, surf, None, None, guess)
+    assert g.last_stats.skipped == 2 and np.array_equal(tf, guess)
+    g.setSubmap(corner, surf)
+    tf = g.scan2MapOptimization(corner, surf, None, None, guess)    # the scan against itself: already aligned
+    assert g.last_stats.skipped == 0 and g.last_stats.iterations >= 1 and np.abs(tf).max() < 1e-3, (g.last_stats.n_selected, g.last_stats.converged)
+    g.close()

@@ -487,3 +487,13 @@ def test_peer_exchange_distinct_frames_with_captures_out_of_step(tmp_path):
         assert np.array_equal(got[:, 19], w[:, 19])                     # every frame's exchanged covariances are THAT frame's, bit for bit
         assert np.abs(got[:, :19] - w[:, :19]).max() < 1e-9
     assert np.array_equal(res[0][:-2], res[1][:-2])
+
+
+def test_peer_selftest_needs_a_connection():
+    from rolo_amd.rotvgicp import RotVGICP
+    from rolo_amd._lib import RoloError
+    g = RotVGICP(0)
+    with pytest.raises(RoloError) as ei:
+        g.peer_selftest(2)
+    assert ei.value.code == -5 and "not connected" in str(ei.value)
+    g.close()

@@ -969,7 +969,10 @@ def _edge_keys_main():
     d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "polar_edge_points.npz"))
     g = RotVGICP(); g.setPolarResolution(0.175, 0.175, 2.0)
     g.setInputTarget(d["points"]); g.setInputSource(d["points"])
-    print("EDGEDIFF", int((g.targetVoxelKeys() != d["keys"]).any(axis=1).sum()))
+    wrong = int((g.targetVoxelKeys() != d["keys"]).any(axis=1).sum())
+    g.so3_linearize(np.eye(4))
+    found, keys = g.correspondences()
+    print("EDGEDIFF", wrong, "LOOKUPMISS", int((~found[:, 0].astype(bool)).sum()))
 
 
 def test_polar_keys_at_planted_bin_edges():
@@ -997,7 +1000,17 @@ def test_polar_keys_at_planted_bin_edges():
     ko, co, _, _ = o.voxels()
     og, oo = np.lexsort(kg.T[::-1]), np.lexsort(ko.T[::-1])
     assert np.array_equal(kg[og], ko[oo]) and np.array_equal(cg[og], co[oo])   # the same voxels with the same point counts
+    # the pass kernels' LOOKUP of a (transformed) source point goes through the same re-keying: with the planted points as the source at the identity pose
+    # every one of them must find the voxel it was filed under as a target point, and the correspondence list equals the oracle's
+    g.setInputSource(pts); o.set_source(pts)
+    assert o.compute_covariances() == 0
+    g.so3_linearize(np.eye(4)); o.so3_linearize(np.eye(4))
+    found, keys = g.correspondences()
+    s_o, v_o = o.correspondences()
+    assert found[:, 0].all() and np.array_equal(keys[:, 0], d["keys"])
+    order = np.argsort(s_o, kind="stable")
+    assert np.array_equal(np.nonzero(found[:, 0])[0], np.sort(s_o)) and np.array_equal(keys[s_o[order], 0], ko[v_o[order]])
     r = subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, %r); from tests.test_gpu_registration import _edge_keys_main; _edge_keys_main()" % root],
                        env=dict(os.environ, ROLO_POLAR_EXACT="0"), capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-1500:]
-    print("keys the fast device atan2 / acos alone get wrong among the planted points:", r.stdout.strip().split("EDGEDIFF")[-1].strip())
+    print("fast device atan2 / acos alone among the planted points (wrong keys, then lookups that miss their own voxel):", r.stdout.strip().split("EDGEDIFF")[-1].strip())
