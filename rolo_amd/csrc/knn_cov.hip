@@ -703,6 +703,10 @@ extern "C" int rolo_debug_wave_records(unsigned* out /* 16384 x 8 */) {
 
 static inline int slice_blocks(const KnnCloud& c) { return (c.q_end - c.q_begin + 255) / 256; }
 
+// the 4-lanes-per-query walk up to this many 64-query packets in the launch (measured, rocprofv3: one ~48.7 k-point feature cloud = 761 packets 0.138 -> 0.064 ms;
+// the pipeline's source + target launch = 1522 packets: raw frame -> pose 0.489 -> 0.440 ms. Above: 2 x 65 536 points = 2048 packets, four contexts (config 5)
+// 4403 -> 4091 scans/s with it, 2 x 131 072 = 4096 packets 2931 -> 2525: there the inserts bound the walk and its 100 VGPRs crowd the other contexts' kernels)
+constexpr int KNN_SUB_MAX_PACKETS = 1536;
 hipError_t launch_knn_walk(const KnnPair& A, int k, int regularization_or_minus1, const VoxelFuse& vf, hipStream_t s, int coop_budget) {
   constexpr int QPB = 256;   // queries per workgroup of the plain walk: four wavefronts of 64
   const int n0 = A.c[0].q_end - A.c[0].q_begin, n1 = A.n_clouds > 1 ? A.c[1].q_end - A.c[1].q_begin : 0;
@@ -735,7 +739,15 @@ hipError_t launch_knn_walk(const KnnPair& A, int k, int regularization_or_minus1
       else if (nw == 8) knn_walk_coop_kernel<8><<<G, 512, 0, s>>>(A, g0, G4, coop_budget);
       else knn_walk_coop_kernel<4><<<G, 256, 0, s>>>(A, g0, G4, coop_budget);
     }
-    else knn_walk_kernel<20, false><<<g0 + g1, 256, pad, s>>>(A, g0, k, -1);
+    else {
+      // small clouds: 16 queries x 4 lanes per wavefront (knn_walk_sub_kernel) — below ~2 packets of 64 per SIMD the walk is a chain of fetches, not
+      // inserts. ROLO_KNN_SUB = 0 never / 1 always / unset: by size
+      static const int sub_env = [] { const char* e = getenv("ROLO_KNN_SUB"); return e ? atoi(e) : -1; }();
+      const int packets = (n0 + 63) / 64 + (n1 + 63) / 64;
+      const bool use_sub = sub_env < 0 ? packets <= KNN_SUB_MAX_PACKETS : sub_env != 0;
+      if (use_sub) { const int s0 = (n0 + 63) / 64, s1 = (n1 + 63) / 64; knn_walk_sub_kernel<<<s0 + s1, 256, 0, s>>>(A, s0); }
+      else knn_walk_kernel<20, false><<<g0 + g1, 256, pad, s>>>(A, g0, k, -1);
+    }
   }
   else {
     if (k > 32) {   // up to 64 neighbours: 128 key registers per lane — correct, not tuned (the reference accepts any k; its default is 20)

@@ -37,10 +37,38 @@ ROLO_DEV double vmax_f64(double a, double b) { double r; asm("v_max_f64 %0, %1, 
 // one slot of the sorted insert, K[s] = max(K[s-1], min(c, K[s])), as ONE asm statement: between two statements the compiler puts an s_nop for the
 // read-after-write it cannot see into (20 per full insert); inside one statement the hardware interlock does the same job without the slot
 #ifndef ROLO_KNN_SPLIT_MINMAX
-ROLO_DEV void insert_slot(double& ks, double ksm1, double c) { asm("v_min_f64 %0, %1, %0\n\tv_max_f64 %0, %2, %0" : "+v"(ks) : "v"(c), "v"(ksm1)); }
+// ("+&v": the first instruction writes %0 before the second reads %2 — without the early-clobber mark the compiler may give K[s-1] the register of K[s]
+// whenever it knows the two hold the same value, e.g. two sentinels of a fresh list: seen in knn_walk_sub_kernel as lists full of repeated keys)
+ROLO_DEV void insert_slot(double& ks, double ksm1, double c) { asm("v_min_f64 %0, %1, %0\n\tv_max_f64 %0, %2, %0" : "+&v"(ks) : "v"(c), "v"(ksm1)); }
 #else
 ROLO_DEV void insert_slot(double& ks, double ksm1, double c) { ks = vmax_f64(ksm1, vmin_f64(c, ks)); }
 #endif
+// sorted insert of ck into the ascending K[0 .. KMAX), in four tiers (see knn_score_leaf): the lower tiers run only if some lane's candidate sorts below them
+#ifndef ROLO_KNN_B1
+#define ROLO_KNN_B1 15
+#define ROLO_KNN_B2 10
+#define ROLO_KNN_B3 5
+#endif
+template <int KMAX>
+ROLO_DEV void insert_tiered(double (&K)[KMAX], double ck) {
+  constexpr int B1 = KMAX == 20 ? ROLO_KNN_B1 : 3 * (KMAX / 4), B2 = KMAX == 20 ? ROLO_KNN_B2 : 2 * (KMAX / 4), B3 = KMAX == 20 ? ROLO_KNN_B3 : KMAX / 4;
+#pragma unroll
+  for (int s = KMAX - 1; s >= B1; s--) insert_slot(K[s], K[s - 1], ck);
+  if (__any(ck < K[B1 - 1])) {
+#pragma unroll
+    for (int s = B1 - 1; s >= B2; s--) insert_slot(K[s], K[s - 1], ck);
+    if (__any(ck < K[B2 - 1])) {
+#pragma unroll
+      for (int s = B2 - 1; s >= B3; s--) insert_slot(K[s], K[s - 1], ck);
+      if (__any(ck < K[B3 - 1])) {
+#pragma unroll
+        for (int s = B3 - 1; s >= 1; s--) insert_slot(K[s], K[s - 1], ck);
+        K[0] = vmin_f64(ck, K[0]);
+      }
+    }
+  }
+}
+
 // ---- wave-uniform fetches as EXPLICIT scalar loads ----------------------------------------------------------------------------------------
 // Node boxes and leaf points are fetched through wave-uniform addresses: one s_load per 64 bytes per WAVE instead of a vector load per lane. Rounds
 // 1-3 left that to the compiler, which emits scalar loads only while it can prove that nothing in the kernel may have written memory before them
@@ -132,28 +160,7 @@ ROLO_DEV void knn_score_leaf(const float4* __restrict__ sorted, int g, const flo
       // neighbour is already <= the candidate in EVERY lane keeps its value (min(ck, K[s]) = K[s] and K[s-1] <= K[s]), so the lower tiers
       // run only if some lane's candidate sorts below them. Late in the walk candidates barely beat the k-th best: most executions stop
       // after the first tier (the insert is two thirds of the walk's VALU instructions; v_min_f64 / v_max_f64 issue at the fp32 rate, profiles/tools/valu_rate.hip).
-      // tier boundaries (slots [B1, KMAX) always, then [B2, B1), [B3, B2), [0, B3)); tunable for KMAX = 20 (-DROLO_KNN_B1/B2/B3)
-#ifndef ROLO_KNN_B1
-#define ROLO_KNN_B1 15
-#define ROLO_KNN_B2 10
-#define ROLO_KNN_B3 5
-#endif
-      constexpr int B1 = KMAX == 20 ? ROLO_KNN_B1 : 3 * (KMAX / 4), B2 = KMAX == 20 ? ROLO_KNN_B2 : 2 * (KMAX / 4), B3 = KMAX == 20 ? ROLO_KNN_B3 : KMAX / 4;
-#pragma unroll
-      for (int s = KMAX - 1; s >= B1; s--) insert_slot(K[s], K[s - 1], ck);
-      if (__any(ck < K[B1 - 1])) {
-#pragma unroll
-        for (int s = B1 - 1; s >= B2; s--) insert_slot(K[s], K[s - 1], ck);
-        if (__any(ck < K[B2 - 1])) {
-#pragma unroll
-          for (int s = B2 - 1; s >= B3; s--) insert_slot(K[s], K[s - 1], ck);
-          if (__any(ck < K[B3 - 1])) {
-#pragma unroll
-            for (int s = B3 - 1; s >= 1; s--) insert_slot(K[s], K[s - 1], ck);
-            K[0] = vmin_f64(ck, K[0]);
-          }
-        }
-      }
+      insert_tiered<KMAX>(K, ck);
 #pragma unroll
       for (int s = 0; s < KMAX; s++) if (s == kk - 1) bkey = K[s];
       if (CAP) bkey = vmin_f64(bkey, bcap);
@@ -169,6 +176,53 @@ ROLO_DEV void knn_score_leaf(const float4* __restrict__ sorted, int g, const flo
     for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off, 64));
     rounds += m; }
 #endif
+#endif
+}
+
+// ---- SUB lanes per query (round 4): exchanges among 2 / 4 / 8 adjacent lanes by DPP -------------------------------------------------------------------
+template <int CTRL>
+ROLO_DEV double dpp_f64(double x) {
+  const long long v = __double_as_longlong(x);
+  const int lo = __builtin_amdgcn_mov_dpp((int)(unsigned)(unsigned long long)v, CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_mov_dpp((int)(unsigned)((unsigned long long)v >> 32), CTRL, 0xF, 0xF, true);
+  return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
+}
+// exchange step `st` (0, 1, 2) of a reduction over SUB = 2, 4, 8 adjacent lanes: lane ^ 1, lane ^ 2 (quad_perm), then the mirror of the 8-lane half row
+// (which maps each quad onto the other one)
+template <int ST> ROLO_DEV double sub_xchg(double x) { return ST == 0 ? dpp_f64<0xB1>(x) : ST == 1 ? dpp_f64<0x4E>(x) : dpp_f64<0x141>(x); }
+template <int SUB> ROLO_DEV double sub_min(double x) {
+  x = vmin_f64(x, sub_xchg<0>(x));
+  if (SUB >= 4) x = vmin_f64(x, sub_xchg<1>(x));
+  if (SUB >= 8) x = vmin_f64(x, sub_xchg<2>(x));
+  return x;
+}
+template <int SUB> ROLO_DEV double sub_max(double x) {
+  x = vmax_f64(x, sub_xchg<0>(x));
+  if (SUB >= 4) x = vmax_f64(x, sub_xchg<1>(x));
+  if (SUB >= 8) x = vmax_f64(x, sub_xchg<2>(x));
+  return x;
+}
+
+// Workgroup b of a launch runs on XCD b % 8 (round-robin dispatch), each XCD with its own 4 MB L2. Neighbouring packets of the
+// Hilbert-sorted cloud read the same leaves and boxes, so give every XCD a CONTIGUOUS eighth of the packets: what one wavefront
+// pulled in from HBM (1-2 us per cold fetch — the walk's real bound on the ~48k-point feature clouds) the next ones find in L2.
+// Small launches (<= 512 blocks: the ~48k-point feature clouds of the odometry pipeline, where every fetch is a cold miss and the walk is
+// pure latency) give each XCD ONE contiguous eighth (pipeline frame latency 0.787 -> 0.731 ms, 1552 -> 1769 frames/s); big launches deal
+// runs of 64 blocks round-robin instead, because the work per packet varies along the curve and whole eighths balance worse
+// (2 x 131 072 points: 0.226 ms contiguous, 0.199 ms in runs, 0.207 ms unmapped). Both are bijections on [0, G).
+// wpb = wavefronts (packets) per block: the thresholds are in packets, whatever the workgroup size
+ROLO_DEV int xcd_contiguous_block(int b, int G, int wpb = 4) {
+#ifdef ROLO_KNN_NO_XCD_REMAP
+  return b;
+#else
+  if (G * wpb <= 2048) {
+    const int x = b & 7, k = b >> 3, q = G >> 3, r = G & 7;   // XCD x owns G / 8 (+1 for x < G % 8) consecutive blocks
+    return x * q + min(x, r) + k;
+  }
+  const int RUN = 256 / wpb, GROUP = 8 * RUN;                  // runs of 256 packets
+  if (b >= G / GROUP * GROUP) return b;                       // the whole groups are permuted, the remainder stays put
+  const int grp = b / GROUP, o = b - grp * GROUP;             // o = k * 8 + x : the k-th block this group sends to XCD x
+  return grp * GROUP + (o & 7) * RUN + (o >> 3);
 #endif
 }
 

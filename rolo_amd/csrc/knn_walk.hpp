@@ -37,29 +37,6 @@ ROLO_DEV double* stage_area(const KnnCloud& cl, unsigned add) {
   return s;
 }
 
-// Workgroup b of a launch runs on XCD b % 8 (round-robin dispatch), each XCD with its own 4 MB L2. Neighbouring packets of the
-// Hilbert-sorted cloud read the same leaves and boxes, so give every XCD a CONTIGUOUS eighth of the packets: what one wavefront
-// pulled in from HBM (1-2 us per cold fetch — the walk's real bound on the ~48k-point feature clouds) the next ones find in L2.
-// Small launches (<= 512 blocks: the ~48k-point feature clouds of the odometry pipeline, where every fetch is a cold miss and the walk is
-// pure latency) give each XCD ONE contiguous eighth (pipeline frame latency 0.787 -> 0.731 ms, 1552 -> 1769 frames/s); big launches deal
-// runs of 64 blocks round-robin instead, because the work per packet varies along the curve and whole eighths balance worse
-// (2 x 131 072 points: 0.226 ms contiguous, 0.199 ms in runs, 0.207 ms unmapped). Both are bijections on [0, G).
-// wpb = wavefronts (packets) per block: the thresholds are in packets, whatever the workgroup size
-ROLO_DEV int xcd_contiguous_block(int b, int G, int wpb = 4) {
-#ifdef ROLO_KNN_NO_XCD_REMAP
-  return b;
-#else
-  if (G * wpb <= 2048) {
-    const int x = b & 7, k = b >> 3, q = G >> 3, r = G & 7;   // XCD x owns G / 8 (+1 for x < G % 8) consecutive blocks
-    return x * q + min(x, r) + k;
-  }
-  const int RUN = 256 / wpb, GROUP = 8 * RUN;                  // runs of 256 packets
-  if (b >= G / GROUP * GROUP) return b;                       // the whole groups are permuted, the remainder stays put
-  const int grp = b / GROUP, o = b - grp * GROUP;             // o = k * 8 + x : the k-th block this group sends to XCD x
-  return grp * GROUP + (o & 7) * RUN + (o >> 3);
-#endif
-}
-
 // Instrumented build (-DROLO_KNN_STATS): one record per wavefront of the walk. Everything is counted in scalar registers and stored once at
 // the very end; the start time comes from a NON-volatile asm that also produces the root node index, so it cannot move. (A store, an atomic, a
 // clock builtin or a volatile asm before the loop is a potential memory clobber to the compiler: after it the wave-uniform box / leaf loads are
@@ -201,6 +178,151 @@ __global__ __launch_bounds__(256, KMAX > 32 ? 2 : ROLO_KNN_WALK_OCC) void knn_wa
     double c6[6]; knn_covariance_tail<KMAX>(ki, kk, cl.xyz, 1, 0, reg, o, c6);
   } else {
     double c6[6]; knn_covariance_tail<KMAX>(ki, kk, cl.xyz, cl.n, qi, reg, cl.cov, c6);
+  }
+}
+
+// ---- four lanes per query (round 4): the walk of the SMALL clouds ------------------------------------------------------------------------------------
+// The pipeline's feature clouds (~48 k points) are 760 packets of 64: not one wavefront per SIMD, every one a chain of ~100 dependent fetches at
+// ~1 us each — the launch (0.137 ms, a quarter of the frame) lasts as long as its longest chain and the chip idles. Here a wavefront carries 16 queries
+// (one leaf's worth), four adjacent lanes per query: four times the wavefronts, each with a shorter chain (a quarter packet's frontier), a visited leaf
+// costs each lane 4 candidates (point u of the leaf goes to sub-lane u % 4), and where the tree allows it a step takes TWO levels with the four
+// grandchild boxes tested one per sub-lane. Each sub-lane keeps the 20 best of ITS candidates; the query's pruning bound is shared by its four lanes:
+//     B = min( min_s K_s[19],  max_s K_s[4] )
+// — twenty real candidates at or below it either way (twenty in one list; five in each of four), so nothing beyond B can belong to the twenty nearest
+// and the walk stays exact. At the end the four lists are merged (sorted inserts of the partners' keys, stopped where no lane's list changes any more):
+// the same 20 (d2, index) keys in the same order as the one-lane search — lists and float distances bit-identical (test_knn_lists_bit_exact runs both).
+// The 2 x 131 072-point frame keeps the 64-query packets: there the inserts bound the walk, not the chains (launch_knn_walk picks by size).
+template <int ST> ROLO_DEV void merge20(double (&K)[20]) {   // K <- the twenty smallest of K and the partner's K (both lanes end up with the same list)
+  double o[20];
+#pragma unroll
+  for (int u = 0; u < 20; u++) o[u] = sub_xchg<ST>(K[u]);
+  bool go = true;
+#pragma unroll
+  for (int u = 0; u < 20; u++) {
+    if (go) {
+      go = __any(o[u] < K[19]);   // o is ascending: once o[u] changes no lane's list, neither does the rest
+      if (go) insert_tiered<20>(K, o[u]);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256, ROLO_KNN_WALK_OCC) void knn_walk_sub_kernel(KnnPair A, int split /* first block of cloud 1 */) {
+  constexpr int SUB = 4, QPW = 64 / SUB, PPL = KNN_LEAF / SUB, KMAX = 20;
+  static_assert(KNN_LEAF == 16, "one leaf = the 16 queries of a wavefront");
+  __shared__ int stk_[4][WALK_STACK];
+  const int tid = threadIdx.x;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, sub = lane & (SUB - 1), ql = lane >> 2;
+  const int blk = xcd_contiguous_block((int)blockIdx.x, (int)gridDim.x, 4);
+  const int which = blk >= split ? 1 : 0;
+  const KnnCloud& cl = A.c[which];
+  const float4* __restrict__ sorted = cl.sorted;
+  const float4* __restrict__ boxes = cl.boxes;
+  const int n_sorted = cl.n_sorted, P = cl.P, n_leaves = n_sorted / KNN_LEAF;
+  const int j0 = cl.q_begin + ((blk - (which ? split : 0)) * 4 + wv) * QPW;   // wave-uniform
+  const int j = j0 + ql;
+  float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+  int qi = INT_MAX;
+  if (j < cl.q_end) { q = sorted[j]; qi = __float_as_int(q.w); }
+  const bool active = qi != INT_MAX;   // not padding
+  const double sentinel = key_pack(INFINITY, INT_MAX);
+  double K[KMAX];
+#pragma unroll
+  for (int u = 0; u < KMAX; u++) K[u] = sentinel;
+  double B = active ? sentinel : key_pack(0.f, 0);   // (no key is below (0, 0): an idle query accepts nothing)
+  float bd = active ? INFINITY : -1.0f;
+  auto score = [&](int g) {
+    const float4* __restrict__ leaf = sorted + KNN_LEAF * (size_t)g;
+    float4 c[PPL];
+#pragma unroll
+    for (int t = 0; t < PPL; t++) c[t] = leaf[t * SUB + sub];
+    bool changed = false;
+#pragma unroll
+    for (int t = 0; t < PPL; t++) {
+      const float dx = q.x - c[t].x, dy = q.y - c[t].y, dz = q.z - c[t].z;
+      const float cd = ((dx * dx) + (dy * dy)) + (dz * dz);   // (-ffp-contract=off)
+      const double ck = key_pack(cd, __float_as_int(c[t].w));
+      if (ck < B) { insert_tiered<KMAX>(K, ck); changed = true; }
+    }
+    if (__any(changed)) {
+      B = vmin_f64(vmin_f64(B, sub_min<SUB>(K[KMAX - 1])), sub_max<SUB>(K[KMAX / SUB - 1]));
+      bd = key_d2(B);
+    }
+  };
+  // ---- seeds: the wavefront's own leaf, then ROLO_KNN_SEED_EXTRA leaves on either side along the curve ----
+  const int g_mine = min(j0 / KNN_LEAF, n_leaves - 1);
+  const int g_own0 = max(g_mine - ROLO_KNN_SEED_EXTRA, 0), g_own1 = min(g_mine + 1 + ROLO_KNN_SEED_EXTRA, n_leaves);
+  score(g_mine);
+  for (int g = g_own0; g < g_own1; g++) if (g != g_mine) score(g);
+  // ---- the walk ----
+  {
+    lds_int* stk = (lds_int*)&stk_[wv][0];
+    int sp = 0, h = 1;
+    while (true) {
+      h = __builtin_amdgcn_readfirstlane(h);
+      if (2 * h < P) {
+        // two levels per step: sub-lane c tests grandchild c of h (nodes 4h .. 4h + 3, their boxes 128 contiguous bytes)
+        const float4 blo = boxes[8 * (size_t)h + 2 * sub], bhi = boxes[8 * (size_t)h + 2 * sub + 1];
+        const float d = box_d2(blo, bhi, q);
+        const bool ok = (d <= bd) && (d < INFINITY);
+        const unsigned long long m = __ballot(ok);
+        float dm = ok ? d : INFINITY;   // the query's nearest live grandchild votes (ties: every lane at the minimum)
+        dm = fminf(dm, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(dm), 0xB1, 0xF, 0xF, true)));
+        dm = fminf(dm, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(dm), 0x4E, 0xF, 0xF, true)));
+        const unsigned long long v = __ballot(ok && d == dm);
+        int key[4];   // wave-uniform: votes * 4 + (3 - c) for a live grandchild, -1 for one no lane reaches
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+          const unsigned long long sel = 0x1111111111111111ull << c;
+          key[c] = (m & sel) != 0ull ? __popcll(v & sel) * 4 + (3 - c) : -1;
+        }
+        auto cx = [](int& a, int& bb) { const int hi = max(a, bb), lo = min(a, bb); a = hi; bb = lo; };
+        cx(key[0], key[1]); cx(key[2], key[3]); cx(key[0], key[2]); cx(key[1], key[3]); cx(key[1], key[2]);   // descending
+        if (key[0] >= 0) {
+#pragma unroll
+          for (int r = 3; r >= 1; r--) if (key[r] >= 0 && sp < WALK_STACK) { stk[sp] = 4 * h + (3 - (key[r] & 3)); sp++; }   // worst first: the second best is popped first
+          h = 4 * h + (3 - (key[0] & 3));
+          continue;
+        }
+      } else if (h < P) {
+        float4 llo, lhi, rlo, rhi;
+        sload_node<false>(boxes + 4 * (size_t)h, llo, lhi, rlo, rhi);
+        const float bl = box_d2(llo, lhi, q), br = box_d2(rlo, rhi, q);
+        const bool okl = (bl <= bd) && (bl < INFINITY), okr = (br <= bd) && (br < INFINITY);
+        const unsigned long long ml = __ballot(okl), mr = __ballot(okr);
+        if (ml != 0ull && mr != 0ull) {
+          const unsigned long long pref = __ballot((okl || okr) && (bl <= br));
+          const bool left_first = 2 * __popcll(pref) >= __popcll(ml | mr);
+          if (sp < WALK_STACK) { stk[sp] = left_first ? 2 * h + 1 : 2 * h; sp++; }
+          h = left_first ? 2 * h : 2 * h + 1;
+          continue;
+        }
+        if (ml != 0ull) { h = 2 * h; continue; }
+        if (mr != 0ull) { h = 2 * h + 1; continue; }
+      } else {
+        const int g = h - P;
+        if (g < g_own0 || g >= g_own1) score(g);   // (the seeds were scored already)
+      }
+      if (sp == 0) break;
+      sp--;
+      h = stk[sp];
+    }
+  }
+  merge20<0>(K);
+  merge20<1>(K);
+  if (!active) return;
+  // every sub-lane writes five of the twenty slots (slot-major index array for knn_tail_kernel: a store covers four slots x 16 queries)
+  int ki[5];
+#pragma unroll
+  for (int t = 0; t < 5; t++) {
+    const double k01 = sub & 1 ? K[5 + t] : K[t], k23 = sub & 1 ? K[15 + t] : K[10 + t];
+    ki[t] = key_idx(sub & 2 ? k23 : k01);
+  }
+  int32_t* __restrict__ nbr = cl.nbr;
+#pragma unroll
+  for (int t = 0; t < 5; t++) nbr[(size_t)(sub * 5 + t) * n_sorted + j] = ki[t];
+  if (cl.knn_idx && sub == 0) {   // the debug lists (rolo_get_knn)
+#pragma unroll
+    for (int u = 0; u < KMAX; u++) { cl.knn_idx[(size_t)qi * KMAX + u] = key_idx(K[u]); cl.knn_d2[(size_t)qi * KMAX + u] = key_d2(K[u]); }
   }
 }
 

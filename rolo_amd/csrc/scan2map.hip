@@ -20,6 +20,7 @@
 #include <cfloat>
 #include <climits>
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 #include <vector>
 
@@ -45,6 +46,10 @@ struct S2mArgs {
   float T[12];             // transPointAssociateToMap rows (float Affine3f of pcl::getTransformation)
   float srx, crx, sry, cry, srz, crz;   // LMOptimization :942-947
   double* partials;        // grid x S2M_NV
+  int xcd_remap;
+  int cap;                 // 1: the search is capped at the radius the fits accept (d2 < 1.0)
+  int4* wstats;            // ROLO_S2M_STATS: per wavefront (nodes, leaves, clock ticks of the walk, block) of the LAST iteration
+  int qpp;                 // features per packet (wavefront) of s2m_packet_kernel: 64, or fewer (the remaining lanes idle) for more wavefronts in flight
   unsigned char* selected; // per feature point: 1 = laserCloudOri*Flag (debug / tests)
   float4* coeff;           // per feature point: coeffSel (debug / tests)
 };
@@ -382,7 +387,7 @@ __global__ __launch_bounds__(256) void s2m_packet_kernel(S2mArgs A, int split /*
   const bool corner = (int)blockIdx.x < split;   // workgroup-uniform
   const KnnCloud& Q = A.qry[corner ? 0 : 1];
   const KnnCloud& M = A.map[corner ? 0 : 1];
-  const int j = ((int)blockIdx.x - (corner ? 0 : split)) * 256 + wv * 64 + lane;
+  const int j = lane < A.qpp ? (((int)blockIdx.x - (corner ? 0 : split)) * 4 + wv) * A.qpp + lane : INT_MAX;
   double acc[S2M_NV];
 #pragma unroll
   for (int v = 0; v < S2M_NV; v++) acc[v] = 0.0;
@@ -438,6 +443,200 @@ __global__ __launch_bounds__(256) void s2m_packet_kernel(S2mArgs A, int split /*
 #pragma unroll
     for (int w = 0; w < 4; w++) s += red[w][threadIdx.x];
     A.partials[(size_t)blockIdx.x * S2M_NV + threadIdx.x] = s;
+  }
+}
+
+// ---- the same with SUB lanes per feature (round 4, second step) -----------------------------------------------------------------------------------------
+// Measured on the packet kernel above (profiles/r04/s2m_kernel_stats.txt): 0.30 ms per iteration for 48.7 k features — 764 wavefronts, not even one
+// per SIMD, each scoring all 16 points of ~160 leaves in every lane: the scan's features are thinned to 0.4 m (64 of them along the curve span metres)
+// while the sub-map is five key frames dense, so a 64-feature packet's frontier is wide and every lane pays for the union. Here a wavefront carries
+// 64 / SUB features, SUB adjacent lanes per feature: the frontier shrinks with the packet, there are SUB times as many wavefronts to hide the fetch
+// latency, and a visited leaf costs each lane 16 / SUB candidates (point u of the leaf goes to sub-lane u % SUB: every sub-lane sees an even sample
+// of the neighbourhood). Each sub-lane keeps the 5 best of ITS candidates; the feature's pruning bound is shared by its SUB lanes:
+//     B = min( min_s K_s[4],  max_s K_s[ceil(5 / SUB) - 1] )
+// — both are keys with at least five real candidates at or below them (five in one sub-lane's list; ceil(5/SUB) in each of SUB lists), so a candidate or
+// a box beyond B cannot belong to the five nearest: the walk stays exact. After the walk the SUB lists are merged (sorted inserts of the partners'
+// keys): the same five (d2, index) keys in the same order as the one-lane search, and the fits, flags and rows downstream are the same floats.
+ROLO_DEV void insert5(double (&K)[5], double ck) {
+#pragma unroll
+  for (int s = 4; s >= 1; s--) insert_slot(K[s], K[s - 1], ck);
+  K[0] = vmin_f64(ck, K[0]);
+}
+template <int ST> ROLO_DEV void merge5(double (&K)[5]) {   // K <- the five smallest of K and the partner's K (both lanes end up with the same list)
+  double o[5];
+#pragma unroll
+  for (int u = 0; u < 5; u++) o[u] = sub_xchg<ST>(K[u]);
+#pragma unroll
+  for (int u = 0; u < 5; u++) insert5(K, o[u]);
+}
+
+template <int SUB, int MODE /* 4: two tree levels per step (SUB = 4); + 2: two leaves per fetch */>
+__global__ __launch_bounds__(256) void s2m_sub_kernel(S2mArgs A, int split /* first block of the surface features */) {
+  constexpr int QPW = 64 / SUB, PPL = KNN_LEAF / SUB, SH = SUB == 2 ? 1 : SUB == 4 ? 2 : 3, NEED = (5 + SUB - 1) / SUB;
+  static_assert(SUB == 2 || SUB == 4 || SUB == 8, "sub-lanes per feature");
+  __shared__ int stk_[4][WALK_STACK];
+  __shared__ double red[4][S2M_NV];
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, sub = lane & (SUB - 1), ql = lane >> SH;
+  const int blk = A.xcd_remap ? xcd_contiguous_block((int)blockIdx.x, (int)gridDim.x, 4) : (int)blockIdx.x;   // curve-adjacent features on one XCD: they read the same boxes and leaves
+  const bool corner = blk < split;   // workgroup-uniform
+  const KnnCloud& Q = A.qry[corner ? 0 : 1];
+  const KnnCloud& M = A.map[corner ? 0 : 1];
+  const int j = ((blk - (corner ? 0 : split)) * 4 + wv) * QPW + ql;
+  double acc[S2M_NV];
+#pragma unroll
+  for (int v = 0; v < S2M_NV; v++) acc[v] = 0.0;
+  float4 qs = make_float4(0.f, 0.f, 0.f, __int_as_float(INT_MAX));
+  if (j < Q.n_sorted) qs = Q.sorted[j];
+  const int qidx = __float_as_int(qs.w);
+  const bool active = qidx != INT_MAX;
+  const float* T = A.T;
+  // pointAssociateToMap :293-299 (float, left to right)
+  const float sx = T[0] * qs.x + T[1] * qs.y + T[2] * qs.z + T[3];
+  const float sy = T[4] * qs.x + T[5] * qs.y + T[6] * qs.z + T[7];
+  const float sz = T[8] * qs.x + T[9] * qs.y + T[10] * qs.z + T[11];
+  const float4 q = make_float4(active ? sx : 0.f, active ? sy : 0.f, active ? sz : 0.f, 0.f);
+  const double sentinel = key_pack(INFINITY, INT_MAX);
+  double K[5] = {sentinel, sentinel, sentinel, sentinel, sentinel};
+  // The fits use a feature's neighbours only "if (pointSearchSqDis[4] < 1.0)" (:745, :852): a neighbour at d2 >= 1 can never matter — either the fifth
+  // nearest is closer than 1 m, and so are the other four, or the feature is dropped. The search therefore starts with the bound (1.0f, index 0): every
+  // key it accepts is below it, a feature without five neighbours inside the ball keeps sentinels in its list and is dropped by the same test as before.
+  // Without the cap a feature far from the sub-map walks until it has ANY five points: those were the launch's heaviest wavefronts (A.cap = 0: the A/B).
+  double B = active ? (A.cap ? key_pack(1.0f, 0) : sentinel) : key_pack(0.f, 0);   // (no key is below (0, 0): an idle feature accepts nothing)
+  float bd = active ? (A.cap ? 1.0f : INFINITY) : -1.0f;
+  int n_nodes = 0, n_leaves = 0;
+  const long long t_walk0 = A.wstats ? wall_clock64() : 0;
+  {
+    const float4* __restrict__ sorted = M.sorted;
+    const float4* __restrict__ boxes = M.boxes;
+    const int P = M.P;
+    lds_int* stk = (lds_int*)&stk_[wv][0];
+    int sp = 0, h = 1;
+    // Per-wavefront counters (ROLO_S2M_STATS, profiles/r04/s2m_wave_stats.txt): 123 nodes + 40 leaves per wavefront on average, 353 + 107 in the worst one,
+    // ~0.4 us per step whichever it is — the launch (every wavefront resident at once) lasts as long as its heaviest wavefront, and a step costs what it
+    // ISSUES. So (MODE 4) where the tree allows it a step takes TWO levels: the four grandchild boxes of h (nodes 4h .. 4h + 3, 128 contiguous bytes) are
+    // tested one per sub-lane, the grandchild most features are nearest to is entered, the other live ones are pushed, best on top — one box test per
+    // lane where two binary steps cost four (nodes per wavefront 123 -> 63, heaviest wavefront 167 -> 136 us). (+2) fetches a leaf together with the
+    // entry on top of the stack when that is a leaf too: no further gain, kept as the A/B.
+    auto score = [&](const float4 (&c)[PPL]) {
+      bool changed = false;
+#pragma unroll
+      for (int t = 0; t < PPL; t++) {
+        const float dx = q.x - c[t].x, dy = q.y - c[t].y, dz = q.z - c[t].z;
+        const float cd = ((dx * dx) + (dy * dy)) + (dz * dz);   // (-ffp-contract=off)
+        const double ck = key_pack(cd, __float_as_int(c[t].w));
+        if (ck < B) { insert5(K, ck); changed = true; }
+      }
+      if (__any(changed)) {
+        B = vmin_f64(vmin_f64(B, sub_min<SUB>(K[4])), sub_max<SUB>(K[NEED - 1]));
+        bd = key_d2(B);
+      }
+    };
+    while (true) {
+      h = __builtin_amdgcn_readfirstlane(h);
+      if ((MODE & 4) && SUB == 4 && 2 * h < P) {
+        // two levels per step with the four box tests SPREAD over the feature's four lanes: sub-lane c tests grandchild c (the walk is bound by the
+        // instructions it issues, not by its fetches: this step costs one box test per lane where two binary steps cost four)
+        n_nodes++;
+        const float4 blo = boxes[8 * (size_t)h + 2 * sub], bhi = boxes[8 * (size_t)h + 2 * sub + 1];
+        const float d = box_d2(blo, bhi, q);
+        const bool ok = (d <= bd) && (d < INFINITY);
+        const unsigned long long m = __ballot(ok);
+        float dm = ok ? d : INFINITY;   // the feature's nearest live grandchild votes (ties: every lane at the minimum)
+        dm = fminf(dm, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(dm), 0xB1, 0xF, 0xF, true)));
+        dm = fminf(dm, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(dm), 0x4E, 0xF, 0xF, true)));
+        const unsigned long long v = __ballot(ok && d == dm);
+        int key[4];   // wave-uniform: votes * 4 + (3 - c) for a live grandchild, -1 for one no lane reaches
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+          const unsigned long long sel = 0x1111111111111111ull << c;
+          key[c] = (m & sel) != 0ull ? __popcll(v & sel) * 4 + (3 - c) : -1;
+        }
+        auto cx = [](int& a, int& bb) { const int hi = max(a, bb), lo = min(a, bb); a = hi; bb = lo; };
+        cx(key[0], key[1]); cx(key[2], key[3]); cx(key[0], key[2]); cx(key[1], key[3]); cx(key[1], key[2]);   // descending
+        if (key[0] >= 0) {
+#pragma unroll
+          for (int r = 3; r >= 1; r--) if (key[r] >= 0 && sp < WALK_STACK) { stk[sp] = 4 * h + (3 - (key[r] & 3)); sp++; }   // worst first: the second best is popped first
+          h = 4 * h + (3 - (key[0] & 3));
+          continue;
+        }
+      } else if (h < P) {
+        n_nodes++;
+        float4 llo, lhi, rlo, rhi;
+        sload_node<false>(boxes + 4 * (size_t)h, llo, lhi, rlo, rhi);
+        const float bl = box_d2(llo, lhi, q), br = box_d2(rlo, rhi, q);
+        const bool okl = (bl <= bd) && (bl < INFINITY), okr = (br <= bd) && (br < INFINITY);
+        const unsigned long long ml = __ballot(okl), mr = __ballot(okr);
+        if (ml != 0ull && mr != 0ull) {
+          const unsigned long long pref = __ballot((okl || okr) && (bl <= br));
+          const bool left_first = 2 * __popcll(pref) >= __popcll(ml | mr);
+          if (sp < WALK_STACK) { stk[sp] = left_first ? 2 * h + 1 : 2 * h; sp++; }
+          h = left_first ? 2 * h : 2 * h + 1;
+          continue;
+        }
+        if (ml != 0ull) { h = 2 * h; continue; }
+        if (mr != 0ull) { h = 2 * h + 1; continue; }
+      } else {
+        const float4* __restrict__ leaf = sorted + KNN_LEAF * (size_t)(h - P);
+        int h2 = -1;
+        if ((MODE & 2) && sp > 0) { h2 = __builtin_amdgcn_readfirstlane(stk[sp - 1]); if (h2 < P) h2 = -1; }
+        float4 c[PPL];
+#pragma unroll
+        for (int t = 0; t < PPL; t++) c[t] = leaf[t * SUB + sub];
+        if ((MODE & 2) && h2 >= 0) {
+          const float4* __restrict__ leaf2 = sorted + KNN_LEAF * (size_t)(h2 - P);
+          float4 c2[PPL];
+#pragma unroll
+          for (int t = 0; t < PPL; t++) c2[t] = leaf2[t * SUB + sub];
+          score(c);
+          score(c2);
+          sp--;
+          n_leaves += 2;
+        } else {
+          score(c);
+          n_leaves++;
+        }
+      }
+      if (sp == 0) break;
+      sp--;
+      h = stk[sp];
+    }
+  }
+  if (A.wstats && lane == 0) A.wstats[blk * 4 + wv] = make_int4(n_nodes, n_leaves, (int)(wall_clock64() - t_walk0), blk);
+  merge5<0>(K);
+  if (SUB >= 4) merge5<1>(K);
+  if (SUB >= 8) merge5<2>(K);
+  bool sel = false;
+  float4 coeff = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int gi = (corner ? 0 : A.n_corner) + qidx;   // position in the caller's order
+  if (active && sub == 0) {
+    float bdv[5]; int bi[5];
+#pragma unroll
+    for (int u = 0; u < 5; u++) { bdv[u] = key_d2(K[u]); bi[u] = key_idx(K[u]); }
+    const float4 po = qs;
+    if (bi[4] != INT_MAX && bdv[4] < 1.0f) {
+      float px[5], py[5], pz[5];
+#pragma unroll
+      for (int u = 0; u < 5; u++) { const float4 p = M.xyz[bi[u]]; px[u] = p.x; py[u] = p.y; pz[u] = p.z; }
+      s2m_fit(corner, sx, sy, sz, po, px, py, pz, sel, coeff);
+    }
+    if (A.selected) A.selected[gi] = sel ? 1 : 0;
+    if (A.coeff) A.coeff[gi] = sel ? coeff : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (sel) s2m_row(A, po, coeff, acc);
+  }
+  // workgroup sum, fixed order
+#pragma unroll
+  for (int v = 0; v < S2M_NV; v++) {
+    double x = acc[v];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
+    if (lane == 0) red[wv][v] = x;
+  }
+  __syncthreads();
+  if (threadIdx.x < S2M_NV) {
+    double s = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) s += red[w][threadIdx.x];
+    A.partials[(size_t)blk * S2M_NV + threadIdx.x] = s;
   }
 }
 
@@ -575,6 +774,11 @@ extern "C" int rolo_scan2map_optimize(rolo_ctx* c, const float* corner, int n_co
   // ROLO_S2M_PACKETS=0: one tree walk per lane in the caller's order (rounds 2-3, the A/B); default: the features sorted along the curve once per call,
   // 64 consecutive ones walk the sub-map's tree as one packet (s2m_packet_kernel)
   static const bool use_packets = [] { const char* e = getenv("ROLO_S2M_PACKETS"); return !(e && atoi(e) == 0); }();
+  static const int qpp = [] { const char* e = getenv("ROLO_S2M_QPP"); const int v = e ? atoi(e) : 64; return v == 8 || v == 16 || v == 32 ? v : 64; }();
+  // ROLO_S2M_SUB = 2 / 4 / 8 lanes per feature (s2m_sub_kernel); 1 = the 64-feature packets (s2m_packet_kernel, the A/B)
+  static const int sub = [] { const char* e = getenv("ROLO_S2M_SUB"); const int v = e ? atoi(e) : 4; return v == 1 || v == 2 || v == 8 ? v : 4; }();
+  static const int wide = [] { const char* e = getenv("ROLO_S2M_WIDE"); const int v = e ? atoi(e) : 4; return v == 0 || v == 6 ? v : 4; }();
+  const int fpw = sub > 1 ? 64 / sub : qpp;   // features per wavefront
   KnnPair qp{};
   int grid = (n + S2M_THREADS - 1) / S2M_THREADS, split = 0;
   if (use_packets) {
@@ -584,8 +788,8 @@ extern "C" int rolo_scan2map_optimize(rolo_ctx* c, const float* corner, int n_co
     if (rq) return rq;
     SCHK(hipEventRecord(Wq->qev, ctx_stream(Wq->qctx)));
     SCHK(hipStreamWaitEvent(s, Wq->qev, 0));
-    split = (qp.c[0].n_sorted + 255) / 256;
-    grid = split + (qp.c[1].n_sorted + 255) / 256;
+    split = (qp.c[0].n_sorted + 4 * fpw - 1) / (4 * fpw);
+    grid = split + (qp.c[1].n_sorted + 4 * fpw - 1) / (4 * fpw);
   }
   // scratch lives with the context and only grows: hipFree is a device-wide synchronisation that would stall the frames other contexts have in flight
   S2mScratch* W = static_cast<S2mScratch*>(*ctx_s2m_slot(c));
@@ -607,7 +811,12 @@ extern "C" int rolo_scan2map_optimize(rolo_ctx* c, const float* corner, int n_co
        hipMemcpyAsync(d_feat + n_corner, surf, sizeof(float4) * (size_t)n_surf, hipMemcpyHostToDevice, s) != hipSuccess)) { cleanup(); ctx_set_error("upload failed (scan2map)"); return ROLO_EHIP; }
   S2mArgs A{};
   A.feat = d_feat; A.n_corner = n_corner; A.n_surf = n_surf; A.map[0] = maps.c[0]; A.map[1] = maps.c[1]; A.partials = d_part; A.selected = d_sel; A.coeff = d_coeff;
-  A.qry[0] = qp.c[0]; A.qry[1] = qp.c[1];
+  A.qry[0] = qp.c[0]; A.qry[1] = qp.c[1]; A.qpp = qpp;
+  { static const int xr = [] { const char* e = getenv("ROLO_S2M_XCD"); return e ? atoi(e) : 1; }(); A.xcd_remap = xr; }
+  { static const int cp = [] { const char* e = getenv("ROLO_S2M_CAP"); return e ? atoi(e) : 1; }(); A.cap = cp; }
+  static const char* stats_path = getenv("ROLO_S2M_STATS");
+  int4* d_wstats = nullptr;
+  if (stats_path && use_packets && sub > 1) { SCHK(hipMalloc((void**)&d_wstats, sizeof(int4) * 4 * (size_t)grid)); SCHK(hipMemsetAsync(d_wstats, 0, sizeof(int4) * 4 * (size_t)grid, s)); A.wstats = d_wstats; }
   float* tf = transformTobeMapped;
   bool isDegenerate = false;
   float matP[36]; for (int i = 0; i < 36; i++) matP[i] = (i % 7 == 0) ? 1.f : 0.f;
@@ -623,7 +832,12 @@ extern "C" int rolo_scan2map_optimize(rolo_ctx* c, const float* corner, int n_co
       A.T[8] = -Dx; A.T[9] = Cx * Fx; A.T[10] = Cx * Ex; A.T[11] = tf[5];
     }
     A.srx = std::sin(tf[1]); A.crx = std::cos(tf[1]); A.sry = std::sin(tf[2]); A.cry = std::cos(tf[2]); A.srz = std::sin(tf[0]); A.crz = std::cos(tf[0]);
-    if (use_packets) s2m_packet_kernel<<<grid, 256, 0, s>>>(A, split);
+    if (use_packets && sub == 4 && wide == 4) s2m_sub_kernel<4, 4><<<grid, 256, 0, s>>>(A, split);
+    else if (use_packets && sub == 4 && wide == 6) s2m_sub_kernel<4, 6><<<grid, 256, 0, s>>>(A, split);
+    else if (use_packets && sub == 4) s2m_sub_kernel<4, 0><<<grid, 256, 0, s>>>(A, split);
+    else if (use_packets && sub == 2) s2m_sub_kernel<2, 0><<<grid, 256, 0, s>>>(A, split);
+    else if (use_packets && sub == 8) s2m_sub_kernel<8, 0><<<grid, 256, 0, s>>>(A, split);
+    else if (use_packets) s2m_packet_kernel<<<grid, 256, 0, s>>>(A, split);
     else s2m_kernel<<<grid, S2M_THREADS, 0, s>>>(A);
     SCHK(hipGetLastError());
     s2m_sum_kernel<<<1, 256, 0, s>>>(d_part, grid, h_sum);
@@ -654,6 +868,12 @@ extern "C" int rolo_scan2map_optimize(rolo_ctx* c, const float* corner, int n_co
     const float deltaR = (float)std::sqrt(std::pow((double)(X[0] * r2d), 2) + std::pow((double)(X[1] * r2d), 2) + std::pow((double)(X[2] * r2d), 2));
     const float deltaT = (float)std::sqrt(std::pow((double)(X[3] * 100), 2) + std::pow((double)(X[4] * 100), 2) + std::pow((double)(X[5] * 100), 2));
     if (deltaR < 0.05f && deltaT < 0.05f) { st.converged = 1; break; }
+  }
+  if (d_wstats) {   // one line per wavefront: nodes, leaves, walk ticks (100 MHz), block
+    std::vector<int4> hw(4 * (size_t)grid);
+    SCHK(hipMemcpy(hw.data(), d_wstats, sizeof(int4) * hw.size(), hipMemcpyDeviceToHost));
+    if (FILE* f = fopen(stats_path, "w")) { for (const int4& r : hw) fprintf(f, "%d %d %d %d\n", r.x, r.y, r.z, r.w); fclose(f); }
+    (void)hipFree(d_wstats);
   }
   st.degenerate = isDegenerate ? 1 : 0;
   if (selected_out) SCHK(hipMemcpy(selected_out, d_sel, (size_t)n, hipMemcpyDeviceToHost));

@@ -963,6 +963,20 @@ def test_cooperative_walk_lists_bit_exact(budget):
     assert "COOP" in r.stdout
 
 
+@pytest.mark.parametrize("sub", [0, 1])
+def test_both_walk_kernels_lists_bit_exact(sub):
+    """launch_knn_walk picks the k = 20 walk by size: 16 queries x 4 lanes per wavefront for small clouds (knn_walk_sub_kernel: per-sub-lane lists under a shared
+    bound, two tree levels per step, merged at the end), 64-query packets for large ones. ROLO_KNN_SUB forces one or the other: both must give the oracle's
+    neighbour lists and float distances bit for bit at every size (the cases of the cooperative walk's test: 131 072, a heavy pool pair, 65 536, 43 776, 28 800)."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ROLO_KNN_SUB=str(sub)); env.pop("ROLO_KNN_BUDGET", None)
+    r = subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, %r); from tests.test_gpu_registration import _coop_walk_main; _coop_walk_main()" % root],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "COOP" in r.stdout
+
+
 def _edge_keys_main():
     """body of the fast-path leg of test_polar_keys_at_planted_bin_edges (own process: ROLO_POLAR_EXACT is read once per process)"""
     import os
