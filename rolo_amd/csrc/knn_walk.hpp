@@ -189,20 +189,30 @@ __global__ __launch_bounds__(256, KMAX > 32 ? 2 : ROLO_KNN_WALK_OCC) void knn_wa
 // grandchild boxes tested one per sub-lane. Each sub-lane keeps the 20 best of ITS candidates; the query's pruning bound is shared by its four lanes:
 //     B = min( min_s K_s[19],  max_s K_s[4] )
 // — twenty real candidates at or below it either way (twenty in one list; five in each of four), so nothing beyond B can belong to the twenty nearest
-// and the walk stays exact. At the end the four lists are merged into sub-lane 0's (sorted inserts of the partners' keys, stopped where no list changes any more):
+// and the walk stays exact. At the end the four lists are merged pairwise (two bitonic merges in registers, the partner's keys through DPP):
 // the same 20 (d2, index) keys in the same order as the one-lane search — lists and float distances bit-identical (test_knn_lists_bit_exact runs both).
 // The 2 x 131 072-point frame keeps the 64-query packets: there the inserts bound the walk, not the chains (launch_knn_walk picks by size).
-// K of the RECEIVING lane (bit ST of its sub-lane index clear) <- the twenty smallest of K and the partner's K. The partner only sends: its list stays as it
-// is while the receiver reads it key by key, so no copy of the twenty keys is held (40 registers less than a symmetric exchange)
-template <int ST> ROLO_DEV void merge20(double (&K)[20], int sub) {
-  const bool recv = (sub & (1 << ST)) == 0;
-  bool go = true;
+// K <- the twenty smallest of K and the partner's K, sorted (both lanes end up with the same list), as a bitonic merge in place: with a and b ascending,
+// c[i] = min(a[i], b[19 - i]) holds exactly the twenty smallest of the forty and rises, then falls; the half-cleaner network of 32 inputs sorts it — the
+// sequence padded IN FRONT with twelve -inf that never move, so only the 40 compare-exchanges between real positions are issued. ~140 instructions where
+// twenty sorted inserts cost up to 800. (Pairs (j, 19 - j) are fetched before either is overwritten: the partner runs the same instructions on its list.)
+template <int ST> ROLO_DEV void merge20(double (&K)[20]) {
 #pragma unroll
-  for (int u = 0; u < 20; u++) {
-    if (go) {
-      const double o = sub_xchg<ST>(K[u]);
-      go = __any(recv && o < K[19]);   // the partner's keys ascend: once one changes no receiver's list, neither does the rest
-      if (go && recv) insert_tiered<20>(K, o);
+  for (int j = 0; j < 10; j++) {
+    const double o1 = sub_xchg<ST>(K[19 - j]), o2 = sub_xchg<ST>(K[j]);
+    K[j] = vmin_f64(K[j], o1);
+    K[19 - j] = vmin_f64(K[19 - j], o2);
+  }
+#pragma unroll
+  for (int d = 16; d >= 1; d >>= 1) {
+#pragma unroll
+    for (int p = 12; p < 32; p++) {
+      if ((p & d) == 0) {
+        const int x = p - 12, y = p + d - 12;
+        const double lo = vmin_f64(K[x], K[y]);
+        K[y] = vmax_f64(K[x], K[y]);
+        K[x] = lo;
+      }
     }
   }
 }
@@ -308,17 +318,14 @@ __global__ __launch_bounds__(256, ROLO_KNN_WALK_OCC) void knn_walk_sub_kernel(Kn
       h = stk[sp];
     }
   }
-  merge20<0>(K, sub);   // sub-lanes 0 and 2 take in 1 and 3
-  merge20<1>(K, sub);   // sub-lane 0 takes in 2: it holds the query's list now
-  // every sub-lane writes five of the twenty slots (slot-major index array for knn_tail_kernel: a store covers four slots x 16 queries): the indices are
-  // broadcast from sub-lane 0 (quad_perm [0, 0, 0, 0])
+  merge20<0>(K);
+  merge20<1>(K);   // all four lanes hold the query's list now
+  // every sub-lane writes five of the twenty slots (slot-major index array for knn_tail_kernel: a store covers four slots x 16 queries)
   int ki[5];
 #pragma unroll
   for (int t = 0; t < 5; t++) {
-    int i0 = key_idx(K[t]), i1 = key_idx(K[5 + t]), i2 = key_idx(K[10 + t]), i3 = key_idx(K[15 + t]);
-    i0 = __builtin_amdgcn_mov_dpp(i0, 0x00, 0xF, 0xF, true); i1 = __builtin_amdgcn_mov_dpp(i1, 0x00, 0xF, 0xF, true);
-    i2 = __builtin_amdgcn_mov_dpp(i2, 0x00, 0xF, 0xF, true); i3 = __builtin_amdgcn_mov_dpp(i3, 0x00, 0xF, 0xF, true);
-    ki[t] = sub & 2 ? (sub & 1 ? i3 : i2) : (sub & 1 ? i1 : i0);
+    const double k01 = sub & 1 ? K[5 + t] : K[t], k23 = sub & 1 ? K[15 + t] : K[10 + t];
+    ki[t] = key_idx(sub & 2 ? k23 : k01);
   }
   if (!active) return;
   int32_t* __restrict__ nbr = cl.nbr;

@@ -97,3 +97,16 @@ def test_resident_submap_call_order():
     tf = g.scan2MapOptimization(corner, surf, None, None, guess)    # the scan against itself: aligned up to the fits through five neighbours
     assert g.last_stats.skipped == 0 and g.last_stats.iterations >= 1 and np.abs(tf).max() < 1e-2, (g.last_stats.n_selected, g.last_stats.converged)
     g.close()
+
+
+@pytest.mark.parametrize("switch", ["ROLO_S2M_SUB=1", "ROLO_S2M_SUB=8", "ROLO_S2M_CAP=0", "ROLO_S2M_WIDE=0", "ROLO_S2M_WIDE=6", "ROLO_S2M_PACKETS=0"])
+def test_association_kernel_variants_keep_the_oracles_flags(switch):
+    """the association kernel's earlier forms and A/B switches (64-feature packets, 8 lanes per feature, no radius cap, binary steps, paired leaf fetches, one walk
+    per lane) are all exact searches: the parity test above — selection flags bit-identical to the C++ oracle's, same iterations, same pose — must pass with
+    each of them (own process: the switches are read once)"""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    k, v = switch.split("=")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_backend.py"), "-m", "gpu", "-x", "-q", "-k", "matches_twin and vlp16"],
+                       env=dict(os.environ, **{k: v}), capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0 and "1 passed" in r.stdout, r.stdout[-2500:] + r.stderr[-1500:]
