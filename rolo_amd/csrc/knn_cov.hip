@@ -742,10 +742,11 @@ hipError_t launch_knn_walk(const KnnPair& A, int k, int regularization_or_minus1
     else {
       // small clouds: 16 queries x 4 lanes per wavefront (knn_walk_sub_kernel) — below ~2 packets of 64 per SIMD the walk is a chain of fetches, not
       // inserts. ROLO_KNN_SUB = 0 never / 1 always / unset: by size
-      static const int sub_env = [] { const char* e = getenv("ROLO_KNN_SUB"); return e ? atoi(e) : -1; }();
+      static const int sub_env = [] { const char* e = getenv("ROLO_KNN_SUB"); return e ? atoi(e) : -1; }();   // 0 never / 1 or 4: four lanes always / 2: two lanes always / unset: by size
       const int packets = (n0 + 63) / 64 + (n1 + 63) / 64;
-      const bool use_sub = sub_env < 0 ? packets <= KNN_SUB_MAX_PACKETS : sub_env != 0;
-      if (use_sub) { const int s0 = (n0 + 63) / 64, s1 = (n1 + 63) / 64; knn_walk_sub_kernel<<<s0 + s1, 256, 0, s>>>(A, s0); }
+      const int lanes = sub_env < 0 ? (packets <= KNN_SUB_MAX_PACKETS ? 4 : 0) : (sub_env == 2 ? 2 : (sub_env ? 4 : 0));
+      if (lanes == 4) { const int s0 = (n0 + 63) / 64, s1 = (n1 + 63) / 64; knn_walk_sub_kernel<4><<<s0 + s1, 256, 0, s>>>(A, s0); }
+      else if (lanes == 2) { const int s0 = (n0 + 127) / 128, s1 = (n1 + 127) / 128; knn_walk_sub_kernel<2><<<s0 + s1, 256, 0, s>>>(A, s0); }
       else knn_walk_kernel<20, false><<<g0 + g1, 256, pad, s>>>(A, g0, k, -1);
     }
   }

@@ -217,12 +217,14 @@ template <int ST> ROLO_DEV void merge20(double (&K)[20]) {
   }
 }
 
+template <int SUB>
 __global__ __launch_bounds__(256, ROLO_KNN_WALK_OCC) void knn_walk_sub_kernel(KnnPair A, int split /* first block of cloud 1 */) {
-  constexpr int SUB = 4, QPW = 64 / SUB, PPL = KNN_LEAF / SUB, KMAX = 20;
-  static_assert(KNN_LEAF == 16, "one leaf = the 16 queries of a wavefront");
+  constexpr int SH = SUB == 2 ? 1 : 2, QPW = 64 / SUB, PPL = KNN_LEAF / SUB, KMAX = 20, E = 4 / SUB /* grandchild boxes per lane */, OWN = QPW / KNN_LEAF;
+  static_assert(SUB == 2 || SUB == 4, "lanes per query");
+  static_assert(KNN_LEAF == 16, "a wavefront's queries are whole leaves");
   __shared__ int stk_[4][WALK_STACK];
   const int tid = threadIdx.x;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, sub = lane & (SUB - 1), ql = lane >> 2;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, sub = lane & (SUB - 1), ql = lane >> SH;
   const int blk = xcd_contiguous_block((int)blockIdx.x, (int)gridDim.x, 4);
   const int which = blk >= split ? 1 : 0;
   const KnnCloud& cl = A.c[which];
@@ -243,27 +245,30 @@ __global__ __launch_bounds__(256, ROLO_KNN_WALK_OCC) void knn_walk_sub_kernel(Kn
   float bd = active ? INFINITY : -1.0f;
   auto score = [&](int g) {
     const float4* __restrict__ leaf = sorted + KNN_LEAF * (size_t)g;
-    float4 c[PPL];
-#pragma unroll
-    for (int t = 0; t < PPL; t++) c[t] = leaf[t * SUB + sub];
     bool changed = false;
 #pragma unroll
-    for (int t = 0; t < PPL; t++) {
-      const float dx = q.x - c[t].x, dy = q.y - c[t].y, dz = q.z - c[t].z;
-      const float cd = ((dx * dx) + (dy * dy)) + (dz * dz);   // (-ffp-contract=off)
-      const double ck = key_pack(cd, __float_as_int(c[t].w));
-      if (ck < B) { insert_tiered<KMAX>(K, ck); changed = true; }
+    for (int t0 = 0; t0 < PPL; t0 += 4) {   // four candidates in flight at a time
+      float4 c[4];
+#pragma unroll
+      for (int t = 0; t < 4; t++) c[t] = leaf[(t0 + t) * SUB + sub];
+#pragma unroll
+      for (int t = 0; t < 4; t++) {
+        const float dx = q.x - c[t].x, dy = q.y - c[t].y, dz = q.z - c[t].z;
+        const float cd = ((dx * dx) + (dy * dy)) + (dz * dz);   // (-ffp-contract=off)
+        const double ck = key_pack(cd, __float_as_int(c[t].w));
+        if (ck < B) { insert_tiered<KMAX>(K, ck); changed = true; }
+      }
     }
     if (__any(changed)) {
       B = vmin_f64(vmin_f64(B, sub_min<SUB>(K[KMAX - 1])), sub_max<SUB>(K[KMAX / SUB - 1]));
       bd = key_d2(B);
     }
   };
-  // ---- seeds: the wavefront's own leaf, then ROLO_KNN_SEED_EXTRA leaves on either side along the curve ----
+  // ---- seeds: the wavefront's own leaves, then ROLO_KNN_SEED_EXTRA leaves on either side along the curve ----
   const int g_mine = min(j0 / KNN_LEAF, n_leaves - 1);
-  const int g_own0 = max(g_mine - ROLO_KNN_SEED_EXTRA, 0), g_own1 = min(g_mine + 1 + ROLO_KNN_SEED_EXTRA, n_leaves);
-  score(g_mine);
-  for (int g = g_own0; g < g_own1; g++) if (g != g_mine) score(g);
+  const int g_own0 = max(g_mine - ROLO_KNN_SEED_EXTRA, 0), g_own1 = min(g_mine + OWN + ROLO_KNN_SEED_EXTRA, n_leaves);
+  for (int g = g_mine; g < min(g_mine + OWN, n_leaves); g++) score(g);
+  for (int g = g_own0; g < g_own1; g++) if (g < g_mine || g >= g_mine + OWN) score(g);
   // ---- the walk ----
   {
     lds_int* stk = (lds_int*)&stk_[wv][0];
@@ -271,20 +276,27 @@ __global__ __launch_bounds__(256, ROLO_KNN_WALK_OCC) void knn_walk_sub_kernel(Kn
     while (true) {
       h = __builtin_amdgcn_readfirstlane(h);
       if (2 * h < P) {
-        // two levels per step: sub-lane c tests grandchild c of h (nodes 4h .. 4h + 3, their boxes 128 contiguous bytes)
-        const float4 blo = boxes[8 * (size_t)h + 2 * sub], bhi = boxes[8 * (size_t)h + 2 * sub + 1];
-        const float d = box_d2(blo, bhi, q);
-        const bool ok = (d <= bd) && (d < INFINITY);
-        const unsigned long long m = __ballot(ok);
-        float dm = ok ? d : INFINITY;   // the query's nearest live grandchild votes (ties: every lane at the minimum)
+        // two levels per step: the four grandchildren of h (nodes 4h .. 4h + 3, their boxes 128 contiguous bytes) are tested by the query's SUB lanes, E each
+        float d[E]; bool ok[E];
+        float dm = INFINITY;   // the query's nearest live grandchild votes (ties: every one at the minimum)
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+          const int c = sub * E + e;
+          const float4 blo = boxes[8 * (size_t)h + 2 * c], bhi = boxes[8 * (size_t)h + 2 * c + 1];
+          d[e] = box_d2(blo, bhi, q);
+          ok[e] = (d[e] <= bd) && (d[e] < INFINITY);
+          dm = fminf(dm, ok[e] ? d[e] : INFINITY);
+        }
         dm = fminf(dm, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(dm), 0xB1, 0xF, 0xF, true)));
-        dm = fminf(dm, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(dm), 0x4E, 0xF, 0xF, true)));
-        const unsigned long long v = __ballot(ok && d == dm);
+        if (SUB == 4) dm = fminf(dm, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(dm), 0x4E, 0xF, 0xF, true)));
+        unsigned long long m[E], v[E];
+#pragma unroll
+        for (int e = 0; e < E; e++) { m[e] = __ballot(ok[e]); v[e] = __ballot(ok[e] && d[e] == dm); }
         int key[4];   // wave-uniform: votes * 4 + (3 - c) for a live grandchild, -1 for one no lane reaches
 #pragma unroll
         for (int c = 0; c < 4; c++) {
-          const unsigned long long sel = 0x1111111111111111ull << c;
-          key[c] = (m & sel) != 0ull ? __popcll(v & sel) * 4 + (3 - c) : -1;
+          const unsigned long long sel = (SUB == 4 ? 0x1111111111111111ull : 0x5555555555555555ull) << (c / E);   // the lanes that tested grandchild c
+          key[c] = (m[c % E] & sel) != 0ull ? __popcll(v[c % E] & sel) * 4 + (3 - c) : -1;
         }
         auto cx = [](int& a, int& bb) { const int hi = max(a, bb), lo = min(a, bb); a = hi; bb = lo; };
         cx(key[0], key[1]); cx(key[2], key[3]); cx(key[0], key[2]); cx(key[1], key[3]); cx(key[1], key[2]);   // descending
@@ -319,18 +331,23 @@ __global__ __launch_bounds__(256, ROLO_KNN_WALK_OCC) void knn_walk_sub_kernel(Kn
     }
   }
   merge20<0>(K);
-  merge20<1>(K);   // all four lanes hold the query's list now
-  // every sub-lane writes five of the twenty slots (slot-major index array for knn_tail_kernel: a store covers four slots x 16 queries)
-  int ki[5];
+  if (SUB == 4) merge20<1>(K);   // all the query's lanes hold its list now
+  // every sub-lane writes 20 / SUB of the twenty slots (slot-major index array for knn_tail_kernel: a store covers SUB slots x QPW queries)
+  constexpr int NS = KMAX / SUB;
+  int ki[NS];
 #pragma unroll
-  for (int t = 0; t < 5; t++) {
-    const double k01 = sub & 1 ? K[5 + t] : K[t], k23 = sub & 1 ? K[15 + t] : K[10 + t];
-    ki[t] = key_idx(sub & 2 ? k23 : k01);
+  for (int t = 0; t < NS; t++) {
+    if (SUB == 4) {
+      const double k01 = sub & 1 ? K[NS + t] : K[t], k23 = sub & 1 ? K[3 * NS + t] : K[2 * NS + t];
+      ki[t] = key_idx(sub & 2 ? k23 : k01);
+    } else {
+      ki[t] = key_idx(sub & 1 ? K[NS + t] : K[t]);
+    }
   }
   if (!active) return;
   int32_t* __restrict__ nbr = cl.nbr;
 #pragma unroll
-  for (int t = 0; t < 5; t++) nbr[(size_t)(sub * 5 + t) * n_sorted + j] = ki[t];
+  for (int t = 0; t < NS; t++) nbr[(size_t)(sub * NS + t) * n_sorted + j] = ki[t];
   if (cl.knn_idx && sub == 0) {   // the debug lists (rolo_get_knn)
 #pragma unroll
     for (int u = 0; u < KMAX; u++) { cl.knn_idx[(size_t)qi * KMAX + u] = key_idx(K[u]); cl.knn_d2[(size_t)qi * KMAX + u] = key_d2(K[u]); }

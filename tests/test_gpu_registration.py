@@ -963,7 +963,7 @@ def test_cooperative_walk_lists_bit_exact(budget):
     assert "COOP" in r.stdout
 
 
-@pytest.mark.parametrize("sub", [0, 1])
+@pytest.mark.parametrize("sub", [0, 1, 2])
 def test_both_walk_kernels_lists_bit_exact(sub):
     """launch_knn_walk picks the k = 20 walk by size: 16 queries x 4 lanes per wavefront for small clouds (knn_walk_sub_kernel: per-sub-lane lists under a shared
     bound, two tree levels per step, merged at the end), 64-query packets for large ones. ROLO_KNN_SUB forces one or the other: both must give the oracle's
