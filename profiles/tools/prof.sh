@@ -1,4 +1,4 @@
-# rocprofv3 summaries for profiles/r03 (kernel-trace stats; separate PMC passes — never combined with sys / hip traces). Run on a GPU box:
+# rocprofv3 summaries for profiles/rNN (kernel-trace stats; separate PMC passes — never combined with sys / hip traces). Run on a GPU box:
 #   gpurun --timeout 1500 -- 'bash profiles/tools/prof.sh r03'
 # then summarise the passes under gpurun_out/<tag>prof (find ... counter_collection.csv) with profiles/summarize_pmc.py / summarize_sq.py.
 set -x

@@ -704,9 +704,9 @@ extern "C" int rolo_debug_wave_records(unsigned* out /* 16384 x 8 */) {
 static inline int slice_blocks(const KnnCloud& c) { return (c.q_end - c.q_begin + 255) / 256; }
 
 // the 4-lanes-per-query walk up to this many 64-query packets in the launch (measured, rocprofv3: one ~48.7 k-point feature cloud = 761 packets 0.138 -> 0.064 ms;
-// the pipeline's source + target launch = 1522 packets: raw frame -> pose 0.489 -> 0.440 ms. Above: 2 x 65 536 points = 2048 packets, four contexts (config 5)
+// the pipeline's source + target launch = 1450-1600 packets: raw frame -> pose 0.489 -> 0.440 ms. Above: 2 x 65 536 points = 2048 packets, four contexts (config 5)
 // 4403 -> 4091 scans/s with it, 2 x 131 072 = 4096 packets 2931 -> 2525: there the inserts bound the walk and its 100 VGPRs crowd the other contexts' kernels)
-constexpr int KNN_SUB_MAX_PACKETS = 1536;
+constexpr int KNN_SUB_MAX_PACKETS = 1792;   // (the pipeline's pair launch is 1450-1600 packets, frame by frame: the limit sits clear of it, and of configs[4]'s 2048)
 hipError_t launch_knn_walk(const KnnPair& A, int k, int regularization_or_minus1, const VoxelFuse& vf, hipStream_t s, int coop_budget) {
   constexpr int QPB = 256;   // queries per workgroup of the plain walk: four wavefronts of 64
   const int n0 = A.c[0].q_end - A.c[0].q_begin, n1 = A.n_clouds > 1 ? A.c[1].q_end - A.c[1].q_begin : 0;
