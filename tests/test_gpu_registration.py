@@ -977,6 +977,17 @@ def test_both_walk_kernels_lists_bit_exact(sub):
     assert "COOP" in r.stdout
 
 
+@pytest.mark.parametrize("sub", [0, 2])
+def test_forced_walk_kernels_on_degenerate_and_odd_clouds(sub):
+    """the default policy sends every small cloud through the four-lanes-per-query walk; the 64-query packets (ROLO_KNN_SUB=0) and the two-lane form (=2) must
+    pass the same tie / duplicate / rank-deficient / odd-size cases (own process: the switch is read once)"""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_registration.py"), "-m", "gpu", "-x", "-q", "-k",
+                        "degenerate_geometry or odd_sizes or knn_lists_bit_exact"], env=dict(os.environ, ROLO_KNN_SUB=str(sub)), capture_output=True, text=True, timeout=1200, cwd=root)
+    assert r.returncode == 0 and " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-2500:] + r.stderr[-1500:]
+
+
 def _edge_keys_main():
     """body of the fast-path leg of test_polar_keys_at_planted_bin_edges (own process: ROLO_POLAR_EXACT is read once per process)"""
     import os
