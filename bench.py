@@ -669,7 +669,7 @@ def main():
         pmc, pmc_desc = pmc_traffic_file()
         if pmc and os.path.exists(pmc) and args.sensor == "os1-128":
             tr = json.load(open(pmc))
-            nfr = max(tr.get("knn_walk_kernel", {}).get("launches", 0), 1)
+            nfr = max(tr.get("knn_walk_kernel", {}).get("launches", 0) + tr.get("knn_walk_sub_kernel", {}).get("launches", 0), 1)   # one search launch per frame, whichever walk kernel the size picks
             # (the 1 GiB device-to-device copies of this script's own HBM copy test show up as __amd_rocclr_copyBuffer: not part of a frame)
             fabric = sum(v["hbm_bytes_per_launch"] * v["launches"] for k, v in tr.items()
                          if isinstance(v, dict) and "launches" in v and not k.startswith("__amd_rocclr_copyBuffer")) / nfr

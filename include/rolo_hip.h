@@ -242,7 +242,8 @@ int rolo_peer_info(rolo_ctx* ctx, int* rank, int* world, char* mem_kind16);
 /* Bookkeeping of rolo_register_async / _wait on this context since its creation (what bench.py reports next to the throughput):
  * out[0] frames registered, [1] of them replayed from the hipGraph, [2] captured, [3] enqueued eagerly, [4] frames whose first launch
  * schedule was too short (rolo_register_wait had to top up with host round trips), [5] synchronous chunks of predicated passes enqueued
- * by the drivers (top-ups + rolo_align / rolo_compute_translation), [6] / [7] passes the next frame's first schedule holds per stage. */
+ * by the drivers (top-ups + rolo_align / rolo_compute_translation), [6] / [7] passes the next frame's first schedule holds per stage, [8] lanes per query
+ * of the last neighbour search enqueued (1: 64-query packets, 2 / 4: knn_walk_sub_kernel — picked by launch size, ROLO_KNN_SUB overrides). */
 int rolo_ctx_counters(rolo_ctx* ctx, long long* out, int n);
 
 /* Per-kernel timing with HIP events on the context's stream (bench.py's "roofline" object). While enabled, every

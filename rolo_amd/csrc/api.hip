@@ -178,6 +178,7 @@ struct rolo_ctx {
   // passes the last frames needed per stage (+1): the next frame enqueues that many predicated pass/controller pairs up
   // front instead of a fixed worst-case chunk; rolo_register_wait tops up if a frame needs more
   int hint_rot = 0, hint_trans = 0;
+  int walk_lanes = 1;   // lanes per query of the last K5 walk enqueued (rolo_ctx_counters [8])
   struct NeedWindow { int need[64] = {0}; int n = 0, pos = 0; } win_rot, win_trans;   // passes the last 64 frames needed per stage
   bool gseen_valid = false;
   hipGraph_t graph = nullptr;
@@ -359,7 +360,7 @@ int build_clouds(rolo_ctx* c, bool do_src, bool do_tgt, hipStream_t stream, bool
     return ROLO_OK;
   }
   const bool split_tail = !fused_tail_env() || kc > 64;
-  { ProfScope ps(c, ROLO_PROF_KNN_WALK, stream); HIPCHK(launch_knn_walk(A, c->P.k_correspondences, split_tail ? -1 : c->P.regularization, vf, stream, (kc == 20 && split_tail) ? knn_budget_env() : 0)); }
+  { ProfScope ps(c, ROLO_PROF_KNN_WALK, stream); HIPCHK(launch_knn_walk(A, c->P.k_correspondences, split_tail ? -1 : c->P.regularization, vf, stream, (kc == 20 && split_tail) ? knn_budget_env() : 0, &c->walk_lanes)); }
   if (split_tail) { ProfScope ps(c, ROLO_PROF_KNN_TAIL, stream); HIPCHK(launch_knn_tail(A, c->P.k_correspondences, c->P.regularization, vf, stream)); }
   if (sharded) {
     const size_t seg = A.c[0].seg;
@@ -1362,8 +1363,8 @@ int rolo_transform_cloud(rolo_ctx* c, const float* in, float* out, int n, int st
 
 int rolo_ctx_counters(rolo_ctx* c, long long* out, int n) {
   if (!c || !out || n < 0) return ROLO_EINVAL;
-  const long long v[8] = {c->n_frames, c->n_replays, c->n_captures, c->n_eager, c->n_topup_frames, c->n_topup_chunks, c->hint_rot, c->hint_trans};
-  for (int i = 0; i < n && i < 8; i++) out[i] = v[i];
+  const long long v[9] = {c->n_frames, c->n_replays, c->n_captures, c->n_eager, c->n_topup_frames, c->n_topup_chunks, c->hint_rot, c->hint_trans, c->walk_lanes};
+  for (int i = 0; i < n && i < 9; i++) out[i] = v[i];
   return ROLO_OK;
 }
 

@@ -703,11 +703,17 @@ extern "C" int rolo_debug_wave_records(unsigned* out /* 16384 x 8 */) {
 
 static inline int slice_blocks(const KnnCloud& c) { return (c.q_end - c.q_begin + 255) / 256; }
 
-// the 4-lanes-per-query walk up to this many 64-query packets in the launch (measured, rocprofv3: one ~48.7 k-point feature cloud = 761 packets 0.138 -> 0.064 ms;
-// the pipeline's source + target launch = 1450-1600 packets: raw frame -> pose 0.489 -> 0.440 ms. Above: 2 x 65 536 points = 2048 packets, four contexts (config 5)
-// 4403 -> 4091 scans/s with it, 2 x 131 072 = 4096 packets 2931 -> 2525: there the inserts bound the walk and its 100 VGPRs crowd the other contexts' kernels)
+// Which walk (k = 20): four lanes per query up to this many 64-query packets in the launch, two lanes per query above (rocprofv3 / bench.py, round 4):
+//   one ~48.7 k-point feature cloud (761 packets): 0.138 ms with 64-query packets, 0.064 ms with four lanes; the pipeline's source + target launch
+//   (1450-1600 packets): raw frame -> pose 0.489 -> 0.423 ms (two lanes: 0.449);
+//   2 x 65 536 points (2048 packets, four contexts, BASELINE configs[4]): 4.40 k scans/s with packets, 4.35 k four lanes, 4.42 k two lanes;
+//   2 x 131 072 points (4096 packets): walk over the pool 0.218 / 0.169 / 0.175 ms, single-frame latency 0.79 / - / 0.76 ms, four contexts in flight
+//   2.87 / 2.74 / 2.85 k scans/s (paired runs) with packets / four / two lanes — two lanes issue the packets' instruction count (SQ_INSTS_VALU 51.5 M against
+//   52.4 M per launch) in chains half as long; four lanes issue 8 % more and twice the scalar instructions.
+// ROLO_KNN_SUB=0 keeps the 64-query packets at every size (the A/B, and the kernel of every k other than 20).
 constexpr int KNN_SUB_MAX_PACKETS = 1792;   // (the pipeline's pair launch is 1450-1600 packets, frame by frame: the limit sits clear of it, and of configs[4]'s 2048)
-hipError_t launch_knn_walk(const KnnPair& A, int k, int regularization_or_minus1, const VoxelFuse& vf, hipStream_t s, int coop_budget) {
+hipError_t launch_knn_walk(const KnnPair& A, int k, int regularization_or_minus1, const VoxelFuse& vf, hipStream_t s, int coop_budget, int* lanes_out) {
+  if (lanes_out) *lanes_out = 1;
   constexpr int QPB = 256;   // queries per workgroup of the plain walk: four wavefronts of 64
   const int n0 = A.c[0].q_end - A.c[0].q_begin, n1 = A.n_clouds > 1 ? A.c[1].q_end - A.c[1].q_begin : 0;
   const int g0 = (n0 + QPB - 1) / QPB, g1 = (n1 + QPB - 1) / QPB;
@@ -744,7 +750,8 @@ hipError_t launch_knn_walk(const KnnPair& A, int k, int regularization_or_minus1
       // inserts. ROLO_KNN_SUB = 0 never / 1 always / unset: by size
       static const int sub_env = [] { const char* e = getenv("ROLO_KNN_SUB"); return e ? atoi(e) : -1; }();   // 0 never / 1 or 4: four lanes always / 2: two lanes always / unset: by size
       const int packets = (n0 + 63) / 64 + (n1 + 63) / 64;
-      const int lanes = sub_env < 0 ? (packets <= KNN_SUB_MAX_PACKETS ? 4 : 0) : (sub_env == 2 ? 2 : (sub_env ? 4 : 0));
+      const int lanes = sub_env < 0 ? (packets <= KNN_SUB_MAX_PACKETS ? 4 : 2) : (sub_env == 2 ? 2 : (sub_env ? 4 : 0));
+      if (lanes_out) *lanes_out = lanes ? lanes : 1;
       if (lanes == 4) { const int s0 = (n0 + 63) / 64, s1 = (n1 + 63) / 64; knn_walk_sub_kernel<4><<<s0 + s1, 256, 0, s>>>(A, s0); }
       else if (lanes == 2) { const int s0 = (n0 + 127) / 128, s1 = (n1 + 127) / 128; knn_walk_sub_kernel<2><<<s0 + s1, 256, 0, s>>>(A, s0); }
       else knn_walk_kernel<20, false><<<g0 + g1, 256, pad, s>>>(A, g0, k, -1);

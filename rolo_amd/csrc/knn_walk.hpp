@@ -307,14 +307,18 @@ __global__ __launch_bounds__(256, ROLO_KNN_WALK_OCC) void knn_walk_sub_kernel(Kn
           continue;
         }
       } else if (h < P) {
-        float4 llo, lhi, rlo, rhi;
-        sload_node<false>(boxes + 4 * (size_t)h, llo, lhi, rlo, rhi);
-        const float bl = box_d2(llo, lhi, q), br = box_d2(rlo, rhi, q);
-        const bool okl = (bl <= bd) && (bl < INFINITY), okr = (br <= bd) && (br < INFINITY);
-        const unsigned long long ml = __ballot(okl), mr = __ballot(okr);
+        // one level (the children of h are leaves): even sub-lanes test the left child, odd ones the right, the partner's distance comes through DPP
+        const int c = sub & 1;
+        const float4 blo = boxes[4 * (size_t)h + 2 * c], bhi = boxes[4 * (size_t)h + 2 * c + 1];
+        const float d = box_d2(blo, bhi, q);
+        const float o = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(d), 0xB1, 0xF, 0xF, true));
+        const bool ok = (d <= bd) && (d < INFINITY), oko = (o <= bd) && (o < INFINITY);
+        const unsigned long long m = __ballot(ok);
+        const unsigned long long ml = m & 0x5555555555555555ull, mr = m & 0xaaaaaaaaaaaaaaaaull;
         if (ml != 0ull && mr != 0ull) {
-          const unsigned long long pref = __ballot((okl || okr) && (bl <= br));
-          const bool left_first = 2 * __popcll(pref) >= __popcll(ml | mr);
+          const unsigned long long pref = __ballot(c == 0 && (ok || oko) && (d <= o));    // even lanes: d = left, o = right
+          const unsigned long long either = (ml | (mr >> 1)) & 0x5555555555555555ull;    // even lanes of the queries that reach a child
+          const bool left_first = 2 * __popcll(pref) >= __popcll(either);
           if (sp < WALK_STACK) { stk[sp] = left_first ? 2 * h + 1 : 2 * h; sp++; }
           h = left_first ? 2 * h : 2 * h + 1;
           continue;

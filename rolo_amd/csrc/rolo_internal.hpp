@@ -165,7 +165,7 @@ constexpr int KNN_WALK_STACK = 48;
 // regularization >= 0: the walk ends in the covariance tail (A.c[].cov / the exchange buffer); -1: neighbour indices -> A.c[].nbr only
 // coop_budget > 0 (k = 20, own covariance launch): the cooperative walk — a packet that has scored that many leaves with sub-trees left publishes them to the
 // idle wavefronts of its workgroup (knn_walk.hpp); 0: the plain walk, every wavefront for itself
-hipError_t launch_knn_walk(const KnnPair& A, int k, int regularization_or_minus1, const VoxelFuse& vf, hipStream_t s, int coop_budget = 0);
+hipError_t launch_knn_walk(const KnnPair& A, int k, int regularization_or_minus1, const VoxelFuse& vf, hipStream_t s, int coop_budget = 0, int* lanes_out = nullptr);
 hipError_t launch_knn_tail(const KnnPair& A, int k, int regularization, const VoxelFuse& vf, hipStream_t s);   // covariances from A.c[].nbr
 // multi-GPU: exchange buffer (sorted order, all ranks' slices after the all-gather, or [q_begin, q_end) only) -> cov[] by original index
 // vf.enabled: the target's points are accumulated into the voxel map by this scatter (sharded VoxelFuse)

@@ -110,12 +110,18 @@ def roofline(g, run_one_step, n_src, n_tgt, passes_per_frame, hbm_peak_gbs, reps
     pmc, pmc_desc = pmc_traffic_file()
     if pmc and os.path.exists(pmc):
         try:
-            traffic = json.load(open(pmc)).get(dom + "_kernel", {}).get("hbm_bytes_per_launch")
+            tr = json.load(open(pmc))
+            names = [dom + "_kernel"] + (["knn_walk_sub_kernel"] if dom == "knn_walk" else [])   # the walk has two kernels: the profile holds the one the launch size picks
+            traffic = next((tr[k]["hbm_bytes_per_launch"] for k in names if k in tr), None)
         except Exception:
             traffic = None
     # the same kernel per profiled step (bench.py profiles one step per pair of its input pool, in pool order: step 0 = the nominal pair of SURVEY 8d)
     per_step_ms = [float(r.mean()) for r in real_runs.get(dom, []) if len(r)]
-    return {"bound": "hbm", "kernel": dom + "_kernel", "achieved": achieved, "peak": hbm_peak_gbs, "unit": "GB/s",
+    kname = dom + "_kernel"
+    if dom == "knn_walk":   # which of the walk's kernels the launch size picked (rolo_ctx_counters [8])
+        lanes = g.counters().get("walk_lanes", 1)
+        kname = "knn_walk_kernel" if lanes <= 1 else f"knn_walk_sub_kernel<{lanes}>"
+    return {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": hbm_peak_gbs, "unit": "GB/s",
             "frac": achieved / hbm_peak_gbs, "traffic": traffic, "avg_launch_ms_per_profiled_step": per_step_ms,
             "traffic_source": pmc_desc,
             "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": avg_ms[dom], "top3": top3, "per_frame_ms": per_frame_ms, "avg_ms": avg_ms}

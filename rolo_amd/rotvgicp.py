@@ -330,9 +330,9 @@ class RotVGICP:
 
     def counters(self) -> dict:
         """rolo_ctx_counters as a dict"""
-        v = (C.c_longlong * 8)()
-        check(lib().rolo_ctx_counters(self._h, v, 8), "rolo_ctx_counters")
-        return dict(zip(("frames", "graph_replays", "graph_captures", "eager_frames", "topup_frames", "sync_chunks", "hint_rot", "hint_trans"), [int(x) for x in v]))
+        v = (C.c_longlong * 9)()
+        check(lib().rolo_ctx_counters(self._h, v, 9), "rolo_ctx_counters")
+        return dict(zip(("frames", "graph_replays", "graph_captures", "eager_frames", "topup_frames", "sync_chunks", "hint_rot", "hint_trans", "walk_lanes"), [int(x) for x in v]))
 
     @property
     def stream(self) -> int:
