@@ -74,7 +74,8 @@ ROLO_DEV void walk_write_lists(const KnnCloud& cl, const double (&K)[KMAX], int 
 #endif
 #ifndef ROLO_KNN_SEED_EXTRA
 #define ROLO_KNN_SEED_EXTRA 1   // leaves on either side of the wavefront's own ones (along the curve) scored before the tree walk starts: curve neighbours are space neighbours,
-                                // so every lane enters the walk with a tighter bound (0 / 1 / 2 / 4: walk 0.188 / 0.177 / 0.178 / 0.187 ms at 2 x 131 072 points, 0.147 / 0.136 / 0.138 / 0.138 at 2 x 65 536)
+                                // so every lane enters the walk with a tighter bound (packets, 0 / 1 / 2 / 4: walk 0.188 / 0.177 / 0.178 / 0.187 ms at 2 x 131 072 points, 0.147 / 0.136 / 0.138 / 0.138 at 2 x 65 536;
+                                // the sub-lane walks, 0 / 1 / 2: 0.194 / 0.179 / 0.180 ms over the pool, 0.138 / 0.082 / 0.080 at 2 x 43 776)
 #endif
 static_assert(ROLO_KNN_PACKET == 64, "one query per lane");
 
