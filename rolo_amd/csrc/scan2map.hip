@@ -453,9 +453,9 @@ __global__ __launch_bounds__(256) void s2m_packet_kernel(S2mArgs A, int split /*
 // 64 / SUB features, SUB adjacent lanes per feature: the frontier shrinks with the packet, there are SUB times as many wavefronts to hide the fetch
 // latency, and a visited leaf costs each lane 16 / SUB candidates (point u of the leaf goes to sub-lane u % SUB: every sub-lane sees an even sample
 // of the neighbourhood). Each sub-lane keeps the 5 best of ITS candidates; the feature's pruning bound is shared by its SUB lanes:
-//     B = min( min_s K_s[4],  max_s K_s[ceil(5 / SUB) - 1] )
-// — both are keys with at least five real candidates at or below them (five in one sub-lane's list; ceil(5/SUB) in each of SUB lists), so a candidate or
-// a box beyond B cannot belong to the five nearest: the walk stays exact. After the walk the SUB lists are merged (sorted inserts of the partners'
+//     B = min( min_s K_s[4],  max_s K_s[ceil(5 / SUB) - 1] )          (SUB = 4: the second term is max( max_s K_s[0], min_s K_s[1] ))
+// — all are keys with at least five real candidates at or below them (five in one sub-lane's list; ceil(5/SUB) in each of SUB lists; two in one list and
+// the best of each other one), so a candidate or a box beyond B cannot belong to the five nearest: the walk stays exact. After the walk the SUB lists are merged (sorted inserts of the partners'
 // keys): the same five (d2, index) keys in the same order as the one-lane search, and the fits, flags and rows downstream are the same floats.
 ROLO_DEV void insert5(double (&K)[5], double ck) {
 #pragma unroll
@@ -527,7 +527,13 @@ __global__ __launch_bounds__(256) void s2m_sub_kernel(S2mArgs A, int split /* fi
         if (ck < B) { insert5(K, ck); changed = true; }
       }
       if (__any(changed)) {
-        B = vmin_f64(vmin_f64(B, sub_min<SUB>(K[4])), sub_max<SUB>(K[NEED - 1]));
+        if (SUB == 4) {
+          // exactly five candidates instead of eight: two from the sub-lane whose second key is smallest, the best key of each of the other three
+          // (max_s K_s[0] also covers that sub-lane's own first key) — never above max_s K_s[1], the bound of two from each
+          B = vmin_f64(vmin_f64(B, sub_min<SUB>(K[4])), vmax_f64(sub_max<SUB>(K[0]), sub_min<SUB>(K[1])));
+        } else {
+          B = vmin_f64(vmin_f64(B, sub_min<SUB>(K[4])), sub_max<SUB>(K[NEED - 1]));
+        }
         bd = key_d2(B);
       }
     };
