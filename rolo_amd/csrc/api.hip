@@ -409,7 +409,7 @@ void fill_table_params(rolo_ctx* c) {
   static const int polar_exact = [] { const char* e = getenv("ROLO_POLAR_EXACT"); return (e && atoi(e) == 0) ? 0 : 1; }();
   c->tab.polar_exact = polar_exact;
   c->tab.voxel_type = c->P.voxel_type;
-  c->tab.voxel_resolution = c->P.voxel_resolution;
+  c->tab.voxel_resolution = c->P.voxel_resolution; c->tab.inv_voxel_resolution = 1.0 / c->P.voxel_resolution;
   for (int i = 0; i < 3; i++) c->tab.polar_res[i] = c->P.polar_resolution[i];
 }
 
@@ -467,6 +467,8 @@ int prepare_pass(rolo_ctx* c, PassArgs& a, int& grid) {
   if ((rc = ensure(c->partials, c->partials_cap, std::max((size_t)grid, 2 * (size_t)c->lm_rows) * NV_MAX))) return rc;
   a.src = c->src.xyz; a.cov = c->src.cov; a.n_total = c->src.n; a.begin = begin; a.end = end; a.n_off = noff;
   a.corr[0] = c->corr[0]; a.corr[1] = c->corr[1]; a.partials = c->partials; a.tab = c->tab;
+  static const bool xcd_on = [] { const char* e = getenv("ROLO_PASS_XCD"); return !e || atoi(e) != 0; }();
+  a.xcd_map = xcd_on ? 1 : 0;
   return ROLO_OK;
 }
 

@@ -71,61 +71,68 @@ ROLO_DEV double wave_sum_dpp63(double v) {
   return v;
 }
 
-// Sum NV per-lane values over the 64 lanes of the wavefront as a reduce-scatter: at every halving step a lane hands the
-// half of its values it will not own to the partner lane (offset 32, 16, ...) and adds what it receives, so the value
-// count halves with the distance — 17 cross-lane exchanges for 12..16 values, 32 for 17..32, instead of 6 per value
-// (72 / 180), and none of them through the LDS crossbar (lane_xor_f64). With 30 values (translation and 6-dof passes) the separate butterflies were half of the kernel's
-// wavefront lifetime: 15.6 -> 9.5 us per translation pass.
-// Afterwards lane L holds the complete sum of value idx(L); the order of the additions is fixed (deterministic).
+// Sum NV per-lane values over the 64 lanes of the wavefront as a reduce-scatter WITHOUT selects (round 5). At every halving step the
+// values are taken in pairs (k, k + half): the lanes whose step bit is 0 will own value k, the others value k + half, and each hands the
+// value it does not own to its partner and adds what it receives. gfx950's v_permlane32_swap / v_permlane16_swap do the hand-over of a
+// whole pair in place — swap(X, Y) leaves [X.lo | Y.lo] in X and [X.hi | Y.hi] in Y, so X + Y IS the step (2 swaps + 1 add per pair of
+// doubles, no v_cndmask); inside a row of 16 the same step is three DPP moves under a bank mask (keep = X with Y's banks patched in,
+// received = row_ror:8 / row_shl:4 + row_shr:4 of the other value) and the last two distances are plain butterflies on what is left.
+// 12 values (SO(3) pass): 63 VALU instructions against 216 for one DPP butterfly per value; 30 values (translation / 6-dof passes): 126
+// against ~400 for round 2's reduce-scatter, whose generic lane-xor moves paid four v_cndmask per exchanged double (half of that
+// kernel's instructions). Afterwards lane l holds the complete sums of the NP / 16 values j + (NP / 16) * (b2 + 2 b3 + 4 b4 + 8 b5),
+// b_i = bit i of l — identical in the four lanes of a quad; the order of the additions is fixed (deterministic).
+ROLO_DEV void rs_swap32(double& x, double& y) {
+  const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(x), (unsigned)__double2loint(y), false, false);
+  const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(y), false, false);
+  x = __hiloint2double((int)hi[0], (int)lo[0]); y = __hiloint2double((int)hi[1], (int)lo[1]);
+}
+ROLO_DEV void rs_swap16(double& x, double& y) {
+  const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(x), (unsigned)__double2loint(y), false, false);
+  const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(y), false, false);
+  x = __hiloint2double((int)hi[0], (int)lo[0]); y = __hiloint2double((int)hi[1], (int)lo[1]);
+}
+// one reduce-scatter step inside a row of 16 lanes: OFF = 8 (banks 0,1 own x, banks 2,3 own y) or 4 (banks 0,2 own x, banks 1,3 own y)
+template <int OFF>
+ROLO_DEV double rs_row_step(double x, double y) {
+  constexpr int YB = OFF == 8 ? 0xc : 0xa, XB = OFF == 8 ? 0x3 : 0x5;   // bank masks of the lanes that own y / x
+  constexpr int UP = OFF == 8 ? 0x128 : 0x104, DN = OFF == 8 ? 0x128 : 0x114;   // lane <- lane + OFF (row_ror:8 / row_shl:4), lane <- lane - OFF (row_ror:8 / row_shr:4)
+  const int xl = __double2loint(x), xh = __double2hiint(x), yl = __double2loint(y), yh = __double2hiint(y);
+  const int kl = __builtin_amdgcn_update_dpp(xl, yl, 0xE4, 0xf, YB, false), kh = __builtin_amdgcn_update_dpp(xh, yh, 0xE4, 0xf, YB, false);   // keep: x, y where y is owned
+  int rl = __builtin_amdgcn_update_dpp(0, xl, UP, 0xf, XB, false), rh = __builtin_amdgcn_update_dpp(0, xh, UP, 0xf, XB, false);               // received: the partner's x ...
+  rl = __builtin_amdgcn_update_dpp(rl, yl, DN, 0xf, YB, false); rh = __builtin_amdgcn_update_dpp(rh, yh, DN, 0xf, YB, false);                 // ... or the partner's y
+  return __hiloint2double(kh, kl) + __hiloint2double(rh, rl);
+}
 template <int NV>
 ROLO_DEV void wave_reduce_scatter(const double (&acc)[NV], double* __restrict__ red_row /* LDS, NV_MAX */) {
   constexpr int NP = NV <= 16 ? 16 : 32;
-  constexpr int NSTEPS = NP == 16 ? 4 : 5;
+  constexpr int NL = NP / 16;   // values left per lane after the four scatter steps
   static_assert(NV <= 32, "at most 32 values");
   const int lane = threadIdx.x & 63;
   double v[NP];
 #pragma unroll
   for (int k = 0; k < NP; k++) v[k] = k < NV ? acc[k] : 0.0;
-  int idx = 0;
-  auto step = [&](auto off_c, auto half_c) {
-    constexpr int off = decltype(off_c)::value, half = decltype(half_c)::value;
-    const bool upper = (lane & off) != 0;
-    idx = (idx << 1) | (upper ? 1 : 0);
-    double got[half];
 #pragma unroll
-    for (int k = 0; k < half; k++) got[k] = lane_xor_f64<off>(upper ? v[k] : v[k + half]);
+  for (int k = 0; k < NP / 2; k++) { rs_swap32(v[k], v[k + NP / 2]); v[k] += v[k + NP / 2]; }
 #pragma unroll
-    for (int k = 0; k < half; k++) v[k] = (upper ? v[k + half] : v[k]) + got[k];
-  };
-  using std::integral_constant;
-  step(integral_constant<int, 32>{}, integral_constant<int, NP / 2>{});
-  step(integral_constant<int, 16>{}, integral_constant<int, NP / 4>{});
-  step(integral_constant<int, 8>{}, integral_constant<int, NP / 8>{});
-  step(integral_constant<int, 4>{}, integral_constant<int, NP / 16>{});
-  if constexpr (NSTEPS == 5) {
-    step(integral_constant<int, 2>{}, integral_constant<int, 1>{});
-    v[0] += lane_xor_f64<1>(v[0]);
-  } else {
-    v[0] += lane_xor_f64<2>(v[0]);
-    v[0] += lane_xor_f64<1>(v[0]);
+  for (int k = 0; k < NP / 4; k++) { rs_swap16(v[k], v[k + NP / 4]); v[k] += v[k + NP / 4]; }
+#pragma unroll
+  for (int k = 0; k < NP / 8; k++) v[k] = rs_row_step<8>(v[k], v[k + NP / 8]);
+#pragma unroll
+  for (int k = 0; k < NL; k++) v[k] = rs_row_step<4>(v[k], v[k + NL]);
+#pragma unroll
+  for (int k = 0; k < NL; k++) { v[k] += lane_xor_f64<2>(v[k]); v[k] += lane_xor_f64<1>(v[k]); }
+  if ((lane & 3) == 0) {
+    const int base = NL * (((lane >> 2) & 1) + 2 * ((lane >> 3) & 1) + 4 * ((lane >> 4) & 1) + 8 * ((lane >> 5) & 1));
+#pragma unroll
+    for (int k = 0; k < NL; k++) if (base + k < NV) red_row[base + k] = v[k];
   }
-  if ((lane & ((64 >> NSTEPS) - 1)) == 0 && idx < NV) red_row[idx] = v[0];
 }
 
 template <int NV, int THREADS = PASS_THREADS>
 ROLO_DEV void block_reduce_store(double (&acc)[NV], const int (&slot)[NV], double* __restrict__ out_row) {
   __shared__ double red[THREADS / 64][NV_MAX];
   const int wv = threadIdx.x >> 6;
-  if constexpr (NV > 16) {   // 30 values: reduce-scatter (9.6 us per translation pass; one DPP reduction per value: 10.7)
-    wave_reduce_scatter<NV>(acc, red[wv]);
-  } else {  // few values (SO(3) pass: 12): one DPP reduction per value
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int k = 0; k < NV; k++) {
-      const double t = wave_sum_dpp63(acc[k]);
-      if (lane == 63) red[wv][k] = t;
-    }
-  }
+  wave_reduce_scatter<NV>(acc, red[wv]);
   __syncthreads();
   if (threadIdx.x < NV) {
     double s = 0;
@@ -139,34 +146,42 @@ ROLO_DEV void block_reduce_store(double (&acc)[NV], const int (&slot)[NV], doubl
   }
 }
 
-// u_i = column i of J = [skew(a) | -I]  (rot_vgicp_impl.hpp:264-266, 353, 576-578)
-template <int DOF>
-ROLO_DEV void jacobian_cols(const Vec3& a, Vec3 (&u)[DOF]) {
-  u[0] = Vec3{0.0, a.z, -a.y};
-  u[1] = Vec3{-a.z, 0.0, a.x};
-  u[2] = Vec3{a.y, -a.x, 0.0};
-  if constexpr (DOF == 6) {
-    u[3] = Vec3{-1.0, 0.0, 0.0};
-    u[4] = Vec3{0.0, -1.0, 0.0};
-    u[5] = Vec3{0.0, 0.0, -1.0};
-  }
-}
-
+// H += wh * J^T M J, b += J^T Mv_b for J = [skew(a) | -I]  (rot_vgicp_impl.hpp:264-266, 353, 576-578). The columns u_i of J are
+// u_0 = (0, a.z, -a.y), u_1 = (-a.z, 0, a.x), u_2 = (a.y, -a.x, 0), u_3.. = -e_x, -e_y, -e_z. Round 5: the structure is written out — the
+// zero components are dropped (0 * x + y IS y for the finite values a pass sees) and the -I columns are read off M: -M's columns, H's
+// translation block wh * M, the mixed block -wh * (M u_j) — instead of the generic dot3(u_i, M u_j) with its multiplications by 0.0 and
+// -1.0, which the compiler must keep. Same operation order for what remains, so H and b keep their bits (up to the sign of a zero);
+// 42 fp64 instructions against 60 (SO(3)), 60 against 156 (6 dof).
 // acc layout inside the kernels: [0]=yi [1]=y [2]=n [3 .. 3+NH) H lower triangle, then b
 template <int DOF>
 ROLO_DEV void accumulate_hb(const Sym3& M, const Vec3& a, double wh, double wb_unused, const Vec3& Mv_b, double* Hacc, double* bacc) {
   (void)wb_unused;
-  Vec3 u[DOF];
-  jacobian_cols<DOF>(a, u);
-  Vec3 Mu[DOF];
-#pragma unroll
-  for (int j = 0; j < DOF; j++) Mu[j] = sym3_mulv(M, u[j]);
-  int t = 0;
-#pragma unroll
-  for (int i = 0; i < DOF; i++) {
-#pragma unroll
-    for (int j = 0; j <= i; j++) { Hacc[t] += wh * dot3(u[i], Mu[j]); t++; }
-    bacc[i] += dot3(u[i], Mv_b);
+  // (p2: the generic expression's own order once its zero term is gone — the first product rounded, the second fused into the sum)
+  auto p2 = [](double x1, double y1, double x2, double y2) { return fma(x2, y2, x1 * y1); };
+  // M u_j for the three skew columns: two products per component
+  const Vec3 Mu0{p2(M.xy, a.z, M.xz, -a.y), p2(M.yy, a.z, M.yz, -a.y), p2(M.yz, a.z, M.zz, -a.y)};
+  const Vec3 Mu1{p2(M.xx, -a.z, M.xz, a.x), p2(M.xy, -a.z, M.yz, a.x), p2(M.xz, -a.z, M.zz, a.x)};
+  const Vec3 Mu2{p2(M.xx, a.y, M.xy, -a.x), p2(M.xy, a.y, M.yy, -a.x), p2(M.xz, a.y, M.yz, -a.x)};
+  // rotation block, lower triangle row-major: (0,0) (1,0) (1,1) (2,0) (2,1) (2,2); u_i . v with the zero component left out
+  auto d0 = [&](const Vec3& v) { return p2(a.z, v.y, -a.y, v.z); };
+  auto d1 = [&](const Vec3& v) { return p2(-a.z, v.x, a.x, v.z); };
+  auto d2 = [&](const Vec3& v) { return p2(a.y, v.x, -a.x, v.y); };
+  if constexpr (DOF == 3) {
+    Hacc[0] += wh * d0(Mu0);
+    Hacc[1] += wh * d1(Mu0); Hacc[2] += wh * d1(Mu1);
+    Hacc[3] += wh * d2(Mu0); Hacc[4] += wh * d2(Mu1); Hacc[5] += wh * d2(Mu2);
+    bacc[0] += d0(Mv_b); bacc[1] += d1(Mv_b); bacc[2] += d2(Mv_b);
+  } else {
+    static_assert(DOF == 6, "3 or 6 degrees of freedom");
+    // row-major lower triangle of the 6 x 6: rows 0..2 as above, row 3+c = [ -(M u_0).c  -(M u_1).c  -(M u_2).c | M(c, 0..c) ]
+    Hacc[0] += wh * d0(Mu0);
+    Hacc[1] += wh * d1(Mu0); Hacc[2] += wh * d1(Mu1);
+    Hacc[3] += wh * d2(Mu0); Hacc[4] += wh * d2(Mu1); Hacc[5] += wh * d2(Mu2);
+    Hacc[6] += wh * (-Mu0.x); Hacc[7] += wh * (-Mu1.x); Hacc[8] += wh * (-Mu2.x); Hacc[9] += wh * M.xx;
+    Hacc[10] += wh * (-Mu0.y); Hacc[11] += wh * (-Mu1.y); Hacc[12] += wh * (-Mu2.y); Hacc[13] += wh * M.xy; Hacc[14] += wh * M.yy;
+    Hacc[15] += wh * (-Mu0.z); Hacc[16] += wh * (-Mu1.z); Hacc[17] += wh * (-Mu2.z); Hacc[18] += wh * M.xz; Hacc[19] += wh * M.yz; Hacc[20] += wh * M.zz;
+    bacc[0] += d0(Mv_b); bacc[1] += d1(Mv_b); bacc[2] += d2(Mv_b);
+    bacc[3] -= Mv_b.x; bacc[4] -= Mv_b.y; bacc[5] -= Mv_b.z;
   }
 }
 
@@ -207,6 +222,9 @@ ROLO_DEV void rot_pass_compute(const PassArgs& a, const LmState* __restrict__ st
     tp.x += t1[0]; tp.y += t1[1]; tp.z += t1[2];
     const int n_off = a.n_off;
     // (A) compute_error(xi): cached correspondences, Mahalanobis of the linearisation pose x0
+    // (round 5 measured the reference's per-correspondence Mahalanobis cache here — six fp64 of M(x0) per point, written by the (B) half, read by the next
+    // trial's (A) half, rot_vgicp_impl.hpp:204-222 — and it LOST: 96 B per point and pass of extra traffic cost more than the ~100 instructions saved,
+    // 2694 against 2875 scans/s; profiles/DEAD_ENDS.md. The translation stage, whose M is constant, does cache it: trans_pass_compute.)
     if (phase == 1) {
       const Sym3 RCA0 = sym3_rotate(R0, CA);
       for (int o = 0; o < n_off; o++) {
@@ -291,43 +309,50 @@ ROLO_DEV void rot_pass_body(const PassArgs& a, const LmState* __restrict__ st, c
 ROLO_DEV void trans_pass_compute(const PassArgs& a, const LmState* __restrict__ st, const int i, const bool valid, const PtIn& in, double (&acc)[30]) {
   constexpr int NH = 21;
   const int phase = uni(st->phase);
-  const int* __restrict__ corr = a.corr[uni(st->tr_cur)];
+  const int tr_cur = uni(st->tr_cur);
+  const int* __restrict__ corr = a.corr[tr_cur];
+  // (the stage's Mahalanobis matrices are those of the LAST rotation linearisation — constant over all its passes. Caching the six fp64 per point
+  // after the first pass instead of rotating / inverting again was measured in round 5 and is not kept: 2957 against 2958 scans/s, profiles/DEAD_ENDS.md)
   double R[9];
 #pragma unroll
   for (int k = 0; k < 9; k++) R[k] = uni(st->tr_R[k]);
   const Vec3 tt{uni(st->tt[0]), uni(st->tt[1]), uni(st->tt[2])};
   const Vec3 g{uni(st->g[0]), uni(st->g[1]), uni(st->g[2])};
-  const double dtn = uni(st->dtn), dtn1 = uni(st->dtn1), lam_n = uni(st->lam_over_n);
-  // last_transform keeps its initial value — Zero in t3_linearize (:539), (1,0,0,0) in compute_t_error (:637)
-  Vec3 lastA{1.0, 0.0, 0.0}, lastB{0.0, 0.0, 0.0};
-  if (uni(st->q2_intended)) { lastA = Vec3{uni(st->l[0]), uni(st->l[1]), uni(st->l[2])}; lastB = lastA; }
-  const double inv_dtn = 1.0 / dtn;
+  const double lam_n = uni(st->lam_over_n);
+  // last_transform keeps its initial value — Zero in t3_linearize (:539), (1,0,0,0) in compute_t_error (:637). The quotients
+  // last / dt_{n-1} and 1 / dt_n are the same for every point: formed once when the stage starts (trans_consts), not by every lane of every pass
+  // (seven fp64 divisions = ~100 of the pass's ~700 instructions).
+  const Vec3 lAq{uni(st->lastA_q[0]), uni(st->lastA_q[1]), uni(st->lastA_q[2])}, lBq{uni(st->lastB_q[0]), uni(st->lastB_q[1]), uni(st->lastB_q[2])};
+  const double inv_dtn = uni(st->inv_dtn);
   if (valid) {
     const float4 pf = in.pf;
     const Vec3 p{(double)pf.x, (double)pf.y, (double)pf.z};
-    const Sym3 CA = in.CA;
-    const Sym3 RCA = sym3_rotate(R, CA);
     const Vec3 tp{p.x + tt.x, p.y + tt.y, p.z + tt.z};
     const Vec3 ba{p.x - g.x, p.y - g.y, p.z - g.z};
-    const Vec3 dv{(ba.x - tp.x) / dtn, (ba.y - tp.y) / dtn, (ba.z - tp.z) / dtn};
-    const Vec3 ctA{dv.x - lastA.x / dtn1, dv.y - lastA.y / dtn1, dv.z - lastA.z / dtn1};
-    const Vec3 ctB{dv.x - lastB.x / dtn1, dv.y - lastB.y / dtn1, dv.z - lastB.z / dtn1};
+    // (times 1 / dt_n instead of the reference's division: one rounding of a uniform factor, far below the rounding noise ba - tp already carries — the
+    // difference is -(g + t) for every point in exact arithmetic — and three fp64 divisions = 45 instructions per lane and pass less)
+    const Vec3 dv{(ba.x - tp.x) * inv_dtn, (ba.y - tp.y) * inv_dtn, (ba.z - tp.z) * inv_dtn};
+    const Vec3 ctA{dv.x - lAq.x, dv.y - lAq.y, dv.z - lAq.z};
+    const Vec3 ctB{dv.x - lBq.x, dv.y - lBq.y, dv.z - lBq.z};
     const int n_off = a.n_off;
+    const Sym3 RCA = sym3_rotate(R, in.CA);
     for (int o = 0; o < n_off; o++) {
       const int vid = corr[(size_t)i * n_off + o];
       if (vid < 0) continue;
-      const Rec r = load_rec(a.tab.rec, vid);
-      const Sym3 M = sym3_inverse(sym3_add(r.cov, RCA));
-      const Vec3 e{r.mean.x - tp.x, r.mean.y - tp.y, r.mean.z - tp.z};
+      const double* __restrict__ rr = a.tab.rec + (size_t)vid * REC_DOUBLES;
+      const Vec3 mean{rr[0], rr[1], rr[2]};
+      const double w = rr[9];
+      const Sym3 M = sym3_inverse(sym3_add(Sym3{rr[3], rr[4], rr[5], rr[6], rr[7], rr[8]}, RCA));
+      const Vec3 e{mean.x - tp.x, mean.y - tp.y, mean.z - tp.z};
       const Vec3 Me = sym3_mulv(M, e);
       const double eMe = dot3(e, Me);
-      if (phase == 1) acc[0] += r.w * (eMe + lam_n * dot3(ctA, sym3_mulv(M, ctA)));
+      if (phase == 1) acc[0] += w * (eMe + lam_n * dot3(ctA, sym3_mulv(M, ctA)));
       const Vec3 McB = sym3_mulv(M, ctB);
-      acc[1] += r.w * (eMe + lam_n * dot3(ctB, McB));
+      acc[1] += w * (eMe + lam_n * dot3(ctB, McB));
       acc[2] += 1.0;
       const double s1 = lam_n * inv_dtn;
-      const Vec3 vb{r.w * (Me.x + s1 * McB.x), r.w * (Me.y + s1 * McB.y), r.w * (Me.z + s1 * McB.z)};
-      accumulate_hb<6>(M, tp, r.w * (1.0 + lam_n * inv_dtn * inv_dtn), 0.0, vb, &acc[3], &acc[3 + NH]);
+      const Vec3 vb{w * (Me.x + s1 * McB.x), w * (Me.y + s1 * McB.y), w * (Me.z + s1 * McB.z)};
+      accumulate_hb<6>(M, tp, w * (1.0 + lam_n * inv_dtn * inv_dtn), 0.0, vb, &acc[3], &acc[3 + NH]);
     }
   }
 }
@@ -352,9 +377,19 @@ ROLO_DEV void trans_pass_body(const PassArgs& a, const LmState* __restrict__ st,
   block_reduce_store<NV>(acc, slot, a.partials + (size_t)block * NV_MAX);
 }
 
+// Workgroup b of a launch runs on XCD b mod 8, and every XCD has its own L2, emptied at every kernel boundary: with the points dealt round-robin each
+// XCD fetches (nearly) ALL voxel records and hash slots again in every pass — 8 x the map from the Infinity Cache per launch. A LiDAR cloud arrives in
+// firing order (column-major: consecutive points sweep the azimuth), so giving XCD x the x-th EIGHTH of the point blocks makes it a 45-degree sector
+// whose voxels no other XCD needs (round 5; the permutation of knn_packet.hpp's small-launch case). Rows stay indexed by the logical block: the
+// controller's summation order does not depend on the mapping.
+ROLO_DEV int pass_xcd_block(const PassArgs& a, int b, int G) {
+  if (!a.xcd_map) return b;
+  const int x = b & 7, k = b >> 3, q = G >> 3, r = G & 7;   // XCD x owns G / 8 (+1 for x < G % 8) consecutive blocks
+  return x * q + min(x, r) + k;
+}
 template <int DOF>
-__global__ __launch_bounds__(PASS_THREADS) void rot_pass_kernel(PassArgs a, const LmState* __restrict__ st) { rot_pass_body<DOF>(a, st, blockIdx.x); }
-__global__ __launch_bounds__(PASS_THREADS) void trans_pass_kernel(PassArgs a, const LmState* __restrict__ st) { trans_pass_body(a, st, blockIdx.x); }
+__global__ __launch_bounds__(PASS_THREADS) void rot_pass_kernel(PassArgs a, const LmState* __restrict__ st) { rot_pass_body<DOF>(a, st, pass_xcd_block(a, blockIdx.x, gridDim.x)); }
+__global__ __launch_bounds__(PASS_THREADS) void trans_pass_kernel(PassArgs a, const LmState* __restrict__ st) { trans_pass_body(a, st, pass_xcd_block(a, blockIdx.x, gridDim.x)); }
 
 // Batched form (rolo_batch_*, BASELINE config 5): one launch evaluates the same LM trial of B independent frame
 // pairs. Workgroups [s * bps, (s + 1) * bps) belong to slot s; every slot has its own clouds, voxel table,
@@ -612,7 +647,15 @@ ROLO_DEV void trans_begin_outer(LmState* st) {
   st->nu = 2.0; st->trial = 0;
   trans_compute_step(st);
 }
+// the per-stage constants of the translation passes (same IEEE quotients every lane used to form for itself)
+ROLO_DEV void trans_consts(LmState* st) {
+  double lastA[3] = {1.0, 0.0, 0.0}, lastB[3] = {0.0, 0.0, 0.0};
+  if (st->q2_intended) for (int i = 0; i < 3; i++) { lastA[i] = st->l[i]; lastB[i] = st->l[i]; }
+  for (int i = 0; i < 3; i++) { st->lastA_q[i] = lastA[i] / st->dtn1; st->lastB_q[i] = lastB[i] / st->dtn1; }
+  st->inv_dtn = 1.0 / st->dtn;
+}
 ROLO_DEV void trans_start(LmState* st) {  // lsq_registration_impl.hpp:55-61
+  trans_consts(st);
   st->stage = 2; st->phase = 0; st->outer = 0; st->trial = 0; st->lambda = -1.0;
   st->trans_done = 0; st->trans_failed = 0; st->trans_outer = 0; st->trans_passes = 0;
   for (int i = 0; i < 3; i++) st->tt[i] = st->t0[i];
@@ -1049,6 +1092,7 @@ __global__ void t3_eval_begin_kernel(LmState* st, TransBegin a, int phase) {
   for (int i = 0; i < 3; i++) { st->tt[i] = a.t0[i]; st->t0[i] = a.t0[i]; st->g[i] = a.g[i]; st->l[i] = a.l[i]; }
   st->dtn = a.dtn; st->dtn1 = a.dtn1; st->ct_lambda = a.ct_lambda;
   st->lam_over_n = (double)(a.ct_lambda / (float)st->tr_n_corr);
+  trans_consts(st);
   st->stage = 2; st->phase = phase;
 }
 

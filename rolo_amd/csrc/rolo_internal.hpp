@@ -38,6 +38,7 @@ struct VoxelTable {
   unsigned mask;             // capacity - 1
   int voxel_type;
   double voxel_resolution;
+  double inv_voxel_resolution;   // 1.0 / voxel_resolution (host): the pass kernels' fast path of the UNIFORM key (voxel_dev.hpp voxel_coord_dev)
   double polar_res[3];
   int polar_exact;           // 1 (default): POLAR keys of target points near a bin edge through the correctly rounded atan2 / acos (polar_exact.hpp); 0: counted only (ROLO_POLAR_EXACT=0, the A/B)
 };
@@ -73,6 +74,7 @@ struct LmState {
   double final_H[36];
   // translation stage
   double t0[3], tt[3], g[3], l[3], dtn, dtn1, lam_over_n;
+  double lastA_q[3], lastB_q[3], inv_dtn;   // last_transform / dt_{n-1} as compute_t_error / t3_linearize see it, 1 / dt_n: formed once per stage (trans_consts)
   float ct_lambda;
   // control
   int stage;   // 0 idle, 1 rotation / 6-dof, 2 translation
@@ -101,6 +103,7 @@ struct PassArgs {
   int n_off;          // 1, 7 or 27 neighbour offsets
   int* corr[2];       // n_total * n_off voxel ids (-1 = none)
   double* partials;   // gridDim.x x NV_MAX
+  int xcd_map;        // 1: XCD x evaluates the x-th eighth of the point blocks (passes.hip pass_xcd_block); 0: blocks dealt round-robin (ROLO_PASS_XCD=0, the A/B)
   VoxelTable tab;
 };
 

@@ -34,7 +34,19 @@ ROLO_DEV void voxel_coord_dev_edge(const VoxelTable& tab, double x, double y, do
 
 // vmp_voxel.hpp:199-201 (UNIFORM) and :208-211 (POLAR) for the pass kernels' correspondence lookup of a transformed source point (rot_vgicp_impl.hpp:184-186): the same
 // keys as the map build's, edge points through the correctly rounded functions too (round 4; a rare divergent branch: rot_pass_kernel stays at its register budget)
+// UNIFORM (round 5): the three quotients by the wave-uniform leaf are three fp64 divisions = ~40 instructions per lane and pass. x * (1 / leaf) differs from the correctly
+// rounded x / leaf by at most two ulps of the quotient — below 1e-9 for |key| < 2^21 — so the product decides the floor unless it lands within 1e-9 of an integer; those
+// lanes (two in 1e9 per coordinate) take the division as written in the reference. Keys stay bit-exact; checked against the divisions on the device by the parity tests.
 ROLO_DEV void voxel_coord_dev(const VoxelTable& tab, double x, double y, double z, int& kx, int& ky, int& kz) {
+  if (tab.voxel_type != ROLO_VOXEL_POLAR) {
+    const double inv = tab.inv_voxel_resolution;
+    const double tx = x * inv - 0.5, ty = y * inv - 0.5, tz = z * inv - 0.5;
+    const double fx = floor(tx), fy = floor(ty), fz = floor(tz);
+    const double lo = 1e-9, hi = 1.0 - 1e-9;
+    const double rx = tx - fx, ry = ty - fy, rz = tz - fz;
+    const bool safe = rx > lo && rx < hi && ry > lo && ry < hi && rz > lo && rz < hi && fabs(fx) < 2097152.0 && fabs(fy) < 2097152.0 && fabs(fz) < 2097152.0;
+    if (safe) { kx = (int)fx; ky = (int)fy; kz = (int)fz; return; }
+  }
   bool near_edge;
   voxel_coord_dev_edge(tab, x, y, z, kx, ky, kz, near_edge);
 }
