@@ -46,7 +46,15 @@ def main(fetch_csv, write_csv, out_json):
         fa, wa = sum(fv) / len(fv), sum(wv) / max(len(wv), 1)
         out[k] = {"launches": len(fv), "FETCH_SIZE_KB_avg": round(fa, 1), "WRITE_SIZE_KB_avg": round(wa, 1),
                   "hbm_bytes_per_launch": round((2 * fa + wa) * 1024)}
+    import os
+    import subprocess
+    try:   # the commit the counters were collected at (bench.py cites this file: traffic and avg_launch_ms must describe the same code)
+        commit = os.environ.get("ROLO_PROF_COMMIT") or subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or "?"
+    except Exception:
+        commit = "?"
+    out["_collected"] = {"commit": commit, "command": os.environ.get("ROLO_PROF_COMMAND", "")}
     json.dump(out, open(out_json, "w"), indent=1)
+    del out["_collected"]
     for k, v in out.items():
         print(f"{k:34s} {v['launches']:5d} {v['FETCH_SIZE_KB_avg']:12.1f} {v['WRITE_SIZE_KB_avg']:12.1f} {v['hbm_bytes_per_launch']:14d}")
 

@@ -31,17 +31,28 @@ def main(paths):
                 acc[k]["_dur_ns"].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
             meta[k] = (r["VGPR_Count"], r["SGPR_Count"], r["LDS_Block_Size"], r["Workgroup_Size"])
     w = csv.writer(sys.stdout)
+    # SQ_WAVE_CYCLES (and SQ_WAIT_*, SQ_ACTIVE_INST_*, SQ_BUSY_CYCLES) count QUAD-cycles on gfx950 (MI355X_MICROARCH.md, "s_memtime tick vs SQ PMC units"): one count = 4
+    # shader clocks. Rounds 2-4 printed the raw quotient as "mean_wave_cycles", four times too short (30 514 for a walk whose wavefronts live 50-60 us); the shares, being
+    # ratios of two quad-cycle counters, were right. mean_wave_us uses the shader clock GRBM_GUI_ACTIVE / kernel duration of the same dispatches when that counter was
+    # collected, 2.4 GHz otherwise, and can be held against the s_memrealtime records of profiles/tools/wavestats.py.
     w.writerow(["kernel", "launches", "mean_us", "VGPRs", "SGPRs", "LDS_B", "workgroup", "waves", "VALU_per_wave", "SALU_per_wave", "SMEM_per_wave", "mean_wave_cycles",
-                "busy_cycles_per_SE_sum", "wait_inst_share_of_wave_cycles", "wait_any_share_of_wave_cycles", "valu_thread_utilisation"])
+                "mean_wave_us", "clock_GHz", "busy_quad_cycles_per_SE_sum", "wait_inst_share_of_wave_cycles", "wait_any_share_of_wave_cycles", "valu_thread_utilisation",
+                "valu_insts_per_launch_M", "salu_insts_per_launch_M"])
     mean = lambda v: sum(v) / len(v) if v else float("nan")
     for k in sorted(acc, key=lambda k: -sum(acc[k]["_dur_ns"])):
         a = acc[k]
         waves = mean(a["SQ_WAVES"]); wc = mean(a["SQ_WAVE_CYCLES"])
+        ghz = (mean(a["GRBM_GUI_ACTIVE"]) / mean(a["_dur_ns"])) if a["GRBM_GUI_ACTIVE"] and mean(a["_dur_ns"]) > 0 else 2.4
+        if not (0.5 < ghz < 3.0):
+            ghz = 2.4
+        cyc = 4.0 * wc / waves if waves else float("nan")
         row = [k, len(a["SQ_WAVES"]) or len(a["_dur_ns"]), round(mean(a["_dur_ns"]) / 1e3, 2), *meta[k], round(waves), round(mean(a["SQ_INSTS_VALU"]) / waves, 1) if waves else "",
-               round(mean(a["SQ_INSTS_SALU"]) / waves, 1) if waves else "", round(mean(a["SQ_INSTS_SMEM"]) / waves, 1) if waves else "", round(wc / waves) if waves else "",
+               round(mean(a["SQ_INSTS_SALU"]) / waves, 1) if waves else "", round(mean(a["SQ_INSTS_SMEM"]) / waves, 1) if waves else "", round(cyc) if waves else "",
+               round(cyc / ghz / 1e3, 2) if waves else "", round(ghz, 2),
                round(mean(a["SQ_BUSY_CYCLES"])), round(mean(a["SQ_WAIT_INST_ANY"]) / wc, 3) if wc else "",
                round(mean(a["SQ_WAIT_ANY"]) / wc, 3) if wc and a["SQ_WAIT_ANY"] else "",
-               round(mean(a["SQ_THREAD_CYCLES_VALU"]) / (64 * mean(a["SQ_ACTIVE_INST_VALU"])), 3) if a["SQ_THREAD_CYCLES_VALU"] and a["SQ_ACTIVE_INST_VALU"] else ""]
+               round(mean(a["SQ_THREAD_CYCLES_VALU"]) / (64 * mean(a["SQ_ACTIVE_INST_VALU"])), 3) if a["SQ_THREAD_CYCLES_VALU"] and a["SQ_ACTIVE_INST_VALU"] else "",
+               round(mean(a["SQ_INSTS_VALU"]) / 1e6, 3) if a["SQ_INSTS_VALU"] else "", round(mean(a["SQ_INSTS_SALU"]) / 1e6, 3) if a["SQ_INSTS_SALU"] else ""]
         # (valu_thread_utilisation = live lanes per issued VALU instruction / 64; round 2 divided by 64 * 4 and the column saturated at 0.25)
         w.writerow(row)
 

@@ -11,7 +11,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o s1 -- $B > $
 # the same on the nominal pair alone (--pool 1: what rounds 1 and 2 profiled)
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats0 -o s0 -- $B --pool 1 > $O/stats0.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/pipe -o pipe -- python $R/bench.py --pipeline-only > $O/pipe.log 2>&1
-B2="python $R/bench.py --steps 3 --warmup 1 --no-cpu --no-config5 --no-pipeline --streams 1 --no-graph --single-round --pool 1"   # PMC passes: the nominal pair
+B2="python $R/bench.py --steps 8 --warmup 1 --no-cpu --no-config5 --no-pipeline --streams 1 --no-graph --single-round"   # PMC passes: the bench's own pool, every pair once in the timed steps (round 5: was --pool 1)
+export ROLO_PROF_COMMAND="$B2"   # (ROLO_PROF_COMMIT: the box has no .git — export it from the authoring side: gpurun -- 'ROLO_PROF_COMMIT=<hash> bash profiles/tools/prof.sh r05')
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o f -- $B2 > $O/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o w -- $B2 > $O/pmc_write.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $O/pmc_sq -o q -- $B2 > $O/pmc_sq.log 2>&1
