@@ -216,7 +216,21 @@ private:
   // width / height, every field), then x, y, z replaced by the scalar path's  c0 x + c1 y + c2 z + c3  (left to right) and w by 1. Until round 4 this went
   // through rolo_transform_cloud — the source uploaded a second time, a kernel, a 1 MB download and a host wait, twice per frame (~0.2 of the 0.74 ms a
   // VLP-16 frame took through this class) — for a cloud the reference caller never reads (src/lidarOdometry.cpp:468, :491: `aligned` is cleared and dropped).
-  void transform_into(PointCloudSource& output, const float* T) {
+  // The sums must stay four separate float operations per coordinate (multiply, add, add, add): that is what rolo_transform_cloud and the oracle compute, and what the
+  // bit-equality of `aligned` with them rests on. A caller's compiler is free to contract a * x + b * y into an FMA (GCC defaults to -ffp-contract=fast in gnu++
+  // modes once -march=native / -mfma makes FMA available), so contraction is switched off for this one function whatever the translation unit is built with.
+#if defined(__clang__)
+#define ROLO_HIP_NO_FP_CONTRACT _Pragma("clang fp contract(off)")
+#define ROLO_HIP_NO_FP_CONTRACT_ATTR
+#elif defined(__GNUC__)
+#define ROLO_HIP_NO_FP_CONTRACT
+#define ROLO_HIP_NO_FP_CONTRACT_ATTR __attribute__((optimize("fp-contract=off")))
+#else
+#define ROLO_HIP_NO_FP_CONTRACT
+#define ROLO_HIP_NO_FP_CONTRACT_ATTR
+#endif
+  ROLO_HIP_NO_FP_CONTRACT_ATTR void transform_into(PointCloudSource& output, const float* T) {
+    ROLO_HIP_NO_FP_CONTRACT
     output = *src_;
     constexpr size_t stride = sizeof(PointSource) / sizeof(float);
     float* p = output.points.empty() ? nullptr : reinterpret_cast<float*>(output.points.data());

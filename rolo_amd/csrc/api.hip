@@ -190,6 +190,7 @@ struct rolo_ctx {
   // front end (front.hip)
   void* front = nullptr;
   void* s2m = nullptr;   // scan2map.hip scratch
+  unsigned long long cloud_epoch = 0;   // bumped whenever the source / target clouds (or their buffers) change hands: the resident sub-map of rolo_scan2map_set_submap lives in them
 };
 
 namespace {
@@ -240,6 +241,7 @@ int upload_cloud(rolo_ctx* c, CloudDev& cl, size_t& xyz_cap, const float* pts, i
   cl.have_cov = false;
   cl.have_sorted = false;
   cl.bbox6 = nullptr;
+  c->cloud_epoch++;
   return ROLO_OK;
 }
 
@@ -605,6 +607,7 @@ namespace rolo {
 // accessors for front.hip / odometry.hip (the context layout is private to this file)
 void** ctx_front_slot(rolo_ctx* c) { return &c->front; }
 void** ctx_s2m_slot(rolo_ctx* c) { return &c->s2m; }
+unsigned long long ctx_cloud_epoch(rolo_ctx* c) { return c->cloud_epoch; }
 hipStream_t ctx_stream(rolo_ctx* c) { return c->stream; }
 int ctx_device(rolo_ctx* c) { return c->device; }
 void ctx_set_error(const char* msg) { g_err = msg ? msg : ""; }
@@ -624,6 +627,7 @@ int ctx_set_pair_device(rolo_ctx* c, const float* d_src, int n_src, int stride_s
   HIPCHK(launch_pack_pair(d_src, stride_src, c->src.xyz, n_src, c->src.bbox_part, T16_host_or_null, d_tgt, stride_tgt, c->tgt.xyz, n_tgt, c->tgt.bbox_part, c->stream));
   for (int i = 0; i < 2; i++) { cl[i]->n_bbox_part = (n[i] + 255) / 256; cl[i]->n = n[i]; cl[i]->have_cov = false; cl[i]->have_sorted = false; cl[i]->bbox6 = nullptr; }
   c->have_map = false; c->have_corr = false;
+  c->cloud_epoch++;
   return ROLO_OK;
 }
 // scan2map.hip: the two sub-map clouds (corner, surface) as the context's source / target with their search trees built
@@ -764,6 +768,7 @@ static int ctx_create_impl(int device, bool high_priority, rolo_ctx** out) {
 
 void rolo_front_destroy(rolo_ctx* c);  // front.hip
 void rolo_s2m_destroy(rolo_ctx* c);    // scan2map.hip
+void rolo_s2m_forget(rolo_ctx* c);     // scan2map.hip: a context going back to the pool forgets its resident sub-map and gives its helper context back
 }
 namespace rolo { void front_reset_object_state(rolo_ctx* c); }   // front.hip
 extern "C" {
@@ -809,6 +814,7 @@ constexpr size_t POOL_MAX = 8;
 void reset_to_fresh(rolo_ctx* c) {
   rolo_default_params(&c->P);
   c->src.n = 0; c->tgt.n = 0;
+  c->cloud_epoch++;   // whatever sub-map the previous owner left resident is not the next owner's
   c->src.have_cov = c->tgt.have_cov = false; c->src.have_sorted = c->tgt.have_sorted = false; c->src.cov_user = c->tgt.cov_user = false;
   c->src.bbox6 = c->tgt.bbox6 = nullptr; c->src.n_bbox_part = c->tgt.n_bbox_part = 0;
   c->have_map = false; c->have_corr = false; c->n_voxels = 0; c->n_edge = 0;
@@ -840,6 +846,7 @@ void rolo_ctx_release(rolo_ctx* c) {
   if (!c) return;
   // a context with a communicator / peers, a frame in flight or event timers is not worth keeping: destroy
   if (c->comm || c->peer.base || c->async_pending || !c->prof.empty()) { rolo_ctx_destroy(c); return; }
+  rolo_s2m_forget(c);   // (before the pool's lock is taken: it releases the helper context through this same function)
   {
     std::lock_guard<std::mutex> lk(g_pool_mu);
     if (g_pool.size() < POOL_MAX) { (void)hipSetDevice(c->device); if (c->stream) (void)hipStreamSynchronize(c->stream); reset_to_fresh(c); g_pool.push_back(c); return; }

@@ -12,6 +12,7 @@
 // original point index — the neighbour set is the same pure function of the cloud the oracle computes.
 // Two kernels: the walk (58 VGPRs: 8 wavefronts per SIMD, so searches of several contexts share the chip) hands the
 // neighbour indices to the covariance kernel (whose 3x3 fp64 SVD needs ~150 VGPRs); fused they ran at 4 per SIMD.
+#include <cstdio>
 #include <cstring>
 #include <string.h>
 #include "rolo_internal.hpp"
@@ -738,7 +739,14 @@ hipError_t launch_knn_walk(const KnnPair& A, int k, int regularization_or_minus1
       // the cooperative walk (knn_walk.hpp): NW packets per workgroup, a heavy packet's remaining sub-trees go to the workgroup's idle wavefronts.
       // NW follows the launch size — a workgroup per CU at least: 4 for the pipeline's ~48 k-point feature clouds, 16 for the 2 x 131 072-point frame
       const int packets = (n0 + 63) / 64 + (n1 + 63) / 64;
-      static const int force_nw = [] { const char* e = getenv("ROLO_KNN_COOP_NW"); return e ? atoi(e) : 0; }();
+      static const int force_nw = [] {   // 4 / 8 / 16 wavefronts per workgroup; anything else would run the NW = 4 kernel with a grid sized for another: ignored
+        const char* e = getenv("ROLO_KNN_COOP_NW");
+        if (!e) return 0;
+        const int v = atoi(e);
+        if (v == 4 || v == 8 || v == 16) return v;
+        fprintf(stderr, "librolo_hip: ROLO_KNN_COOP_NW=%s is not one of 4 / 8 / 16: ignored\n", e);
+        return 0;
+      }();
       const int nw = force_nw ? force_nw : (packets >= 16 * 256 ? 16 : (packets >= 8 * 256 ? 8 : 4));
       const int G4 = g0 + g1, G = (G4 + nw / 4 - 1) / (nw / 4);   // a workgroup = nw / 4 runs of four consecutive packets (the plain walk's blocks), strided by G
       if (nw == 16) knn_walk_coop_kernel<16><<<G, 1024, 0, s>>>(A, g0, G4, coop_budget);
@@ -747,8 +755,16 @@ hipError_t launch_knn_walk(const KnnPair& A, int k, int regularization_or_minus1
     }
     else {
       // small clouds: 16 queries x 4 lanes per wavefront (knn_walk_sub_kernel) — below ~2 packets of 64 per SIMD the walk is a chain of fetches, not
-      // inserts. ROLO_KNN_SUB = 0 never / 1 always / unset: by size
-      static const int sub_env = [] { const char* e = getenv("ROLO_KNN_SUB"); return e ? atoi(e) : -1; }();   // 0 never / 1 or 4: four lanes always / 2: two lanes always / unset: by size
+      // inserts. ROLO_KNN_SUB (an A/B switch): 0 = the 64-query packets at every size, 2 = two lanes per query always, 4 (or 1) = four lanes always; unset = by size.
+      // Any other value is ignored with a warning instead of silently picking a kernel (advisor, round 4).
+      static const int sub_env = [] {
+        const char* e = getenv("ROLO_KNN_SUB");
+        if (!e) return -1;
+        const int v = atoi(e);
+        if (v == 0 || v == 1 || v == 2 || v == 4) return v;
+        fprintf(stderr, "librolo_hip: ROLO_KNN_SUB=%s is not one of 0 / 1 / 2 / 4: ignored (the walk is picked by size)\n", e);
+        return -1;
+      }();
       const int packets = (n0 + 63) / 64 + (n1 + 63) / 64;
       const int lanes = sub_env < 0 ? (packets <= KNN_SUB_MAX_PACKETS ? 4 : 2) : (sub_env == 2 ? 2 : (sub_env ? 4 : 0));
       if (lanes_out) *lanes_out = lanes ? lanes : 1;

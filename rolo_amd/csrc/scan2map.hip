@@ -123,7 +123,11 @@ __host__ __device__ inline float cv_hypotf(float a, float b) {
 // scheme (not in the reference tree): only the upper triangle is kept; each step annihilates the off-diagonal element of largest magnitude (per-row and
 // per-column maxima in index arrays, strict comparisons: the first of equals wins), rotation from y = (w_l - w_k) / 2, t = |y| + hypot(p, y),
 // s = hypot(p, t), c = t / s, s = p / s, t = (p / t) p; at most 30 N^2 steps, stop when |p| <= FLT_EPSILON; eigenvalues descending, eigenvectors as rows.
-// The float operation order is the parity target (oracle/rolo_oracle_backend.cpp restates the same scheme independently).
+// The float operation order is the parity target (oracle/rolo_oracle_backend.cpp restates the same scheme independently): "selection flags bit-identical" in the tests
+// and DESIGN.md means bit-identical TO THAT ORACLE. Assumption about the reference's build: cv::eigen runs OpenCV's own Jacobi (modules/core/src/lapack.cpp, JacobiImpl_),
+// which is what a stock OpenCV 4.x does; an OpenCV configured WITH_EIGEN=ON / HAVE_EIGEN routes cv::eigen through Eigen::SelfAdjointEigenSolver instead — eigenvalues
+// and vectors then differ in their last ulps and the borderline "D[0] > 3 * D[1]" / "s > 0.1" decisions can flip for a few features per scan (advisor, round 4). A dump
+// of cornerOptimization's flags from a real ROLO build (tools/README.md) is what would settle which variant a given installation runs.
 template <int N>
 __host__ __device__ inline void cv_eigen_sym(float* A /* N x N, destroyed */, float* W, float* V) {
   int indR[N], indC[N];
@@ -721,9 +725,12 @@ using namespace rolo;
 
 namespace rolo {
 void** ctx_s2m_slot(rolo_ctx* c);   // api.hip
+unsigned long long ctx_cloud_epoch(rolo_ctx* c);   // api.hip: changes whenever the context's source / target clouds change hands
 struct S2mScratch { float4* feat = nullptr; double *part = nullptr, *sum = nullptr; unsigned char* sel = nullptr; float4* coeff = nullptr;
                     size_t feat_cap = 0, part_cap = 0, sum_cap = 0, sel_cap = 0, coeff_cap = 0;
                     KnnPair maps{}; int m_corner = 0, m_surf = 0; bool have_maps = false;   // the resident sub-map (rolo_scan2map_set_submap): trees of the context's two clouds
+                    bool map_set = false; unsigned long long maps_epoch = 0;   // a sub-map was handed in (possibly too small to search); the context's cloud epoch when its trees were built —
+                                                                               // any later upload into the context (rolo_set_input_*, a registration, the pool) makes the raw pointers in `maps` stale
                     rolo_ctx* qctx = nullptr; hipEvent_t qev = nullptr;
                     double* h_sum = nullptr; };   // pinned: the 28 sums of an iteration, written by s2m_sum_kernel itself   // helper context (from the pool): the scan's features sorted along the curve, its two clouds
 }  // namespace rolo
@@ -737,6 +744,13 @@ extern "C" void rolo_s2m_destroy(rolo_ctx* c) {   // called by rolo_ctx_destroy
   delete W; *ctx_s2m_slot(c) = nullptr;
   if (q) rolo_ctx_release(q);
 }
+extern "C" void rolo_s2m_forget(rolo_ctx* c) {   // called by rolo_ctx_release before the context goes back to the pool
+  S2mScratch* W = static_cast<S2mScratch*>(*ctx_s2m_slot(c));
+  if (!W) return;
+  W->have_maps = false; W->map_set = false; W->m_corner = W->m_surf = 0; W->maps = KnnPair{};
+  rolo_ctx* q = W->qctx; W->qctx = nullptr;
+  if (q) rolo_ctx_release(q);   // (the scratch buffers stay: they only grow, and a hipFree would stall every context's frames in flight)
+}
 
 // kdtreeCornerFromMap->setInputCloud(laserCloudCornerFromMapDS) / kdtreeSurfFromMap->setInputCloud(laserCloudSurfFromMapDS) (:690-691) as a call of its own: the
 // sub-map is uploaded and its two search trees are built ONCE and stay in the context (its source / target clouds) until the next call — the surrounding
@@ -746,11 +760,13 @@ extern "C" int rolo_scan2map_set_submap(rolo_ctx* c, const float* map_corner, in
   if (!c || m_corner < 0 || m_surf < 0 || (m_corner && !map_corner) || (m_surf && !map_surf)) return ROLO_EINVAL;
   S2mScratch* W = static_cast<S2mScratch*>(*ctx_s2m_slot(c));
   if (!W) { W = new S2mScratch(); *ctx_s2m_slot(c) = W; }
-  W->have_maps = false; W->m_corner = m_corner; W->m_surf = m_surf;
-  if (m_corner < 5 || m_surf < 5) return ROLO_OK;   // nothing a 5-NN query could be answered from: rolo_scan2map_optimize reports skipped = 2
-  const int rc = ctx_build_map_trees(c, map_corner, m_corner, map_surf, m_surf, 4, &W->maps);
+  W->have_maps = false; W->map_set = false; W->m_corner = 0; W->m_surf = 0;   // nothing is resident until the build below has succeeded
+  if (m_corner < 5 || m_surf < 5) { W->map_set = true; W->m_corner = m_corner; W->m_surf = m_surf; return ROLO_OK; }   // nothing a 5-NN query could be answered from: rolo_scan2map_optimize reports skipped = 2
+  KnnPair built{};
+  const int rc = ctx_build_map_trees(c, map_corner, m_corner, map_surf, m_surf, 4, &built);
   if (rc) return rc;
-  W->have_maps = true;
+  W->maps = built; W->m_corner = m_corner; W->m_surf = m_surf; W->maps_epoch = ctx_cloud_epoch(c);
+  W->have_maps = true; W->map_set = true;
   return ROLO_OK;
 }
 
@@ -765,7 +781,14 @@ extern "C" int rolo_scan2map_optimize(rolo_ctx* c, const float* corner, int n_co
   const bool resident = !map_corner && !map_surf;   // the sub-map of the last rolo_scan2map_set_submap
   if (resident) {
     S2mScratch* W0 = static_cast<S2mScratch*>(*ctx_s2m_slot(c));
-    if (!W0 || (W0->m_corner == 0 && W0->m_surf == 0 && !W0->have_maps)) { ctx_set_error("rolo_scan2map_optimize without a sub-map: call rolo_scan2map_set_submap first"); return ROLO_ESTATE; }
+    if (!W0 || !W0->map_set) { ctx_set_error("rolo_scan2map_optimize without a sub-map: call rolo_scan2map_set_submap first"); return ROLO_ESTATE; }
+    // the resident trees are raw pointers into the context's own source / target clouds: anything uploaded into the context since (rolo_set_input_source /
+    // _target, a registration, a trip through the pool) has overwritten or reallocated them
+    if (W0->have_maps && W0->maps_epoch != ctx_cloud_epoch(c)) {
+      W0->have_maps = false; W0->map_set = false;
+      ctx_set_error("rolo_scan2map_optimize: the resident sub-map was overwritten by a later upload into this context: call rolo_scan2map_set_submap again");
+      return ROLO_ESTATE;
+    }
     m_corner = W0->m_corner; m_surf = W0->m_surf;
   }
   // :689 — "if (laserCloudCornerLastDSNum > edgeFeatureMinValidNum && laserCloudSurfLastDSNum > surfFeatureMinValidNum)"
@@ -774,6 +797,7 @@ extern "C" int rolo_scan2map_optimize(rolo_ctx* c, const float* corner, int n_co
   // pointSearchSqDis[4] of a shorter result, :745 / :852) — nothing to optimise against; report it as skipped instead of an error
   if (m_corner < 5 || m_surf < 5) { st.skipped = 2; if (stats) *stats = st; return ROLO_OK; }
   if (!resident) { const int rc = rolo_scan2map_set_submap(c, map_corner, m_corner, map_surf, m_surf); if (rc) return rc; }
+  if (!static_cast<S2mScratch*>(*ctx_s2m_slot(c))->have_maps) { ctx_set_error("rolo_scan2map_optimize: no searchable sub-map is resident"); return ROLO_ESTATE; }
   const KnnPair maps = static_cast<S2mScratch*>(*ctx_s2m_slot(c))->maps;
   hipStream_t s = ctx_stream(c);
   const int n = n_corner + n_surf;

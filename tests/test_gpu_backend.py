@@ -99,6 +99,45 @@ def test_resident_submap_call_order():
     g.close()
 
 
+def test_resident_submap_goes_stale_with_the_contexts_clouds():
+    """the resident sub-map's trees are raw pointers into the context's own source / target clouds (advisor, round 4): a later upload into the same context, or a
+    trip through the context pool, must turn rolo_scan2map_optimize(NULL, NULL) into ROLO_ESTATE instead of a walk over overwritten / freed memory; a failed or
+    too-small rolo_scan2map_set_submap leaves nothing resident either"""
+    from rolo_amd._lib import RoloError, lib
+    import ctypes as C
+    corner, surf = features("vlp16", dict(n_scan=16, horizon_scan=1800), np.eye(3), np.zeros(3), synth.SEED)
+    guess = np.zeros(6, np.float32)
+    g = Scan2Map()
+    g.setSubmap(corner, surf)
+    tf0 = g.scan2MapOptimization(corner, surf, None, None, guess)
+    assert g.last_stats.skipped == 0
+    # (1) another cloud lands in the context
+    g.reg.setInputSource(np.ascontiguousarray(surf[:4096]))
+    with pytest.raises(RoloError) as ei:
+        g.scan2MapOptimization(corner, surf, None, None, guess)
+    assert ei.value.code == -5 and "overwritten" in str(ei.value)
+    # ... and the next call without a new sub-map is refused as well (nothing is resident any more), a new one works and gives the same bits
+    with pytest.raises(RoloError):
+        g.scan2MapOptimization(corner, surf, None, None, guess)
+    g.setSubmap(corner, surf)
+    assert np.array_equal(g.scan2MapOptimization(corner, surf, None, None, guess), tf0)
+    # (2) through the pool: the next owner of the context does not inherit the sub-map
+    fp = C.POINTER(C.c_float)
+    lib().rolo_ctx_pool_clear()   # so that the context released below is the one the next acquire hands out
+    h = C.c_void_p()
+    assert lib().rolo_ctx_acquire(0, C.byref(h)) == 0
+    a = [np.ascontiguousarray(x, np.float32).reshape(-1, 4) for x in (corner, surf)]
+    assert lib().rolo_scan2map_set_submap(h, a[0].ctypes.data_as(fp), a[0].shape[0], a[1].ctypes.data_as(fp), a[1].shape[0]) == 0
+    lib().rolo_ctx_release(h)
+    h2 = C.c_void_p()
+    assert lib().rolo_ctx_acquire(0, C.byref(h2)) == 0 and h2.value == h.value   # the pool hands the same object out again
+    tf = guess.copy()
+    rc = lib().rolo_scan2map_optimize(h2, a[0].ctypes.data_as(fp), a[0].shape[0], a[1].ctypes.data_as(fp), a[1].shape[0], None, 0, None, 0, tf.ctypes.data_as(fp), 10, 100, None, None, None)
+    assert rc == -5
+    lib().rolo_ctx_release(h2)
+    g.close()
+
+
 @pytest.mark.parametrize("switch", ["ROLO_S2M_SUB=1", "ROLO_S2M_SUB=8", "ROLO_S2M_CAP=0", "ROLO_S2M_WIDE=0", "ROLO_S2M_WIDE=6", "ROLO_S2M_PACKETS=0"])
 def test_association_kernel_variants_keep_the_oracles_flags(switch):
     """the association kernel's earlier forms and A/B switches (64-feature packets, 8 lanes per feature, no radius cap, binary steps, paired leaf fetches, one walk
