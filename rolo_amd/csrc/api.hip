@@ -174,7 +174,9 @@ struct rolo_ctx {
   // hipGraph of one whole frame (rolo_register_async): captured on the second frame with an unchanged key, replayed after
   FrameArgs* h_args = nullptr;   // pinned; a captured H2D copy refreshes d_args on every replay
   FrameArgs* d_args = nullptr; size_t d_args_cap = 0;
-  struct GraphKey { int n_src, n_tgt; const void *src_xyz, *tgt_xyz; rolo_params P; unsigned long long epoch; int nrot, ntrans, rank, world; } gkey{}, gseen{};
+  struct GraphKey { int n_src, n_tgt; const void *src_xyz, *tgt_xyz; rolo_params P; unsigned long long epoch; int nrot, ntrans, rank, world, busy; } gkey{}, gseen{};
+  bool device_busy = false;   // other contexts of this device had frames in flight when this frame was enqueued (picks the walk kernel of large launches: knn_cov.hip launch_knn_walk)
+  bool counted_in_flight = false;
   // passes the last frames needed per stage (+1): the next frame enqueues that many predicated pass/controller pairs up
   // front instead of a fixed worst-case chunk; rolo_register_wait tops up if a frame needs more
   int hint_rot = 0, hint_trans = 0;
@@ -362,7 +364,7 @@ int build_clouds(rolo_ctx* c, bool do_src, bool do_tgt, hipStream_t stream, bool
     return ROLO_OK;
   }
   const bool split_tail = !fused_tail_env() || kc > 64;
-  { ProfScope ps(c, ROLO_PROF_KNN_WALK, stream); HIPCHK(launch_knn_walk(A, c->P.k_correspondences, split_tail ? -1 : c->P.regularization, vf, stream, (kc == 20 && split_tail) ? knn_budget_env() : 0, &c->walk_lanes)); }
+  { ProfScope ps(c, ROLO_PROF_KNN_WALK, stream); HIPCHK(launch_knn_walk(A, c->P.k_correspondences, split_tail ? -1 : c->P.regularization, vf, stream, (kc == 20 && split_tail) ? knn_budget_env() : 0, &c->walk_lanes, c->device_busy)); }
   if (split_tail) { ProfScope ps(c, ROLO_PROF_KNN_TAIL, stream); HIPCHK(launch_knn_tail(A, c->P.k_correspondences, c->P.regularization, vf, stream)); }
   if (sharded) {
     const size_t seg = A.c[0].seg;
@@ -670,6 +672,19 @@ void rolo_default_params(rolo_params* p) {
   p->fused_lm = 0;
 }
 
+// frames in flight per device (rolo_register_async .. rolo_register_wait): a frame enqueued while OTHER contexts of the device have frames in flight takes the
+// kernels that share the chip best (throughput), a frame enqueued on an idle device the ones that finish soonest (latency) — launch_knn_walk
+static std::atomic<int> g_frames_in_flight[64];
+static void count_in_flight(rolo_ctx* c, bool on) {
+  if (on == c->counted_in_flight || c->device < 0 || c->device >= 64) return;
+  c->counted_in_flight = on;
+  g_frames_in_flight[c->device].fetch_add(on ? 1 : -1, std::memory_order_relaxed);
+}
+static bool others_in_flight(const rolo_ctx* c) {
+  if (c->device < 0 || c->device >= 64) return false;
+  return g_frames_in_flight[c->device].load(std::memory_order_relaxed) - (c->counted_in_flight ? 1 : 0) > 0;
+}
+
 static int ctx_create_impl(int device, bool high_priority, rolo_ctx** out);
 int rolo_ctx_create(int device, rolo_ctx** out) { return ctx_create_impl(device, false, out); }
 }  // extern "C"
@@ -775,6 +790,7 @@ extern "C" {
 
 void rolo_ctx_destroy(rolo_ctx* c) {
   if (!c) return;
+  count_in_flight(c, false);
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   rolo_front_destroy(c);
@@ -1260,10 +1276,11 @@ static int register_async_impl(rolo_ctx* c, const float* guess16, const double* 
     rolo_ctx::GraphKey key{};
     key.n_src = c->src.n; key.n_tgt = c->tgt.n; key.src_xyz = c->src.xyz; key.tgt_xyz = c->tgt.xyz; key.P = c->P; key.epoch = g_alloc_epoch;
     key.rank = c->rank; key.world = c->world;   // the captured launches bake the shard range in
+    key.busy = c->device_busy ? 1 : 0;          // ... and the walk kernel picked by the device's load
     frame_chunks(c, key.nrot, key.ntrans);
     auto same = [](const rolo_ctx::GraphKey& a, const rolo_ctx::GraphKey& b) {
       return a.n_src == b.n_src && a.n_tgt == b.n_tgt && a.src_xyz == b.src_xyz && a.tgt_xyz == b.tgt_xyz && a.epoch == b.epoch &&
-             a.nrot == b.nrot && a.ntrans == b.ntrans && a.rank == b.rank && a.world == b.world && memcmp(&a.P, &b.P, sizeof(rolo_params)) == 0;
+             a.nrot == b.nrot && a.ntrans == b.ntrans && a.rank == b.rank && a.world == b.world && a.busy == b.busy && memcmp(&a.P, &b.P, sizeof(rolo_params)) == 0;
     };
     if (c->graph_exec && same(key, c->gkey)) {
       HIPCHK(hipGraphLaunch(c->graph_exec, c->stream));
@@ -1304,8 +1321,9 @@ static int register_async_impl(rolo_ctx* c, const float* guess16, const double* 
 }
 
 int rolo_register_async(rolo_ctx* c, const float* guess16, const double* trans_start, const double* g3, const double* l3, double dtn, double dtn1, float lam) {
+  if (c) c->device_busy = others_in_flight(c);
   const int rc = register_async_impl(c, guess16, trans_start, g3, l3, dtn, dtn1, lam);
-  if (rc == ROLO_OK && c->async_pending) { c->n_frames++; HIPCHK(hipEventRecord(c->ev_done, c->stream)); }
+  if (rc == ROLO_OK && c->async_pending) { c->n_frames++; count_in_flight(c, true); HIPCHK(hipEventRecord(c->ev_done, c->stream)); }
   return rc;
 }
 
@@ -1314,6 +1332,7 @@ int rolo_register_wait(rolo_ctx* c, float* Tf, double* Td, double* trans_out, ro
   if (!c->async_pending) { g_err = "no registration in flight"; return ROLO_ESTATE; }
   int rc = set_device(c); if (rc) return rc;
   c->async_pending = false;
+  count_in_flight(c, false);
   HIPCHK(hipEventSynchronize(c->ev_done));
   if ((rc = peer_check(c))) return rc;
   if (c->h_counters[1] != 0) { g_err = c->h_counters[1] == ROLO_ENONFINITE ? "non-finite point or covariance in the voxel map build" : "voxel coordinate outside the packed key range"; return c->h_counters[1]; }

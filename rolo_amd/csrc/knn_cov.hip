@@ -141,6 +141,7 @@ constexpr int SORT_EPT = ROLO_SORT_EPT;   // elements per thread and round: a wa
 __global__ __launch_bounds__(SORT_T) void sort_scatter_kernel(const uint32_t* __restrict__ kin, const uint32_t* __restrict__ vin, uint32_t* __restrict__ kout,
                                                              uint32_t* __restrict__ vout, int n, int tile, int pass, int* __restrict__ cnt /* [SORT_PASSES][SORT_NB][SORT_D] */,
                                                              VoxelFuse vf) {
+  ROLO_ALL_KERNEL_PRIO();
   if ((int)blockIdx.x >= SORT_NB) {   // VoxelFuse: this pass's share of the target points goes into the voxel hash table on the CUs the sort leaves idle
     const int nt = vf.n_tgt, quarter = (nt + SORT_PASSES - 1) / SORT_PASSES;
     const int i = pass * quarter + ((int)blockIdx.x - SORT_NB) * SORT_T + (int)threadIdx.x;
@@ -237,6 +238,7 @@ __global__ __launch_bounds__(SORT_T) void sort_scatter_kernel(const uint32_t* __
 constexpr int VF_CLEAR_BLOCKS = 64;   // VoxelFuse: workgroups behind the key kernel's that clear the target's voxel table
 __global__ __launch_bounds__(SORT_T) void morton_kernel(KnnPair A, int* __restrict__ bbox, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, int n_total, int tile,
                                                        int* __restrict__ cnt, VoxelFuse vf) {
+  ROLO_ALL_KERNEL_PRIO();
   if ((int)blockIdx.x >= SORT_NB) {
     const size_t n_slots = (size_t)vf.tab.mask + 1;
     for (size_t k = (size_t)((int)blockIdx.x - SORT_NB) * SORT_T + threadIdx.x; k < n_slots; k += (size_t)VF_CLEAR_BLOCKS * SORT_T) vf.tab.keys[k] = KEY_EMPTY;
@@ -300,6 +302,7 @@ __global__ __launch_bounds__(SORT_T) void morton_kernel(KnnPair A, int* __restri
 // digit counts of sort pass `pass` for every tile of the (partially sorted) keys: LDS atomics, plain stores — counting the next pass's digits
 // with global atomics inside the scatter cost 18 us per pass (262 k device-scope atomics cross the fabric), this launch costs 4
 __global__ __launch_bounds__(SORT_T) void sort_hist_kernel(const uint32_t* __restrict__ keys, int n, int tile, int pass, int* __restrict__ cnt) {
+  ROLO_ALL_KERNEL_PRIO();
   __shared__ int hist[SORT_D];
   const int tid = threadIdx.x, blk = blockIdx.x;
   if (tid < SORT_D) hist[tid] = 0;
@@ -361,6 +364,7 @@ ROLO_DEV float4 kd_refine_block(float4 cur) {
 
 // one thread per slot of the sorted copy: gather the point in curve order, write it + (first lane of a leaf) the leaf box
 __global__ __launch_bounds__(256) void leaf_kernel(KnnPair A, int split, const uint32_t* __restrict__ order) {
+  ROLO_ALL_KERNEL_PRIO();
   // one thread per slot of the sorted copy (a thread per leaf gathered its 16 points one after the other: 13 us); the leaf box is a min / max
   // over the 16 lanes of the leaf — exact, so the order of the reduction does not matter
   const int which = (int)blockIdx.x >= split ? 1 : 0;
@@ -427,6 +431,7 @@ __global__ __launch_bounds__(256) void leaf_kernel(KnnPair A, int split, const u
 // Builds log2(chunk) levels of the implicit BVH in LDS: inputs are the `count_in` nodes at heap indices
 // [count_in, 2*count_in); block b owns inputs [b*chunk, (b+1)*chunk).
 __global__ __launch_bounds__(256) void tree_reduce_kernel(float4* boxes0, int count_in0, int chunk0, int split, float4* boxes1, int count_in1, int chunk1) {
+  ROLO_ALL_KERNEL_PRIO();
   __shared__ float4 lo[512], hi[512];
   const bool second = (int)blockIdx.x >= split;
   float4* boxes = second ? boxes1 : boxes0;
@@ -713,7 +718,11 @@ static inline int slice_blocks(const KnnCloud& c) { return (c.q_end - c.q_begin 
 //   52.4 M per launch) in chains half as long; four lanes issue 8 % more and twice the scalar instructions.
 // ROLO_KNN_SUB=0 keeps the 64-query packets at every size (the A/B, and the kernel of every k other than 20).
 constexpr int KNN_SUB_MAX_PACKETS = 1792;   // (the pipeline's pair launch is 1450-1600 packets, frame by frame: the limit sits clear of it, and of configs[4]'s 2048)
-hipError_t launch_knn_walk(const KnnPair& A, int k, int regularization_or_minus1, const VoxelFuse& vf, hipStream_t s, int coop_budget, int* lanes_out) {
+// Round 5: above the limit the choice follows the DEVICE'S LOAD. Alone on the chip the two-lane walk finishes sooner (0.175 against 0.22 ms: single-frame latency 0.71
+// against 0.76 ms); with other contexts' frames in flight the packets — half the wavefronts, the same instructions — leave the other frames' short LM kernels more of
+// every SIMD's issue slots: 3.04 against 2.98 k scans/s, and 3.17 against 3.01 k once those kernels run at raised priority (ROLO_SHORT_PRIO). The caller says which
+// case it is (frames in flight on the device when this one is enqueued, api.hip); a captured hipGraph is keyed on it.
+hipError_t launch_knn_walk(const KnnPair& A, int k, int regularization_or_minus1, const VoxelFuse& vf, hipStream_t s, int coop_budget, int* lanes_out, bool device_busy) {
   if (lanes_out) *lanes_out = 1;
   constexpr int QPB = 256;   // queries per workgroup of the plain walk: four wavefronts of 64
   const int n0 = A.c[0].q_end - A.c[0].q_begin, n1 = A.n_clouds > 1 ? A.c[1].q_end - A.c[1].q_begin : 0;
@@ -766,11 +775,14 @@ hipError_t launch_knn_walk(const KnnPair& A, int k, int regularization_or_minus1
         return -1;
       }();
       const int packets = (n0 + 63) / 64 + (n1 + 63) / 64;
-      const int lanes = sub_env < 0 ? (packets <= KNN_SUB_MAX_PACKETS ? 4 : 2) : (sub_env == 2 ? 2 : (sub_env ? 4 : 0));
+      const int lanes = sub_env < 0 ? (packets <= KNN_SUB_MAX_PACKETS ? 4 : (device_busy ? 0 : 2)) : (sub_env == 2 ? 2 : (sub_env ? 4 : 0));
       if (lanes_out) *lanes_out = lanes ? lanes : 1;
-      if (lanes == 4) { const int s0 = (n0 + 63) / 64, s1 = (n1 + 63) / 64; knn_walk_sub_kernel<4><<<s0 + s1, 256, 0, s>>>(A, s0); }
-      else if (lanes == 2) { const int s0 = (n0 + 127) / 128, s1 = (n1 + 127) / 128; knn_walk_sub_kernel<2><<<s0 + s1, 256, 0, s>>>(A, s0); }
-      else knn_walk_kernel<20, false><<<g0 + g1, 256, pad, s>>>(A, g0, k, -1);
+      // ROLO_KNN_WALK_WGS = workgroups of the walk a CU may hold at a time (through a dynamic-LDS pad; unset / 0: as many as fit): with two lanes per query the
+      // dense frame's 8192 wavefronts fill all 8 wave slots of every SIMD, and whatever another context has queued waits for slots until the walk thins out
+      static const int walk_pad = [] { const char* e = getenv("ROLO_KNN_WALK_WGS"); const int v = e ? atoi(e) : 0; return (v >= 1 && v <= 8) ? (160 * 1024 / v - 1024 - 512) & ~255 : 0; }();
+      if (lanes == 4) { const int s0 = (n0 + 63) / 64, s1 = (n1 + 63) / 64; knn_walk_sub_kernel<4><<<s0 + s1, 256, walk_pad, s>>>(A, s0); }
+      else if (lanes == 2) { const int s0 = (n0 + 127) / 128, s1 = (n1 + 127) / 128; knn_walk_sub_kernel<2><<<s0 + s1, 256, walk_pad, s>>>(A, s0); }
+      else knn_walk_kernel<20, false><<<g0 + g1, 256, walk_pad, s>>>(A, g0, k, -1);
     }
   }
   else {

@@ -218,8 +218,15 @@ template <int ST> ROLO_DEV void merge20(double (&K)[20]) {
   }
 }
 
+// ROLO_KNN_WALK_MAXOCC (A/B builds): an upper bound on the wavefronts per SIMD the compiler allocates registers for — the way to keep wave slots free for
+// other contexts' kernels WITHOUT an LDS pad (which takes the CU's LDS away from them as well)
+#ifdef ROLO_KNN_WALK_MAXOCC
+#define ROLO_KNN_WALK_OCC_ATTR __attribute__((amdgpu_waves_per_eu(ROLO_KNN_WALK_MAXOCC, ROLO_KNN_WALK_MAXOCC)))
+#else
+#define ROLO_KNN_WALK_OCC_ATTR
+#endif
 template <int SUB>
-__global__ __launch_bounds__(256, ROLO_KNN_WALK_OCC) void knn_walk_sub_kernel(KnnPair A, int split /* first block of cloud 1 */) {
+__global__ __launch_bounds__(256, ROLO_KNN_WALK_OCC) ROLO_KNN_WALK_OCC_ATTR void knn_walk_sub_kernel(KnnPair A, int split /* first block of cloud 1 */) {
   constexpr int SH = SUB == 2 ? 1 : 2, QPW = 64 / SUB, PPL = KNN_LEAF / SUB, KMAX = 20, E = 4 / SUB /* grandchild boxes per lane */, OWN = QPW / KNN_LEAF;
   static_assert(SUB == 2 || SUB == 4, "lanes per query");
   static_assert(KNN_LEAF == 16, "a wavefront's queries are whole leaves");
@@ -537,6 +544,7 @@ __global__ __launch_bounds__(64 * NW, ROLO_KNN_WALK_OCC) void knn_walk_coop_kern
 #endif
 template <int KMAX>
 __global__ __launch_bounds__(256, ROLO_KNN_TAIL_OCC) void knn_tail_kernel(KnnPair A, int split, int k, int reg, VoxelFuse vf) {
+  ROLO_TAIL_KERNEL_PRIO();
   const int blk = xcd_contiguous_block((int)blockIdx.x, (int)gridDim.x);
   const int which = blk >= split ? 1 : 0;
   const KnnCloud& cl = A.c[which];

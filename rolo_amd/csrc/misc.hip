@@ -11,6 +11,7 @@ namespace {
 // strided records -> float4 (x, y, z, 1); the same pass leaves the workgroup's partial bounding box (what the neighbour search's key kernel
 // folds — a separate bbox launch re-read the cloud for it)
 __global__ __launch_bounds__(256) void pack_xyz_kernel(const float* __restrict__ in, int stride, float4* __restrict__ out, int n, int* __restrict__ bbox_part) {
+  ROLO_ALL_KERNEL_PRIO();
   __shared__ float smn[4][3], smx[4][3];
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
@@ -82,6 +83,7 @@ __global__ __launch_bounds__(256) void transform_cloud_kernel(const float* __res
 // src/lidarOdometry.cpp:459 — the same float operations as transform_cloud_kernel, then the pack): a transform launch and a pack launch less per frame.
 __global__ __launch_bounds__(256) void pack_pair_kernel(const float* __restrict__ in0, int stride0, float4* __restrict__ out0, int n0, int* __restrict__ bbox0, int split,
                                                        const float* __restrict__ in1, int stride1, float4* __restrict__ out1, int n1, int* __restrict__ bbox1, Mat4f T, int move0) {
+  ROLO_ALL_KERNEL_PRIO();
   __shared__ float smn[4][3], smx[4][3];
   const bool second = (int)blockIdx.x >= split;
   const int blk = (int)blockIdx.x - (second ? split : 0);

@@ -271,6 +271,7 @@ extern "C" int rolo_debug_pass_times(unsigned long long* out8) {
 #endif
 template <int DOF>
 ROLO_DEV void rot_pass_body(const PassArgs& a, const LmState* __restrict__ st, const int block) {
+  ROLO_SHORT_KERNEL_PRIO();
   PT_STAMP(0);
   if (st->stage != 1) return;
   PT_STAMP(1);
@@ -358,6 +359,7 @@ ROLO_DEV void trans_pass_compute(const PassArgs& a, const LmState* __restrict__ 
 }
 
 ROLO_DEV void trans_pass_body(const PassArgs& a, const LmState* __restrict__ st, const int block) {
+  ROLO_SHORT_KERNEL_PRIO();
   if (st->stage != 2) return;
   constexpr int NH = 21, NV = 3 + NH + 6;
   double acc[NV];
@@ -806,6 +808,7 @@ ROLO_DEV void ctrl_body(LmState* st, const double* __restrict__ partials, int nb
   constexpr int NW = sizeof(LmState) / sizeof(int);
   constexpr int NWT = (NW + 255) / 256;
   constexpr int INFLIGHT = 64;
+  ROLO_SHORT_KERNEL_PRIO();
   CT_STAMP(0);
   const int v = threadIdx.x & 31, q = threadIdx.x >> 5;  // 256 threads = 8 strided groups of 32 values
   // Everything this controller reads was written by other CUs a moment ago: every load is a ~1-2 us L2 / fabric round

@@ -4,6 +4,23 @@
 #include <stdint.h>
 #include "../../include/rolo_hip.h"
 
+// Issue priority of the SHORT kernels of a frame (LM passes, controller, the search's build chain): with several contexts in flight their wavefronts share SIMDs with
+// another frame's neighbour search, whose eight older wavefronts per SIMD win the age-ordered issue arbitration; s_setprio lets the latency-bound chain go first
+// and the search fill what is left (MI355X_MICROARCH.md: VALU issue is arbitrated by priority, then age): +3.5 % scans/s with four contexts in flight, levels 1 and 3 alike;
+// raising the build chain and the covariance tail as well adds nothing (ROLO_BUILD_PRIO / ROLO_TAIL_PRIO, off). 0 = off (A/B build: --flag=-DROLO_SHORT_PRIO=0).
+#ifndef ROLO_SHORT_PRIO
+#define ROLO_SHORT_PRIO 1
+#endif
+#define ROLO_SHORT_KERNEL_PRIO() do { if (ROLO_SHORT_PRIO) __builtin_amdgcn_s_setprio(ROLO_SHORT_PRIO); } while (0)
+#ifndef ROLO_BUILD_PRIO
+#define ROLO_BUILD_PRIO 0
+#endif
+#ifndef ROLO_TAIL_PRIO
+#define ROLO_TAIL_PRIO 0
+#endif
+#define ROLO_ALL_KERNEL_PRIO() do { if (ROLO_BUILD_PRIO) __builtin_amdgcn_s_setprio(ROLO_BUILD_PRIO); } while (0)
+#define ROLO_TAIL_KERNEL_PRIO() do { if (ROLO_TAIL_PRIO) __builtin_amdgcn_s_setprio(ROLO_TAIL_PRIO); } while (0)
+
 namespace rolo {
 
 // ---- per-pass reduction layout (fp64): one row of NV_MAX values per workgroup, then one row total ----------
@@ -168,7 +185,8 @@ constexpr int KNN_WALK_STACK = 48;
 // regularization >= 0: the walk ends in the covariance tail (A.c[].cov / the exchange buffer); -1: neighbour indices -> A.c[].nbr only
 // coop_budget > 0 (k = 20, own covariance launch): the cooperative walk — a packet that has scored that many leaves with sub-trees left publishes them to the
 // idle wavefronts of its workgroup (knn_walk.hpp); 0: the plain walk, every wavefront for itself
-hipError_t launch_knn_walk(const KnnPair& A, int k, int regularization_or_minus1, const VoxelFuse& vf, hipStream_t s, int coop_budget = 0, int* lanes_out = nullptr);
+// device_busy: other contexts have frames in flight on this device — large launches then take the 64-query packets (half the wavefronts: shares the chip better) instead of two lanes per query (finishes sooner alone)
+hipError_t launch_knn_walk(const KnnPair& A, int k, int regularization_or_minus1, const VoxelFuse& vf, hipStream_t s, int coop_budget = 0, int* lanes_out = nullptr, bool device_busy = false);
 hipError_t launch_knn_tail(const KnnPair& A, int k, int regularization, const VoxelFuse& vf, hipStream_t s);   // covariances from A.c[].nbr
 // multi-GPU: exchange buffer (sorted order, all ranks' slices after the all-gather, or [q_begin, q_end) only) -> cov[] by original index
 // vf.enabled: the target's points are accumulated into the voxel map by this scatter (sharded VoxelFuse)

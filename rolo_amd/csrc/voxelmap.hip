@@ -139,6 +139,7 @@ __global__ __launch_bounds__(256) void voxel_accum_sorted_kernel(const float4* _
 }
 
 __global__ __launch_bounds__(256) void voxel_finalize_kernel(VoxelTable tab, const int* counters, int n_pts, int fixed_cov, int* pub_counters, LmState* lm_state, const FrameArgs* lm_args) {
+  ROLO_ALL_KERNEL_PRIO();
   const int id = blockIdx.x * blockDim.x + threadIdx.x;
   if (lm_state && blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) frame_begin_dev(lm_state, lm_args);   // the frame's LM state (was: frame_begin_kernel, its own launch); a lane of the last, mostly idle workgroup
   if (pub_counters && id < 4) pub_counters[id] = counters[id];   // the counters are final before this launch
