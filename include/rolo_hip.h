@@ -207,6 +207,11 @@ int rolo_set_shard(rolo_ctx* ctx, int rank, int world);
  * workgroups, equal slices) — but WITHOUT the all-gather: only the covariances of the own slice are valid afterwards (the rest of
  * rolo_get_*_covariances is stale / undefined); the union over the ranks must equal the unsharded result. */
 int rolo_set_shard_knn(rolo_ctx* ctx, int on);
+/* Which kernels rolo_register_async picks where the best one depends on whether the GPU is shared (not in the reference: its operator owns its CPU threads).
+ * -1 (default): decided per frame — other contexts of the device have frames in flight when this one is enqueued => the kernels that share the chip best
+ * (throughput); an idle device => the ones that finish soonest (latency). 0 / 1 pin the idle- / busy-device choice (profiling runs, callers that know their
+ * load). Today this selects the neighbour search of large launches: 64-query packets (busy) or two lanes per query (idle); results are bit-identical. */
+int rolo_set_load_hint(rolo_ctx* ctx, int mode);
 int rolo_comm_unique_id(void* unique_id128);
 int rolo_comm_init(rolo_ctx* ctx, const void* unique_id128, int rank, int world);
 int rolo_comm_destroy(rolo_ctx* ctx);

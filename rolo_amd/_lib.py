@@ -148,6 +148,7 @@ SYMBOLS = {
     "rolo_shard_range": (None, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "rolo_comm_info": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "rolo_set_shard_knn": (C.c_int, [vp, C.c_int]),
+    "rolo_set_load_hint": (C.c_int, [vp, C.c_int]),
     "rolo_set_shard": (C.c_int, [vp, C.c_int, C.c_int]),
     "rolo_comm_unique_id": (C.c_int, [vp]),
     "rolo_comm_init": (C.c_int, [vp, vp, C.c_int, C.c_int]),

@@ -177,6 +177,7 @@ struct rolo_ctx {
   struct GraphKey { int n_src, n_tgt; const void *src_xyz, *tgt_xyz; rolo_params P; unsigned long long epoch; int nrot, ntrans, rank, world, busy; } gkey{}, gseen{};
   bool device_busy = false;   // other contexts of this device had frames in flight when this frame was enqueued (picks the walk kernel of large launches: knn_cov.hip launch_knn_walk)
   bool counted_in_flight = false;
+  int load_hint = -1;         // rolo_set_load_hint: -1 per frame from the device's load, 0 / 1 pinned
   // passes the last frames needed per stage (+1): the next frame enqueues that many predicated pass/controller pairs up
   // front instead of a fixed worst-case chunk; rolo_register_wait tops up if a frame needs more
   int hint_rot = 0, hint_trans = 0;
@@ -835,7 +836,7 @@ void reset_to_fresh(rolo_ctx* c) {
   c->src.bbox6 = c->tgt.bbox6 = nullptr; c->src.n_bbox_part = c->tgt.n_bbox_part = 0;
   c->have_map = false; c->have_corr = false; c->n_voxels = 0; c->n_edge = 0;
   c->want_knn_lists = false; c->prof_on = false; c->shard_knn = false;
-  c->rank = 0; c->world = 1;
+  c->rank = 0; c->world = 1; c->load_hint = -1;
   front_reset_object_state(c);   // no projection, armed de-skew or pre-cleared arrays of the previous owner
   c->n_frames = c->n_replays = c->n_captures = c->n_eager = c->n_topup_frames = c->n_topup_chunks = 0;   // rolo_ctx_counters counts per object
   // (schedule hints, their windows and the captured graph stay on purpose: they are keyed on sizes, buffers and parameters, not on the object's
@@ -1321,7 +1322,7 @@ static int register_async_impl(rolo_ctx* c, const float* guess16, const double* 
 }
 
 int rolo_register_async(rolo_ctx* c, const float* guess16, const double* trans_start, const double* g3, const double* l3, double dtn, double dtn1, float lam) {
-  if (c) c->device_busy = others_in_flight(c);
+  if (c) c->device_busy = c->load_hint < 0 ? others_in_flight(c) : c->load_hint != 0;
   const int rc = register_async_impl(c, guess16, trans_start, g3, l3, dtn, dtn1, lam);
   if (rc == ROLO_OK && c->async_pending) { c->n_frames++; count_in_flight(c, true); HIPCHK(hipEventRecord(c->ev_done, c->stream)); }
   return rc;
@@ -1650,6 +1651,11 @@ int rolo_set_shard(rolo_ctx* c, int rank, int world) {
   return ROLO_OK;
 }
 
+int rolo_set_load_hint(rolo_ctx* c, int mode) {
+  if (!c || mode < -1 || mode > 1) return ROLO_EINVAL;
+  c->load_hint = mode;
+  return ROLO_OK;
+}
 int rolo_set_shard_knn(rolo_ctx* c, int on) {
   if (!c) return ROLO_EINVAL;
   c->shard_knn = on != 0;

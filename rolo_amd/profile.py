@@ -125,3 +125,57 @@ def roofline(g, run_one_step, n_src, n_tgt, passes_per_frame, hbm_peak_gbs, reps
             "frac": achieved / hbm_peak_gbs, "traffic": traffic, "avg_launch_ms_per_profiled_step": per_step_ms,
             "traffic_source": pmc_desc,
             "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": avg_ms[dom], "top3": top3, "per_frame_ms": per_frame_ms, "avg_ms": avg_ms}
+
+
+def sq_counters_file():
+    """(path, commit) of the newest committed profiles/rNN/sq_counters.csv"""
+    import glob
+    c = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]", "sq_counters.csv")))
+    if not c:
+        return None, None
+    commit = "?"
+    try:
+        commit = json.load(open(os.path.join(os.path.dirname(c[-1]), "pmc_traffic.json"))).get("_collected", {}).get("commit", "?")
+    except Exception:
+        pass
+    return c[-1], commit
+
+
+N_SIMD = 256 * 4          # MI355X: 256 CUs x 4 SIMDs
+CYCLES_PER_VALU = 4.0     # per wavefront instruction per SIMD, measured: profiles/tools/valu_rate.hip (v_max_f32, v_min_f64, v_fma_f64, v_cndmask alike)
+CLOCK_GHZ = 2.4           # nominal peak engine clock (the chip clocks lower under sustained load: the fraction below is a lower bound on how busy the VALUs are)
+
+
+def valu_issue(scans_per_s_per_gpu: float):
+    """The instruction-issue roofline of a frame: wave-level VALU (and SALU) instructions per frame, kernel by kernel, from the newest committed rocprofv3 SQ pass
+    (profiles/rNN/sq_counters.csv: SQ_INSTS_VALU / SQ_INSTS_SALU per launch x launches per frame of that profile run), against what the chip's 1024 SIMDs can issue:
+        issue_ms_per_frame = VALU instructions x 4 cycles / (1024 SIMDs x clock);   frac = issue_ms_per_frame x scans/s.
+    Cited like roofline.traffic (collected in its own PMC passes, not in this run); `frac` uses THIS run's scans/s."""
+    import csv
+    path, commit = sq_counters_file()
+    if not path:
+        return {"error": "no profiles/rNN/sq_counters.csv"}
+    rows = [r for r in csv.DictReader(l for l in open(path) if not l.startswith("#")) if r.get("valu_insts_per_launch_M")]
+    if not rows:
+        return {"error": f"{os.path.relpath(path, ROOT)} predates the per-launch instruction columns"}
+    by = {r["kernel"]: r for r in rows}
+    walk = next((by[k] for k in ("knn_walk_kernel", "knn_walk_sub_kernel") if k in by), None)
+    frames = float(walk["launches"]) if walk else 1.0
+    per, salu = {}, {}
+    for k, r in by.items():
+        try:
+            lf = float(r["launches"]) / frames
+            per[k] = round(float(r["valu_insts_per_launch_M"]) * lf, 3)
+            salu[k] = round(float(r["salu_insts_per_launch_M"] or 0) * lf, 3)
+        except Exception:
+            continue
+    tot_v, tot_s = sum(per.values()), sum(salu.values())
+    issue_ms = tot_v * 1e6 * CYCLES_PER_VALU / (N_SIMD * CLOCK_GHZ * 1e9) * 1e3
+    frame_ms = 1e3 / scans_per_s_per_gpu if scans_per_s_per_gpu > 0 else float("nan")
+    top = dict(sorted(per.items(), key=lambda kv: -kv[1])[:8])
+    return {"bound": "valu-issue", "valu_insts_per_frame_M": round(tot_v, 2), "salu_insts_per_frame_M": round(tot_s, 2), "valu_insts_per_frame_M_by_kernel": top,
+            "simds": N_SIMD, "cycles_per_valu_inst": CYCLES_PER_VALU, "clock_GHz_nominal": CLOCK_GHZ,
+            "issue_ms_per_frame": round(issue_ms, 4), "frame_ms_this_run": round(frame_ms, 4), "frac": round(issue_ms / frame_ms, 4),
+            "what": "share of the chip's VALU issue slots (1024 SIMDs, one wavefront instruction per 4 cycles at the nominal clock) the frames of this run's timed region "
+                    "occupy; the rest is latency the contexts in flight did not cover. cycles_per_valu_inst is measured (profiles/tools/valu_rate.hip)",
+            "source": f"{os.path.relpath(path, ROOT)} (collected at commit {commit}; SQ_INSTS_VALU / SQ_INSTS_SALU of a single-context eager run, per launch x launches per frame)"}

@@ -137,6 +137,10 @@ class RotVGICP:
         self._p.use_graph = int(on)
         self._push()
 
+    def setLoadHint(self, mode: int):
+        """-1 (default): register_async picks its kernels per frame from the device's load; 0 / 1 pin the idle- / busy-device choice (rolo_hip.h)"""
+        check(lib().rolo_set_load_hint(self._h, int(mode)), "rolo_set_load_hint")
+
     def setFusedLm(self, on: bool):
         """tuning knob: one launch per LM trial (controller in the prologue of the next pass); see rolo_hip.h"""
         self._p.fused_lm = int(on)
