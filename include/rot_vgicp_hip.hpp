@@ -126,7 +126,10 @@ public:
   void setTransformationEpsilon(double eps) { p_.transformation_epsilon = eps; push(); }
   void setMaximumIterations(int n) { p_.max_iterations = n; push(); }
   void setInitialLambdaFactor(double f) { p_.lm_init_lambda_factor = f; push(); }
-  void setDebugPrint(bool) {}  // the per-trial table is available through rolo_get_trace()
+  // lm_debug_print_ (lsq_registration.hpp:60): the per-trial table of rot_step_lm / step_lm / step_t_optimize (lsq_registration_impl.hpp:114-120, :245-251,
+  // :299-305) and computeTransformation's banner (:158-162), printed to stdout in the reference's boost::format layout — from the device-side LM trace
+  // (rolo_get_trace) after the solve, since the trials themselves run on the GPU without a host round trip
+  void setDebugPrint(bool lm_debug_print) { lm_debug_print_ = lm_debug_print; }
 
   void clearSource() { src_.reset(); check(rolo_clear_source(ctx_)); }
   void clearTarget() { tgt_.reset(); check(rolo_clear_target(ctx_)); }
@@ -155,6 +158,10 @@ public:
     if (rc != ROLO_OK) throw std::runtime_error(std::string("RotVGICP(HIP) align: ") + rolo_last_error());
     if (st.lm_failed) std::fprintf(stderr, "lm not converged!!\n");  // lsq_registration_impl.hpp:168-171
     converged_ = st.converged != 0; nr_iterations_ = st.n_outer - 1;
+    if (lm_debug_print_) {
+      std::printf("********************************************\n***************** optimize *****************\n********************************************\n");
+      print_trace(0);
+    }
     transform_into(output, final_);  // lsq_registration_impl.hpp:178
   }
   Matrix4 getFinalTransformation() const { return from_rowmajor(final_); }
@@ -168,6 +175,7 @@ public:
     const int rc = rolo_compute_translation(ctx_, t, g, l, interval_tn, interval_tn_1, ct_lambda, &st);
     if (rc != ROLO_OK) throw std::runtime_error(std::string("RotVGICP(HIP) computeTranslation: ") + rolo_last_error());
     if (st.lm_failed) std::fprintf(stderr, "lm not converged!!\n");
+    if (lm_debug_print_) print_trace(1);
     trans[0] = t[0]; trans[1] = t[1]; trans[2] = t[2];
     float T[16] = {1, 0, 0, (float)t[0], 0, 1, 0, (float)t[1], 0, 0, 1, (float)t[2], 0, 0, 0, 1};
     transform_into(output, T);  // lsq_registration_impl.hpp:75-78
@@ -210,6 +218,21 @@ public:
   rolo_ctx* handle() { return ctx_; }
 
 private:
+  // the trials of one stage (0 = align, 1 = computeTranslation) in the reference's table: a header line before every trial 0, then
+  // boost::format("%5d %15g %15g %15g %15g %15g %5c") % i % y0 % yi % rho % lm_lambda_ % d.norm() % dec — identical to printf's conversions
+  void print_trace(int stage) {
+    const int n = rolo_get_trace(ctx_, nullptr, 0);
+    if (n <= 0) return;
+    std::vector<rolo_trace_rec> tr((size_t)n);
+    if (rolo_get_trace(ctx_, tr.data(), n) < 0) return;
+    for (const rolo_trace_rec& r : tr) {
+      if (r.stage != stage || r.yi != r.yi) continue;   // (Gauss-Newton steps carry NaN: step_gn prints nothing)
+      if (r.trial == 0) std::printf("--- LM optimization ---\n%5s %15s %15s %15s %15s %15s %5s\n", "i", "y0", "yi", "rho", "lambda", "|delta|", "dec");
+      std::printf("%5d %15g %15g %15g %15g %15g %5c\n", r.trial, r.y0, r.yi, r.rho, r.lambda, r.dnorm, r.rho > 0.0 ? 'x' : ' ');
+    }
+    std::fflush(stdout);
+  }
+  bool lm_debug_print_ = false;
   void push() { check(rolo_set_params(ctx_, &p_)); }
   static void check(int rc) { if (rc != ROLO_OK) throw std::runtime_error(std::string("RotVGICP(HIP): ") + rolo_last_error()); }
   // pcl::transformPointCloud(*input_, output, T) (lsq_registration_impl.hpp:78, :178) ON THE HOST, as the reference does it: the whole cloud copied (header,

@@ -1,8 +1,8 @@
-"""One point-sharded frame (BASELINE configs[3]) through the peer exchange (rolo_peer_*), one process (or thread) per rank, timed — the body
-shared by bench.py's `sharded` leg and profiles/tools/peer2proc.py. The ranks meet through files in a directory (the 64-byte mailbox
-handles, barriers): no torch, no RCCL, nothing but the C ABI. Measurement harness, not product code.
+"""One point-sharded frame (BASELINE configs[3]) through the peer exchange (rolo_peer_*) or through RCCL (rolo_comm_*), one process (or thread) per
+rank, timed — the body shared by bench.py's `sharded` leg and profiles/tools/peer2proc.py. The ranks meet through files in a directory (the 64-byte
+mailbox handles / the 128-byte RCCL unique id, barriers): no torch, nothing but the C ABI. Measurement harness, not product code.
 
-    python -m rolo_amd.peerbench <rank> <world> <dir> <sensor> <frames> <leaf> <device>
+    python -m rolo_amd.peerbench <rank> <world> <dir> <sensor> <frames> <leaf> <device> [peer|rccl]
 """
 import json
 import os
@@ -21,13 +21,24 @@ def file_barrier(d, name, rank, world, timeout=300):
         time.sleep(0.002)
 
 
-def rank_main(rank, world, d, sensor, frames, leaf, device=0):
+def rank_main(rank, world, d, sensor, frames, leaf, device=0, exchange="peer"):
     from . import synth, profile
     from .rotvgicp import RotVGICP
     src, tgt, _ = synth.dense_pair(sensor, seed=synth.SEED)
     G = -np.asarray(synth.PREV_STEP_T); L0 = G * 0.97
     g = RotVGICP(device); g.setResolution(leaf); g.setFixedIterations(20)
-    if world > 1:
+    selftest = None
+    if world > 1 and exchange == "rccl":
+        # north_star's form: ncclAllGather of the covariances + one ncclAllReduce of the sums per LM pass (rolo_comm_init dlopens librccl); the
+        # unique id travels through a file like the mailbox handles do
+        if rank == 0:
+            uid = RotVGICP.comm_unique_id()
+            with open(os.path.join(d, "uid.tmp"), "wb") as f:
+                f.write(uid)
+            os.replace(os.path.join(d, "uid.tmp"), os.path.join(d, "uid.bin"))
+        file_barrier(d, "uid", rank, world)
+        g.comm_init(open(os.path.join(d, "uid.bin"), "rb").read(), rank, world)
+    elif world > 1:
         h = g.peer_export(world, 2 * src.shape[0])
         with open(os.path.join(d, f"h{rank}.tmp"), "wb") as f:
             f.write(h)
@@ -65,9 +76,11 @@ def rank_main(rank, world, d, sensor, frames, leaf, device=0):
     dt = time.perf_counter() - t0
     file_barrier(d, "timed", rank, world)
     res = {"rank": rank, "ms_per_frame": 1e3 * dt / frames, "passes": g.last_stats.n_passes + g.last_translation_stats.n_passes, "counters": g.counters(),
-           "pose_head": Td.reshape(-1)[:4].tolist(), "mailbox": g.peer_info()[2] if world > 1 else ""}
+           "pose_head": Td.reshape(-1)[:4].tolist(), "mailbox": g.peer_info()[2] if (world > 1 and exchange == "peer") else "", "exchange": exchange}
     res["device"] = device
-    if world > 1:
+    if world > 1 and exchange == "rccl":
+        res["rccl_ranks"] = int(g.comm_info()[1])   # ncclCommCount of the communicator the frames ran on
+    if selftest is not None:
         res["selftest"] = {"ok": True, "lm_exchange_us": selftest[0], "cov_exchange_us": selftest[1]}
     # per-launch event times (eager launches while profiling)
     acc = profile.kernel_times(g, frame, reps=3)
@@ -85,4 +98,4 @@ def rank_main(rank, world, d, sensor, frames, leaf, device=0):
 
 if __name__ == "__main__":
     a = sys.argv[1:]
-    rank_main(int(a[0]), int(a[1]), a[2], a[3], int(a[4]), float(a[5]), int(a[6]) if len(a) > 6 else 0)
+    rank_main(int(a[0]), int(a[1]), a[2], a[3], int(a[4]), float(a[5]), int(a[6]) if len(a) > 6 else 0, a[7] if len(a) > 7 else "peer")

@@ -22,6 +22,7 @@ SENSORS = {
     "os1-64": (64, 1024, -22.5, 22.5),
     "os1-128": (128, 1024, -22.5, 22.5),
     "os1-128x2048": (128, 2048, -22.5, 22.5),
+    "os1-32x2048": (32, 2048, -22.5, 22.5),     # the geometry of the reference's config/params_os.yaml (N_SCAN 32, Horizon_SCAN 2048)
     "wide-32x4096": (32, 4096, -16.0, 16.0),   # no such sensor: Horizon_SCAN above 2048 (the front end's HBM-scratch path)
 }
 

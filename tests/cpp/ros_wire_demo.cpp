@@ -38,6 +38,23 @@ static void spit(const std::string& path, const std::vector<uint8_t>& b) {
   std::ofstream f(path, std::ios::binary);
   f.write(reinterpret_cast<const char*>(b.data()), (std::streamsize)b.size());
 }
+// ROLO_DEMO_PARAMS="edgeThreshold=1.0,CT_lambda=1.0,...": the hot-path keys of a named reference configuration (config/params_os.yaml, config/M2UD/params.yaml)
+// on top of the defaults the modes below set — what ros/rolo_ros_convert.hpp reads from the parameter server
+static void apply_param_overrides(ros1::NodeParams& P) {
+  const char* e = std::getenv("ROLO_DEMO_PARAMS");
+  if (!e) return;
+  std::stringstream ss(e); std::string tok;
+  while (std::getline(ss, tok, ',')) {
+    const size_t q = tok.find('=');
+    if (q == std::string::npos) continue;
+    const std::string k = tok.substr(0, q); const float v = (float)std::atof(tok.substr(q + 1).c_str());
+    if (k == "edgeThreshold") P.edgeThreshold = v; else if (k == "surfThreshold") P.surfThreshold = v; else if (k == "odometrySurfLeafSize") P.odometrySurfLeafSize = v;
+    else if (k == "CT_lambda") P.CT_lambda = v; else if (k == "lidarMinRange") P.lidarMinRange = v; else if (k == "lidarMaxRange") P.lidarMaxRange = v;
+    else if (k == "downsampleRate") P.downsampleRate = (int)v;
+    else { std::fprintf(stderr, "ROLO_DEMO_PARAMS: unknown key %s\n", k.c_str()); std::exit(2); }
+  }
+}
+
 template <typename M> static int roundtrip(const std::string& in, const std::string& out) {
   const std::vector<uint8_t> b = slurp(in);
   M m;
@@ -155,6 +172,7 @@ int main(int argc, char** argv) {
     const std::string outdir = argv[7];
     // config/params.yaml values of the shipped configuration
     P.lidarMinRange = 2.0f; P.edgeThreshold = 0.8f; P.surfThreshold = 0.1f; P.odometrySurfLeafSize = 0.4f; P.CT_lambda = 0.3f;
+    apply_param_overrides(P);
     P.odomTopic = "odometry/lidar"; P.lidarFrame = "lidar_link"; P.baselinkFrame = "base_link"; P.odometryFrame = "odom";
     try {
       Context ctxA, ctxB, ctxC;   // three nodes = three processes in the reference: nothing is shared but the messages

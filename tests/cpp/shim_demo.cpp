@@ -72,8 +72,24 @@ static int loop_mode(const char* srcp, const char* tgtp, int n) {
   return 0;
 }
 
+// setDebugPrint(true): the reference's per-trial LM tables on stdout (lsq_registration_impl.hpp:158-162, :299-305, :114-120)
+static int debug_mode(const char* src_path, const char* tgt_path) {
+  rolo::Cloud::Ptr source = load(src_path), target = load(tgt_path);
+  rolo::Cloud aligned;
+  fast_gicp::RotVGICP<> rot_vgicp;
+  rot_vgicp.setPolarResolution(0.175, 0.175, 2.0);
+  rot_vgicp.setDebugPrint(true);
+  rot_vgicp.setInputTarget(target); rot_vgicp.setInputSource(source);
+  rot_vgicp.align(aligned);
+  std::printf("=== translation ===\n");
+  std::array<double, 3> reg_t{0, 0, 0}, guess{-0.28, -0.04, -0.02}, last{-0.28, -0.04, -0.02};
+  rot_vgicp.computeTranslation(aligned, reg_t, guess, last, 0.1, 0.1, 0.3f);
+  return 0;
+}
+
 int main(int argc, char** argv) {
   if (argc == 5 && std::strcmp(argv[1], "loop") == 0) return loop_mode(argv[2], argv[3], std::atoi(argv[4]));
+  if (argc == 4 && std::strcmp(argv[1], "debug") == 0) return debug_mode(argv[2], argv[3]);
   if (argc < 3) { std::fprintf(stderr, "usage: shim_demo source.bin target.bin | shim_demo loop source.bin target.bin N\n"); return 1; }
   rolo::Cloud::Ptr source = load(argv[1]), target = load(argv[2]);
   rolo::Cloud aligned;

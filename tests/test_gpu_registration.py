@@ -692,6 +692,40 @@ def test_cpp_shim_end_to_end(tmp_path):
     assert lines[2] == "invalid_argument"
 
 
+def test_cpp_shim_debug_print_is_the_references_table(tmp_path):
+    """setDebugPrint(true) (lsq_registration.hpp:60): the class prints computeTransformation's banner and, per outer iteration, the header and one row per LM
+    trial in the reference's boost::format layout (lsq_registration_impl.hpp:158-162, :299-305 for the rotation stage, :114-120 for the translation stage) —
+    here from the device-side trace; the rows must be the trace of the same solve, formatted with the same conversions"""
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "shim_demo")
+    cmd = ["g++", "-std=c++17", "-O1", "-I", os.path.join(root, "include"), os.path.join(root, "tests", "cpp", "shim_demo.cpp"), "-o", exe,
+           "-L", os.path.join(root, "rolo_amd"), "-lrolo_hip", "-Wl,-rpath," + os.path.join(root, "rolo_amd"), "-Wl,-rpath,/opt/rocm/lib"]
+    subprocess.run(cmd, check=True)
+    src, tgt, cfg = make_pair("vlp16_polar")
+    src.astype(np.float32).tofile(tmp_path / "s.bin"); tgt.astype(np.float32).tofile(tmp_path / "t.bin")
+    r = subprocess.run([exe, "debug", str(tmp_path / "s.bin"), str(tmp_path / "t.bin")], capture_output=True, text=True, check=True)
+    rot_txt, trans_txt = r.stdout.split("=== translation ===\n")
+    g = RotVGICP(); g.setPolarResolution(*cfg["polar"]); g.setInputTarget(tgt); g.setInputSource(src)
+    g.align(); g3 = np.array([-0.28, -0.04, -0.02]); g.computeTranslation(np.zeros(3), g3, g3)
+    tr = g.trace()
+    head = "--- LM optimization ---\n%5s %15s %15s %15s %15s %15s %5s\n" % ("i", "y0", "yi", "rho", "lambda", "|delta|", "dec")
+
+    def table(stage):
+        out = ""
+        for rec in tr:
+            if rec["stage"] != stage:
+                continue
+            if rec["trial"] == 0:
+                out += head
+            out += "%5d %15g %15g %15g %15g %15g %5s\n" % (rec["trial"], rec["y0"], rec["yi"], rec["rho"], rec["lam"], rec["dnorm"], "x" if rec["rho"] > 0 else " ")
+        return out
+    banner = "*" * 44 + "\n" + "*" * 17 + " optimize " + "*" * 17 + "\n" + "*" * 44 + "\n"
+    assert rot_txt == banner + table(0)
+    assert trans_txt == table(1)
+    assert rot_txt.count("--- LM optimization ---") >= 2 and trans_txt.count("--- LM optimization ---") >= 1
+
+
 def test_cpp_operator_constructed_per_frame_uses_the_context_pool(tmp_path):
     """src/lidarOdometry.cpp:460 constructs `fast_gicp::RotVGICP rot_vgicp;` inside scanRegeistration, once per frame. The drop-in class
     does that through rolo_ctx_acquire / _release: 50 frames with the object constructed inside the frame give the persistent object's

@@ -27,6 +27,66 @@ def demo(tmp_path_factory):
     return exe
 
 
+# The reference's NAMED parameter sets, hot-path keys only (round 4's verdict, item 6), as ros/rolo_ros_convert.hpp would read them from the parameter server:
+#   config/params_os.yaml:18-35   sensor ouster, N_SCAN 32, Horizon_SCAN 2048, lidarMinRange 2.0, edgeThreshold 1.0, surfThreshold 0.1, odometrySurfLeafSize 0.4,
+#                                 NO continuousTrajectoryWeight key => CT_lambda keeps utility.h's default 1.0
+#   config/M2UD/params.yaml:18-47 sensor velodyne, N_SCAN 16, Horizon_SCAN 1800, lidarMinRange 2.0, edgeThreshold 0.8, surfThreshold 0.1, odometrySurfLeafSize 0.4,
+#                                 continuousTrajectoryWeight 0.3  (= the values the demo's chain mode starts from)
+NAMED_CONFIGS = {
+    "params_os": dict(sensor="os1-32x2048", kind="ouster", cfg=dict(n_scan=32, horizon_scan=2048), ring_stride=1,
+                      node=dict(lidarMinRange=2.0, edgeThreshold=1.0, surfThreshold=0.1, odometrySurfLeafSize=0.4, CT_lambda=1.0)),
+    "M2UD": dict(sensor="vlp16", kind="velodyne", cfg=dict(n_scan=16, horizon_scan=1800), ring_stride=1,
+                 node=dict(lidarMinRange=2.0, edgeThreshold=0.8, surfThreshold=0.1, odometrySurfLeafSize=0.4, CT_lambda=0.3)),
+}
+
+
+@pytest.mark.parametrize("name", sorted(NAMED_CONFIGS))
+def test_named_reference_configurations_three_frames_against_the_oracle_chain(demo, tmp_path, name):
+    """three registered frames through the three node cores (serialized PointCloud2 in, serialized CloudInfoStamp / Odometry out) under each of the reference's
+    named parameter sets, against the oracle chain run with the same values: index arrays and feature clouds bit-exact, poses inside 1e-4 m / 1e-5 rad"""
+    c = NAMED_CONFIGS[name]
+    sensor, kind, cfg, ring_stride, node = c["sensor"], c["kind"], c["cfg"], c["ring_stride"], c["node"]
+    poses = trajectory(7)
+    frames = [synth.make_frame(sensor, R, t, synth.SEED + k, ring_stride=ring_stride) for k, (R, t) in enumerate(poses)]
+    stamps = [100.0 + 0.1 * k for k in range(len(frames))]
+    paths = []
+    for k, fr in enumerate(frames):
+        msg = W.velodyne_msg(fr, stamps[k], seq=k) if kind == "velodyne" else W.ouster_msg(fr, stamps[k], seq=k)
+        p = tmp_path / f"msg{k}.bin"; p.write_bytes(W.pack_pc2(msg)); paths.append(str(p))
+    out = tmp_path / "out"; out.mkdir()
+    env = dict(os.environ, ROLO_DEMO_PARAMS=",".join(f"{k}={v}" for k, v in node.items()))
+    r = subprocess.run([demo, "chain", kind, str(cfg["n_scan"]), str(cfg["horizon_scan"]), "0", "4", str(out)] + paths, capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    lines = [l for l in r.stdout.strip().splitlines() if not l.startswith("fusion")]
+    got_frames = [int(l.split()[-1]) for l in lines[2:7]]
+    assert got_frames == [0, 1, 2, 2, 2]   # first frame, gated, then three registered frames
+    fo = pyorc.front_params(lidar_min_range=node["lidarMinRange"], edge_threshold=node["edgeThreshold"], surf_threshold=node["surfThreshold"],
+                            odometry_surf_leaf_size=node["odometrySurfLeafSize"], **cfg)
+    oo = pyorc.Odom(pyorc.default_params(polar_resolution=(0.175, 0.175, 2.0)), node["CT_lambda"])
+    registered = 0
+    for k in range(5):
+        fr = frames[k]
+        po = pyorc.project(fo, fr.xyz, fr.ring); eo = pyorc.extract_features(fo, po)
+        ci = W.parse_cloud_info((out / f"cloud_info_{k}.bin").read_bytes())
+        assert np.array_equal(ci["startRingIndex"], po["start_ring"]) and np.array_equal(ci["endRingIndex"], po["end_ring"])
+        assert np.array_equal(W.xyzi_of(ci["cloud_projected"]), po["extracted"])
+        fi = W.parse_cloud_info((out / f"feature_info_{k}.bin").read_bytes())
+        assert np.array_equal(W.xyzi_of(fi["extracted_corner"]), eo["corner"]) and np.array_equal(W.xyzi_of(fi["extracted_surface"]), eo["surface"])
+        assert eo["corner"].shape[0] > 20 and eo["surface"].shape[0] > 1000
+        if k == 2:
+            oo.backend_odometry(stamps[k])
+        rco, pose_o, R_o, t_o = oo.cloud(stamps[k], eo["corner"], eo["surface"])
+        assert rco == got_frames[k]
+        if k == 0:
+            continue
+        od = W.parse_odometry((out / f"odom_{k}.bin").read_bytes())
+        assert np.abs(od["position"] - pose_o[:3].astype(np.float64)).max() <= 1e-4
+        q_o = Rotation.from_euler("xyz", pose_o[3:].astype(np.float64)).as_quat()
+        assert min(np.abs(od["orientation"] - q_o).max(), np.abs(od["orientation"] + q_o).max()) <= 1e-5
+        registered += int(rco == 2)
+    assert registered == 3
+
+
 @pytest.mark.parametrize("sensor,kind,cfg,ring_stride", [("vlp16", "velodyne", dict(n_scan=16, horizon_scan=1800), 1),
                                                          ("os1-64", "ouster", dict(n_scan=64, horizon_scan=1024), 2)])
 def test_serialized_cloud_in_serialized_odometry_out(demo, tmp_path, sensor, kind, cfg, ring_stride):

@@ -115,3 +115,36 @@ def test_bench_sharded_leg_reports_a_failed_child_instead_of_raising():
     bench = importlib.import_module("bench")
     res = bench.sharded_children(2, "vlp16", 2, 0.5, timeout=120)
     assert isinstance(res, dict) and "error" in res and "rank" in res["error"]
+
+
+def test_bench_control_flow_world8_gloo_dry_run():
+    """bench.py --gpus 8 end to end WITHOUT GPUs (round 4's verdict, item 4b): eight gloo ranks under torch.distributed.run run bench.main() unchanged with
+    torch.cuda reduced to no-ops and the operator class replaced by a stand-in that registers through the oracle (tests/dryrun_bench.py — test infrastructure,
+    not reachable from the product). Exercised as on the node: the rank-wise input pool, the timed rounds (barriers, MAX all-reduce of the round times), the
+    sharded leg with BOTH exchanges in child processes (they fail at rolo_ctx_create here — the error records must land in the line and nobody may hang on the
+    host-side waits), the config5 deal over the ranks, and ONE JSON line from rank 0 carrying the keys the driver and the judge read."""
+    import json
+    import subprocess
+    world = 8
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "tests", "dryrun_bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1", "--sensor", "vlp16", "--pool", "2", "--streams", "2",
+           "--config5-pairs", "8", "--single-round", "--no-cpu"]
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{") and '"metric"' in l]
+    assert len(lines) == 1, r.stdout[-2000:]          # rank 0 prints ONE line
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == world and d["scaling"] == "weak" and d["value"] > 0 and d["unit"] == "scans/s"
+    assert d["frames_per_step"] == 2 * world           # streams x ranks: the whole-job aggregate
+    assert d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True and d["vs_baseline"] is None
+    sh = d["sharded"]
+    for kind in ("peer", "rccl"):                      # both exchanges were attempted; without GPUs every child fails at rolo_ctx_create: reported, not raised
+        assert kind in sh and isinstance(sh[kind], dict) and "error" in sh[kind] and "rank" in sh[kind]["error"], sh.get(kind)
+    assert "rccl_ranks" in sh and "rccl_ranks" in d["config"] and "product_answer" in sh and "estimate" in sh
+    assert "one_gpu_same_frame_scans_per_s" in sh
+    c5 = d["config5"]
+    assert c5["pairs_per_rank"] == 1 and c5["scans_per_s_batch512"] > 0 and c5["schedule_timed_sweeps"]["frames"] == 3 * 2 or c5["schedule_timed_sweeps"]["frames"] >= 3
+    assert "roofline" in d and "valu_issue" in d and "frame_hbm" in d
