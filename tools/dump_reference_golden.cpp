@@ -27,6 +27,7 @@
 #include <cstdlib>
 #include <fstream>
 #include <map>
+#include <memory>
 #include <sstream>
 #include <string>
 #include <vector>
@@ -174,7 +175,6 @@ int main(int argc, char** argv) {
     Eigen::Matrix<double, 6, 6> H6; Eigen::Matrix<double, 6, 1> b6;
     // lambda_ (the CT weight) is set by computeTranslation only; reach it the same way the oracle's fixtures do: ct_lambda from params
     {
-      pcl::PointCloud<PointT> tmp; Eigen::Vector3d t0 = T;
       // (t3_linearize reads lambda_; set it without running a solve: the member is protected, this subclass may write it)
       struct L_ : Dump { static void set(Dump& d, float v) { static_cast<L_&>(d).lambda_ = v; } };
       L_::set(*g, (float)P["ct_lambda"]);
