@@ -241,7 +241,7 @@ int upload_cloud(rolo_ctx* c, CloudDev& cl, size_t& xyz_cap, const float* pts, i
   HIPCHK(launch_pack_xyz(dsrc, stride, cl.xyz, n, c->stream, cl.bbox_part));
   cl.n_bbox_part = nparts;
   cl.n = n;
-  cl.have_cov = false;
+  cl.have_cov = false; cl.have_nrm = false;
   cl.have_sorted = false;
   cl.bbox6 = nullptr;
   c->cloud_epoch++;
@@ -258,13 +258,14 @@ int prepare_cloud(rolo_ctx* c, CloudDev& cl, size_t& cov_cap, size_t& sorted_cap
   cl.P = P;
   int rc;
   if ((rc = ensure(cl.cov, cov_cap, 6 * (size_t)n))) return rc;
+  if (!tree_only && (rc = ensure(cl.nrm, cl.nrm_cap, 3 * (size_t)n))) return rc;
   if ((rc = ensure(cl.sorted, sorted_cap, KNN_LEAF * (size_t)cl.n_leaves))) return rc;
   if ((rc = ensure(cl.boxes, boxes_cap, 4 * (size_t)P))) return rc;
   if (c->want_knn_lists) {
     if ((rc = ensure(cl.knn_idx, knn_cap, (size_t)n * k))) return rc;
     if ((rc = ensure(cl.knn_d2, knnd_cap, (size_t)n * k))) return rc;
   }
-  out.xyz = cl.xyz; out.sorted = cl.sorted; out.boxes = cl.boxes; out.cov = cl.cov;
+  out.xyz = cl.xyz; out.sorted = cl.sorted; out.boxes = cl.boxes; out.cov = cl.cov; out.nrm = tree_only ? nullptr : cl.nrm;
   out.knn_idx = c->want_knn_lists ? cl.knn_idx : nullptr; out.knn_d2 = c->want_knn_lists ? cl.knn_d2 : nullptr;
   out.n = n; out.n_leaves = cl.n_leaves; out.P = P; out.n_sorted = KNN_LEAF * cl.n_leaves;
   out.q_begin = 0; out.q_end = out.n_sorted; out.stage = nullptr; out.chunk = out.n_sorted; out.stage_off = 0; out.seg = 0; out.stage_epoch = nullptr; out.stage_alt = 0;
@@ -378,8 +379,10 @@ int build_clouds(rolo_ctx* c, bool do_src, bool do_tgt, hipStream_t stream, bool
     // without a communicator / peers (rolo_set_shard test hook) only the own slice is valid afterwards
     HIPCHK(launch_knn_unstage(A, c->comm == nullptr && !peers(c), vf, stream));
   }
-  if (do_src) { c->src.have_cov = true; c->src.have_sorted = true; c->src.cov_user = false; c->src.bbox6 = S.bbox; }
-  if (do_tgt) { c->tgt.have_cov = true; c->tgt.have_sorted = true; c->tgt.cov_user = false; c->tgt.bbox6 = S.bbox + (do_src ? 6 : 0); }
+  // (the tail leaves the PLANE covariances as I - m m^T too — CloudDev::nrm — unless the slices went through an exchange buffer: passes.hip load_pt)
+  const bool nrm_written = !sharded && c->P.regularization == ROLO_REG_PLANE;
+  if (do_src) { c->src.have_cov = true; c->src.have_sorted = true; c->src.cov_user = false; c->src.have_nrm = nrm_written; c->src.bbox6 = S.bbox; }
+  if (do_tgt) { c->tgt.have_cov = true; c->tgt.have_sorted = true; c->tgt.cov_user = false; c->tgt.have_nrm = nrm_written; c->tgt.bbox6 = S.bbox + (do_src ? 6 : 0); }
   return ROLO_OK;
 }
 
@@ -471,6 +474,9 @@ int prepare_pass(rolo_ctx* c, PassArgs& a, int& grid) {
   c->lm_rows = std::max(1, (end - begin + lm_threads() * lm_ppt() - 1) / (lm_threads() * lm_ppt()));
   if ((rc = ensure(c->partials, c->partials_cap, std::max((size_t)grid, 2 * (size_t)c->lm_rows) * NV_MAX))) return rc;
   a.src = c->src.xyz; a.cov = c->src.cov; a.n_total = c->src.n; a.begin = begin; a.end = end; a.n_off = noff;
+  // the source covariances as I - m m^T: only what the library computed itself for THIS cloud under PLANE (ROLO_PASS_NRM=0: the six-entry form always — the A/B)
+  static const bool nrm_on = [] { const char* e = getenv("ROLO_PASS_NRM"); return !e || atoi(e) != 0; }();
+  a.nrm = (nrm_on && c->src.have_cov && c->src.have_nrm && !c->src.cov_user && c->src.nrm && c->P.regularization == ROLO_REG_PLANE) ? c->src.nrm : nullptr;
   a.corr[0] = c->corr[0]; a.corr[1] = c->corr[1]; a.partials = c->partials; a.tab = c->tab;
   static const bool xcd_on = [] { const char* e = getenv("ROLO_PASS_XCD"); return !e || atoi(e) != 0; }();
   a.xcd_map = xcd_on ? 1 : 0;
@@ -628,7 +634,7 @@ int ctx_set_pair_device(rolo_ctx* c, const float* d_src, int n_src, int stride_s
     if ((rc = ensure(cl[i]->bbox_part, cl[i]->bbox_part_cap, (size_t)((n[i] + 255) / 256) * 6))) return rc;
   }
   HIPCHK(launch_pack_pair(d_src, stride_src, c->src.xyz, n_src, c->src.bbox_part, T16_host_or_null, d_tgt, stride_tgt, c->tgt.xyz, n_tgt, c->tgt.bbox_part, c->stream));
-  for (int i = 0; i < 2; i++) { cl[i]->n_bbox_part = (n[i] + 255) / 256; cl[i]->n = n[i]; cl[i]->have_cov = false; cl[i]->have_sorted = false; cl[i]->bbox6 = nullptr; }
+  for (int i = 0; i < 2; i++) { cl[i]->n_bbox_part = (n[i] + 255) / 256; cl[i]->n = n[i]; cl[i]->have_cov = false; cl[i]->have_nrm = false; cl[i]->have_sorted = false; cl[i]->bbox6 = nullptr; }
   c->have_map = false; c->have_corr = false;
   c->cloud_epoch++;
   return ROLO_OK;
@@ -798,7 +804,7 @@ void rolo_ctx_destroy(rolo_ctx* c) {
   rolo_s2m_destroy(c);
   peer_release(c);
   if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
-  void* bufs[] = {c->src.bbox_part, c->tgt.bbox_part, c->src.xyz, c->src.cov, c->src.sorted, c->src.boxes, c->src.knn_idx, c->src.knn_d2, c->tgt.xyz, c->tgt.cov, c->tgt.sorted,
+  void* bufs[] = {c->src.nrm, c->tgt.nrm, c->src.bbox_part, c->tgt.bbox_part, c->src.xyz, c->src.cov, c->src.sorted, c->src.boxes, c->src.knn_idx, c->src.knn_d2, c->tgt.xyz, c->tgt.cov, c->tgt.sorted,
                   c->tgt.boxes, c->tgt.knn_idx, c->tgt.knn_d2, c->ks[0].sort_tmp, c->ks[0].keys0, c->ks[0].keys1, c->ks[0].vals0, c->ks[0].vals1, c->ks[0].bbox,
                   c->ks[1].sort_tmp, c->ks[1].keys0, c->ks[1].keys1, c->ks[1].vals0, c->ks[1].vals1, c->ks[1].bbox, c->ks[0].nbr, c->ks[1].nbr, c->ks[0].stage, c->ks[1].stage, c->ks[0].lower, c->ks[1].lower, c->tab.keys,
                   c->tab.ids, c->tab.rec, c->tab.id_keys, c->tgt_keys, c->tgt_slot, c->counters, c->corr[0], c->corr[1], c->partials, c->sums,
@@ -832,7 +838,7 @@ void reset_to_fresh(rolo_ctx* c) {
   rolo_default_params(&c->P);
   c->src.n = 0; c->tgt.n = 0;
   c->cloud_epoch++;   // whatever sub-map the previous owner left resident is not the next owner's
-  c->src.have_cov = c->tgt.have_cov = false; c->src.have_sorted = c->tgt.have_sorted = false; c->src.cov_user = c->tgt.cov_user = false;
+  c->src.have_cov = c->tgt.have_cov = false; c->src.have_sorted = c->tgt.have_sorted = false; c->src.cov_user = c->tgt.cov_user = false; c->src.have_nrm = c->tgt.have_nrm = false;
   c->src.bbox6 = c->tgt.bbox6 = nullptr; c->src.n_bbox_part = c->tgt.n_bbox_part = 0;
   c->have_map = false; c->have_corr = false; c->n_voxels = 0; c->n_edge = 0;
   c->want_knn_lists = false; c->prof_on = false; c->shard_knn = false;
@@ -936,6 +942,8 @@ int rolo_adopt_target_covariances(rolo_ctx* c) {
   if (!c->tgt.have_cov || c->tgt.n <= 0 || c->src.n != c->tgt.n) { g_err = "no target covariances of matching size to adopt"; return ROLO_ESTATE; }
   std::swap(c->src.cov, c->tgt.cov);
   std::swap(c->src_cov_cap, c->tgt_cov_cap);
+  std::swap(c->src.nrm, c->tgt.nrm); std::swap(c->src.nrm_cap, c->tgt.nrm_cap);
+  c->src.have_nrm = c->tgt.have_nrm; c->tgt.have_nrm = false; c->src.cov_user = c->tgt.cov_user;
   c->src.have_cov = true; c->tgt.have_cov = false;
   c->have_map = false; c->have_corr = false;
   return ROLO_OK;
@@ -972,7 +980,7 @@ static int set_covs(rolo_ctx* c, CloudDev& cl, size_t& cov_cap, const double* co
   HIPCHK(hipMemcpyAsync(c->stage_d, covs, sizeof(double) * 16 * (size_t)cl.n, hipMemcpyHostToDevice, c->stream));
   HIPCHK(launch_cov_pack(c->stage_d, cl.n, cl.cov, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
-  cl.have_cov = true; cl.cov_user = true;
+  cl.have_cov = true; cl.cov_user = true; cl.have_nrm = false;
   return ROLO_OK;
 }
 int rolo_set_source_covariances(rolo_ctx* c, const double* covs) { if (!c) return ROLO_EINVAL; int rc = set_device(c); if (rc) return rc; c->have_corr = false; return set_covs(c, c->src, c->src_cov_cap, covs); }
@@ -1287,6 +1295,7 @@ static int register_async_impl(rolo_ctx* c, const float* guess16, const double* 
       HIPCHK(hipGraphLaunch(c->graph_exec, c->stream));
       c->n_replays++;
       c->src.have_cov = true; c->tgt.have_cov = true; c->src.have_sorted = true; c->tgt.have_sorted = true;
+      c->src.have_nrm = c->tgt.have_nrm = c->P.regularization == ROLO_REG_PLANE && !(c->comm || peers(c) || (c->world > 1 && c->shard_knn));   // as the captured build_clouds left them
       c->async_pending = true;
       return ROLO_OK;
     }
@@ -1579,7 +1588,8 @@ int rolo_batch_register_async(rolo_batch* b, const float* guess16, const double*
   if (graphable) {
     if (b->graph_exec && same_keys(keys, b->gkey.k)) {
       HIPCHK(hipGraphLaunch(b->graph_exec, st));
-      for (rolo_ctx* c : b->m) { c->src.have_cov = true; c->tgt.have_cov = true; c->src.have_sorted = true; c->tgt.have_sorted = true; }
+      for (rolo_ctx* c : b->m) { c->src.have_cov = true; c->tgt.have_cov = true; c->src.have_sorted = true; c->tgt.have_sorted = true;
+                                 c->src.have_nrm = c->tgt.have_nrm = c->P.regularization == ROLO_REG_PLANE; }
       b->pending = true;
       return ROLO_OK;
     }

@@ -548,7 +548,7 @@ ROLO_DEV void inv3(const double (&A)[9], double (&o)[9]) {
 
 // regularisation of the neighbourhood covariance (rot_vgicp_impl.hpp:457-490) and the store of its six unique entries
 ROLO_DEV void knn_covariance_finish(double cxx, double cxy, double cxz, double cyy, double cyz, double czz, int n, int qi, int reg,
-                                    double* __restrict__ cov, double (&c6)[6]) {
+                                    double* __restrict__ cov, double (&c6)[6], double* __restrict__ nrm = nullptr) {
   double out[9];
 
   if (reg == ROLO_REG_NONE) {
@@ -575,6 +575,14 @@ ROLO_DEV void knn_covariance_finish(double cxx, double cxy, double cxz, double c
     for (int a = 0; a < 3; a++)
 #pragma unroll
       for (int b = 0; b < 3; b++) out[a * 3 + b] = (U[a * 3 + 0] * v0) * V[b * 3 + 0] + (U[a * 3 + 1] * v1) * V[b * 3 + 1] + (U[a * 3 + 2] * v2) * V[b * 3 + 2];
+    if (nrm && reg == ROLO_REG_PLANE) {
+      // U diag(1, 1, 1e-3) V^T with orthonormal V and U = V up to the sign fix of each column: u0 u0^T + u1 u1^T + s 1e-3 u2 u2^T = I - (1 - s 1e-3) u2 u2^T,
+      // s = U's sign on the third column (-1 only for a rank-deficient neighbourhood whose zero singular value came out of the sweep with a minus sign)
+      const double s3 = U[0 * 3 + 2] * V[0 * 3 + 2] + U[1 * 3 + 2] * V[1 * 3 + 2] + U[2 * 3 + 2] * V[2 * 3 + 2];   // +-1 to rounding
+      const double al = sqrt(1.0 - (s3 < 0 ? -1e-3 : 1e-3));
+      const size_t pn = (size_t)n;
+      nrm[qi] = al * V[0 * 3 + 2]; nrm[pn + qi] = al * V[1 * 3 + 2]; nrm[2 * pn + qi] = al * V[2 * 3 + 2];
+    }
   }
   const size_t pitch = (size_t)n;
   c6[0] = out[0]; c6[1] = 0.5 * (out[1] + out[3]); c6[2] = 0.5 * (out[2] + out[6]); c6[3] = out[4]; c6[4] = 0.5 * (out[5] + out[7]); c6[5] = out[8];
@@ -585,7 +593,7 @@ ROLO_DEV void knn_covariance_finish(double cxx, double cxy, double cxz, double c
 // covariance of the neighbourhood + regularisation, one lane per query
 template <int KMAX>
 ROLO_DEV void knn_covariance_tail(const int (&ki)[KMAX], int kk, const float4* __restrict__ orig, int n, int qi, int reg,
-                                  double* __restrict__ cov, double (&c6)[6]) {
+                                  double* __restrict__ cov, double (&c6)[6], double* __restrict__ nrm = nullptr) {
   // ---- covariance of the neighbourhood (rot_vgicp_impl.hpp:438-455), fp64, centred two-pass ----
   // the K neighbours are gathered once and stay in registers for both passes (this kernel is not occupancy-critical)
   float px[KMAX], py[KMAX], pz[KMAX];
@@ -605,12 +613,12 @@ ROLO_DEV void knn_covariance_tail(const int (&ki)[KMAX], int kk, const float4* _
     cxx += ax * ax; cxy += ax * ay; cxz += ax * az; cyy += ay * ay; cyz += ay * az; czz += az * az;
   }
   cxx /= kk; cxy /= kk; cxz /= kk; cyy /= kk; cyz /= kk; czz /= kk;
-  knn_covariance_finish(cxx, cxy, cxz, cyy, cyz, czz, n, qi, reg, cov, c6);
+  knn_covariance_finish(cxx, cxy, cxz, cyy, cyz, czz, n, qi, reg, cov, c6, nrm);
 }
 
 // the same for any number of neighbours (k_correspondences > 64): the neighbours are gathered twice, slot by slot, in the same order
 ROLO_DEV void knn_covariance_tail_loop(const int32_t* __restrict__ nbr, size_t n_sorted, int j, int kk, const float4* __restrict__ orig, int n, int qi, int reg,
-                                       double* __restrict__ cov, double (&c6)[6]) {
+                                       double* __restrict__ cov, double (&c6)[6], double* __restrict__ nrm = nullptr) {
   double mx = 0, my = 0, mz = 0;
   for (int u = 0; u < kk; u++) { const float4 p = orig[nbr[(size_t)u * n_sorted + j]]; mx += (double)p.x; my += (double)p.y; mz += (double)p.z; }
   mx /= kk; my /= kk; mz /= kk;
@@ -621,7 +629,7 @@ ROLO_DEV void knn_covariance_tail_loop(const int32_t* __restrict__ nbr, size_t n
     cxx += ax * ax; cxy += ax * ay; cxz += ax * az; cyy += ay * ay; cyz += ay * az; czz += az * az;
   }
   cxx /= kk; cxy /= kk; cxz /= kk; cyy /= kk; cyz /= kk; czz /= kk;
-  knn_covariance_finish(cxx, cxy, cxz, cyy, cyz, czz, n, qi, reg, cov, c6);
+  knn_covariance_finish(cxx, cxy, cxz, cyy, cyz, czz, n, qi, reg, cov, c6, nrm);
 }
 }  // namespace
 }  // namespace rolo

@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256, KMAX > 32 ? 2 : ROLO_KNN_WALK_OCC) void knn_wa
     double* o = stage_area(cl, 1) + (size_t)(j / cl.chunk) * cl.seg + cl.stage_off + (size_t)(j % cl.chunk) * 6;
     double c6[6]; knn_covariance_tail<KMAX>(ki, kk, cl.xyz, 1, 0, reg, o, c6);
   } else {
-    double c6[6]; knn_covariance_tail<KMAX>(ki, kk, cl.xyz, cl.n, qi, reg, cl.cov, c6);
+    double c6[6]; knn_covariance_tail<KMAX>(ki, kk, cl.xyz, cl.n, qi, reg, cl.cov, c6, cl.nrm);
   }
 }
 
@@ -567,7 +567,7 @@ __global__ __launch_bounds__(256, ROLO_KNN_TAIL_OCC) void knn_tail_kernel(KnnPai
       double* o = stage_area(cl, 1) + (size_t)(j / cl.chunk) * cl.seg + cl.stage_off + (size_t)(j % cl.chunk) * 6;
       knn_covariance_tail<KMAX>(ki, (KMAX == 20) ? 20 : k, cl.xyz, 1, 0, reg, o, c6);   // pitch 1, index 0: six consecutive doubles
     } else {
-      knn_covariance_tail<KMAX>(ki, (KMAX == 20) ? 20 : k, cl.xyz, cl.n, qi, reg, cl.cov, c6);
+      knn_covariance_tail<KMAX>(ki, (KMAX == 20) ? 20 : k, cl.xyz, cl.n, qi, reg, cl.cov, c6, cl.nrm);
     }
   }
   if (fuse) {   // every lane of the wavefront takes part in the segmented fold
@@ -595,7 +595,7 @@ __global__ __launch_bounds__(256) void knn_tail_loop_kernel(KnnPair A, int split
       double* o = stage_area(cl, 1) + (size_t)(j / cl.chunk) * cl.seg + cl.stage_off + (size_t)(j % cl.chunk) * 6;
       knn_covariance_tail_loop(cl.nbr, (size_t)cl.n_sorted, j, k, cl.xyz, 1, 0, reg, o, c6);
     } else {
-      knn_covariance_tail_loop(cl.nbr, (size_t)cl.n_sorted, j, k, cl.xyz, cl.n, qi, reg, cl.cov, c6);
+      knn_covariance_tail_loop(cl.nbr, (size_t)cl.n_sorted, j, k, cl.xyz, cl.n, qi, reg, cl.cov, c6, cl.nrm);
     }
   }
   if (fuse) {

@@ -192,13 +192,23 @@ ROLO_DEV double uni(double v) {
 ROLO_DEV int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 // what a pass needs of one source point: loaded before anything that depends on the LM state
-struct PtIn { float4 pf; Sym3 CA; };
+// CA: the six-entry covariance; or, when the PLANE covariances were computed by the library (a.nrm), m with C_A = I - m m^T: 24 bytes per point and pass
+// instead of 48, and the rotation R C_A R^T = I - (R m)(R m)^T is nine multiply-adds instead of forty-five (rotated_cov)
+struct PtIn { float4 pf; Sym3 CA; Vec3 m; };
 ROLO_DEV PtIn load_pt(const PassArgs& a, int i) {
-  PtIn o;
+  PtIn o{};
   o.pf = a.src[i];
   const size_t pitch = (size_t)a.n_total;
-  o.CA = Sym3{a.cov[i], a.cov[pitch + i], a.cov[2 * pitch + i], a.cov[3 * pitch + i], a.cov[4 * pitch + i], a.cov[5 * pitch + i]};
+  if (a.nrm) o.m = Vec3{a.nrm[i], a.nrm[pitch + i], a.nrm[2 * pitch + i]};
+  else o.CA = Sym3{a.cov[i], a.cov[pitch + i], a.cov[2 * pitch + i], a.cov[3 * pitch + i], a.cov[4 * pitch + i], a.cov[5 * pitch + i]};
   return o;
+}
+ROLO_DEV Sym3 rotated_cov(const PassArgs& a, const double* R, const PtIn& in) {
+  if (a.nrm) {
+    const Vec3 q = mat3_mulv(R, in.m);
+    return Sym3{1.0 - q.x * q.x, -(q.x * q.y), -(q.x * q.z), 1.0 - q.y * q.y, -(q.y * q.z), 1.0 - q.z * q.z};
+  }
+  return sym3_rotate(R, in.CA);
 }
 
 template <int DOF>
@@ -217,7 +227,6 @@ ROLO_DEV void rot_pass_compute(const PassArgs& a, const LmState* __restrict__ st
   if (valid) {
     const float4 pf = in.pf;
     const Vec3 p{(double)pf.x, (double)pf.y, (double)pf.z};
-    const Sym3 CA = in.CA;
     Vec3 tp = mat3_mulv(R1, p);
     tp.x += t1[0]; tp.y += t1[1]; tp.z += t1[2];
     const int n_off = a.n_off;
@@ -226,7 +235,7 @@ ROLO_DEV void rot_pass_compute(const PassArgs& a, const LmState* __restrict__ st
     // trial's (A) half, rot_vgicp_impl.hpp:204-222 — and it LOST: 96 B per point and pass of extra traffic cost more than the ~100 instructions saved,
     // 2694 against 2875 scans/s; profiles/DEAD_ENDS.md. The translation stage, whose M is constant, does cache it: trans_pass_compute.)
     if (phase == 1) {
-      const Sym3 RCA0 = sym3_rotate(R0, CA);
+      const Sym3 RCA0 = rotated_cov(a, R0, in);
       for (int o = 0; o < n_off; o++) {
         const int vid = corr_old[(size_t)i * n_off + o];
         if (vid >= 0) {
@@ -240,7 +249,7 @@ ROLO_DEV void rot_pass_compute(const PassArgs& a, const LmState* __restrict__ st
     // (B) so3_linearize / linearize at xi, with update_correspondences(xi) fused in
     int kx, ky, kz;
     voxel_coord_dev(a.tab, tp.x, tp.y, tp.z, kx, ky, kz);
-    const Sym3 RCA1 = sym3_rotate(R1, CA);
+    const Sym3 RCA1 = rotated_cov(a, R1, in);
     const int ob = offset_base(n_off);
     for (int o = 0; o < n_off; o++) {
       const int vid = voxel_lookup(a.tab, kx + c_offsets[ob + o][0], ky + c_offsets[ob + o][1], kz + c_offsets[ob + o][2]);
@@ -336,7 +345,7 @@ ROLO_DEV void trans_pass_compute(const PassArgs& a, const LmState* __restrict__ 
     const Vec3 ctA{dv.x - lAq.x, dv.y - lAq.y, dv.z - lAq.z};
     const Vec3 ctB{dv.x - lBq.x, dv.y - lBq.y, dv.z - lBq.z};
     const int n_off = a.n_off;
-    const Sym3 RCA = sym3_rotate(R, in.CA);
+    const Sym3 RCA = rotated_cov(a, R, in);
     for (int o = 0; o < n_off; o++) {
       const int vid = corr[(size_t)i * n_off + o];
       if (vid < 0) continue;

