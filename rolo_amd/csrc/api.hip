@@ -136,7 +136,7 @@ struct rolo_ctx {
   int bank_slot = -1;              // >= 0: stream / stream2 belong to the device's stream bank (given back, not destroyed)
   // voxel map
   VoxelTable tab{};
-  size_t tab_keys_cap = 0, tab_ids_cap = 0, tab_rec_cap = 0, tab_idk_cap = 0;
+  size_t tab_keys_cap = 0, tab_rec_cap = 0, tab_idk_cap = 0;
   unsigned long long* tgt_keys = nullptr; size_t tgt_keys_cap = 0;
   int* tgt_slot = nullptr; size_t tgt_slot_cap = 0;
   int* counters = nullptr; size_t counters_cap = 0;
@@ -427,8 +427,7 @@ int ensure_map(rolo_ctx* c) {
   if (c->have_map) return ROLO_OK;
   const int n = c->tgt.n;
   size_t capslots = 1024; while (capslots < 2 * (size_t)n) capslots <<= 1;
-  if ((rc = ensure(c->tab.keys, c->tab_keys_cap, capslots))) return rc;
-  if ((rc = ensure(c->tab.ids, c->tab_ids_cap, capslots))) return rc;
+  if ((rc = ensure(c->tab.keys, c->tab_keys_cap, 2 * capslots))) return rc;   // 16 bytes per slot: key + id
   if ((rc = ensure(c->tab.rec, c->tab_rec_cap, (size_t)n * REC_DOUBLES))) return rc;
   if ((rc = ensure(c->tab.id_keys, c->tab_idk_cap, (size_t)n))) return rc;
   if ((rc = ensure(c->tgt_keys, c->tgt_keys_cap, (size_t)n))) return rc;
@@ -807,7 +806,7 @@ void rolo_ctx_destroy(rolo_ctx* c) {
   void* bufs[] = {c->src.nrm, c->tgt.nrm, c->src.bbox_part, c->tgt.bbox_part, c->src.xyz, c->src.cov, c->src.sorted, c->src.boxes, c->src.knn_idx, c->src.knn_d2, c->tgt.xyz, c->tgt.cov, c->tgt.sorted,
                   c->tgt.boxes, c->tgt.knn_idx, c->tgt.knn_d2, c->ks[0].sort_tmp, c->ks[0].keys0, c->ks[0].keys1, c->ks[0].vals0, c->ks[0].vals1, c->ks[0].bbox,
                   c->ks[1].sort_tmp, c->ks[1].keys0, c->ks[1].keys1, c->ks[1].vals0, c->ks[1].vals1, c->ks[1].bbox, c->ks[0].nbr, c->ks[1].nbr, c->ks[0].stage, c->ks[1].stage, c->ks[0].lower, c->ks[1].lower, c->tab.keys,
-                  c->tab.ids, c->tab.rec, c->tab.id_keys, c->tgt_keys, c->tgt_slot, c->counters, c->corr[0], c->corr[1], c->partials, c->sums,
+                  c->tab.rec, c->tab.id_keys, c->tgt_keys, c->tgt_slot, c->counters, c->corr[0], c->corr[1], c->partials, c->sums,
                   c->state, c->trace, c->stage_in, c->stage_out, c->stage_d, c->stage_i};
   for (void* b : bufs) if (b) (void)hipFree(b);
   if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
@@ -1219,8 +1218,7 @@ static int enqueue_frame(rolo_ctx* c, bool with_trans) {   // with_trans = false
   {
     const int n = c->tgt.n;
     size_t capslots = 1024; while (capslots < 2 * (size_t)n) capslots <<= 1;
-    if ((rc = ensure(c->tab.keys, c->tab_keys_cap, capslots))) return rc;
-    if ((rc = ensure(c->tab.ids, c->tab_ids_cap, capslots))) return rc;
+    if ((rc = ensure(c->tab.keys, c->tab_keys_cap, 2 * capslots))) return rc;   // 16 bytes per slot: key + id
     if ((rc = ensure(c->tab.rec, c->tab_rec_cap, (size_t)n * REC_DOUBLES))) return rc;
     if ((rc = ensure(c->tab.id_keys, c->tab_idk_cap, (size_t)n))) return rc;
     if ((rc = ensure(c->tgt_keys, c->tgt_keys_cap, (size_t)n))) return rc;
@@ -1531,8 +1529,7 @@ static int enqueue_batch(rolo_batch* b, bool fork) {
     if (!c->tgt.have_cov && (rc = build_tgt(c, s2))) return rc;
     const int n = c->tgt.n;
     size_t capslots = 1024; while (capslots < 2 * (size_t)n) capslots <<= 1;
-    if ((rc = ensure(c->tab.keys, c->tab_keys_cap, capslots))) return rc;
-    if ((rc = ensure(c->tab.ids, c->tab_ids_cap, capslots))) return rc;
+    if ((rc = ensure(c->tab.keys, c->tab_keys_cap, 2 * capslots))) return rc;   // 16 bytes per slot: key + id
     if ((rc = ensure(c->tab.rec, c->tab_rec_cap, (size_t)n * REC_DOUBLES))) return rc;
     if ((rc = ensure(c->tab.id_keys, c->tab_idk_cap, (size_t)n))) return rc;
     if ((rc = ensure(c->tgt_keys, c->tgt_keys_cap, (size_t)n))) return rc;

@@ -240,8 +240,8 @@ __global__ __launch_bounds__(SORT_T) void morton_kernel(KnnPair A, int* __restri
                                                        int* __restrict__ cnt, VoxelFuse vf) {
   ROLO_ALL_KERNEL_PRIO();
   if ((int)blockIdx.x >= SORT_NB) {
-    const size_t n_slots = (size_t)vf.tab.mask + 1;
-    for (size_t k = (size_t)((int)blockIdx.x - SORT_NB) * SORT_T + threadIdx.x; k < n_slots; k += (size_t)VF_CLEAR_BLOCKS * SORT_T) vf.tab.keys[k] = KEY_EMPTY;
+    const size_t n_words = 2 * ((size_t)vf.tab.mask + 1);   // 16 bytes per slot: key + id (voxel_dev.hpp)
+    for (size_t k = (size_t)((int)blockIdx.x - SORT_NB) * SORT_T + threadIdx.x; k < n_words; k += (size_t)VF_CLEAR_BLOCKS * SORT_T) vf.tab.keys[k] = KEY_EMPTY;
     if (blockIdx.x == SORT_NB && threadIdx.x < 3) vf.counters[threadIdx.x] = 0;   // counters[3] (max |coordinate|) is block 0's
     return;
   }

@@ -572,7 +572,7 @@ __global__ __launch_bounds__(256, ROLO_KNN_TAIL_OCC) void knn_tail_kernel(KnnPai
   }
   if (fuse) {   // every lane of the wavefront takes part in the segmented fold
     int id = -1;
-    if (act) { const int slot = vf.tgt_slot[qi]; if (slot >= 0) id = vf.tab.ids[slot]; }
+    if (act) { const int slot = vf.tgt_slot[qi]; if (slot >= 0) id = slot_id(vf.tab, (unsigned)slot); }
     accumulate_point(vf.tab, id, sp, c6, fix_scales(cl.n, vf.counters), true, const_cast<int*>(vf.counters) + 1);
   }
 }
@@ -600,7 +600,7 @@ __global__ __launch_bounds__(256) void knn_tail_loop_kernel(KnnPair A, int split
   }
   if (fuse) {
     int id = -1;
-    if (act) { const int slot = vf.tgt_slot[qi]; if (slot >= 0) id = vf.tab.ids[slot]; }
+    if (act) { const int slot = vf.tgt_slot[qi]; if (slot >= 0) id = slot_id(vf.tab, (unsigned)slot); }
     accumulate_point(vf.tab, id, sp, c6, fix_scales(cl.n, vf.counters), true, const_cast<int*>(vf.counters) + 1);
   }
 }
@@ -628,7 +628,7 @@ __global__ __launch_bounds__(256) void knn_unstage_kernel(KnnPair A, int split, 
   }
   if (fuse) {   // every lane of the wavefront takes part in the segmented fold
     int id = -1;
-    if (act) { const int slot = vf.tgt_slot[qi]; if (slot >= 0) id = vf.tab.ids[slot]; }
+    if (act) { const int slot = vf.tgt_slot[qi]; if (slot >= 0) id = slot_id(vf.tab, (unsigned)slot); }
     accumulate_point(vf.tab, id, sp, c6, fix_scales(cl.n, vf.counters), true, const_cast<int*>(vf.counters) + 1);
   }
 }

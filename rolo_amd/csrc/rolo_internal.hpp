@@ -48,8 +48,8 @@ constexpr int KNN_LEAF = ROLO_KNN_LEAF;
 static_assert(KNN_LEAF == 8 || KNN_LEAF == 16, "leaf size");
 
 struct VoxelTable {
-  unsigned long long* keys;  // capacity packed keys (KEY_EMPTY = free)
-  int* ids;                  // capacity: compact voxel id of the slot
+  unsigned long long* keys;  // 2 words per slot (round 5): [2h] = packed key (KEY_EMPTY = free), [2h + 1] = compact voxel id in the low 32 bits — ONE 16-byte
+                             // load returns both (voxel_dev.hpp slot_key / slot_id); rounds 1-4 kept the ids in an array of their own: a second dependent fetch per lookup
   double* rec;               // V x REC_DOUBLES
   unsigned long long* id_keys;  // V: packed key of each compact voxel id (for the getters)
   unsigned mask;             // capacity - 1

@@ -70,15 +70,20 @@ ROLO_DEV unsigned hash_key(unsigned long long k) {  // splitmix64 finaliser
   return (unsigned)k;
 }
 
-// lookup_voxel (vmp_voxel.hpp:226-233): compact voxel id or -1
+// slot h of the table: 16 bytes = { packed key, compact voxel id }
+ROLO_DEV unsigned long long* slot_key(const VoxelTable& tab, unsigned h) { return tab.keys + 2 * (size_t)h; }
+ROLO_DEV int slot_id(const VoxelTable& tab, unsigned h) { return (int)(unsigned)tab.keys[2 * (size_t)h + 1]; }
+ROLO_DEV void set_slot_id(const VoxelTable& tab, unsigned h, int id) { tab.keys[2 * (size_t)h + 1] = (unsigned long long)(unsigned)id; }
+
+// lookup_voxel (vmp_voxel.hpp:226-233): compact voxel id or -1. Key and id of a slot come back in one 16-byte load.
 ROLO_DEV int voxel_lookup(const VoxelTable& tab, int kx, int ky, int kz) {
   unsigned long long key;
   if (!pack_key(kx, ky, kz, key)) return -1;
   unsigned h = hash_key(key) & tab.mask;
   while (true) {
-    const unsigned long long cur = tab.keys[h];
-    if (cur == key) return tab.ids[h];
-    if (cur == KEY_EMPTY) return -1;
+    const ulonglong2 s = *reinterpret_cast<const ulonglong2*>(tab.keys + 2 * (size_t)h);
+    if (s.x == key) return (int)(unsigned)s.y;
+    if (s.x == KEY_EMPTY) return -1;
     h = (h + 1) & tab.mask;
   }
 }
@@ -186,10 +191,10 @@ ROLO_DEV void voxel_insert_point(const VoxelTable& tab, const float4* __restrict
   if (!pack_key(kx, ky, kz, key)) { atomicMin(&counters[1], ROLO_EKEYRANGE); tgt_slot[i] = -1; tgt_keys[i] = KEY_EMPTY; return; }
   unsigned h = hash_key(key) & tab.mask;
   while (true) {
-    unsigned long long prev = atomicCAS(&tab.keys[h], KEY_EMPTY, key);
+    unsigned long long prev = atomicCAS(slot_key(tab, h), KEY_EMPTY, key);
     if (prev == KEY_EMPTY) {
       int id = atomicAdd(&counters[0], 1);
-      tab.ids[h] = id;
+      set_slot_id(tab, h, id);
       tab.id_keys[id] = key;
       double* r = tab.rec + (size_t)id * REC_DOUBLES;
 #pragma unroll
@@ -205,7 +210,7 @@ ROLO_DEV void voxel_insert_point(const VoxelTable& tab, const float4* __restrict
 
 // clears the hash table and the four counters (thread t of nthreads); with the bounding box at hand counters[3] gets max |coordinate| right here
 ROLO_DEV void voxel_clear_body(unsigned long long* __restrict__ keys, size_t n_slots, const int* __restrict__ bbox6, int* counters, size_t t, size_t nthreads) {
-  for (size_t k = t; k < n_slots; k += nthreads) keys[k] = KEY_EMPTY;
+  for (size_t k = t; k < 2 * n_slots; k += nthreads) keys[k] = KEY_EMPTY;   // both words of every slot (key = free, id = -1)
   if (t < 3) counters[t] = 0;
   if (t == 3) {
     float m = 0.f;

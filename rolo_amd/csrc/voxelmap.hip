@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void voxel_accum_kernel(const float4* __restri
   if (i < n) {
     const int slot = tgt_slot[i];
     if (slot >= 0) {
-      id = tab.ids[slot];
+      id = slot_id(tab, (unsigned)slot);
       p = pts[i];
 #pragma unroll
       for (int d = 0; d < 6; d++) c[d] = cov[(size_t)d * n + i];
@@ -96,10 +96,10 @@ __global__ __launch_bounds__(256) void voxel_insert_sorted_kernel(const float4* 
   if (head) {
     unsigned hh = hash_key(key) & tab.mask;
     while (true) {
-      const unsigned long long prev = atomicCAS(&tab.keys[hh], KEY_EMPTY, key);
+      const unsigned long long prev = atomicCAS(slot_key(tab, hh), KEY_EMPTY, key);
       if (prev == KEY_EMPTY) {
         const int id = atomicAdd(&counters[0], 1);
-        tab.ids[hh] = id;
+        set_slot_id(tab, hh, id);
         tab.id_keys[id] = key;
         double* r = tab.rec + (size_t)id * REC_DOUBLES;
 #pragma unroll
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void voxel_accum_sorted_kernel(const float4* _
   if (j < n_sorted) {
     const int slot = slot_sorted[j];
     if (slot >= 0) {
-      id = tab.ids[slot];   // written by another lane / workgroup of the insert kernel: visible after the kernel boundary
+      id = slot_id(tab, (unsigned)slot);   // written by another lane / workgroup of the insert kernel: visible after the kernel boundary
       p = sorted[j];
       const int i = __float_as_int(p.w);
 #pragma unroll

