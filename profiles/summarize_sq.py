@@ -42,9 +42,15 @@ def main(paths):
     for k in sorted(acc, key=lambda k: -sum(acc[k]["_dur_ns"])):
         a = acc[k]
         waves = mean(a["SQ_WAVES"]); wc = mean(a["SQ_WAVE_CYCLES"])
-        ghz = (mean(a["GRBM_GUI_ACTIVE"]) / mean(a["_dur_ns"])) if a["GRBM_GUI_ACTIVE"] and mean(a["_dur_ns"]) > 0 else 2.4
-        if not (0.5 < ghz < 3.0):
-            ghz = 2.4
+        # shader clock of the run = GRBM_GUI_ACTIVE / kernel duration; rocprofv3 reports the counter summed over the chip's 8 XCDs on this stack (ratio ~17-19 per ns):
+        # take the divisor that lands in a plausible clock range, else the nominal 2.4 GHz
+        ghz = 2.4
+        if a["GRBM_GUI_ACTIVE"] and mean(a["_dur_ns"]) > 0:
+            r = mean(a["GRBM_GUI_ACTIVE"]) / mean(a["_dur_ns"])
+            for div in (1.0, 8.0, 32.0):
+                if 0.8 < r / div < 2.6:
+                    ghz = r / div
+                    break
         cyc = 4.0 * wc / waves if waves else float("nan")
         row = [k, len(a["SQ_WAVES"]) or len(a["_dur_ns"]), round(mean(a["_dur_ns"]) / 1e3, 2), *meta[k], round(waves), round(mean(a["SQ_INSTS_VALU"]) / waves, 1) if waves else "",
                round(mean(a["SQ_INSTS_SALU"]) / waves, 1) if waves else "", round(mean(a["SQ_INSTS_SMEM"]) / waves, 1) if waves else "", round(cyc) if waves else "",

@@ -178,6 +178,8 @@ struct rolo_ctx {
   bool device_busy = false;   // other contexts of this device had frames in flight when this frame was enqueued (picks the walk kernel of large launches: knn_cov.hip launch_knn_walk)
   bool counted_in_flight = false;
   int load_hint = -1;         // rolo_set_load_hint: -1 per frame from the device's load, 0 / 1 pinned
+  int busy_credit = 0;        // frames this context keeps the busy-device choice after it last saw other frames in flight (a frame enqueued right after a caller's
+                              // barrier would otherwise flip the choice — and with it the captured hipGraph — once per round of a multi-context loop)
   // passes the last frames needed per stage (+1): the next frame enqueues that many predicated pass/controller pairs up
   // front instead of a fixed worst-case chunk; rolo_register_wait tops up if a frame needs more
   int hint_rot = 0, hint_trans = 0;
@@ -841,7 +843,7 @@ void reset_to_fresh(rolo_ctx* c) {
   c->src.bbox6 = c->tgt.bbox6 = nullptr; c->src.n_bbox_part = c->tgt.n_bbox_part = 0;
   c->have_map = false; c->have_corr = false; c->n_voxels = 0; c->n_edge = 0;
   c->want_knn_lists = false; c->prof_on = false; c->shard_knn = false;
-  c->rank = 0; c->world = 1; c->load_hint = -1;
+  c->rank = 0; c->world = 1; c->load_hint = -1; c->busy_credit = 0;
   front_reset_object_state(c);   // no projection, armed de-skew or pre-cleared arrays of the previous owner
   c->n_frames = c->n_replays = c->n_captures = c->n_eager = c->n_topup_frames = c->n_topup_chunks = 0;   // rolo_ctx_counters counts per object
   // (schedule hints, their windows and the captured graph stay on purpose: they are keyed on sizes, buffers and parameters, not on the object's
@@ -1329,7 +1331,10 @@ static int register_async_impl(rolo_ctx* c, const float* guess16, const double* 
 }
 
 int rolo_register_async(rolo_ctx* c, const float* guess16, const double* trans_start, const double* g3, const double* l3, double dtn, double dtn1, float lam) {
-  if (c) c->device_busy = c->load_hint < 0 ? others_in_flight(c) : c->load_hint != 0;
+  if (c) {
+    if (others_in_flight(c)) c->busy_credit = 8; else if (c->busy_credit > 0) c->busy_credit--;
+    c->device_busy = c->load_hint < 0 ? c->busy_credit > 0 : c->load_hint != 0;
+  }
   const int rc = register_async_impl(c, guess16, trans_start, g3, l3, dtn, dtn1, lam);
   if (rc == ROLO_OK && c->async_pending) { c->n_frames++; count_in_flight(c, true); HIPCHK(hipEventRecord(c->ev_done, c->stream)); }
   return rc;

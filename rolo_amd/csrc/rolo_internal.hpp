@@ -37,7 +37,10 @@ constexpr int PASS_THREADS = ROLO_PASS_THREADS;
 
 constexpr unsigned long long KEY_EMPTY = ~0ull;
 constexpr int KEY_BIAS = 1 << 20;
-constexpr int REC_DOUBLES = 12;  // voxel record: mean xyz, cov xx xy xz yy yz zz, sqrt(n), n, pad
+#ifndef ROLO_REC_DOUBLES
+#define ROLO_REC_DOUBLES 12
+#endif
+constexpr int REC_DOUBLES = ROLO_REC_DOUBLES;  // voxel record: mean xyz, cov xx xy xz yy yz zz, sqrt(n), n, pad (A/B: 16 = one 128-byte line per record)
 constexpr int TRACE_CAP = 2048;
 #ifndef ROLO_KNN_LEAF
 #define ROLO_KNN_LEAF 16
