@@ -8,7 +8,11 @@
 #include <climits>
 
 #ifndef KNN_STAT
+#ifdef ROLO_KNN_STATS   // (the instrumented build: every includer sees the same definition — scan2map.hip includes this file without knn_walk.hpp)
+#define KNN_STAT(x) x
+#else
 #define KNN_STAT(x)
+#endif
 #endif
 
 namespace rolo {
