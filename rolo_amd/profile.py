@@ -142,14 +142,25 @@ def sq_counters_file():
 
 
 N_SIMD = 256 * 4          # MI355X: 256 CUs x 4 SIMDs
-CYCLES_PER_VALU = 4.0     # per wavefront instruction per SIMD, measured: profiles/tools/valu_rate.hip (v_max_f32, v_min_f64, v_fma_f64, v_cndmask alike)
-CLOCK_GHZ = 2.4           # nominal peak engine clock (the chip clocks lower under sustained load: the fraction below is a lower bound on how busy the VALUs are)
+
+
+def valu_ns_per_inst():
+    """(ns per wavefront VALU instruction per SIMD, source): the newest committed profiles/rNN/valu_rate.txt (profiles/tools/valu_rate.hip on the box: v_fma_f64, v_min_f64,
+    v_max_f32, v_pk_add_f32, v_cmp at four wavefronts per SIMD — the instruction mix of the hot kernels; all within 4 % of each other), or 2.0 ns as measured in round 5"""
+    import glob
+    import re
+    c = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]", "valu_rate.txt")))
+    if c:
+        v = [float(m.group(1)) for l in open(c[-1]) if "waves/SIMD 4" in l and not l.startswith("v_cndmask") for m in [re.search(r"-> ([0-9.]+) ns per instruction", l)] if m]
+        if v:
+            return float(np.mean(v)), os.path.relpath(c[-1], ROOT)
+    return 2.0, "round-5 measurement (profiles/tools/valu_rate.hip)"
 
 
 def valu_issue(scans_per_s_per_gpu: float):
     """The instruction-issue roofline of a frame: wave-level VALU (and SALU) instructions per frame, kernel by kernel, from the newest committed rocprofv3 SQ pass
     (profiles/rNN/sq_counters.csv: SQ_INSTS_VALU / SQ_INSTS_SALU per launch x launches per frame of that profile run), against what the chip's 1024 SIMDs can issue:
-        issue_ms_per_frame = VALU instructions x 4 cycles / (1024 SIMDs x clock);   frac = issue_ms_per_frame x scans/s.
+        issue_ms_per_frame = VALU instructions x (measured ns per instruction per SIMD) / 1024 SIMDs;   frac = issue_ms_per_frame x scans/s.
     Cited like roofline.traffic (collected in its own PMC passes, not in this run); `frac` uses THIS run's scans/s."""
     import csv
     path, commit = sq_counters_file()
@@ -170,12 +181,14 @@ def valu_issue(scans_per_s_per_gpu: float):
         except Exception:
             continue
     tot_v, tot_s = sum(per.values()), sum(salu.values())
-    issue_ms = tot_v * 1e6 * CYCLES_PER_VALU / (N_SIMD * CLOCK_GHZ * 1e9) * 1e3
+    ns, ns_src = valu_ns_per_inst()
+    issue_ms = tot_v * 1e6 * ns * 1e-9 / N_SIMD * 1e3
     frame_ms = 1e3 / scans_per_s_per_gpu if scans_per_s_per_gpu > 0 else float("nan")
     top = dict(sorted(per.items(), key=lambda kv: -kv[1])[:8])
     return {"bound": "valu-issue", "valu_insts_per_frame_M": round(tot_v, 2), "salu_insts_per_frame_M": round(tot_s, 2), "valu_insts_per_frame_M_by_kernel": top,
-            "simds": N_SIMD, "cycles_per_valu_inst": CYCLES_PER_VALU, "clock_GHz_nominal": CLOCK_GHZ,
-            "issue_ms_per_frame": round(issue_ms, 4), "frame_ms_this_run": round(frame_ms, 4), "frac": round(issue_ms / frame_ms, 4),
-            "what": "share of the chip's VALU issue slots (1024 SIMDs, one wavefront instruction per 4 cycles at the nominal clock) the frames of this run's timed region "
-                    "occupy; the rest is latency the contexts in flight did not cover. cycles_per_valu_inst is measured (profiles/tools/valu_rate.hip)",
-            "source": f"{os.path.relpath(path, ROOT)} (collected at commit {commit}; SQ_INSTS_VALU / SQ_INSTS_SALU of a single-context eager run, per launch x launches per frame)"}
+            "simds": N_SIMD, "ns_per_valu_inst_per_simd": round(ns, 3), "issue_ms_per_frame": round(issue_ms, 4), "frame_ms_this_run": round(frame_ms, 4),
+            "frac": round(issue_ms / frame_ms, 4),
+            "what": "share of the chip's VALU issue capacity (1024 SIMDs x one wavefront instruction per measured ns_per_valu_inst_per_simd) that the frames of this run's "
+                    "timed region occupy; the rest is latency the contexts in flight did not cover",
+            "source": f"{os.path.relpath(path, ROOT)} (collected at commit {commit}: SQ_INSTS_VALU / SQ_INSTS_SALU of a single-context eager run with the busy-device kernels, "
+                      f"per launch x launches per frame); issue rate: {ns_src}"}
