@@ -728,7 +728,7 @@ def main():
         if busy:   # the same frames with the idle-device choice (what a caller with ONE context in flight gets: the latency form)
             g.setLoadHint(0); cursor[0] = 0
             r0 = profile.roofline(g, lambda: run_steps(g, 1, data), n, n, passes, HBM_PEAK_GBS, reps=len(d_pool) if len(d_pool) > 1 else 3)
-            out["roofline"]["idle_device"] = {k_: r0[k_] for k_ in ("kernel", "achieved", "frac", "avg_launch_ms", "traffic")}
+            out["roofline"]["idle_device"] = {k_: r0[k_] for k_ in ("kernel", "achieved", "frac", "avg_launch_ms")}   # (no PMC pass of this kernel is committed: profiles/r04 has round 4's)
         g.setLoadHint({"auto": -1, "idle": 0, "busy": 1}[args.load_hint])
         ps = out["roofline"].get("avg_launch_ms_per_profiled_step") or []
         if len(d_pool) > 1 and ps:
