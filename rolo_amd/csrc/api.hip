@@ -560,12 +560,15 @@ void frame_chunks(const rolo_ctx* c, int& nrot, int& ntrans) {
 // frame alone: every other frame either re-captured its hipGraph (the schedule length is part of the graph's key) or topped up through
 // host round trips — 351 top-ups, 297 captures and 753 eager frames in 1536. A 16-frame window still re-captured 90 times (the maximum slides
 // in and out of a short window) and a capture is milliseconds of host time; a predicated no-op pair costs ~5 us of GPU time.
-void update_hint(int& hint, rolo_ctx::NeedWindow& w, int used) {
+// Round 5: with pass + controller launches the schedule holds EXACTLY the window's maximum — through round 4 it held one pair more, rounded up to an even count (what
+// the fused launches' double-buffered state needs): 22 + 12 pairs for frames that use 21 + 9..10, i.e. six to eight no-op launches of ~2.5 us on every frame's
+// critical path. A frame that needs more than any of the last 64 did tops up through one host round trip and raises the hint.
+void update_hint(int& hint, rolo_ctx::NeedWindow& w, int used, bool fused) {
   constexpr int WN = 64;
   w.need[w.pos] = used; w.pos = (w.pos + 1) % WN; if (w.n < WN) w.n++;
   int mx = 0;
   for (int i = 0; i < w.n; i++) mx = std::max(mx, w.need[i]);
-  const int want = std::min((std::max(mx + 1, 2) + 1) & ~1, 96);
+  const int want = fused ? std::min((std::max(mx + 1, 2) + 1) & ~1, 96) : std::min(std::max(mx, 2), 96);
   if (hint == 0 || want > hint || want <= hint - 6) hint = want;
 }
 
@@ -1179,7 +1182,7 @@ int rolo_align(rolo_ctx* c, const float* guess16, float* Tf, double* Td, rolo_st
     if ((rc = run_stage(c, a, grid, 1, 8))) return rc;
   }
   c->have_corr = true;
-  if (!c->h_state->error) update_hint(c->hint_rot, c->win_rot, c->h_state->rot_passes);
+  if (!c->h_state->error) update_hint(c->hint_rot, c->win_rot, c->h_state->rot_passes, lm_fused(c));
   fill_rot_outputs(c->h_state, Tf, Td, stats);
   if (c->h_state->error) { g_err = c->h_state->error == ROLO_ENOCORR ? "no correspondences" : "device-side error during align"; return c->h_state->error; }
   return ROLO_OK;
@@ -1346,6 +1349,7 @@ int rolo_register_wait(rolo_ctx* c, float* Tf, double* Td, double* trans_out, ro
   int rc = set_device(c); if (rc) return rc;
   c->async_pending = false;
   count_in_flight(c, false);
+  c->device_busy = c->load_hint == 1;   // the choice belongs to the frame that was enqueued: synchronous entry points (rolo_compute_covariances, rolo_align, ...) run alone
   HIPCHK(hipEventSynchronize(c->ev_done));
   if ((rc = peer_check(c))) return rc;
   if (c->h_counters[1] != 0) { g_err = c->h_counters[1] == ROLO_ENONFINITE ? "non-finite point or covariance in the voxel map build" : "voxel coordinate outside the packed key range"; return c->h_counters[1]; }
@@ -1360,7 +1364,7 @@ int rolo_register_wait(rolo_ctx* c, float* Tf, double* Td, double* trans_out, ro
   if (!c->h_state->trans_done && !c->h_state->error) { if ((rc = run_stage(c, a, grid, 2, 8))) return rc; }
   c->have_corr = true;
   const LmState* s = c->h_state;
-  if (!s->error) { update_hint(c->hint_rot, c->win_rot, s->rot_passes); update_hint(c->hint_trans, c->win_trans, s->trans_passes); }
+  if (!s->error) { update_hint(c->hint_rot, c->win_rot, s->rot_passes, lm_fused(c)); update_hint(c->hint_trans, c->win_trans, s->trans_passes, lm_fused(c)); }
   fill_rot_outputs(s, Tf, Td, rs);
   if (trans_out) for (int i = 0; i < 3; i++) trans_out[i] = s->t0[i];
   if (ts) { ts->n_outer = s->trans_outer; ts->converged = s->trans_failed ? 0 : 1; ts->lm_failed = s->trans_failed; ts->n_passes = s->trans_passes; ts->n_correspondences = s->tr_n_corr; }

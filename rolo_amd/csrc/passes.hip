@@ -203,10 +203,18 @@ ROLO_DEV PtIn load_pt(const PassArgs& a, int i) {
   else o.CA = Sym3{a.cov[i], a.cov[pitch + i], a.cov[2 * pitch + i], a.cov[3 * pitch + i], a.cov[4 * pitch + i], a.cov[5 * pitch + i]};
   return o;
 }
+// R (I - m m^T) R^T = R R^T - (R m)(R m)^T. R R^T is NOT taken as the identity: a caller's guess arrives as a float matrix, orthonormal to 1e-7 only, and the
+// reference rotates the covariance with exactly that matrix (rot_vgicp_impl.hpp:204-222) — the first version of this path assumed I and was 2e-6 off in the cost of a
+// solve started from a float guess. The product is wave-uniform work done per lane (18 multiply-adds); the rotation is still 27 instead of 45.
+ROLO_DEV Sym3 rrt_of(const double* R) {
+  return Sym3{R[0] * R[0] + R[1] * R[1] + R[2] * R[2], R[0] * R[3] + R[1] * R[4] + R[2] * R[5], R[0] * R[6] + R[1] * R[7] + R[2] * R[8],
+              R[3] * R[3] + R[4] * R[4] + R[5] * R[5], R[3] * R[6] + R[4] * R[7] + R[5] * R[8], R[6] * R[6] + R[7] * R[7] + R[8] * R[8]};
+}
 ROLO_DEV Sym3 rotated_cov(const PassArgs& a, const double* R, const PtIn& in) {
   if (a.nrm) {
+    const Sym3 S = rrt_of(R);
     const Vec3 q = mat3_mulv(R, in.m);
-    return Sym3{1.0 - q.x * q.x, -(q.x * q.y), -(q.x * q.z), 1.0 - q.y * q.y, -(q.y * q.z), 1.0 - q.z * q.z};
+    return Sym3{S.xx - q.x * q.x, S.xy - q.x * q.y, S.xz - q.x * q.z, S.yy - q.y * q.y, S.yz - q.y * q.z, S.zz - q.z * q.z};
   }
   return sym3_rotate(R, in.CA);
 }

@@ -71,7 +71,7 @@ struct CloudDev {          // one point cloud resident in HBM
   bool have_cov = false;
   bool cov_user = false;   // covariances handed in by the caller (rolo_set_*_covariances): entries not bounded by the regularisation
   // PLANE regularisation only (round 5): the covariance U diag(1, 1, 1e-3) V^T IS I - m m^T with m = sqrt(1 -+ 1e-3) * (third singular vector) — three doubles
-  // per point instead of six, and R C R^T = I - (R m)(R m)^T: the LM passes read and rotate THIS when the covariances were computed here (knn_covariance_finish)
+  // per point instead of six, and R C R^T = R R^T - (R m)(R m)^T: the LM passes read and rotate THIS when the covariances were computed here (knn_covariance_finish)
   double* nrm = nullptr;   // 3 x n SoA; valid while have_nrm
   size_t nrm_cap = 0;
   bool have_nrm = false;
