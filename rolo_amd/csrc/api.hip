@@ -1336,7 +1336,9 @@ static int register_async_impl(rolo_ctx* c, const float* guess16, const double* 
 int rolo_register_async(rolo_ctx* c, const float* guess16, const double* trans_start, const double* g3, const double* l3, double dtn, double dtn1, float lam) {
   if (c) {
     if (others_in_flight(c)) c->busy_credit = 8; else if (c->busy_credit > 0) c->busy_credit--;
-    c->device_busy = c->load_hint < 0 ? c->busy_credit > 0 : c->load_hint != 0;
+    // (ranks that share ONE frame — peers, a communicator, a shard range — always have each other's frames "in flight": that is cooperation, not load)
+    const bool sharded_ctx = c->comm != nullptr || peers(c) || c->world > 1;
+    c->device_busy = c->load_hint < 0 ? (!sharded_ctx && c->busy_credit > 0) : c->load_hint != 0;
   }
   const int rc = register_async_impl(c, guess16, trans_start, g3, l3, dtn, dtn1, lam);
   if (rc == ROLO_OK && c->async_pending) { c->n_frames++; count_in_flight(c, true); HIPCHK(hipEventRecord(c->ev_done, c->stream)); }

@@ -5,8 +5,16 @@
 
 namespace rolo {
 
+// S = R R^T (six unique entries) — NOT assumed to be the identity: a caller's guess is a float matrix, orthonormal to 1e-7 only
+__device__ inline void lm_set_rrt(double* S, const double* R) {
+  S[0] = R[0] * R[0] + R[1] * R[1] + R[2] * R[2]; S[1] = R[0] * R[3] + R[1] * R[4] + R[2] * R[5]; S[2] = R[0] * R[6] + R[1] * R[7] + R[2] * R[8];
+  S[3] = R[3] * R[3] + R[4] * R[4] + R[5] * R[5]; S[4] = R[3] * R[6] + R[4] * R[7] + R[5] * R[8]; S[5] = R[6] * R[6] + R[7] * R[7] + R[8] * R[8];
+}
+
 __device__ inline void rot_begin_dev(LmState* st, const RotBegin& a) {
   for (int i = 0; i < 9; i++) { st->xt_R[i] = a.R[i]; st->x0_R[i] = a.R[i]; st->tr_R[i] = a.R[i]; }
+  lm_set_rrt(st->xt_S, st->xt_R);
+  for (int i = 0; i < 6; i++) { st->x0_S[i] = st->xt_S[i]; st->tr_S[i] = st->xt_S[i]; }
   for (int i = 0; i < 3; i++) { st->xt_t[i] = a.t[i]; st->x0_t[i] = a.t[i]; }
   for (int i = 0; i < 36; i++) { st->H[i] = 0; st->final_H[i] = (i % 7 == 0) ? 1.0 : 0.0; }
   for (int i = 0; i < 6; i++) { st->b[i] = 0; st->d[i] = 0; }

@@ -193,7 +193,7 @@ ROLO_DEV int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 // what a pass needs of one source point: loaded before anything that depends on the LM state
 // CA: the six-entry covariance; or, when the PLANE covariances were computed by the library (a.nrm), m with C_A = I - m m^T: 24 bytes per point and pass
-// instead of 48, and the rotation R C_A R^T = I - (R m)(R m)^T is nine multiply-adds instead of forty-five (rotated_cov)
+// instead of 48, and the rotation R C_A R^T = R R^T - (R m)(R m)^T is 27 multiply-adds instead of 45 (rotated_cov)
 struct PtIn { float4 pf; Sym3 CA; Vec3 m; };
 ROLO_DEV PtIn load_pt(const PassArgs& a, int i) {
   PtIn o{};
@@ -205,14 +205,11 @@ ROLO_DEV PtIn load_pt(const PassArgs& a, int i) {
 }
 // R (I - m m^T) R^T = R R^T - (R m)(R m)^T. R R^T is NOT taken as the identity: a caller's guess arrives as a float matrix, orthonormal to 1e-7 only, and the
 // reference rotates the covariance with exactly that matrix (rot_vgicp_impl.hpp:204-222) — the first version of this path assumed I and was 2e-6 off in the cost of a
-// solve started from a float guess. The product is wave-uniform work done per lane (18 multiply-adds); the rotation is still 27 instead of 45.
-ROLO_DEV Sym3 rrt_of(const double* R) {
-  return Sym3{R[0] * R[0] + R[1] * R[1] + R[2] * R[2], R[0] * R[3] + R[1] * R[4] + R[2] * R[5], R[0] * R[6] + R[1] * R[7] + R[2] * R[8],
-              R[3] * R[3] + R[4] * R[4] + R[5] * R[5], R[3] * R[6] + R[4] * R[7] + R[5] * R[8], R[6] * R[6] + R[7] * R[7] + R[8] * R[8]};
-}
-ROLO_DEV Sym3 rotated_cov(const PassArgs& a, const double* R, const PtIn& in) {
+// solve started from a float guess. The product comes from the LM state, where the controller keeps it next to each rotation (lm_set_rrt): 9 + 6 multiply-adds per
+// lane are left of the rotation's 45.
+ROLO_DEV Sym3 rotated_cov(const PassArgs& a, const double* R, const double* __restrict__ S6 /* R R^T from the LM state (lm_set_rrt) */, const PtIn& in) {
   if (a.nrm) {
-    const Sym3 S = rrt_of(R);
+    const Sym3 S{uni(S6[0]), uni(S6[1]), uni(S6[2]), uni(S6[3]), uni(S6[4]), uni(S6[5])};
     const Vec3 q = mat3_mulv(R, in.m);
     return Sym3{S.xx - q.x * q.x, S.xy - q.x * q.y, S.xz - q.x * q.z, S.yy - q.y * q.y, S.yz - q.y * q.z, S.zz - q.z * q.z};
   }
@@ -243,7 +240,7 @@ ROLO_DEV void rot_pass_compute(const PassArgs& a, const LmState* __restrict__ st
     // trial's (A) half, rot_vgicp_impl.hpp:204-222 — and it LOST: 96 B per point and pass of extra traffic cost more than the ~100 instructions saved,
     // 2694 against 2875 scans/s; profiles/DEAD_ENDS.md. The translation stage, whose M is constant, does cache it: trans_pass_compute.)
     if (phase == 1) {
-      const Sym3 RCA0 = rotated_cov(a, R0, in);
+      const Sym3 RCA0 = rotated_cov(a, R0, st->x0_S, in);
       for (int o = 0; o < n_off; o++) {
         const int vid = corr_old[(size_t)i * n_off + o];
         if (vid >= 0) {
@@ -257,7 +254,7 @@ ROLO_DEV void rot_pass_compute(const PassArgs& a, const LmState* __restrict__ st
     // (B) so3_linearize / linearize at xi, with update_correspondences(xi) fused in
     int kx, ky, kz;
     voxel_coord_dev(a.tab, tp.x, tp.y, tp.z, kx, ky, kz);
-    const Sym3 RCA1 = rotated_cov(a, R1, in);
+    const Sym3 RCA1 = rotated_cov(a, R1, st->xt_S, in);
     const int ob = offset_base(n_off);
     for (int o = 0; o < n_off; o++) {
       const int vid = voxel_lookup(a.tab, kx + c_offsets[ob + o][0], ky + c_offsets[ob + o][1], kz + c_offsets[ob + o][2]);
@@ -353,7 +350,7 @@ ROLO_DEV void trans_pass_compute(const PassArgs& a, const LmState* __restrict__ 
     const Vec3 ctA{dv.x - lAq.x, dv.y - lAq.y, dv.z - lAq.z};
     const Vec3 ctB{dv.x - lBq.x, dv.y - lBq.y, dv.z - lBq.z};
     const int n_off = a.n_off;
-    const Sym3 RCA = rotated_cov(a, R, in);
+    const Sym3 RCA = rotated_cov(a, R, st->tr_S, in);
     for (int o = 0; o < n_off; o++) {
       const int vid = corr[(size_t)i * n_off + o];
       if (vid < 0) continue;
@@ -640,6 +637,7 @@ ROLO_DEV void rot_compute_step(LmState* __restrict__ st) {
     for (int j = 0; j < 3; j++) st->xt_R[i * 3 + j] = st->delta_R[i * 3] * st->x0_R[j] + st->delta_R[i * 3 + 1] * st->x0_R[3 + j] + st->delta_R[i * 3 + 2] * st->x0_R[6 + j];
     st->xt_t[i] = st->delta_R[i * 3] * st->x0_t[0] + st->delta_R[i * 3 + 1] * st->x0_t[1] + st->delta_R[i * 3 + 2] * st->x0_t[2] + st->delta_t[i];
   }
+  lm_set_rrt(st->xt_S, st->xt_R);
 }
 
 template <int DOF>
@@ -696,10 +694,12 @@ ROLO_DEV void rot_step_t(LmState* __restrict__ st, const double* __restrict__ S,
   st->rot_passes++;
   if (st->phase == 0) {
     for (int i = 0; i < 9; i++) st->x0_R[i] = st->xt_R[i];
+    for (int i = 0; i < 6; i++) st->x0_S[i] = st->xt_S[i];
     for (int i = 0; i < 3; i++) st->x0_t[i] = st->xt_t[i];
     unpack_hb<DOF>(st, S);
     st->tr_cur = st->cur; st->tr_n_corr = st->n_corr;
     for (int i = 0; i < 9; i++) st->tr_R[i] = st->x0_R[i];
+    for (int i = 0; i < 6; i++) st->tr_S[i] = st->x0_S[i];
     if (st->n_corr <= 0) { st->error = ROLO_ENOCORR; rot_finish(st, false, true); return; }
     st->phase = 1;
     rot_begin_outer<DOF>(st);
@@ -729,6 +729,7 @@ ROLO_DEV void rot_step_t(LmState* __restrict__ st, const double* __restrict__ S,
   }
   trace_push<DOF>(st, trace, 0, 1, gn ? NAN : yi, gn ? NAN : rho);
   for (int i = 0; i < 9; i++) st->x0_R[i] = st->xt_R[i];
+  for (int i = 0; i < 6; i++) st->x0_S[i] = st->xt_S[i];
   for (int i = 0; i < 3; i++) st->x0_t[i] = st->xt_t[i];
   if (!gn) { const double q = 2 * rho - 1; st->lambda = st->lambda * fmax(1.0 / 3.0, 1 - q * q * q); }
   if (dof == 6) for (int i = 0; i < 36; i++) st->final_H[i] = st->H[i];  // final_hessian_ = H
@@ -741,6 +742,7 @@ ROLO_DEV void rot_step_t(LmState* __restrict__ st, const double* __restrict__ S,
   st->cur ^= 1;
   st->tr_cur = st->cur; st->tr_n_corr = st->n_corr;
   for (int i = 0; i < 9; i++) st->tr_R[i] = st->x0_R[i];
+  for (int i = 0; i < 6; i++) st->tr_S[i] = st->x0_S[i];
   if (st->n_corr <= 0) { st->error = ROLO_ENOCORR; rot_finish(st, false, true); return; }
   rot_begin_outer<DOF>(st);
 }
@@ -1090,12 +1092,14 @@ __global__ void frame_begin_batch_kernel(const BatchSlot* __restrict__ slots, co
 __global__ void eval_begin_kernel(LmState* st, RotBegin a, int mode) {
   if (threadIdx.x != 0) return;
   for (int i = 0; i < 9; i++) st->xt_R[i] = a.R[i];
+  lm_set_rrt(st->xt_S, st->xt_R);
   for (int i = 0; i < 3; i++) st->xt_t[i] = a.t[i];
   st->optimizer = a.optimizer; st->q2_intended = a.q2_intended;
   st->stage = 1; st->error = 0;
   if (mode == 0) {
     st->phase = 0; st->cur = 0; st->tr_cur = 0;
     for (int i = 0; i < 9; i++) { st->x0_R[i] = a.R[i]; st->tr_R[i] = a.R[i]; }
+    for (int i = 0; i < 6; i++) { st->x0_S[i] = st->xt_S[i]; st->tr_S[i] = st->xt_S[i]; }
     for (int i = 0; i < 3; i++) st->x0_t[i] = a.t[i];
   } else {
     st->phase = 1;

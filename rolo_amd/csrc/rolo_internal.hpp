@@ -92,6 +92,8 @@ struct LmState {
   double x0_R[9], x0_t[3];  // pose of the current linearisation (x0)
   double xt_R[9], xt_t[3];  // trial pose (xi) evaluated by the next pass
   double tr_R[9];           // rotation of the last reference linearize call: Mahalanobis of the translation stage
+  double x0_S[6], xt_S[6], tr_S[6];   // R R^T of the three rotations above (xx xy xz yy yz zz), kept next to them by whoever writes them (lm_set_rrt): the passes rotate a PLANE
+                                      // covariance I - m m^T as R R^T - (R m)(R m)^T and would otherwise form the uniform product in every lane of every trial
   double H[36], b[6], y0;
   double lambda, nu;
   double d[6];
