@@ -781,7 +781,7 @@ def main():
                 leg = None
                 torch.cuda.synchronize()
                 if rank == 0:
-                    res = sharded_children(world, "os1-128x2048", stp, args.leaf, exchange=kind)
+                    res = sharded_children(world, "os1-128x2048", stp, args.leaf, exchange=kind, timeout=300 if kind == "peer" else 180)   # (a lost peer gives up after ROLO_PEER_TIMEOUT_MS = 10 s by itself; RCCL has no such bound)
                     if isinstance(res, dict):
                         leg = res
                     else:
