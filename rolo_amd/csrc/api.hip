@@ -180,7 +180,7 @@ struct rolo_ctx {
   int load_hint = -1;         // rolo_set_load_hint: -1 per frame from the device's load, 0 / 1 pinned
   int busy_credit = 0;        // frames this context keeps the busy-device choice after it last saw other frames in flight (a frame enqueued right after a caller's
                               // barrier would otherwise flip the choice — and with it the captured hipGraph — once per round of a multi-context loop)
-  // passes the last frames needed per stage (+1): the next frame enqueues that many predicated pass/controller pairs up
+  // passes the last frames needed per stage (update_hint): the next frame enqueues that many predicated pass/controller pairs up
   // front instead of a fixed worst-case chunk; rolo_register_wait tops up if a frame needs more
   int hint_rot = 0, hint_trans = 0;
   int walk_lanes = 1;   // lanes per query of the last K5 walk enqueued (rolo_ctx_counters [8])
@@ -554,8 +554,8 @@ void frame_chunks(const rolo_ctx* c, int& nrot, int& ntrans) {
   nrot = c->hint_rot > 0 ? c->hint_rot : rot_first_chunk(c);
   ntrans = c->hint_trans > 0 ? c->hint_trans : 12;
 }
-// The first schedule of the next frame holds (the most passes any of the last 64 frames needed) + 1 predicated pass / controller pairs, rounded
-// up to an even count; it grows at once and shrinks only when the window's maximum has fallen 6 below it.
+// The first schedule of the next frame holds the most passes any of the last 64 frames needed as predicated pass / controller pairs (fused launches: one more,
+// rounded up to an even count); it grows at once and shrinks only when the window's maximum has fallen 6 below it.
 // A stream of DIFFERENT frame pairs needs different numbers of LM trials (BASELINE configs[4]: 24 ... 41 per pair). Round 2 followed the last
 // frame alone: every other frame either re-captured its hipGraph (the schedule length is part of the graph's key) or topped up through
 // host round trips — 351 top-ups, 297 captures and 753 eager frames in 1536. A 16-frame window still re-captured 90 times (the maximum slides
