@@ -532,6 +532,8 @@ RotBegin make_rot_begin(const rolo_ctx* c, const double* R9, const double* t3, i
   b.optimizer = c->P.optimizer; b.max_iterations = c->P.max_iterations; b.fixed_iterations = c->P.fixed_iterations;
   b.lm_max = c->P.lm_max_iterations; b.q2_intended = c->P.q2_intended; b.rot_eps = c->P.rotation_epsilon;
   b.trans_eps = c->P.transformation_epsilon; b.lm_init = c->P.lm_init_lambda_factor; b.run_trans = run_trans;
+  static const int spec_lin = [] { const char* e = getenv("ROLO_LM_SPEC_LIN"); return (e && atoi(e) == 0) ? 0 : 1; }();   // 0: every pass carries both halves (the A/B, rounds 1-4)
+  b.spec_lin = spec_lin;
   return b;
 }
 

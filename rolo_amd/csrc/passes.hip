@@ -128,10 +128,31 @@ ROLO_DEV void wave_reduce_scatter(const double (&acc)[NV], double* __restrict__ 
   }
 }
 
+// only_first (wave-uniform): a pass that evaluated the trial cost alone (LmState::lin_skip) has ONE value to sum — acc[0] — and writes zeros to the other slots
 template <int NV, int THREADS = PASS_THREADS>
-ROLO_DEV void block_reduce_store(double (&acc)[NV], const int (&slot)[NV], double* __restrict__ out_row) {
+ROLO_DEV void block_reduce_store(double (&acc)[NV], const int (&slot)[NV], double* __restrict__ out_row, bool only_first = false) {
   __shared__ double red[THREADS / 64][NV_MAX];
   const int wv = threadIdx.x >> 6;
+  if (only_first) {
+    // the additions value 0 goes through in wave_reduce_scatter, in the same order (lane ^ 32, ^ 16, ^ 8, ^ 4, ^ 2, ^ 1: lane 0 ends up with the same bits), so a
+    // trial's cost does not depend on whether its pass carried the linearisation half
+    double t = acc[0];
+    t += lane_xor_f64<32>(t); t += lane_xor_f64<16>(t); t += lane_xor_f64<8>(t); t += lane_xor_f64<4>(t); t += lane_xor_f64<2>(t); t += lane_xor_f64<1>(t);
+    if ((threadIdx.x & 63) == 0) red[wv][0] = t;
+    __syncthreads();
+    if (threadIdx.x < NV) {
+      double s0 = 0;
+      if (threadIdx.x == 0) {
+#pragma unroll
+        for (int w = 0; w < THREADS / 64; w++) s0 += red[w][0];
+      }
+      int sl = 0;
+#pragma unroll
+      for (int v = 0; v < NV; v++) if (threadIdx.x == v) sl = slot[v];
+      out_row[sl] = s0;
+    }
+    return;
+  }
   wave_reduce_scatter<NV>(acc, red[wv]);
   __syncthreads();
   if (threadIdx.x < NV) {
@@ -222,6 +243,7 @@ ROLO_DEV void rot_pass_compute(const PassArgs& a, const LmState* __restrict__ st
   constexpr int NH = DOF * (DOF + 1) / 2;
   const int phase = uni(st->phase);
   const int cur = uni(st->cur);
+  const bool skip_lin = phase == 1 && uni(st->lin_skip) != 0;   // (A) only: the trial before this one was rejected (LmState::lin_skip)
   const int* __restrict__ corr_old = a.corr[cur];
   int* __restrict__ corr_new = a.corr[phase == 0 ? cur : (cur ^ 1)];
   double R0[9], R1[9], t1[3];
@@ -252,6 +274,7 @@ ROLO_DEV void rot_pass_compute(const PassArgs& a, const LmState* __restrict__ st
       }
     }
     // (B) so3_linearize / linearize at xi, with update_correspondences(xi) fused in
+    if (skip_lin) return;
     int kx, ky, kz;
     voxel_coord_dev(a.tab, tp.x, tp.y, tp.z, kx, ky, kz);
     const Sym3 RCA1 = rotated_cov(a, R1, st->xt_S, in);
@@ -309,7 +332,7 @@ ROLO_DEV void rot_pass_body(const PassArgs& a, const LmState* __restrict__ st, c
   for (int v = 0; v < NH; v++) slot[3 + v] = V_H + v;
 #pragma unroll
   for (int v = 0; v < DOF; v++) slot[3 + NH + v] = V_B + v;
-  block_reduce_store<NV>(acc, slot, a.partials + (size_t)block * NV_MAX);
+  block_reduce_store<NV>(acc, slot, a.partials + (size_t)block * NV_MAX, st->phase == 1 && st->lin_skip != 0);
 #ifdef ROLO_PASS_STATS
   if (threadIdx.x == 0) {   // state flag known | point data + voxel records in, accumulators final | block reduction + row store
     const long long pt3 = clock64();
@@ -324,6 +347,7 @@ ROLO_DEV void rot_pass_body(const PassArgs& a, const LmState* __restrict__ st, c
 ROLO_DEV void trans_pass_compute(const PassArgs& a, const LmState* __restrict__ st, const int i, const bool valid, const PtIn& in, double (&acc)[30]) {
   constexpr int NH = 21;
   const int phase = uni(st->phase);
+  const bool skip_lin = phase == 1 && uni(st->lin_skip) != 0;
   const int tr_cur = uni(st->tr_cur);
   const int* __restrict__ corr = a.corr[tr_cur];
   // (the stage's Mahalanobis matrices are those of the LAST rotation linearisation — constant over all its passes. Caching the six fp64 per point
@@ -362,6 +386,7 @@ ROLO_DEV void trans_pass_compute(const PassArgs& a, const LmState* __restrict__ 
       const Vec3 Me = sym3_mulv(M, e);
       const double eMe = dot3(e, Me);
       if (phase == 1) acc[0] += w * (eMe + lam_n * dot3(ctA, sym3_mulv(M, ctA)));
+      if (skip_lin) continue;   // the trial before this one was rejected: the cost alone (LmState::lin_skip)
       const Vec3 McB = sym3_mulv(M, ctB);
       acc[1] += w * (eMe + lam_n * dot3(ctB, McB));
       acc[2] += 1.0;
@@ -390,7 +415,7 @@ ROLO_DEV void trans_pass_body(const PassArgs& a, const LmState* __restrict__ st,
   for (int v = 0; v < NH; v++) slot[3 + v] = V_H + v;
 #pragma unroll
   for (int v = 0; v < 6; v++) slot[3 + NH + v] = V_B + v;
-  block_reduce_store<NV>(acc, slot, a.partials + (size_t)block * NV_MAX);
+  block_reduce_store<NV>(acc, slot, a.partials + (size_t)block * NV_MAX, st->phase == 1 && st->lin_skip != 0);
 }
 
 // Workgroup b of a launch runs on XCD b mod 8, and every XCD has its own L2, emptied at every kernel boundary: with the points dealt round-robin each
@@ -673,7 +698,7 @@ ROLO_DEV void trans_consts(LmState* st) {
 }
 ROLO_DEV void trans_start(LmState* st) {  // lsq_registration_impl.hpp:55-61
   trans_consts(st);
-  st->stage = 2; st->phase = 0; st->outer = 0; st->trial = 0; st->lambda = -1.0;
+  st->stage = 2; st->phase = 0; st->lin_skip = 0; st->outer = 0; st->trial = 0; st->lambda = -1.0;
   st->trans_done = 0; st->trans_failed = 0; st->trans_outer = 0; st->trans_passes = 0;
   for (int i = 0; i < 3; i++) st->tt[i] = st->t0[i];
   // lambda_/pt_size: float / size_t -> float (rot_vgicp.hpp:124, rot_vgicp_impl.hpp:557)
@@ -701,7 +726,7 @@ ROLO_DEV void rot_step_t(LmState* __restrict__ st, const double* __restrict__ S,
     for (int i = 0; i < 9; i++) st->tr_R[i] = st->x0_R[i];
     for (int i = 0; i < 6; i++) st->tr_S[i] = st->x0_S[i];
     if (st->n_corr <= 0) { st->error = ROLO_ENOCORR; rot_finish(st, false, true); return; }
-    st->phase = 1;
+    st->phase = 1; st->lin_skip = 0;
     rot_begin_outer<DOF>(st);
     return;
   }
@@ -718,6 +743,7 @@ ROLO_DEV void rot_step_t(LmState* __restrict__ st, const double* __restrict__ S,
       const bool done = st->fixed_iterations > 0 ? (st->outer >= st->fixed_iterations) : true;
       if (done) { rot_finish(st, true, false); return; }
       rot_begin_outer<DOF>(st);  // the reference re-linearises at the same x0: identical H, b, y0, correspondences
+      st->lin_skip = st->spec_lin;   // a rejected trial: the next pass evaluates its trial's cost alone (LmState::lin_skip)
       return;
     }
     trace_push<DOF>(st, trace, 0, 0, yi, rho);
@@ -725,6 +751,7 @@ ROLO_DEV void rot_step_t(LmState* __restrict__ st, const double* __restrict__ S,
     st->trial++;
     if (st->trial >= st->lm_max) { rot_finish(st, false, true); return; }  // "lm not converged!!"
     rot_compute_step<DOF>(st);
+    st->lin_skip = st->spec_lin;
     return;
   }
   trace_push<DOF>(st, trace, 0, 1, gn ? NAN : yi, gn ? NAN : rho);
@@ -737,6 +764,10 @@ ROLO_DEV void rot_step_t(LmState* __restrict__ st, const double* __restrict__ S,
   const bool conv = delta_converged(st, false);
   const bool done = st->fixed_iterations > 0 ? (st->outer >= st->fixed_iterations) : (conv || st->outer >= st->max_iterations);
   if (done) { rot_finish(st, conv, false); return; }
+  if (st->lin_skip) {   // the accepted trial's pass carried no linearisation (the bet after a rejection was "rejected again"): the next pass is so3_linearize(x0_new) alone —
+    st->cur ^= 1; st->phase = 0; st->lin_skip = 0;   // phase 0 = "linearise at xt (= x0 now) into corr[cur], then begin the outer iteration": the state after it is the one below
+    return;
+  }
   // next outer iteration: the (B) half of this pass IS so3_linearize(x0_new)
   unpack_hb<DOF>(st, S);
   st->cur ^= 1;
@@ -769,7 +800,7 @@ ROLO_DEV void trans_step(LmState* __restrict__ st, const double* __restrict__ S,
     const int keep = st->n_corr;
     unpack_hb<6>(st, S);
     st->n_corr = keep;
-    st->phase = 1;
+    st->phase = 1; st->lin_skip = 0;
     trans_begin_outer(st);
     return;
   }
@@ -785,6 +816,7 @@ ROLO_DEV void trans_step(LmState* __restrict__ st, const double* __restrict__ S,
     st->trial++;
     if (st->trial >= st->lm_max) { trans_finish(st, true); return; }
     trans_compute_step(st);
+    st->lin_skip = st->spec_lin;   // a rejected trial: the next pass evaluates its trial's cost alone
     return;
   }
   trace_push<6>(st, trace, 1, 1, yi, rho);
@@ -793,6 +825,7 @@ ROLO_DEV void trans_step(LmState* __restrict__ st, const double* __restrict__ S,
   st->outer++;
   const bool conv = t_converged(st);
   if (conv || st->outer >= st->max_iterations) { trans_finish(st, false); return; }
+  if (st->lin_skip) { st->phase = 0; st->lin_skip = 0; return; }   // accepted after a cost-only pass: the next pass is t3_linearize at tt (= t0 now) alone
   const int keep = st->n_corr;
   unpack_hb<6>(st, S);
   st->n_corr = keep;
@@ -1042,7 +1075,7 @@ __global__ __launch_bounds__(THREADS) void lm_kernel(PassArgs a, const LmState* 
       if (valid) in = load_pt(a, i);
       rot_pass_compute<DOF>(a, &sst, i, valid, in, acc);
     }
-    block_reduce_store<NVR, THREADS>(acc, slot, out_row);
+    block_reduce_store<NVR, THREADS>(acc, slot, out_row, sst.phase == 1 && sst.lin_skip != 0);
   } else {
     double acc[30];
     int slot[30];
@@ -1055,7 +1088,7 @@ __global__ __launch_bounds__(THREADS) void lm_kernel(PassArgs a, const LmState* 
       if (valid) in = load_pt(a, i);
       trans_pass_compute(a, &sst, i, valid, in, acc);
     }
-    block_reduce_store<30, THREADS>(acc, slot, out_row);
+    block_reduce_store<30, THREADS>(acc, slot, out_row, sst.phase == 1 && sst.lin_skip != 0);
   }
 }
 
@@ -1095,7 +1128,7 @@ __global__ void eval_begin_kernel(LmState* st, RotBegin a, int mode) {
   lm_set_rrt(st->xt_S, st->xt_R);
   for (int i = 0; i < 3; i++) st->xt_t[i] = a.t[i];
   st->optimizer = a.optimizer; st->q2_intended = a.q2_intended;
-  st->stage = 1; st->error = 0;
+  st->stage = 1; st->error = 0; st->lin_skip = 0;
   if (mode == 0) {
     st->phase = 0; st->cur = 0; st->tr_cur = 0;
     for (int i = 0; i < 9; i++) { st->x0_R[i] = a.R[i]; st->tr_R[i] = a.R[i]; }
@@ -1117,7 +1150,7 @@ __global__ void t3_eval_begin_kernel(LmState* st, TransBegin a, int phase) {
   st->dtn = a.dtn; st->dtn1 = a.dtn1; st->ct_lambda = a.ct_lambda;
   st->lam_over_n = (double)(a.ct_lambda / (float)st->tr_n_corr);
   trans_consts(st);
-  st->stage = 2; st->phase = phase;
+  st->stage = 2; st->phase = phase; st->lin_skip = 0;
 }
 
 }  // namespace

@@ -116,6 +116,11 @@ struct LmState {
   int trace_count;
   int error;  // ROLO_E* raised on the device (key range, no correspondences)
   int pending;  // fused LM launches: the rows of the previous launch wait to be summed and stepped on
+  // Speculation control of the fused pass (round 5). A pass evaluates a trial's cost (A) AND, betting on acceptance, the linearisation at the trial pose (B). After a
+  // REJECTED trial the bet is poor — with 20 forced iterations the rotation stage repeats one rejected-but-converged trial fourteen times, the translation stage ends in
+  // six rejections — so the controller marks the next pass lin_skip = 1: (A) only. If that trial is accepted after all, the controller sets phase = 0 and the next pass
+  // linearises at the accepted pose: the state after it is the one the full pass would have left, one launch later. spec_lin = 0 (ROLO_LM_SPEC_LIN=0) never skips.
+  int lin_skip, spec_lin;
   // parameters
   int optimizer, max_iterations, fixed_iterations, lm_max, q2_intended;
   double rot_eps, trans_eps, lm_init;
@@ -236,7 +241,7 @@ hipError_t launch_peer_cov_exchange(const PeerArgs& peer, size_t area_bytes, siz
 hipError_t launch_peer_selftest_fill(const PeerArgs& peer, size_t area_bytes, size_t seg_doubles, hipStream_t s);
 hipError_t launch_peer_selftest_check(const PeerArgs& peer, size_t area_bytes, size_t seg_doubles, unsigned* bad, hipStream_t s);
 
-struct RotBegin { double R[9], t[3]; int optimizer, max_iterations, fixed_iterations, lm_max, q2_intended; double rot_eps, trans_eps, lm_init; int run_trans; };
+struct RotBegin { double R[9], t[3]; int optimizer, max_iterations, fixed_iterations, lm_max, q2_intended; double rot_eps, trans_eps, lm_init; int run_trans; int spec_lin; };
 struct TransBegin { double t0[3], g[3], l[3], dtn, dtn1; float ct_lambda; int direct; /* 1: start now (rotation already done) */ };
 struct FrameArgs { RotBegin rot; TransBegin trans; };
 hipError_t launch_rot_begin(LmState* st, const RotBegin& a, hipStream_t s);

@@ -820,6 +820,56 @@ def test_fused_lm_equals_pass_plus_controller_launches(guess_deg):
         assert sa[1] > 8   # the rotation stage did need more than the first chunk: the top-up path ran
 
 
+_SPEC_AB = r"""
+import sys, hashlib, json, numpy as np
+sys.path.insert(0, sys.argv[1])
+from rolo_amd import synth
+from rolo_amd.rotvgicp import RotVGICP
+G = -np.asarray(synth.PREV_STEP_T); L0 = G * 0.97
+out = {}
+import bench
+for name, kind, stride, leaf, polar, fixed, lm_init in (("uniform20", "os1-64", 4, 1.0, None, 20, None), ("polar", "vlp16", 2, None, (0.175, 0.175, 2.0), 0, None),
+                                                        ("pool7", "os1-128", 1, 0.5, None, 20, None)):
+    # pool7: pair 7 of bench.py's input pool — its translation stage ends "... R R A A": acceptances right after rejections
+    src, tgt = bench._pool_pair((kind, synth.SEED, 7)) if name == "pool7" else synth.dense_pair(kind, col_stride=stride)[:2]
+    for fused in (0, 1):
+        g = RotVGICP(); g.setUseGraph(False); g.setFusedLm(bool(fused))
+        g.setResolution(leaf) if leaf else g.setPolarResolution(*polar)
+        g.setFixedIterations(fixed)
+        if lm_init: g.setInitialLambdaFactor(lm_init); g.setRotationEpsilon(1e-7)
+        g.setInputTarget(tgt); g.setInputSource(src)
+        g.register_async(None, np.zeros(3), G, L0); Tf, Td, t = g.register_wait()
+        tr = g.trace()
+        out[name + str(fused)] = dict(T=hashlib.sha256(Td.tobytes()).hexdigest(), t=hashlib.sha256(np.asarray(t).tobytes()).hexdigest(), outer=(g.last_stats.n_outer, g.last_translation_stats.n_outer),
+                         passes=(g.last_stats.n_passes, g.last_translation_stats.n_passes), pattern="".join("RAC"[r["accepted"]] for r in tr),
+                         trace=hashlib.sha256(json.dumps([[r[k] for k in ("stage", "outer", "trial", "accepted", "y0", "yi", "rho", "lam", "dnorm")] for r in tr]).encode()).hexdigest())
+        g.close()
+print(json.dumps(out))
+"""
+
+
+def test_speculative_linearisation_skipping_changes_no_bit():
+    """LmState::lin_skip (round 5): after a rejected trial the next pass evaluates its trial's cost alone; if that trial is accepted after all, one more pass
+    linearises at the accepted pose. Against ROLO_LM_SPEC_LIN=0 (every pass carries both halves, rounds 1-4): poses, translations, iteration counts and the WHOLE LM
+    trace are the same bits — 20 forced iterations (a run of rejected-but-converged trials), a convergence-driven POLAR solve, and a frame of the bench's pool whose
+    translation stage accepts right after rejections (the mis-predicted case with its extra linearise-only pass), each with pass + controller launches and with one
+    launch per trial."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = []
+    for spec in ("1", "0"):
+        r = subprocess.run([sys.executable, "-c", _SPEC_AB, root], env=dict(os.environ, ROLO_LM_SPEC_LIN=spec), capture_output=True, text=True, timeout=600, cwd=root)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+        res.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    on, off = res
+    for k in on:
+        for f in ("T", "t", "outer", "pattern", "trace"):
+            assert on[k][f] == off[k][f], (k, f, on[k], off[k])
+    assert "C" in on["uniform200"]["pattern"] or "R" in on["uniform200"]["pattern"]           # there were rejected trials to skip after
+    assert any("RA" in on[k]["pattern"] or "CA" in on[k]["pattern"] for k in on), {k: on[k]["pattern"] for k in on}   # ... and an acceptance right after a rejection (the extra pass)
+    assert any(on[k]["passes"] != off[k]["passes"] for k in on)                                    # which shows as extra linearise-only passes, nothing else
+
+
 def test_load_hint_picks_the_walk_and_the_result_does_not_depend_on_it():
     """rolo_set_load_hint / the per-frame choice of round 5: a large launch takes the 64-query packet walk (rolo_ctx_counters "walk_lanes" = 1) when the device is
     busy and two lanes per query when it is idle; pinned by the hint, decided from the frames other contexts have in flight otherwise (sticky for a few frames).
