@@ -600,6 +600,17 @@ def main():
     pass_log_on[0] = True
     dt, rounds = timed(ctxs, args.steps, args.warmup, data)
     pass_log_on[0] = False
+    # how many of a frame's passes were cost-only (a pass right after a rejected trial stops after the trial's cost: LmState::lin_skip) — read off
+    # the device's LM trace of one more, UNTIMED frame per pool pair: a trial record whose predecessor in the same stage was not an acceptance
+    cost_only = None
+    if args.mode == "replicas" and not isinstance(ctxs[0], Batch) and os.environ.get("ROLO_LM_SPEC_LIN", "1") != "0":
+        per = []
+        for d_ in (data if isinstance(data, list) else [data]):
+            enqueue(ctxs[0], d_); ctxs[0].register_wait()
+            tr_ = ctxs[0].trace()
+            per.append(sum(1 for a_, b_ in zip(tr_, tr_[1:]) if a_["stage"] == b_["stage"] and a_["accepted"] != 1))
+        cost_only = {"per_pool_pair": per, "median": float(np.median(per)),
+                     "what": "passes that evaluated the trial cost alone (SURVEY 8d's error pass), from the LM trace of one untimed frame per pool pair"}
     frames_total = args.steps * len(ctxs) * B * (world if args.mode == "replicas" else 1)
     value = frames_total / dt
     rs, ts = ctxs[0].last_stats, ctxs[0].last_translation_stats
@@ -644,6 +655,8 @@ def main():
         out["config"]["schedule"] = {k_: int(sum(c_[k_] for c_ in cnt)) for k_ in ("frames", "graph_replays", "graph_captures", "eager_frames", "topup_frames")}
         passes = int(round(float(np.median(tot))))
         out["config"]["passes_per_frame"] = passes
+        if cost_only:
+            out["config"]["cost_only_passes"] = cost_only
 
     # ---- layout check: throughput must not depend on WHEN the contexts are created relative to other streams of the process ----------------
     # (HIP deals streams to its four hardware queues in creation order; rounds 1-3 depended on it: 2140 vs 2940 scans/s for the same four contexts.
@@ -672,9 +685,10 @@ def main():
     try:
         from rolo_amd._lib import lib as _rl
         V = max(int(_rl().rolo_num_voxels(g._h)), 0)
+        n_cost = int(round(cost_only["median"])) if cost_only else 0   # SURVEY 8d prices an error pass like a linearising one: 104 B/pt either way
         frame_bytes = 360.0 * 2 * n + 136.0 * n + 96.0 * V + 104.0 * n * passes
         fh = {"algorithmic_bytes_per_frame": frame_bytes, "achieved": frame_bytes * value / 1e9, "peak": HBM_PEAK_GBS * world,
-              "unit": "GB/s", "frac": frame_bytes * value / 1e9 / (HBM_PEAK_GBS * world), "voxels": V, "fused_pass_launches": passes}
+              "unit": "GB/s", "frac": frame_bytes * value / 1e9 / (HBM_PEAK_GBS * world), "voxels": V, "fused_pass_launches": passes, "cost_only_pass_launches": n_cost}
         from rolo_amd.profile import pmc_traffic_file
         pmc, pmc_desc = pmc_traffic_file()
         if pmc and os.path.exists(pmc) and args.sensor == "os1-128":
