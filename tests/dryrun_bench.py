@@ -109,6 +109,9 @@ class FakeRotVGICP:
         self.last_translation_stats = _Stats(n_passes=9, n_outer=2)
         return np.eye(4, dtype=np.float32), np.eye(4), np.zeros(3)
 
+    def trace(self):
+        return []   # (bench.py counts the cost-only passes of one untimed frame per pool pair from the device's LM trace)
+
     def counters(self):
         return dict(frames=self.n_frames, graph_replays=0, graph_captures=0, eager_frames=self.n_frames, topup_frames=0, sync_chunks=0, hint_rot=0, hint_trans=0, walk_lanes=1)
 
