@@ -742,7 +742,9 @@ ROLO_DEV void rot_step_t(LmState* __restrict__ st, const double* __restrict__ S,
       st->outer++;
       const bool done = st->fixed_iterations > 0 ? (st->outer >= st->fixed_iterations) : true;
       if (done) { rot_finish(st, true, false); return; }
-      rot_begin_outer<DOF>(st);  // the reference re-linearises at the same x0: identical H, b, y0, correspondences
+      // the reference re-linearises at the same x0: identical H, b, y0, correspondences — and, lambda staying what this trial's step was solved with, the identical
+      // step: d, delta and xt are already what rot_begin_outer's LDLT + exponential would write again, bit for bit (the scalar step is a third of this launch)
+      st->nu = 2.0; st->trial = 0;
       st->lin_skip = st->spec_lin;   // a rejected trial: the next pass evaluates its trial's cost alone (LmState::lin_skip)
       return;
     }
