@@ -62,6 +62,7 @@ def parse():
     ap.add_argument("--pipeline-only", action="store_true", help="run only the pipeline leg and print its dict (profiling runs)")
     ap.add_argument("--no-config5", action="store_true", help="skip the 512-pair OS1-64 leg (BASELINE configs[4])")
     ap.add_argument("--no-layout-check", action="store_true", help="skip the re-measurement with contexts re-created after foreign streams")
+    ap.add_argument("--no-side-legs", action="store_true", help="skip convergence_driven / iteration_sweep / host_clouds (profiling runs)")
     ap.add_argument("--config5-pairs", type=int, default=512)
     ap.add_argument("--single-round", action="store_true", help="one timed round only (profiling runs)")
     ap.add_argument("--pool", type=int, default=8,
@@ -465,10 +466,10 @@ def main():
     guess = -np.asarray(synth.PREV_STEP_T, np.float64)
     last = guess * 0.97
 
-    def new_ctx(alone=False, g=None, leaf=None):
+    def new_ctx(alone=False, g=None, leaf=None, iters=None):
         g = g or RotVGICP(local_rank)
         g.setResolution(args.leaf if leaf is None else leaf)
-        g.setFixedIterations(int(os.environ.get("ROLO_BENCH_ITERS", "20")))
+        g.setFixedIterations(int(os.environ.get("ROLO_BENCH_ITERS", "20")) if iters is None else iters)   # 0: convergence-driven, the reference's own loop (lsq_registration_impl.hpp:161)
         g.setOverlapKnn(args.pair_search == "on")
         g.setUseGraph(not args.no_graph)
         g.setLoadHint({"auto": -1, "idle": 0, "busy": 1}[args.load_hint])
@@ -532,7 +533,8 @@ def main():
             for g in gs:
                 g.register_wait()
                 if pass_log_on[0] and not isinstance(g, Batch):
-                    pass_log.append((g.last_stats.n_passes, g.last_translation_stats.n_passes))
+                    pass_log.append((g.last_stats.n_passes, g.last_translation_stats.n_passes, g.last_stats.n_cost_only + g.last_translation_stats.n_cost_only,
+                                     g.last_stats.n_outer, g.last_translation_stats.n_outer))
                 if it + 1 < k:
                     enqueue(g, nxt())
 
@@ -554,7 +556,7 @@ def main():
             dt = float(t.item())
         return dt
 
-    def timed(g, steps, warmup, data):
+    def timed(g, steps, warmup, data, min_s=None):
         """rounds of exactly `steps` steps; >= 5 rounds and >= 0.5 s in total (the round times are max-over-ranks values, so every
         rank takes the same decisions); returns (median round time, all round times)"""
         run_steps(g, warmup, data)
@@ -562,7 +564,7 @@ def main():
         while True:
             rounds.append(timed_round(g, steps, data))
             # >= 5 rounds and >= 3 s of timed work (round 4: 0.5 s — 18 rounds x 28 ms inside a 40 s run, which a driver-side 5-second GPU-busy sampler cannot see)
-            if args.single_round or (len(rounds) >= 5 and (sum(rounds) >= MIN_TIMED_S or len(rounds) >= 400)):
+            if args.single_round or (len(rounds) >= 5 and (sum(rounds) >= (MIN_TIMED_S if min_s is None else min_s) or len(rounds) >= 400)):
                 break
         return float(np.median(rounds)), rounds
 
@@ -600,17 +602,14 @@ def main():
     pass_log_on[0] = True
     dt, rounds = timed(ctxs, args.steps, args.warmup, data)
     pass_log_on[0] = False
-    # how many of a frame's passes were cost-only (a pass right after a rejected trial stops after the trial's cost: LmState::lin_skip) — read off
-    # the device's LM trace of one more, UNTIMED frame per pool pair: a trial record whose predecessor in the same stage was not an acceptance
+    # how many of a frame's passes were cost-only (a pass right after a rejected trial stops after the trial's cost: LmState::lin_skip): counted ON THE
+    # DEVICE by the controller that consumes such a pass (rolo_stats::n_cost_only), over every frame of the timed rounds — round 5 inferred it from the LM trace of one
+    # untimed frame per pool pair
     cost_only = None
-    if args.mode == "replicas" and not isinstance(ctxs[0], Batch) and os.environ.get("ROLO_LM_SPEC_LIN", "1") != "0":
-        per = []
-        for d_ in (data if isinstance(data, list) else [data]):
-            enqueue(ctxs[0], d_); ctxs[0].register_wait()
-            tr_ = ctxs[0].trace()
-            per.append(sum(1 for a_, b_ in zip(tr_, tr_[1:]) if a_["stage"] == b_["stage"] and a_["accepted"] != 1))
-        cost_only = {"per_pool_pair": per, "median": float(np.median(per)),
-                     "what": "passes that evaluated the trial cost alone (SURVEY 8d's error pass), from the LM trace of one untimed frame per pool pair"}
+    if pass_log and len(pass_log[0]) > 2:
+        co_ = np.array([p_[2] for p_ in pass_log])
+        cost_only = {"median": float(np.median(co_)), "min": int(co_.min()), "max": int(co_.max()), "frames": int(co_.shape[0]),
+                     "what": "passes that evaluated the trial cost alone (SURVEY 8d's error pass), counted on the device (rolo_stats.n_cost_only) over the frames of the timed rounds"}
     frames_total = args.steps * len(ctxs) * B * (world if args.mode == "replicas" else 1)
     value = frames_total / dt
     rs, ts = ctxs[0].last_stats, ctxs[0].last_translation_stats
@@ -645,7 +644,7 @@ def main():
     # and how often the first launch schedule of a frame was too short (rolo_register_wait then tops up through host round trips)
     if pass_log:
         pl = np.array(pass_log)
-        tot = pl.sum(axis=1)
+        tot = pl[:, 0] + pl[:, 1]
         cnt = [c_.counters() for c_ in ctxs if not isinstance(c_, Batch)]
         out["config"]["inputs"] = (f"{len(d_pool)} distinct resident frame pairs rotated through the contexts (pair 0 = the nominal pair of SURVEY 8d; pair i = the same "
                                    "motion from stand point i of the hall, own noise)") if len(d_pool) > 1 else "one resident frame pair registered by every context"
@@ -675,6 +674,99 @@ def main():
                                    "what": "the headline's contexts closed, three foreign HIP streams created, the same number of contexts created again, the same timed rounds"}
         except Exception as e:  # pragma: no cover
             out["layout_check"] = {"error": repr(e)}
+
+    # ---- the two regimes a ROLO user runs, next to the forced-20 headline (round 5's verdict, item 3) + the iteration sweep ----------------------------------
+    # `value` above forces 20 outer iterations (BASELINE.json's metric); the reference itself stops at convergence (lsq_registration_impl.hpp:161-176) and hands
+    # HOST clouds to setInputTarget / setInputSource (src/lidarOdometry.cpp:466-467). Same pool, same contexts layout, short timed rounds (>= 5 rounds, >= 1 s).
+    def side_leg(iters, host=None, nctx=None):
+        """scans/s of `nctx` contexts in flight with `iters` forced iterations (0 = convergence-driven); host = None: device-resident pairs, "pinned" / "pageable": the pair
+        handed over as host arrays through rolo_set_target / rolo_set_source, the upload inside the timed region"""
+        nctx = len(ctxs) if nctx is None else nctx
+        cs = [new_ctx(iters=iters) for _ in range(nctx)]
+        log0 = len(pass_log)
+        try:
+            if host is None:
+                pass_log_on[0] = True
+                dt_, rr_ = timed(cs, args.steps, args.warmup, data, min_s=1.0)
+                pass_log_on[0] = False
+            else:
+                hp = host_pools[host]
+                k_ = [0]
+
+                def enq(g_):
+                    s_, t_ = hp[k_[0] % len(hp)]; k_[0] += 1
+                    g_.setInputTarget(t_); g_.setInputSource(s_)       # host arrays: hipMemcpyAsync H2D + pack on the context's stream, inside the timed region
+                    g_.register_async(None, zero3, guess, last, 0.1, 0.1, 0.3)
+
+                def steps_(k):
+                    for g_ in cs:
+                        enq(g_)
+                    for it_ in range(k):
+                        for g_ in cs:
+                            g_.register_wait()
+                            if it_ + 1 < k:
+                                enq(g_)
+                steps_(args.warmup)
+                rr_ = []
+                import gc
+                while True:
+                    gc.collect(); gc.disable(); barrier(); t0_ = time.perf_counter(); steps_(args.steps); barrier(); rr_.append(time.perf_counter() - t0_); gc.enable()
+                    if args.single_round or (len(rr_) >= 5 and (sum(rr_) >= 1.0 or len(rr_) >= 100)):
+                        break
+                dt_ = float(np.median(rr_))
+            r_ = {"scans_per_s": args.steps * nctx / dt_ * (world if args.mode == "replicas" else 1), "contexts": nctx, "timed_rounds": len(rr_)}
+            if host is None and len(pass_log) > log0:
+                pl_ = np.array(pass_log[log0:])
+                r_.update({"passes_per_frame": {"median": float(np.median(pl_[:, 0] + pl_[:, 1])), "min": int((pl_[:, 0] + pl_[:, 1]).min()), "max": int((pl_[:, 0] + pl_[:, 1]).max())},
+                           "cost_only_passes_median": float(np.median(pl_[:, 2])),
+                           "rot_outer": {"median": float(np.median(pl_[:, 3])), "min": int(pl_[:, 3].min()), "max": int(pl_[:, 3].max())},
+                           "trans_outer": {"median": float(np.median(pl_[:, 4])), "min": int(pl_[:, 4].min()), "max": int(pl_[:, 4].max())}})
+                del pass_log[log0:]
+            return r_
+        finally:
+            pass_log_on[0] = False
+            for c_ in cs:
+                c_.close()
+
+    if args.mode == "replicas" and B == 1 and not args.no_side_legs:
+        try:
+            out["convergence_driven"] = dict(side_leg(0), what="the same pool and contexts with fixed_iterations = 0: both stages stop at the reference's own convergence tests "
+                                                               "(lsq_registration_impl.hpp:161-176, :63-73) — what a ROLO node runs; `value` forces 20 rotation iterations")
+        except Exception as e:  # pragma: no cover
+            out["convergence_driven"] = {"error": repr(e)}
+        try:
+            sweep = {"20": {"scans_per_s": value}}
+            for it_ in (10, 2):
+                sweep[str(it_)] = side_leg(it_)
+            v20, v10, v2 = sweep["20"]["scans_per_s"], sweep["10"]["scans_per_s"], sweep["2"]["scans_per_s"]
+            p20 = passes; p10 = sweep["10"].get("passes_per_frame", {}).get("median", 0); p2 = sweep["2"].get("passes_per_frame", {}).get("median", 0)
+            # per-trial cost under load = d(frame time) / d(passes); what is left at zero passes = the search + map + build share of a frame
+            per_trial_us = 1e6 * (1.0 / v20 - 1.0 / v2) / max(p20 - p2, 1)
+            out["iteration_sweep"] = dict(sweep, per_trial_us_under_load=per_trial_us, frame_share_without_lm_ms=1e3 * (1.0 / v20) - 1e-3 * per_trial_us * p20,
+                                          what="forced rotation iterations 20 / 10 / 2 with the headline's contexts: the slope prices one LM trial (pass + controller launch) under load, "
+                                               "the intercept the search + map + build of a frame (frame time = 1 / scans_per_s: the contexts overlap)")
+        except Exception as e:  # pragma: no cover
+            out["iteration_sweep"] = {"error": repr(e)}
+        try:
+            host_pools = {}
+            for kind_ in ("pageable", "pinned"):
+                hp_ = []
+                for s_, t_ in [pairs[i_ % len(pairs)] for i_ in range(5)]:   # (five: with four contexts in flight a context then sees a different array every frame — the same array again is a no-op, rot_vgicp_impl.hpp:113-115)
+                    if kind_ == "pinned":
+                        hp_.append((torch.from_numpy(np.ascontiguousarray(s_)).pin_memory().numpy(), torch.from_numpy(np.ascontiguousarray(t_)).pin_memory().numpy()))
+                    else:
+                        hp_.append((np.ascontiguousarray(s_).copy(), np.ascontiguousarray(t_).copy()))
+                host_pools[kind_] = hp_
+            hc = {}
+            for kind_ in ("pinned", "pageable"):
+                for nc_ in (1, len(ctxs)):
+                    hc[f"{kind_}_{nc_}ctx"] = side_leg(None, host=kind_, nctx=nc_)
+            hc["bytes_uploaded_per_frame"] = 2 * n * 16
+            hc["what"] = ("the 131 072-point pair handed over as HOST arrays through rolo_set_target / rolo_set_source (lidarOdometry.cpp:466-467: what the unchanged caller does), "
+                          "H2D inside the timed region, 20 forced iterations; pinned = page-locked caller buffers, pageable = plain malloc'd arrays (the runtime stages them)")
+            out["host_clouds"] = hc
+        except Exception as e:  # pragma: no cover
+            out["host_clouds"] = {"error": repr(e)}
 
     # ---- frame-level HBM figures of BASELINE.json's metric ("scans/sec ...; achieved HBM GB/s") -------------------------------------
     # algorithmic: SURVEY.md 8d's bytes of one frame — 360 B/pt covariances for both clouds, 136 B/pt + 96 B/voxel map build, and

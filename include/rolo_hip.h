@@ -72,6 +72,7 @@ typedef struct rolo_stats {
   int lm_failed;      /* "lm not converged!!" (lsq_registration_impl.hpp:66-69,168-171); result still returned */
   int n_passes;       /* fused linearize/error passes over the source points */
   int n_correspondences;
+  int n_cost_only;    /* of n_passes: passes that evaluated a trial's cost alone (compute_error / compute_t_error without the linearisation half) — counted on the device */
 } rolo_stats;
 
 typedef struct rolo_trace_rec { /* one LM trial; lm_debug_print_ table of lsq_registration_impl.hpp:299-305 */
@@ -207,6 +208,24 @@ int rolo_set_shard(rolo_ctx* ctx, int rank, int world);
  * workgroups, equal slices) — but WITHOUT the all-gather: only the covariances of the own slice are valid afterwards (the rest of
  * rolo_get_*_covariances is stale / undefined); the union over the ranks must equal the unsharded result. */
 int rolo_set_shard_knn(rolo_ctx* ctx, int on);
+/* test hook: the LM drivers of lsq_registration_impl.hpp:55-179, 225-324 — the controller kernels of passes.hip — fed with SCRIPTED pass results instead of pass
+ * kernels: the linearisation opened by outer iteration o returns lin_*[o], the trial cost of (o, trial t) returns err_y[o][t] (indices beyond the extents repeat the
+ * last entry); slots of a pass row that the step must not read are poisoned with NaN. Every exit of the drivers (LM failure, iteration cap, rejected-but-converged,
+ * NaN / infinite gain ratios, the cost-only passes' late linearisation) can be reached with inputs that are the same bits as a CPU statement's.
+ * rolo_debug_lm_script_align: computeTransformation from `guess16` with the context's parameters; generic_ctrl != 0 runs the one-size-fits-all controller of the
+ * batched launches instead of the specialised one. rolo_debug_lm_script_translation: computeTranslation afterwards (it needs the correspondence count the
+ * rotation script left, as the reference's does). Results as rolo_align / rolo_compute_translation; rolo_get_trace reads the trace. */
+typedef struct rolo_lm_script {
+  int n_outer, n_trial;
+  const double* lin_y;    /* [n_outer] */
+  const double* lin_H;    /* [n_outer][36] row-major 6 x 6; a 3-dof optimiser reads the top-left 3 x 3 */
+  const double* lin_b;    /* [n_outer][6] */
+  const int32_t* lin_n;   /* [n_outer] correspondences of that linearisation */
+  const double* err_y;    /* [n_outer][n_trial] */
+} rolo_lm_script;
+int rolo_debug_lm_script_align(rolo_ctx* ctx, const rolo_lm_script* script, const float* guess16, int generic_ctrl, float* T_out_f16, double* T_out_d16, rolo_stats* stats);
+int rolo_debug_lm_script_translation(rolo_ctx* ctx, const rolo_lm_script* script, double* trans3_io, const double* init_guess3, const double* last_t03,
+                                     double dtn, double dtn1, float ct_lambda, int generic_ctrl, rolo_stats* stats);
 /* Which kernels rolo_register_async picks where the best one depends on whether the GPU is shared (not in the reference: its operator owns its CPU threads).
  * -1 (default): decided per frame — other contexts of the device have frames in flight when this one is enqueued => the kernels that share the chip best
  * (throughput); an idle device => the ones that finish soonest (latency). 0 / 1 pin the idle- / busy-device choice (profiling runs, callers that know their

@@ -157,7 +157,7 @@ public:
     const int rc = rolo_align(ctx_, g, final_, nullptr, &st);
     if (rc != ROLO_OK) throw std::runtime_error(std::string("RotVGICP(HIP) align: ") + rolo_last_error());
     if (st.lm_failed) std::fprintf(stderr, "lm not converged!!\n");  // lsq_registration_impl.hpp:168-171
-    converged_ = st.converged != 0; nr_iterations_ = st.n_outer - 1;
+    converged_ = st.converged != 0; if (st.n_outer > 0) nr_iterations_ = st.n_outer - 1;   // (:163 — a loop that never runs leaves the member as it was)
     if (lm_debug_print_) {
       std::printf("********************************************\n***************** optimize *****************\n********************************************\n");
       print_trace(0);
@@ -216,6 +216,10 @@ public:
   }
 
   rolo_ctx* handle() { return ctx_; }
+
+protected:
+  // lsq_registration.hpp:104: lm_max_iterations_ is a protected member without a setter in the reference — what a subclass can change there, a subclass can change here
+  void set_lm_max_iterations(int n) { p_.lm_max_iterations = n; push(); }
 
 private:
   // the trials of one stage (0 = align, 1 = computeTranslation) in the reference's table: a header line before every trial 0, then

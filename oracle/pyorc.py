@@ -38,6 +38,11 @@ class FrontParams(C.Structure):
                 ("surf_threshold", C.c_float), ("odometry_surf_leaf_size", C.c_float)]
 
 
+class LmScript(C.Structure):
+    _fields_ = [("n_outer", C.c_int), ("n_trial", C.c_int), ("lin_y", C.POINTER(C.c_double)), ("lin_H", C.POINTER(C.c_double)),
+                ("lin_b", C.POINTER(C.c_double)), ("lin_n", C.POINTER(C.c_int32)), ("err_y", C.POINTER(C.c_double))]
+
+
 class TraceRec(C.Structure):
     _fields_ = [("stage", C.c_int), ("outer", C.c_int), ("trial", C.c_int), ("accepted", C.c_int),
                 ("y0", C.c_double), ("yi", C.c_double), ("rho", C.c_double), ("lambda_", C.c_double),
@@ -86,6 +91,8 @@ def lib():
                                                   C.POINTER(C.c_int)]
         L.orc_reg_trace.argtypes = [C.c_void_p, C.POINTER(TraceRec), C.c_int]
         L.orc_reg_clear_trace.argtypes = [C.c_void_p]
+        L.orc_reg_set_script.argtypes = [C.c_void_p, C.POINTER(LmScript)]
+        L.orc_reg_set_driver_params.argtypes = [C.c_void_p, C.POINTER(Params)]
         L.orc_knn.argtypes = [fp, C.c_int, C.c_int, C.c_int, C.c_int, ip, fp]
         L.orc_voxel_keys.argtypes = [fp, C.c_int, C.c_int, C.c_int, C.c_double, dp, dp, ip]
         L.orc_so3_exp.argtypes = [dp, dp]
@@ -247,6 +254,25 @@ class Reg:
 
     def clear_trace(self):
         lib().orc_reg_clear_trace(self.h)
+
+    def set_driver_params(self, **kw):
+        """the LM drivers' knobs on the live object (caches kept): optimizer, max_iterations, rotation_epsilon, transformation_epsilon, lm_max_iterations, lm_init_lambda_factor, fixed_iterations"""
+        for k, v in kw.items():
+            setattr(self.p, k, v)
+        lib().orc_reg_set_driver_params(self.h, C.byref(self.p))
+
+    def set_script(self, lin_y=None, lin_H=None, lin_b=None, lin_n=None, err_y=None):
+        """scripted evaluations (orc_reg_set_script): lin_y [O], lin_H [O, 6, 6], lin_b [O, 6], lin_n [O], err_y [O, T]; no arguments: back to real evaluations"""
+        if lin_y is None:
+            lib().orc_reg_set_script(self.h, None); self._script = None
+            return
+        a = dict(lin_y=np.ascontiguousarray(lin_y, np.float64), lin_H=np.ascontiguousarray(lin_H, np.float64), lin_b=np.ascontiguousarray(lin_b, np.float64),
+                 lin_n=np.ascontiguousarray(lin_n, np.int32), err_y=np.ascontiguousarray(err_y, np.float64))
+        O, T = a["err_y"].shape
+        assert a["lin_y"].shape == (O,) and a["lin_H"].shape == (O, 6, 6) and a["lin_b"].shape == (O, 6) and a["lin_n"].shape == (O,)
+        sc = LmScript(O, T, _d(a["lin_y"]), _d(a["lin_H"]), _d(a["lin_b"]), _i(a["lin_n"]), _d(a["err_y"]))
+        self._script = (sc, a)   # the oracle keeps pointers into these
+        lib().orc_reg_set_script(self.h, C.byref(sc))
 
 
 def knn(pts, k=20, threads=0):

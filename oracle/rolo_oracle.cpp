@@ -127,6 +127,11 @@ struct orc_reg {
   float lambda_ = 1.0f;  // rot_vgicp.hpp:124 (float)
   double lm_lambda = -1.0;
   std::vector<orc_trace_rec> trace;
+  // Scripted evaluations (tests of the LM drivers' branches, orc_reg_set_script): while set, so3_linearize / linearize6 / compute_error / t3_eval return the
+  // script's numbers — indexed by the (outer iteration, trial) the drivers are in — instead of evaluating clouds; the drivers themselves (the restatement of
+  // lsq_registration_impl.hpp:55-179, 225-324) run unchanged, so every exit of theirs can be reached with inputs that are the same bits on both sides of a test.
+  const orc_lm_script* script = nullptr;
+  int cur_outer = 0, cur_trial = 0;
 };
 
 namespace {
@@ -278,8 +283,26 @@ inline double quad3(const M3& M, const V3& e) {  // e^T M e, Eigen evaluates (e^
   return s;
 }
 
+// scripted evaluations (orc_reg::script): the linearisation opened by outer iteration o, the trial cost of (o, t)
+inline int script_o(const orc_reg* r) { return std::min(std::max(r->cur_outer, 0), r->script->n_outer - 1); }
+double script_lin(orc_reg* r, int dof, double* H, double* b) {
+  const orc_lm_script* S = r->script;
+  const int o = script_o(r);
+  r->corr_src.assign((size_t)std::max(S->lin_n[o], 0), 0); r->corr_vox.assign(r->corr_src.size(), 0);
+  if (H && b) {
+    for (int a = 0; a < dof; a++) { for (int c = 0; c < dof; c++) H[a * dof + c] = S->lin_H[(size_t)o * 36 + a * 6 + c]; b[a] = S->lin_b[(size_t)o * 6 + a]; }
+  }
+  return S->lin_y[o];
+}
+double script_err(const orc_reg* r) {
+  const orc_lm_script* S = r->script;
+  const int t = std::min(std::max(r->cur_trial, 0), S->n_trial - 1);
+  return S->err_y[(size_t)script_o(r) * S->n_trial + t];
+}
+
 // rot_vgicp_impl.hpp:293-388
 double so3_linearize(orc_reg* r, const Pose& T, double* H9, double* b3) {
+  if (r->script) return script_lin(r, 3, H9, b3);
   if (ensure_map(r) != 0) return NAN;
   update_correspondences(r, T);
   const int nc = (int)r->corr_src.size();
@@ -342,6 +365,7 @@ inline void accum6(const M3& M, const V3& ta, double w, const V3& e, double scal
 
 // rot_vgicp_impl.hpp:225-290 (6-dof variant; reachable through setOptimizerType)
 double linearize6(orc_reg* r, const Pose& T, double* H36, double* b6) {
+  if (r->script) return script_lin(r, 6, H36, b6);
   if (ensure_map(r) != 0) return NAN;
   update_correspondences(r, T);
   const int nc = (int)r->corr_src.size();
@@ -376,6 +400,7 @@ double linearize6(orc_reg* r, const Pose& T, double* H36, double* b6) {
 
 // rot_vgicp_impl.hpp:391-417 : cached correspondences and Mahalanobis, trial pose
 double compute_error(orc_reg* r, const Pose& T) {
+  if (r->script) return script_err(r);
   const int nc = (int)r->corr_src.size();
   const int nt = resolve_threads(r->P.num_threads);
   double sum_errors = 0;
@@ -398,6 +423,7 @@ double compute_error(orc_reg* r, const Pose& T) {
 // q2_intended = 1 uses last_t0 in both.
 double t3_eval(orc_reg* r, const V3& trans, const V3& init_guess, const V3& last_t0, double dtn, double dtn1,
                bool is_error_variant, double* H36, double* b6) {
+  if (r->script) { if (is_error_variant) return script_err(r); const size_t keep = r->corr_src.size(); const double y = script_lin(r, 6, H36, b6); r->corr_src.resize(keep); r->corr_vox.resize(keep); return y; }
   const int nc = (int)r->corr_src.size();
   const int nt = resolve_threads(r->P.num_threads);
   struct Acc { double H[6][6]; double b[6]; };
@@ -476,6 +502,7 @@ bool rot_step_lm(orc_reg* r, Pose& x0, Pose& delta, int outer) {
     double q[4]; so3_exp_quat(dv, q);
     delta.R = quat_to_rot(q); delta.t = {{0, 0, 0}};
     Pose xi = pose_mul(delta, x0);
+    r->cur_trial = i;
     double yi = compute_error(r, xi);
     double den = 0; for (int a = 0; a < 3; a++) den += d[a] * (r->lm_lambda * d[a] - b3[a]);
     double rho = (y0 - yi) / den;
@@ -506,6 +533,7 @@ bool step_lm6(orc_reg* r, Pose& x0, Pose& delta, int outer) {
     ldlt_solve<6>(A, rhs, d);
     se3_exp(d, delta.R, delta.t);
     Pose xi = pose_mul(delta, x0);
+    r->cur_trial = i;
     double yi = compute_error(r, xi);
     double den = 0, dn = 0; for (int a = 0; a < 6; a++) { den += d[a] * (r->lm_lambda * d[a] - b6[a]); dn += d[a] * d[a]; }
     double rho = (y0 - yi) / den;
@@ -548,6 +576,7 @@ bool step_t_optimize(orc_reg* r, V3& x0, V3& delta, const V3& g, const V3& l, do
     ldlt_solve<6>(A, rhs, d);
     M3 Rd; se3_exp(d, Rd, delta);
     V3 xi = {{delta[0] + x0[0], delta[1] + x0[1], delta[2] + x0[2]}};
+    r->cur_trial = i;
     double yi = t3_eval(r, xi, g, l, dtn, dtn1, true, nullptr, nullptr);
     double den = 0, dn = 0; for (int a = 0; a < 6; a++) { den += d[a] * (r->lm_lambda * d[a] - b6[a]); dn += d[a] * d[a]; }
     double rho = (y0 - yi) / den;
@@ -682,10 +711,12 @@ double orc_reg_compute_t_error(orc_reg* r, const double* t3, const double* g, co
 
 // rot_vgicp_impl.hpp:146-160 computeTransformation + lsq_registration_impl.hpp:152-179
 int orc_reg_align(orc_reg* r, const float* guess16, float* Tf, double* Td, int* n_outer, int* converged) {
-  if (r->source.empty() || r->target.empty()) return -1;
-  r->have_map = false;  // voxelmap_.reset()
-  int rc = orc_reg_compute_covariances(r);
-  if (rc) return rc;
+  if (!r->script) {
+    if (r->source.empty() || r->target.empty()) return -1;
+    r->have_map = false;  // voxelmap_.reset()
+    int rc = orc_reg_compute_covariances(r);
+    if (rc) return rc;
+  }
   Pose x0;
   if (guess16) { double g[16]; for (int i = 0; i < 16; i++) g[i] = (double)guess16[i]; x0 = pose_from_rowmajor(g); }
   else { x0.R = m3_identity(); x0.t = {{0, 0, 0}}; }
@@ -696,6 +727,7 @@ int orc_reg_align(orc_reg* r, const float* guess16, float* Tf, double* Td, int* 
   int status = 0;
   for (int i = 0; i < maxit && (r->P.fixed_iterations > 0 || !conv); i++) {
     iters = i + 1;
+    r->cur_outer = i;
     Pose delta; delta.R = m3_identity(); delta.t = {{0, 0, 0}};
     bool ok;
     switch (r->P.optimizer) {
@@ -725,6 +757,7 @@ int orc_reg_compute_translation(orc_reg* r, double* trans, const double* g3, con
   int iters = 0, status = 0;
   for (int i = 0; i < r->P.max_iterations && !conv; i++) {
     iters = i + 1;
+    r->cur_outer = i;
     V3 delta = {{0, 0, 0}};
     if (!step_t_optimize(r, t0, delta, g, l, dtn, dtn1, i)) { status = 1; break; }
     conv = is_t_converged(r, delta);
@@ -733,6 +766,12 @@ int orc_reg_compute_translation(orc_reg* r, double* trans, const double* g3, con
   if (n_outer) *n_outer = iters;
   return status;
 }
+
+void orc_reg_set_driver_params(orc_reg* r, const orc_params* p) {
+  r->P.optimizer = p->optimizer; r->P.max_iterations = p->max_iterations; r->P.rotation_epsilon = p->rotation_epsilon; r->P.transformation_epsilon = p->transformation_epsilon;
+  r->P.lm_max_iterations = p->lm_max_iterations; r->P.lm_init_lambda_factor = p->lm_init_lambda_factor; r->P.fixed_iterations = p->fixed_iterations;
+}
+void orc_reg_set_script(orc_reg* r, const orc_lm_script* s) { r->script = s; r->cur_outer = 0; r->cur_trial = 0; }
 
 int orc_reg_trace(orc_reg* r, orc_trace_rec* out, int cap) {
   int n = (int)r->trace.size();

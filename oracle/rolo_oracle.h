@@ -78,6 +78,21 @@ int orc_reg_align(orc_reg* r, const float* guess16, float* T_out_f16, double* T_
 int orc_reg_compute_translation(orc_reg* r, double* trans3_io, const double* init_guess3, const double* last_t03,
                                 double dtn, double dtn1, float ct_lambda, int* n_outer);
 int orc_reg_trace(orc_reg* r, orc_trace_rec* out, int cap); /* returns number of records (may exceed cap) */
+/* Scripted evaluations for tests of the LM drivers' exits (lsq_registration_impl.hpp:55-179, 225-324): while a script is set, every linearisation
+ * (so3_linearize / linearize / t3_linearize) opened by outer iteration o returns lin_*[o] and every trial cost (compute_error / compute_t_error) of
+ * (o, trial t) returns err_y[o][t]; no clouds are needed. The arrays stay owned by the caller; NULL switches back to real evaluations. */
+typedef struct orc_lm_script {
+  int n_outer, n_trial;  /* extents; indices beyond them repeat the last entry */
+  const double* lin_y;   /* [n_outer] */
+  const double* lin_H;   /* [n_outer][36] row-major 6 x 6; a 3-dof optimiser reads the top-left 3 x 3 */
+  const double* lin_b;   /* [n_outer][6] */
+  const int* lin_n;      /* [n_outer] number of correspondences of that linearisation */
+  const double* err_y;   /* [n_outer][n_trial] */
+} orc_lm_script;
+void orc_reg_set_script(orc_reg* r, const orc_lm_script* s);
+/* the setters of the LM drivers' knobs on a live object (setRotationEpsilon, setTransformationEpsilon, setMaximumIterations, setInitialLambdaFactor, setOptimizerType,
+ * lm_max_iterations_): everything cached — covariances, map, correspondences — is kept, as the reference's setters keep it */
+void orc_reg_set_driver_params(orc_reg* r, const orc_params* p);
 void orc_reg_clear_trace(orc_reg* r);
 
 /* stand-alone pieces, for unit parity */

@@ -23,7 +23,13 @@ class Params(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("n_outer", C.c_int), ("converged", C.c_int), ("lm_failed", C.c_int), ("n_passes", C.c_int),
-                ("n_correspondences", C.c_int)]
+                ("n_correspondences", C.c_int), ("n_cost_only", C.c_int)]
+
+
+class LmScript(C.Structure):
+    """rolo_lm_script (include/rolo_hip.h): scripted pass results for the test hook rolo_debug_lm_script_*"""
+    _fields_ = [("n_outer", C.c_int), ("n_trial", C.c_int), ("lin_y", C.POINTER(C.c_double)), ("lin_H", C.POINTER(C.c_double)),
+                ("lin_b", C.POINTER(C.c_double)), ("lin_n", C.POINTER(C.c_int32)), ("err_y", C.POINTER(C.c_double))]
 
 
 class TraceRec(C.Structure):
@@ -148,6 +154,8 @@ SYMBOLS = {
     "rolo_shard_range": (None, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "rolo_comm_info": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "rolo_set_shard_knn": (C.c_int, [vp, C.c_int]),
+    "rolo_debug_lm_script_align": (C.c_int, [vp, C.POINTER(LmScript), fp, C.c_int, fp, dp, C.POINTER(Stats)]),
+    "rolo_debug_lm_script_translation": (C.c_int, [vp, C.POINTER(LmScript), dp, dp, dp, C.c_double, C.c_double, C.c_float, C.c_int, C.POINTER(Stats)]),
     "rolo_set_load_hint": (C.c_int, [vp, C.c_int]),
     "rolo_set_shard": (C.c_int, [vp, C.c_int, C.c_int]),
     "rolo_comm_unique_id": (C.c_int, [vp]),

@@ -188,6 +188,7 @@ struct rolo_ctx {
   bool gseen_valid = false;
   hipGraph_t graph = nullptr;
   hipGraphExec_t graph_exec = nullptr;
+  bool graph_nrm_written = false;   // the captured build_clouds left the PLANE covariances as I - m m^T too (CloudDev::have_nrm after a replay)
   // per-kernel event timing (rolo_prof_*)
   bool prof_on = false;
   struct ProfEv { int slot; hipEvent_t a, b; };
@@ -547,7 +548,7 @@ void fill_rot_outputs(const LmState* s, float* Tf, double* Td, rolo_stats* st) {
   T[12] = T[13] = T[14] = 0; T[15] = 1;
   if (Td) memcpy(Td, T, sizeof(T));
   if (Tf) for (int i = 0; i < 16; i++) Tf[i] = (float)T[i];
-  if (st) { st->n_outer = s->rot_outer; st->converged = s->rot_converged; st->lm_failed = s->rot_failed; st->n_passes = s->rot_passes; st->n_correspondences = s->rot_ncorr; }
+  if (st) { st->n_outer = s->rot_outer; st->converged = s->rot_converged; st->lm_failed = s->rot_failed; st->n_passes = s->rot_passes; st->n_correspondences = s->rot_ncorr; st->n_cost_only = s->rot_cost_only; }
 }
 
 int rot_first_chunk(const rolo_ctx* c) { return c->P.fixed_iterations > 0 ? c->P.fixed_iterations + 3 : 8; }
@@ -1203,9 +1204,66 @@ int rolo_compute_translation(rolo_ctx* c, double* trans, const double* g3, const
   if ((rc = run_stage(c, a, grid, 2, 12))) return rc;
   const LmState* s = c->h_state;
   for (int i = 0; i < 3; i++) trans[i] = s->t0[i];
-  if (stats) { stats->n_outer = s->trans_outer; stats->converged = s->trans_failed ? 0 : 1; stats->lm_failed = s->trans_failed; stats->n_passes = s->trans_passes; stats->n_correspondences = s->tr_n_corr; }
+  if (stats) { stats->n_outer = s->trans_outer; stats->converged = s->trans_failed ? 0 : 1; stats->lm_failed = s->trans_failed; stats->n_passes = s->trans_passes; stats->n_correspondences = s->tr_n_corr; stats->n_cost_only = s->trans_cost_only; }
   if (s->error) { g_err = "device-side error during computeTranslation"; return s->error; }
   return ROLO_OK;
+}
+
+// ---- test hook: the controller kernels on scripted pass results (include/rolo_hip.h rolo_lm_script) -------------------------------------------
+static int script_stage(rolo_ctx* c, const rolo_lm_script* S, int stage, int dof, int generic_ctrl) {
+  if (!S || S->n_outer < 1 || S->n_trial < 1 || !S->lin_y || !S->lin_H || !S->lin_b || !S->lin_n || !S->err_y) { g_err = "bad LM script"; return ROLO_EINVAL; }
+  int rc = ensure(c->partials, c->partials_cap, (size_t)NV_MAX);
+  if (rc) return rc;
+  const int hard_cap = (std::max(c->P.max_iterations, c->P.fixed_iterations) + 2) * (std::max(c->P.lm_max_iterations, 0) + 2) + 8;
+  for (int it = 0; it <= hard_cap; it++) {
+    if ((rc = fetch_state(c))) return rc;
+    const LmState* s = c->h_state;
+    if (stage == 1 ? s->rot_done != 0 : s->trans_done != 0) return ROLO_OK;
+    double row[NV_MAX];
+    for (double& v : row) v = __builtin_nan("");
+    auto put_lin = [&](int o) {
+      o = std::min(std::max(o, 0), S->n_outer - 1);
+      row[V_Y] = S->lin_y[o]; row[V_N] = (double)S->lin_n[o];
+      int t = 0;
+      for (int i = 0; i < dof; i++) for (int j = 0; j <= i; j++) row[V_H + t++] = S->lin_H[(size_t)o * 36 + i * 6 + j];
+      for (int i = 0; i < dof; i++) row[V_B + i] = S->lin_b[(size_t)o * 6 + i];
+    };
+    if (s->phase == 0) put_lin(s->outer);   // a linearise-only pass: the stage's first, or the one after a trial accepted on a cost-only pass
+    else {
+      row[V_YI] = S->err_y[(size_t)std::min(std::max(s->outer, 0), S->n_outer - 1) * S->n_trial + std::min(std::max(s->trial, 0), S->n_trial - 1)];
+      if (!s->lin_skip) put_lin(s->outer + 1);   // half (B) of a full pass: the linearisation at the trial pose = the one that opens the next outer iteration
+    }
+    HIPCHK(hipMemcpyAsync(c->partials, row, sizeof(row), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(launch_ctrl(c->state, c->partials, 1, nullptr, c->trace, stage, c->stream, nullptr, nullptr, generic_ctrl ? 0 : dof));
+  }
+  g_err = "scripted LM stage did not terminate";
+  return ROLO_ESTATE;
+}
+extern "C" int rolo_debug_lm_script_align(rolo_ctx* c, const rolo_lm_script* S, const float* guess16, int generic_ctrl, float* Tf, double* Td, rolo_stats* stats) {
+  if (!c) return ROLO_EINVAL;
+  if (c->async_pending) { g_err = "a registration is in flight on this context"; return ROLO_ESTATE; }
+  int rc = set_device(c); if (rc) return rc;
+  double R[9], t[3]; guess_to_Rt(guess16, R, t);
+  HIPCHK(launch_rot_begin(c->state, make_rot_begin(c, R, t, 0), c->stream));
+  if ((rc = script_stage(c, S, 1, c->P.optimizer == ROLO_OPT_SO3_LM ? 3 : 6, generic_ctrl))) return rc;
+  c->have_corr = c->h_state->tr_n_corr > 0;   // what computeTranslation asks for: a linearisation that left correspondences
+  fill_rot_outputs(c->h_state, Tf, Td, stats);
+  return c->h_state->error;
+}
+extern "C" int rolo_debug_lm_script_translation(rolo_ctx* c, const rolo_lm_script* S, double* trans, const double* g3, const double* l3, double dtn, double dtn1, float lam,
+                                                int generic_ctrl, rolo_stats* stats) {
+  if (!c || !trans || !g3 || !l3) return ROLO_EINVAL;
+  if (!c->have_corr) { g_err = "computeTranslation needs the correspondences of a previous align"; return ROLO_ENOCORR; }
+  int rc = set_device(c); if (rc) return rc;
+  TransBegin tb{};
+  for (int i = 0; i < 3; i++) { tb.t0[i] = trans[i]; tb.g[i] = g3[i]; tb.l[i] = l3[i]; }
+  tb.dtn = dtn; tb.dtn1 = dtn1; tb.ct_lambda = lam; tb.direct = 1;
+  HIPCHK(launch_trans_begin(c->state, tb, c->stream));
+  if ((rc = script_stage(c, S, 2, 6, generic_ctrl))) return rc;
+  const LmState* s = c->h_state;
+  for (int i = 0; i < 3; i++) trans[i] = s->t0[i];
+  if (stats) { stats->n_outer = s->trans_outer; stats->converged = s->trans_failed ? 0 : 1; stats->lm_failed = s->trans_failed; stats->n_passes = s->trans_passes; stats->n_correspondences = s->tr_n_corr; stats->n_cost_only = s->trans_cost_only; }
+  return s->error;
 }
 
 // everything of one frame after the clouds are on the device; per-frame arguments come from c->h_args (pinned)
@@ -1300,7 +1358,7 @@ static int register_async_impl(rolo_ctx* c, const float* guess16, const double* 
       HIPCHK(hipGraphLaunch(c->graph_exec, c->stream));
       c->n_replays++;
       c->src.have_cov = true; c->tgt.have_cov = true; c->src.have_sorted = true; c->tgt.have_sorted = true;
-      c->src.have_nrm = c->tgt.have_nrm = c->P.regularization == ROLO_REG_PLANE && !(c->comm || peers(c) || (c->world > 1 && c->shard_knn));   // as the captured build_clouds left them
+      c->src.have_nrm = c->tgt.have_nrm = c->graph_nrm_written;   // what build_clouds decided when this graph was captured (recorded then, not re-derived: advisor, round 5)
       c->async_pending = true;
       return ROLO_OK;
     }
@@ -1314,6 +1372,7 @@ static int register_async_impl(rolo_ctx* c, const float* guess16, const double* 
       const bool epoch_moved = key.epoch != g_alloc_epoch;  // an allocation inside the capture would be a bug; fall back
       if (rc == ROLO_OK && e == hipSuccess && gph && !epoch_moved && hipGraphInstantiate(&c->graph_exec, gph, nullptr, nullptr, 0) == hipSuccess) {
         c->graph = gph; c->gkey = key;
+        c->graph_nrm_written = c->src.have_nrm && c->tgt.have_nrm;
         HIPCHK(hipGraphLaunch(c->graph_exec, c->stream));
         c->n_captures++;
         c->async_pending = true;
@@ -1371,7 +1430,7 @@ int rolo_register_wait(rolo_ctx* c, float* Tf, double* Td, double* trans_out, ro
   if (!s->error) { update_hint(c->hint_rot, c->win_rot, s->rot_passes, lm_fused(c)); update_hint(c->hint_trans, c->win_trans, s->trans_passes, lm_fused(c)); }
   fill_rot_outputs(s, Tf, Td, rs);
   if (trans_out) for (int i = 0; i < 3; i++) trans_out[i] = s->t0[i];
-  if (ts) { ts->n_outer = s->trans_outer; ts->converged = s->trans_failed ? 0 : 1; ts->lm_failed = s->trans_failed; ts->n_passes = s->trans_passes; ts->n_correspondences = s->tr_n_corr; }
+  if (ts) { ts->n_outer = s->trans_outer; ts->converged = s->trans_failed ? 0 : 1; ts->lm_failed = s->trans_failed; ts->n_passes = s->trans_passes; ts->n_correspondences = s->tr_n_corr; ts->n_cost_only = s->trans_cost_only; }
   if (s->error) { g_err = "device-side error during registration"; return s->error; }
   return ROLO_OK;
 }
@@ -1599,7 +1658,7 @@ int rolo_batch_register_async(rolo_batch* b, const float* guess16, const double*
     if (b->graph_exec && same_keys(keys, b->gkey.k)) {
       HIPCHK(hipGraphLaunch(b->graph_exec, st));
       for (rolo_ctx* c : b->m) { c->src.have_cov = true; c->tgt.have_cov = true; c->src.have_sorted = true; c->tgt.have_sorted = true;
-                                 c->src.have_nrm = c->tgt.have_nrm = c->P.regularization == ROLO_REG_PLANE; }
+                                 c->src.have_nrm = c->tgt.have_nrm = c->graph_nrm_written; }   // as recorded when the batch's graph was captured
       b->pending = true;
       return ROLO_OK;
     }
@@ -1613,6 +1672,7 @@ int rolo_batch_register_async(rolo_batch* b, const float* guess16, const double*
       const bool epoch_moved = keys[0].epoch != g_alloc_epoch;
       if (rc == ROLO_OK && e == hipSuccess && gph && !epoch_moved && hipGraphInstantiate(&b->graph_exec, gph, nullptr, nullptr, 0) == hipSuccess) {
         b->graph = gph; b->gkey.k = keys;
+        for (rolo_ctx* c : b->m) c->graph_nrm_written = c->src.have_nrm && c->tgt.have_nrm;
         HIPCHK(hipGraphLaunch(b->graph_exec, st));
         b->pending = true;
         return ROLO_OK;
@@ -1656,7 +1716,7 @@ int rolo_batch_register_wait(rolo_batch* b, float* Tf, double* Td, double* trans
     const LmState* s = c->h_state;
     fill_rot_outputs(s, Tf ? Tf + 16 * (size_t)i : nullptr, Td ? Td + 16 * (size_t)i : nullptr, rs ? rs + i : nullptr);
     if (trans_out) for (int d = 0; d < 3; d++) trans_out[3 * i + d] = s->t0[d];
-    if (ts) { ts[i].n_outer = s->trans_outer; ts[i].converged = s->trans_failed ? 0 : 1; ts[i].lm_failed = s->trans_failed; ts[i].n_passes = s->trans_passes; ts[i].n_correspondences = s->tr_n_corr; }
+    if (ts) { ts[i].n_outer = s->trans_outer; ts[i].converged = s->trans_failed ? 0 : 1; ts[i].lm_failed = s->trans_failed; ts[i].n_passes = s->trans_passes; ts[i].n_correspondences = s->tr_n_corr; ts[i].n_cost_only = s->trans_cost_only; }
     if (s->error && !first_err) { g_err = "device-side error in a batch member"; first_err = s->error; }
   }
   return first_err;

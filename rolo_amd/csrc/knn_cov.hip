@@ -580,8 +580,14 @@ ROLO_DEV void knn_covariance_finish(double cxx, double cxy, double cxz, double c
       // s = U's sign on the third column (-1 only for a rank-deficient neighbourhood whose zero singular value came out of the sweep with a minus sign)
       const double s3 = U[0 * 3 + 2] * V[0 * 3 + 2] + U[1 * 3 + 2] * V[1 * 3 + 2] + U[2 * 3 + 2] * V[2 * 3 + 2];   // +-1 to rounding
       const double al = sqrt(1.0 - (s3 < 0 ? -1e-3 : 1e-3));
+      // The identity needs u0 = v0 and u1 = v1. A neighbourhood of rank <= 1 (collinear or coincident neighbours: TWO singular values ~ 0) can leave the sweep with the
+      // sign fix on the second column as well (or, for coincident points, on all three): the six entries above are then NOT I - m m^T, and they are what the voxel map
+      // and every getter see. Such a point is poisoned — NaN in m.x — and the passes take its six entries instead (passes.hip load_pt / rotated_cov): advisor, round 5.
+      const double s1 = U[0 * 3 + 0] * V[0 * 3 + 0] + U[1 * 3 + 0] * V[1 * 3 + 0] + U[2 * 3 + 0] * V[2 * 3 + 0];
+      const double s2 = U[0 * 3 + 1] * V[0 * 3 + 1] + U[1 * 3 + 1] * V[1 * 3 + 1] + U[2 * 3 + 1] * V[2 * 3 + 1];
+      const bool plane_form = s1 > 0 && s2 > 0;
       const size_t pn = (size_t)n;
-      nrm[qi] = al * V[0 * 3 + 2]; nrm[pn + qi] = al * V[1 * 3 + 2]; nrm[2 * pn + qi] = al * V[2 * 3 + 2];
+      nrm[qi] = plane_form ? al * V[0 * 3 + 2] : __builtin_nan(""); nrm[pn + qi] = al * V[1 * 3 + 2]; nrm[2 * pn + qi] = al * V[2 * 3 + 2];
     }
   }
   const size_t pitch = (size_t)n;
@@ -787,7 +793,17 @@ hipError_t launch_knn_walk(const KnnPair& A, int k, int regularization_or_minus1
       if (lanes_out) *lanes_out = lanes ? lanes : 1;
       // ROLO_KNN_WALK_WGS = workgroups of the walk a CU may hold at a time (through a dynamic-LDS pad; unset / 0: as many as fit): with two lanes per query the
       // dense frame's 8192 wavefronts fill all 8 wave slots of every SIMD, and whatever another context has queued waits for slots until the walk thins out
-      static const int walk_pad = [] { const char* e = getenv("ROLO_KNN_WALK_WGS"); const int v = e ? atoi(e) : 0; return (v >= 1 && v <= 8) ? (160 * 1024 / v - 1024 - 512) & ~255 : 0; }();
+      static const int walk_pad = [] {
+        const char* e = getenv("ROLO_KNN_WALK_WGS"); const int v = e ? atoi(e) : 0;
+        const int pad_bytes = (v >= 1 && v <= 8) ? (160 * 1024 / v - 1024 - 512) & ~255 : 0;
+        if (pad_bytes > 48 * 1024) {   // above the default limit of dynamic LDS a launch needs the attribute raised (1 or 2 workgroups per CU); if the runtime refuses, the pad is dropped
+          bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_walk_kernel<20, false>), hipFuncAttributeMaxDynamicSharedMemorySize, pad_bytes) == hipSuccess;
+          ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_walk_sub_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, pad_bytes) == hipSuccess;
+          ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_walk_sub_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, pad_bytes) == hipSuccess;
+          if (!ok) { (void)hipGetLastError(); fprintf(stderr, "librolo_hip: ROLO_KNN_WALK_WGS=%d needs %d bytes of dynamic LDS, which this runtime refuses: ignored\n", v, pad_bytes); return 0; }
+        }
+        return pad_bytes;
+      }();
       if (lanes == 4) { const int s0 = (n0 + 63) / 64, s1 = (n1 + 63) / 64; knn_walk_sub_kernel<4><<<s0 + s1, 256, walk_pad, s>>>(A, s0); }
       else if (lanes == 2) { const int s0 = (n0 + 127) / 128, s1 = (n1 + 127) / 128; knn_walk_sub_kernel<2><<<s0 + s1, 256, walk_pad, s>>>(A, s0); }
       else knn_walk_kernel<20, false><<<g0 + g1, 256, walk_pad, s>>>(A, g0, k, -1);

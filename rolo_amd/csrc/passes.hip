@@ -220,8 +220,11 @@ ROLO_DEV PtIn load_pt(const PassArgs& a, int i) {
   PtIn o{};
   o.pf = a.src[i];
   const size_t pitch = (size_t)a.n_total;
-  if (a.nrm) o.m = Vec3{a.nrm[i], a.nrm[pitch + i], a.nrm[2 * pitch + i]};
-  else o.CA = Sym3{a.cov[i], a.cov[pitch + i], a.cov[2 * pitch + i], a.cov[3 * pitch + i], a.cov[4 * pitch + i], a.cov[5 * pitch + i]};
+  if (a.nrm) {
+    o.m = Vec3{a.nrm[i], a.nrm[pitch + i], a.nrm[2 * pitch + i]};
+    if (o.m.x == o.m.x) return o;   // (NaN: a rank <= 1 neighbourhood whose covariance is not of the plane form — knn_covariance_finish — takes its six entries)
+  }
+  o.CA = Sym3{a.cov[i], a.cov[pitch + i], a.cov[2 * pitch + i], a.cov[3 * pitch + i], a.cov[4 * pitch + i], a.cov[5 * pitch + i]};
   return o;
 }
 // R (I - m m^T) R^T = R R^T - (R m)(R m)^T. R R^T is NOT taken as the identity: a caller's guess arrives as a float matrix, orthonormal to 1e-7 only, and the
@@ -229,7 +232,7 @@ ROLO_DEV PtIn load_pt(const PassArgs& a, int i) {
 // solve started from a float guess. The product comes from the LM state, where the controller keeps it next to each rotation (lm_set_rrt): 9 + 6 multiply-adds per
 // lane are left of the rotation's 45.
 ROLO_DEV Sym3 rotated_cov(const PassArgs& a, const double* R, const double* __restrict__ S6 /* R R^T from the LM state (lm_set_rrt) */, const PtIn& in) {
-  if (a.nrm) {
+  if (a.nrm && in.m.x == in.m.x) {
     const Sym3 S{uni(S6[0]), uni(S6[1]), uni(S6[2]), uni(S6[3]), uni(S6[4]), uni(S6[5])};
     const Vec3 q = mat3_mulv(R, in.m);
     return Sym3{S.xx - q.x * q.x, S.xy - q.x * q.y, S.xz - q.x * q.z, S.yy - q.y * q.y, S.yz - q.y * q.z, S.zz - q.z * q.z};
@@ -260,7 +263,7 @@ ROLO_DEV void rot_pass_compute(const PassArgs& a, const LmState* __restrict__ st
     // (A) compute_error(xi): cached correspondences, Mahalanobis of the linearisation pose x0
     // (round 5 measured the reference's per-correspondence Mahalanobis cache here — six fp64 of M(x0) per point, written by the (B) half, read by the next
     // trial's (A) half, rot_vgicp_impl.hpp:204-222 — and it LOST: 96 B per point and pass of extra traffic cost more than the ~100 instructions saved,
-    // 2694 against 2875 scans/s; profiles/DEAD_ENDS.md. The translation stage, whose M is constant, does cache it: trans_pass_compute.)
+    // 2694 against 2875 scans/s; profiles/DEAD_ENDS.md. Neither stage caches M: the translation stage's cache, whose M is constant, measured neutral and is not kept either.)
     if (phase == 1) {
       const Sym3 RCA0 = rotated_cov(a, R0, st->x0_S, in);
       for (int o = 0; o < n_off; o++) {
@@ -630,6 +633,16 @@ ROLO_DEV void trace_push(LmState* __restrict__ st, rolo_trace_rec* __restrict__ 
   r.dnorm = sqrt(dn);
 }
 
+// The damping update lambda * max(1/3, 1 - pow(2 rho - 1, 3)) (lsq_registration_impl.hpp:129, 262, 318): std::pow(double, int) is glibc's pow, whose result is the
+// correctly rounded cube but for arguments within ~0.02 ulp of a rounding tie; q * q * q rounds twice and lands one ulp off for about a quarter of all q. The cube here
+// carries the rounding errors of both products along (two-product through fma) and rounds once: lambda — and with it every later step of the stage — follows the CPU's bits.
+ROLO_DEV double cube_rn(double q) {
+  const double p = q * q, ep = fma(q, q, -p);        // q^2 = p + ep exactly
+  const double r = p * q, er = fma(p, q, -r);        // p q = r + er exactly
+  return r + (er + ep * q);
+}
+ROLO_DEV double lm_lambda_after_accept(double lambda, double rho) { return lambda * fmax(1.0 / 3.0, 1 - cube_rn(2 * rho - 1)); }
+
 // ---- rotation / 6-dof stage -------------------------------------------------------------------------------
 ROLO_DEV bool delta_converged(const LmState* __restrict__ st, bool rot_only) {  // lsq_registration_impl.hpp:182-191 / :328-335
   const double ir = st->inv_rot_eps;   // (1.0 / eps) * |.| as the reference writes it; the quotient is formed once per frame (rot_begin_dev)
@@ -699,7 +712,7 @@ ROLO_DEV void trans_consts(LmState* st) {
 ROLO_DEV void trans_start(LmState* st) {  // lsq_registration_impl.hpp:55-61
   trans_consts(st);
   st->stage = 2; st->phase = 0; st->lin_skip = 0; st->outer = 0; st->trial = 0; st->lambda = -1.0;
-  st->trans_done = 0; st->trans_failed = 0; st->trans_outer = 0; st->trans_passes = 0;
+  st->trans_done = 0; st->trans_failed = 0; st->trans_outer = 0; st->trans_passes = 0; st->trans_cost_only = 0;
   for (int i = 0; i < 3; i++) st->tt[i] = st->t0[i];
   // lambda_/pt_size: float / size_t -> float (rot_vgicp.hpp:124, rot_vgicp_impl.hpp:557)
   st->lam_over_n = (double)(st->ct_lambda / (float)st->tr_n_corr);
@@ -708,7 +721,9 @@ ROLO_DEV void trans_start(LmState* st) {  // lsq_registration_impl.hpp:55-61
 
 ROLO_DEV void rot_finish(LmState* st, bool converged, bool failed) {
   st->rot_done = 1; st->rot_converged = converged ? 1 : 0; st->rot_failed = failed ? 1 : 0;
-  st->rot_outer = st->outer; st->rot_ncorr = st->tr_n_corr;
+  // outer iterations STARTED = nr_iterations_ + 1 (lsq_registration_impl.hpp:163): `outer` counts the completed ones, and a step that returns false ("lm not converged!!",
+  // :166-169) leaves the loop inside an iteration it never completes
+  st->rot_outer = st->outer + (failed && !st->error ? 1 : 0); st->rot_ncorr = st->tr_n_corr;
   if (st->run_trans && !st->error) trans_start(st);
   else st->stage = 0;
 }
@@ -717,7 +732,10 @@ template <int DOF>
 ROLO_DEV void rot_step_t(LmState* __restrict__ st, const double* __restrict__ S, rolo_trace_rec* __restrict__ trace) {
   constexpr int dof = DOF;
   st->rot_passes++;
+  if (st->phase == 1 && st->lin_skip) st->rot_cost_only++;
   if (st->phase == 0) {
+    // max_iterations <= 0: the loop of computeTransformation (:161) never runs — no linearisation, no correspondences, the guess comes back (this first pass was evaluated for nothing)
+    if (st->outer == 0 && st->fixed_iterations <= 0 && st->max_iterations <= 0) { st->tr_n_corr = 0; st->n_corr = 0; rot_finish(st, false, false); return; }
     for (int i = 0; i < 9; i++) st->x0_R[i] = st->xt_R[i];
     for (int i = 0; i < 6; i++) st->x0_S[i] = st->xt_S[i];
     for (int i = 0; i < 3; i++) st->x0_t[i] = st->xt_t[i];
@@ -728,6 +746,8 @@ ROLO_DEV void rot_step_t(LmState* __restrict__ st, const double* __restrict__ S,
     if (st->n_corr <= 0) { st->error = ROLO_ENOCORR; rot_finish(st, false, true); return; }
     st->phase = 1; st->lin_skip = 0;
     rot_begin_outer<DOF>(st);
+    // lm_max_iterations <= 0: the trial loop (:233, :287) has no iteration — the step returns false right after its linearisation (Gauss-Newton has no such loop)
+    if (st->optimizer != ROLO_OPT_GN && st->lm_max <= 0) rot_finish(st, false, true);
     return;
   }
   const double yi = S[V_YI];
@@ -760,7 +780,7 @@ ROLO_DEV void rot_step_t(LmState* __restrict__ st, const double* __restrict__ S,
   for (int i = 0; i < 9; i++) st->x0_R[i] = st->xt_R[i];
   for (int i = 0; i < 6; i++) st->x0_S[i] = st->xt_S[i];
   for (int i = 0; i < 3; i++) st->x0_t[i] = st->xt_t[i];
-  if (!gn) { const double q = 2 * rho - 1; st->lambda = st->lambda * fmax(1.0 / 3.0, 1 - q * q * q); }
+  if (!gn) st->lambda = lm_lambda_after_accept(st->lambda, rho);
   if (dof == 6) for (int i = 0; i < 36; i++) st->final_H[i] = st->H[i];  // final_hessian_ = H
   st->outer++;
   const bool conv = delta_converged(st, false);
@@ -793,17 +813,20 @@ ROLO_DEV bool t_converged(const LmState* __restrict__ st) {  // :142-148
   return m < 1;
 }
 ROLO_DEV void trans_finish(LmState* st, bool failed) {
-  st->trans_done = 1; st->trans_failed = failed ? 1 : 0; st->trans_outer = st->outer; st->stage = 0;
+  st->trans_done = 1; st->trans_failed = failed ? 1 : 0; st->trans_outer = st->outer + (failed ? 1 : 0) /* iterations started: rot_finish */; st->stage = 0;
 }
 
 ROLO_DEV void trans_step(LmState* __restrict__ st, const double* __restrict__ S, rolo_trace_rec* __restrict__ trace) {
   st->trans_passes++;
+  if (st->phase == 1 && st->lin_skip) st->trans_cost_only++;
   if (st->phase == 0) {
+    if (st->outer == 0 && st->max_iterations <= 0) { trans_finish(st, false); return; }   // the loop of computeTranslation (:63) never runs: the start value comes back
     const int keep = st->n_corr;
     unpack_hb<6>(st, S);
     st->n_corr = keep;
     st->phase = 1; st->lin_skip = 0;
     trans_begin_outer(st);
+    if (st->lm_max <= 0) trans_finish(st, true);   // no trial at all (:98): "lm not converged!!" right after the linearisation
     return;
   }
   const double yi = S[V_YI];
@@ -823,7 +846,7 @@ ROLO_DEV void trans_step(LmState* __restrict__ st, const double* __restrict__ S,
   }
   trace_push<6>(st, trace, 1, 1, yi, rho);
   for (int i = 0; i < 3; i++) st->t0[i] = st->tt[i];
-  { const double q = 2 * rho - 1; st->lambda = st->lambda * fmax(1.0 / 3.0, 1 - q * q * q); }
+  st->lambda = lm_lambda_after_accept(st->lambda, rho);
   st->outer++;
   const bool conv = t_converged(st);
   if (conv || st->outer >= st->max_iterations) { trans_finish(st, false); return; }

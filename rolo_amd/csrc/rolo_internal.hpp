@@ -121,6 +121,7 @@ struct LmState {
   // six rejections — so the controller marks the next pass lin_skip = 1: (A) only. If that trial is accepted after all, the controller sets phase = 0 and the next pass
   // linearises at the accepted pose: the state after it is the one the full pass would have left, one launch later. spec_lin = 0 (ROLO_LM_SPEC_LIN=0) never skips.
   int lin_skip, spec_lin;
+  int rot_cost_only, trans_cost_only;   // passes of rot_passes / trans_passes that ran with lin_skip set (counted by the step that consumes them): rolo_stats::n_cost_only
   // parameters
   int optimizer, max_iterations, fixed_iterations, lm_max, q2_intended;
   double rot_eps, trans_eps, lm_init;

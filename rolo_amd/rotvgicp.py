@@ -122,6 +122,11 @@ class RotVGICP:
         self._p.lm_init_lambda_factor = f
         self._push()
 
+    def setLmMaxIterations(self, n: int):
+        """lm_max_iterations_: a protected member without a setter in the reference (lsq_registration.hpp:104, default 10) — what a subclass can reach"""
+        self._p.lm_max_iterations = n
+        self._push()
+
     def setFixedIterations(self, n: int):
         """Harness knob (not in the reference): run exactly n outer iterations in align()."""
         self._p.fixed_iterations = n
@@ -313,6 +318,34 @@ class RotVGICP:
         check(lib().rolo_register_wait(self._h, _f(Tf), _d(Td), _d(t), C.byref(rs), C.byref(ts)), "rolo_register_wait")
         self.final_transformation_d = Td; self.last_stats = rs; self.last_translation_stats = ts
         return Tf, Td, t
+
+    # ---- test hook: the LM controllers on scripted pass results (rolo_debug_lm_script_*) ----
+    @staticmethod
+    def _script(lin_y, lin_H, lin_b, lin_n, err_y):
+        from ._lib import LmScript
+        a = dict(lin_y=np.ascontiguousarray(lin_y, np.float64), lin_H=np.ascontiguousarray(lin_H, np.float64), lin_b=np.ascontiguousarray(lin_b, np.float64),
+                 lin_n=np.ascontiguousarray(lin_n, np.int32), err_y=np.ascontiguousarray(err_y, np.float64))
+        O, T = a["err_y"].shape
+        assert a["lin_y"].shape == (O,) and a["lin_H"].shape == (O, 6, 6) and a["lin_b"].shape == (O, 6) and a["lin_n"].shape == (O,)
+        return LmScript(O, T, _d(a["lin_y"]), _d(a["lin_H"]), _d(a["lin_b"]), _i(a["lin_n"]), _d(a["err_y"])), a
+
+    def script_align(self, script, guess=None, generic_ctrl=False):
+        """computeTransformation on scripted evaluations (script = the five arrays of rolo_lm_script); returns the error code (0, or ROLO_ENOCORR, ...)"""
+        sc, keep = self._script(*script)
+        g = np.ascontiguousarray(guess, np.float32) if guess is not None else None
+        Tf = np.zeros((4, 4), np.float32); Td = np.zeros((4, 4)); st = Stats()
+        rc = lib().rolo_debug_lm_script_align(self._h, C.byref(sc), _f(g), int(generic_ctrl), _f(Tf), _d(Td), C.byref(st))
+        self.final_transformation_d = Td; self.last_stats = st
+        return rc
+
+    def script_translation(self, script, trans, init_guess, last_t0, interval_tn=0.1, interval_tn_1=0.1, ct_lambda=0.3, generic_ctrl=False):
+        sc, keep = self._script(*script)
+        t = np.array(trans, np.float64)
+        g = np.ascontiguousarray(init_guess, np.float64); l = np.ascontiguousarray(last_t0, np.float64)
+        st = Stats()
+        rc = lib().rolo_debug_lm_script_translation(self._h, C.byref(sc), _d(t), _d(g), _d(l), interval_tn, interval_tn_1, ct_lambda, int(generic_ctrl), C.byref(st))
+        self.last_translation_stats = st
+        return rc, t
 
     def getFinalHessian(self):
         H = np.zeros((6, 6))

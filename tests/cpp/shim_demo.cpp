@@ -87,7 +87,25 @@ static int debug_mode(const char* src_path, const char* tgt_path) {
   return 0;
 }
 
+// a stage that gives up: "lm not converged!!" on stderr (lsq_registration_impl.hpp:66-69, :166-169), the result still returned. lm_max_iterations_ is protected
+// in the reference (lsq_registration.hpp:104): a subclass sets it, there as here
+struct FewTrials : fast_gicp::RotVGICP<> { void setTrials(int n) { set_lm_max_iterations(n); } };
+static int lmfail_mode(const char* src_path, const char* tgt_path, int trials) {
+  rolo::Cloud::Ptr source = load(src_path), target = load(tgt_path);
+  rolo::Cloud aligned;
+  FewTrials rot_vgicp;
+  rot_vgicp.setPolarResolution(0.175, 0.175, 2.0);
+  rot_vgicp.setTrials(trials);
+  rot_vgicp.setInputTarget(target); rot_vgicp.setInputSource(source);
+  rot_vgicp.align(aligned);
+  std::array<double, 3> reg_t{0, 0, 0}, guess{-0.28, -0.04, -0.02}, last{-0.28, -0.04, -0.02};
+  rot_vgicp.computeTranslation(aligned, reg_t, guess, last, 0.1, 0.1, 0.3f);
+  std::printf("%.17g %.17g %.17g %d %zu\n", reg_t[0], reg_t[1], reg_t[2], rot_vgicp.hasConverged() ? 1 : 0, aligned.size());
+  return 0;
+}
+
 int main(int argc, char** argv) {
+  if (argc == 5 && std::strcmp(argv[1], "lmfail") == 0) return lmfail_mode(argv[2], argv[3], std::atoi(argv[4]));
   if (argc == 5 && std::strcmp(argv[1], "loop") == 0) return loop_mode(argv[2], argv[3], std::atoi(argv[4]));
   if (argc == 4 && std::strcmp(argv[1], "debug") == 0) return debug_mode(argv[2], argv[3]);
   if (argc < 3) { std::fprintf(stderr, "usage: shim_demo source.bin target.bin | shim_demo loop source.bin target.bin N\n"); return 1; }

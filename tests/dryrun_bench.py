@@ -30,6 +30,7 @@ torch.cuda.set_device = lambda *a, **k: None
 torch.cuda.synchronize = lambda *a, **k: None
 torch.cuda.Stream = lambda *a, **k: types.SimpleNamespace()
 torch.Tensor.cuda = lambda self, *a, **k: self
+torch.Tensor.pin_memory = lambda self, *a, **k: self
 _tensor, _empty = torch.tensor, torch.empty
 
 
@@ -69,8 +70,8 @@ class FakeRotVGICP:
         self.src = self.tgt = None
         self.pending = None
         self.n_frames = 0
-        self.last_stats = _Stats(n_passes=0, n_outer=0, n_correspondences=0, converged=1)
-        self.last_translation_stats = _Stats(n_passes=0, n_outer=0)
+        self.last_stats = _Stats(n_passes=0, n_outer=0, n_correspondences=0, converged=1, n_cost_only=0)
+        self.last_translation_stats = _Stats(n_passes=0, n_outer=0, n_cost_only=0)
 
     def setResolution(self, leaf): self.leaf = float(leaf)
     def setFixedIterations(self, n): self.fixed = int(n)
@@ -85,6 +86,8 @@ class FakeRotVGICP:
 
     def setInputTargetDevice(self, ptr, n, stride): self.tgt = self._view(ptr, n, stride)
     def setInputSourceDevice(self, ptr, n, stride): self.src = self._view(ptr, n, stride)
+    def setInputTarget(self, cloud): self.tgt = np.ascontiguousarray(cloud, np.float32)   # (the host_clouds leg hands host arrays over)
+    def setInputSource(self, cloud): self.src = np.ascontiguousarray(cloud, np.float32)
 
     def register_async(self, guess, t0, g, l, dtn=0.1, dtn1=0.1, lam=0.3):
         assert self.pending is None, "a registration is already in flight on this context"
@@ -102,15 +105,15 @@ class FakeRotVGICP:
             rc, Tf, Td, it, cv = o.align()
             rc2, t, tit = o.compute_translation(t0, g, l)
             assert rc == 0 and rc2 == 0
-            self.last_stats = _Stats(n_passes=int(it) + 1, n_outer=int(it), n_correspondences=int(o.correspondences()[0].shape[0]), converged=int(cv))
-            self.last_translation_stats = _Stats(n_passes=int(tit) + 1, n_outer=int(tit))
+            self.last_stats = _Stats(n_passes=int(it) + 1, n_outer=int(it), n_correspondences=int(o.correspondences()[0].shape[0]), converged=int(cv), n_cost_only=0)
+            self.last_translation_stats = _Stats(n_passes=int(tit) + 1, n_outer=int(tit), n_cost_only=0)
             return Tf, Td, t
-        self.last_stats = _Stats(n_passes=21, n_outer=20, n_correspondences=n, converged=1)
-        self.last_translation_stats = _Stats(n_passes=9, n_outer=2)
+        self.last_stats = _Stats(n_passes=21, n_outer=20, n_correspondences=n, converged=1, n_cost_only=14)
+        self.last_translation_stats = _Stats(n_passes=9, n_outer=2, n_cost_only=6)
         return np.eye(4, dtype=np.float32), np.eye(4), np.zeros(3)
 
     def trace(self):
-        return []   # (bench.py counts the cost-only passes of one untimed frame per pool pair from the device's LM trace)
+        return []
 
     def counters(self):
         return dict(frames=self.n_frames, graph_replays=0, graph_captures=0, eager_frames=self.n_frames, topup_frames=0, sync_chunks=0, hint_rot=0, hint_trans=0, walk_lanes=1)

@@ -148,3 +148,8 @@ def test_bench_control_flow_world8_gloo_dry_run():
     c5 = d["config5"]
     assert c5["pairs_per_rank"] == 1 and c5["scans_per_s_batch512"] > 0 and c5["schedule_timed_sweeps"]["frames"] == 3 * 2 or c5["schedule_timed_sweeps"]["frames"] >= 3
     assert "roofline" in d and "valu_issue" in d and "frame_hbm" in d
+    # round 6's keys: the convergence-driven regime, the iteration sweep and the host-cloud hand-over ran on every rank (their barriers line up) and report numbers
+    assert d["convergence_driven"]["scans_per_s"] > 0 and "passes_per_frame" in d["convergence_driven"], d["convergence_driven"]
+    assert set(d["iteration_sweep"]) >= {"20", "10", "2", "per_trial_us_under_load"}, d["iteration_sweep"]
+    assert all(d["host_clouds"][k]["scans_per_s"] > 0 for k in ("pinned_1ctx", "pinned_2ctx", "pageable_1ctx", "pageable_2ctx")), d["host_clouds"]
+    assert "cost_only_passes" in d["config"] and d["config"]["cost_only_passes"]["frames"] > 0
