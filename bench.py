@@ -652,6 +652,13 @@ def main():
                                                    "rotation": {"min": int(pl[:, 0].min()), "max": int(pl[:, 0].max())},
                                                    "translation": {"min": int(pl[:, 1].min()), "max": int(pl[:, 1].max())}, "frames_logged": int(pl.shape[0])}
         out["config"]["schedule"] = {k_: int(sum(c_[k_] for c_ in cnt)) for k_ in ("frames", "graph_replays", "graph_captures", "eager_frames", "topup_frames")}
+        # host side of a frame (round 5's verdict, item 2a): std::chrono inside rolo_register_async (the hipGraphLaunch) and rolo_register_wait, summed over every frame the
+        # contexts saw (warm-up, captures and eager frames included); one Python thread drives all contexts, so enqueue + wait_other per frame must stay well below the frame time
+        nfr_ = max(sum(c_["frames"] for c_ in cnt), 1)
+        out["host_enqueue_us_per_frame"] = 1e-3 * sum(c_.get("host_enqueue_ns", 0) for c_ in cnt) / nfr_
+        out["config"]["host_us_per_frame"] = {"enqueue": out["host_enqueue_us_per_frame"], "wait_blocked": 1e-3 * sum(c_.get("host_wait_blocked_ns", 0) for c_ in cnt) / nfr_,
+                                              "wait_other": 1e-3 * sum(c_.get("host_wait_other_ns", 0) for c_ in cnt) / nfr_, "frame_time_us": 1e6 / value,
+                                              "what": "host time inside rolo_register_async (graph launch) / blocked in rolo_register_wait's event wait / the rest of rolo_register_wait, per frame; one host thread drives all contexts"}
         passes = int(round(float(np.median(tot))))
         out["config"]["passes_per_frame"] = passes
         if cost_only:
@@ -674,99 +681,6 @@ def main():
                                    "what": "the headline's contexts closed, three foreign HIP streams created, the same number of contexts created again, the same timed rounds"}
         except Exception as e:  # pragma: no cover
             out["layout_check"] = {"error": repr(e)}
-
-    # ---- the two regimes a ROLO user runs, next to the forced-20 headline (round 5's verdict, item 3) + the iteration sweep ----------------------------------
-    # `value` above forces 20 outer iterations (BASELINE.json's metric); the reference itself stops at convergence (lsq_registration_impl.hpp:161-176) and hands
-    # HOST clouds to setInputTarget / setInputSource (src/lidarOdometry.cpp:466-467). Same pool, same contexts layout, short timed rounds (>= 5 rounds, >= 1 s).
-    def side_leg(iters, host=None, nctx=None):
-        """scans/s of `nctx` contexts in flight with `iters` forced iterations (0 = convergence-driven); host = None: device-resident pairs, "pinned" / "pageable": the pair
-        handed over as host arrays through rolo_set_target / rolo_set_source, the upload inside the timed region"""
-        nctx = len(ctxs) if nctx is None else nctx
-        cs = [new_ctx(iters=iters) for _ in range(nctx)]
-        log0 = len(pass_log)
-        try:
-            if host is None:
-                pass_log_on[0] = True
-                dt_, rr_ = timed(cs, args.steps, args.warmup, data, min_s=1.0)
-                pass_log_on[0] = False
-            else:
-                hp = host_pools[host]
-                k_ = [0]
-
-                def enq(g_):
-                    s_, t_ = hp[k_[0] % len(hp)]; k_[0] += 1
-                    g_.setInputTarget(t_); g_.setInputSource(s_)       # host arrays: hipMemcpyAsync H2D + pack on the context's stream, inside the timed region
-                    g_.register_async(None, zero3, guess, last, 0.1, 0.1, 0.3)
-
-                def steps_(k):
-                    for g_ in cs:
-                        enq(g_)
-                    for it_ in range(k):
-                        for g_ in cs:
-                            g_.register_wait()
-                            if it_ + 1 < k:
-                                enq(g_)
-                steps_(args.warmup)
-                rr_ = []
-                import gc
-                while True:
-                    gc.collect(); gc.disable(); barrier(); t0_ = time.perf_counter(); steps_(args.steps); barrier(); rr_.append(time.perf_counter() - t0_); gc.enable()
-                    if args.single_round or (len(rr_) >= 5 and (sum(rr_) >= 1.0 or len(rr_) >= 100)):
-                        break
-                dt_ = float(np.median(rr_))
-            r_ = {"scans_per_s": args.steps * nctx / dt_ * (world if args.mode == "replicas" else 1), "contexts": nctx, "timed_rounds": len(rr_)}
-            if host is None and len(pass_log) > log0:
-                pl_ = np.array(pass_log[log0:])
-                r_.update({"passes_per_frame": {"median": float(np.median(pl_[:, 0] + pl_[:, 1])), "min": int((pl_[:, 0] + pl_[:, 1]).min()), "max": int((pl_[:, 0] + pl_[:, 1]).max())},
-                           "cost_only_passes_median": float(np.median(pl_[:, 2])),
-                           "rot_outer": {"median": float(np.median(pl_[:, 3])), "min": int(pl_[:, 3].min()), "max": int(pl_[:, 3].max())},
-                           "trans_outer": {"median": float(np.median(pl_[:, 4])), "min": int(pl_[:, 4].min()), "max": int(pl_[:, 4].max())}})
-                del pass_log[log0:]
-            return r_
-        finally:
-            pass_log_on[0] = False
-            for c_ in cs:
-                c_.close()
-
-    if args.mode == "replicas" and B == 1 and not args.no_side_legs:
-        try:
-            out["convergence_driven"] = dict(side_leg(0), what="the same pool and contexts with fixed_iterations = 0: both stages stop at the reference's own convergence tests "
-                                                               "(lsq_registration_impl.hpp:161-176, :63-73) — what a ROLO node runs; `value` forces 20 rotation iterations")
-        except Exception as e:  # pragma: no cover
-            out["convergence_driven"] = {"error": repr(e)}
-        try:
-            sweep = {"20": {"scans_per_s": value}}
-            for it_ in (10, 2):
-                sweep[str(it_)] = side_leg(it_)
-            v20, v10, v2 = sweep["20"]["scans_per_s"], sweep["10"]["scans_per_s"], sweep["2"]["scans_per_s"]
-            p20 = passes; p10 = sweep["10"].get("passes_per_frame", {}).get("median", 0); p2 = sweep["2"].get("passes_per_frame", {}).get("median", 0)
-            # per-trial cost under load = d(frame time) / d(passes); what is left at zero passes = the search + map + build share of a frame
-            per_trial_us = 1e6 * (1.0 / v20 - 1.0 / v2) / max(p20 - p2, 1)
-            out["iteration_sweep"] = dict(sweep, per_trial_us_under_load=per_trial_us, frame_share_without_lm_ms=1e3 * (1.0 / v20) - 1e-3 * per_trial_us * p20,
-                                          what="forced rotation iterations 20 / 10 / 2 with the headline's contexts: the slope prices one LM trial (pass + controller launch) under load, "
-                                               "the intercept the search + map + build of a frame (frame time = 1 / scans_per_s: the contexts overlap)")
-        except Exception as e:  # pragma: no cover
-            out["iteration_sweep"] = {"error": repr(e)}
-        try:
-            host_pools = {}
-            for kind_ in ("pageable", "pinned"):
-                hp_ = []
-                for s_, t_ in [pairs[i_ % len(pairs)] for i_ in range(5)]:   # (five: with four contexts in flight a context then sees a different array every frame — the same array again is a no-op, rot_vgicp_impl.hpp:113-115)
-                    if kind_ == "pinned":
-                        hp_.append((torch.from_numpy(np.ascontiguousarray(s_)).pin_memory().numpy(), torch.from_numpy(np.ascontiguousarray(t_)).pin_memory().numpy()))
-                    else:
-                        hp_.append((np.ascontiguousarray(s_).copy(), np.ascontiguousarray(t_).copy()))
-                host_pools[kind_] = hp_
-            hc = {}
-            for kind_ in ("pinned", "pageable"):
-                for nc_ in (1, len(ctxs)):
-                    hc[f"{kind_}_{nc_}ctx"] = side_leg(None, host=kind_, nctx=nc_)
-            hc["bytes_uploaded_per_frame"] = 2 * n * 16
-            hc["what"] = ("the 131 072-point pair handed over as HOST arrays through rolo_set_target / rolo_set_source (lidarOdometry.cpp:466-467: what the unchanged caller does), "
-                          "H2D inside the timed region, 20 forced iterations; pinned = page-locked caller buffers, pageable = plain malloc'd arrays (the runtime stages them)")
-            out["host_clouds"] = hc
-        except Exception as e:  # pragma: no cover
-            out["host_clouds"] = {"error": repr(e)}
 
     # ---- frame-level HBM figures of BASELINE.json's metric ("scans/sec ...; achieved HBM GB/s") -------------------------------------
     # algorithmic: SURVEY.md 8d's bytes of one frame — 360 B/pt covariances for both clouds, 136 B/pt + 96 B/voxel map build, and
@@ -957,6 +871,108 @@ def main():
             barrier()
         except Exception as e:  # pragma: no cover
             out["sharded"] = {"error": repr(e)}
+
+    # ---- the two regimes a ROLO user runs, next to the forced-20 headline (round 5's verdict, item 3) + the iteration sweep ----------------------------------
+    # `value` above forces 20 outer iterations (BASELINE.json's metric); the reference itself stops at convergence (lsq_registration_impl.hpp:161-176) and hands
+    # HOST clouds to setInputTarget / setInputSource (src/lidarOdometry.cpp:466-467). Same pool, same contexts layout, short timed rounds (>= 5 rounds, >= 1 s).
+    def side_leg(iters, host=None, nctx=None):
+        """scans/s of `nctx` contexts in flight with `iters` forced iterations (0 = convergence-driven); host = None: device-resident pairs, "pinned" / "pageable": the pair
+        handed over as host arrays through rolo_set_target / rolo_set_source, the upload inside the timed region"""
+        nctx = n_side_ctx if nctx is None else nctx
+        cs = [new_ctx(iters=iters) for _ in range(nctx)]
+        log0 = len(pass_log)
+        try:
+            if host is None:
+                pass_log_on[0] = True
+                dt_, rr_ = timed(cs, args.steps, args.warmup, data, min_s=1.0)
+                pass_log_on[0] = False
+            else:
+                hp = host_pools[host]
+                k_ = [0]
+
+                def enq(g_):
+                    s_, t_ = hp[k_[0] % len(hp)]; k_[0] += 1
+                    g_.setInputTarget(t_); g_.setInputSource(s_)       # host arrays: hipMemcpyAsync H2D + pack on the context's stream, inside the timed region
+                    g_.register_async(None, zero3, guess, last, 0.1, 0.1, 0.3)
+
+                def steps_(k):
+                    for g_ in cs:
+                        enq(g_)
+                    for it_ in range(k):
+                        for g_ in cs:
+                            g_.register_wait()
+                            if it_ + 1 < k:
+                                enq(g_)
+                steps_(args.warmup)
+                rr_ = []
+                import gc
+                while True:
+                    gc.collect(); gc.disable(); barrier(); t0_ = time.perf_counter(); steps_(args.steps); barrier(); rr_.append(time.perf_counter() - t0_); gc.enable()
+                    if args.single_round or (len(rr_) >= 5 and (sum(rr_) >= 1.0 or len(rr_) >= 100)):
+                        break
+                dt_ = float(np.median(rr_))
+            r_ = {"scans_per_s": args.steps * nctx / dt_ * (world if args.mode == "replicas" else 1), "contexts": nctx, "timed_rounds": len(rr_)}
+            if host is None and len(pass_log) > log0:
+                pl_ = np.array(pass_log[log0:])
+                r_.update({"passes_per_frame": {"median": float(np.median(pl_[:, 0] + pl_[:, 1])), "min": int((pl_[:, 0] + pl_[:, 1]).min()), "max": int((pl_[:, 0] + pl_[:, 1]).max())},
+                           "cost_only_passes_median": float(np.median(pl_[:, 2])),
+                           "rot_outer": {"median": float(np.median(pl_[:, 3])), "min": int(pl_[:, 3].min()), "max": int(pl_[:, 3].max())},
+                           "trans_outer": {"median": float(np.median(pl_[:, 4])), "min": int(pl_[:, 4].min()), "max": int(pl_[:, 4].max())}})
+                del pass_log[log0:]
+            return r_
+        finally:
+            pass_log_on[0] = False
+            for c_ in cs:
+                c_.close()
+
+    if args.mode == "replicas" and B == 1 and not args.no_side_legs:
+        # the headline's contexts are closed first: their streams go back to the library's bank and the legs' contexts take the SAME streams — contexts created next to
+        # four idle ones get another burst of streams, which HIP may deal to its hardware queues differently (measured: 10 forced iterations 2715 scans/s beside the idle
+        # headline contexts against 3811 on their streams; DESIGN section 8 "stream bank")
+        n_side_ctx = len(ctxs)
+        for c_ in ctxs:
+            try:
+                c_.close()
+            except Exception:
+                pass
+        try:
+            out["convergence_driven"] = dict(side_leg(0), what="the same pool and contexts with fixed_iterations = 0: both stages stop at the reference's own convergence tests "
+                                                               "(lsq_registration_impl.hpp:161-176, :63-73) — what a ROLO node runs; `value` forces 20 rotation iterations")
+        except Exception as e:  # pragma: no cover
+            out["convergence_driven"] = {"error": repr(e)}
+        try:
+            sweep = {"20": {"scans_per_s": value}}
+            for it_ in (10, 2):
+                sweep[str(it_)] = side_leg(it_)
+            v20, v10, v2 = sweep["20"]["scans_per_s"], sweep["10"]["scans_per_s"], sweep["2"]["scans_per_s"]
+            p20 = passes; p10 = sweep["10"].get("passes_per_frame", {}).get("median", 0); p2 = sweep["2"].get("passes_per_frame", {}).get("median", 0)
+            # per-trial cost under load = d(frame time) / d(passes); what is left at zero passes = the search + map + build share of a frame
+            per_trial_us = 1e6 * (1.0 / v20 - 1.0 / v2) / max(p20 - p2, 1)
+            out["iteration_sweep"] = dict(sweep, per_trial_us_under_load=per_trial_us, frame_share_without_lm_ms=1e3 * (1.0 / v20) - 1e-3 * per_trial_us * p20,
+                                          what="forced rotation iterations 20 / 10 / 2 with the headline's contexts: the slope prices one LM trial (pass + controller launch) under load, "
+                                               "the intercept the search + map + build of a frame (frame time = 1 / scans_per_s: the contexts overlap)")
+        except Exception as e:  # pragma: no cover
+            out["iteration_sweep"] = {"error": repr(e)}
+        try:
+            host_pools = {}
+            for kind_ in ("pageable", "pinned"):
+                hp_ = []
+                for s_, t_ in [pairs[i_ % len(pairs)] for i_ in range(5)]:   # (five: with four contexts in flight a context then sees a different array every frame — the same array again is a no-op, rot_vgicp_impl.hpp:113-115)
+                    if kind_ == "pinned":
+                        hp_.append((torch.from_numpy(np.ascontiguousarray(s_)).pin_memory().numpy(), torch.from_numpy(np.ascontiguousarray(t_)).pin_memory().numpy()))
+                    else:
+                        hp_.append((np.ascontiguousarray(s_).copy(), np.ascontiguousarray(t_).copy()))
+                host_pools[kind_] = hp_
+            hc = {}
+            for kind_ in ("pinned", "pageable"):
+                for nc_ in (1, n_side_ctx):
+                    hc[f"{kind_}_{nc_}ctx"] = side_leg(None, host=kind_, nctx=nc_)
+            hc["bytes_uploaded_per_frame"] = 2 * n * 16
+            hc["what"] = ("the 131 072-point pair handed over as HOST arrays through rolo_set_target / rolo_set_source (lidarOdometry.cpp:466-467: what the unchanged caller does), "
+                          "H2D inside the timed region, 20 forced iterations; pinned = page-locked caller buffers, pageable = plain malloc'd arrays (the runtime stages them)")
+            out["host_clouds"] = hc
+        except Exception as e:  # pragma: no cover
+            out["host_clouds"] = {"error": repr(e)}
 
     # ---- BASELINE configs[4]: 512 distinct OS1-64 pairs streamed through the contexts ----
     if args.mode == "replicas" and not args.no_config5:

@@ -267,8 +267,17 @@ int rolo_peer_info(rolo_ctx* ctx, int* rank, int* world, char* mem_kind16);
  * out[0] frames registered, [1] of them replayed from the hipGraph, [2] captured, [3] enqueued eagerly, [4] frames whose first launch
  * schedule was too short (rolo_register_wait had to top up with host round trips), [5] synchronous chunks of predicated passes enqueued
  * by the drivers (top-ups + rolo_align / rolo_compute_translation), [6] / [7] passes the next frame's first schedule holds per stage, [8] lanes per query
- * of the last neighbour search enqueued (1: 64-query packets, 2 / 4: knn_walk_sub_kernel — picked by launch size, ROLO_KNN_SUB overrides). */
+ * of the last neighbour search enqueued (1: 64-query packets, 2 / 4: knn_walk_sub_kernel — picked by launch size, ROLO_KNN_SUB overrides),
+ * [9] nanoseconds of HOST time spent inside rolo_register_async (graph launch / capture / eager enqueue) since the context was created or recycled,
+ * [10] nanoseconds the host was blocked in rolo_register_wait's hipEventSynchronize, [11] nanoseconds of the rest of rolo_register_wait (std::chrono::steady_clock;
+ * bench.py's host_enqueue_us_per_frame — round 5's verdict, item 2a). */
 int rolo_ctx_counters(rolo_ctx* ctx, long long* out, int n);
+/* experiment hook (profiles/tools/concurrency.py, round 5's verdict item 2b): enqueue `reps` replays of a captured chain of `n_pairs` launch PAIRS on the context's stream —
+ * kind 0: empty kernels shaped like a controller (1 workgroup); 1: empty kernels shaped like a pass (`grid` workgroups of 256); 2: empty pass + empty controller
+ * alternating (the LM chain's boundaries and dispatches without its instructions or traffic); 3: the context's REAL LM chain (frame begin + predicated pass / controller
+ * pairs as rolo_register_async enqueues them, on the map and clouds of its last registration); 4: the real passes without the controller (every launch linearises at
+ * the start pose). Asynchronous: synchronise through rolo_ctx_stream. */
+int rolo_debug_chain(rolo_ctx* ctx, int kind, int n_pairs, int grid, int reps);
 
 /* Per-kernel timing with HIP events on the context's stream (bench.py's "roofline" object). While enabled, every
  * launch of the listed kernels is bracketed by an event pair; rolo_prof_read synchronises the stream and returns

@@ -15,6 +15,7 @@
 #include <array>
 #include <map>
 #include <mutex>
+#include <chrono>
 
 using namespace rolo;
 
@@ -171,6 +172,8 @@ struct rolo_ctx {
   // async registration bookkeeping
   bool async_pending = false;
   long long n_frames = 0, n_replays = 0, n_captures = 0, n_eager = 0, n_topup_frames = 0, n_topup_chunks = 0;   // rolo_ctx_counters
+  long long ns_enqueue = 0, ns_wait_blocked = 0, ns_wait_other = 0;   // host time inside rolo_register_async / the event wait / the rest of rolo_register_wait (steady_clock)
+  hipGraphExec_t dbg_chain_exec = nullptr; int dbg_chain_key[3] = {-1, -1, -1};   // rolo_debug_chain: the captured chain and its (kind, n_pairs, grid)
   // hipGraph of one whole frame (rolo_register_async): captured on the second frame with an unchanged key, replayed after
   FrameArgs* h_args = nullptr;   // pinned; a captured H2D copy refreshes d_args on every replay
   FrameArgs* d_args = nullptr; size_t d_args_cap = 0;
@@ -538,6 +541,11 @@ RotBegin make_rot_begin(const rolo_ctx* c, const double* R9, const double* t3, i
   return b;
 }
 
+void fill_trans_knobs(const rolo_ctx* c, TransBegin& tb) {
+  tb.max_iterations = c->P.max_iterations; tb.lm_max = c->P.lm_max_iterations; tb.q2_intended = c->P.q2_intended;
+  tb.trans_eps = c->P.transformation_epsilon; tb.lm_init = c->P.lm_init_lambda_factor;
+}
+
 void guess_to_Rt(const float* g16, double* R, double* t) {
   for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) R[i * 3 + j] = g16 ? (double)g16[i * 4 + j] : (i == j ? 1.0 : 0.0); t[i] = g16 ? (double)g16[i * 4 + 3] : 0.0; }
 }
@@ -818,6 +826,7 @@ void rolo_ctx_destroy(rolo_ctx* c) {
                   c->state, c->trace, c->stage_in, c->stage_out, c->stage_d, c->stage_i};
   for (void* b : bufs) if (b) (void)hipFree(b);
   if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
+  if (c->dbg_chain_exec) (void)hipGraphExecDestroy(c->dbg_chain_exec);
   if (c->graph) (void)hipGraphDestroy(c->graph);
   if (c->h_args) (void)hipHostFree(c->h_args);
   if (c->d_args) (void)hipFree(c->d_args);
@@ -852,6 +861,7 @@ void reset_to_fresh(rolo_ctx* c) {
   c->rank = 0; c->world = 1; c->load_hint = -1; c->busy_credit = 0;
   front_reset_object_state(c);   // no projection, armed de-skew or pre-cleared arrays of the previous owner
   c->n_frames = c->n_replays = c->n_captures = c->n_eager = c->n_topup_frames = c->n_topup_chunks = 0;   // rolo_ctx_counters counts per object
+  c->ns_enqueue = c->ns_wait_blocked = c->ns_wait_other = 0;
   // (schedule hints, their windows and the captured graph stay on purpose: they are keyed on sizes, buffers and parameters, not on the object's
   // identity — a frame loop that constructs its operator per frame, src/lidarOdometry.cpp:460, keeps replaying its graph. Drivers created on the
   // context, rolo_odom_create, must be destroyed before the context is released: the pool does not track them.)
@@ -1131,7 +1141,7 @@ static int eval_t3(rolo_ctx* c, const double* t3, const double* g3, const double
   if ((rc = prepare_pass(c, a, grid))) return rc;
   TransBegin tb{};
   for (int i = 0; i < 3; i++) { tb.t0[i] = t3[i]; tb.g[i] = g3[i]; tb.l[i] = l3[i]; }
-  tb.dtn = dtn; tb.dtn1 = dtn1; tb.ct_lambda = lam; tb.direct = 0;
+  tb.dtn = dtn; tb.dtn1 = dtn1; tb.ct_lambda = lam; tb.direct = 0; fill_trans_knobs(c, tb);
   HIPCHK(launch_t3_eval_begin(c->state, tb, phase, c->stream));
   HIPCHK(launch_trans_pass(a, c->state, grid, c->stream));
   HIPCHK(launch_reduce(c->partials, grid, c->sums, c->state, -1, c->stream));
@@ -1171,7 +1181,7 @@ int rolo_align(rolo_ctx* c, const float* guess16, float* Tf, double* Td, rolo_st
   c->have_map = false;  // computeTransformation: voxelmap_.reset() (rot_vgicp_impl.hpp:147)
   double R[9], t[3]; guess_to_Rt(guess16, R, t);
   c->h_args->rot = make_rot_begin(c, R, t, 0);
-  c->h_args->trans = TransBegin{};
+  c->h_args->trans = TransBegin{}; fill_trans_knobs(c, c->h_args->trans);
   if ((rc = enqueue_frame(c, false))) return rc;
   HIPCHK(hipStreamSynchronize(c->stream));
   if ((rc = peer_check(c))) return rc;
@@ -1199,7 +1209,7 @@ int rolo_compute_translation(rolo_ctx* c, double* trans, const double* g3, const
   if ((rc = prepare_pass(c, a, grid))) return rc;
   TransBegin tb{};
   for (int i = 0; i < 3; i++) { tb.t0[i] = trans[i]; tb.g[i] = g3[i]; tb.l[i] = l3[i]; }
-  tb.dtn = dtn; tb.dtn1 = dtn1; tb.ct_lambda = lam; tb.direct = 1;
+  tb.dtn = dtn; tb.dtn1 = dtn1; tb.ct_lambda = lam; tb.direct = 1; fill_trans_knobs(c, tb);
   HIPCHK(launch_trans_begin(c->state, tb, c->stream));
   if ((rc = run_stage(c, a, grid, 2, 12))) return rc;
   const LmState* s = c->h_state;
@@ -1257,7 +1267,7 @@ extern "C" int rolo_debug_lm_script_translation(rolo_ctx* c, const rolo_lm_scrip
   int rc = set_device(c); if (rc) return rc;
   TransBegin tb{};
   for (int i = 0; i < 3; i++) { tb.t0[i] = trans[i]; tb.g[i] = g3[i]; tb.l[i] = l3[i]; }
-  tb.dtn = dtn; tb.dtn1 = dtn1; tb.ct_lambda = lam; tb.direct = 1;
+  tb.dtn = dtn; tb.dtn1 = dtn1; tb.ct_lambda = lam; tb.direct = 1; fill_trans_knobs(c, tb);
   HIPCHK(launch_trans_begin(c->state, tb, c->stream));
   if ((rc = script_stage(c, S, 2, 6, generic_ctrl))) return rc;
   const LmState* s = c->h_state;
@@ -1339,7 +1349,7 @@ static int register_async_impl(rolo_ctx* c, const float* guess16, const double* 
   c->h_args->rot = make_rot_begin(c, R, t, 1);
   TransBegin& tb = c->h_args->trans;
   for (int i = 0; i < 3; i++) { tb.t0[i] = trans_start ? trans_start[i] : 0.0; tb.g[i] = g3[i]; tb.l[i] = l3[i]; }
-  tb.dtn = dtn; tb.dtn1 = dtn1; tb.ct_lambda = lam; tb.direct = 0;
+  tb.dtn = dtn; tb.dtn1 = dtn1; tb.ct_lambda = lam; tb.direct = 0; fill_trans_knobs(c, tb);
 
   // hipGraph: the schedule of a frame is fixed (predicated launches), so with unchanged sizes / buffers / parameters
   // the ~95 launches are captured once and replayed with one hipGraphLaunch (host cost 0.35 ms -> ~0.02 ms per frame)
@@ -1401,8 +1411,10 @@ int rolo_register_async(rolo_ctx* c, const float* guess16, const double* trans_s
     const bool sharded_ctx = c->comm != nullptr || peers(c) || c->world > 1;
     c->device_busy = c->load_hint < 0 ? (!sharded_ctx && c->busy_credit > 0) : c->load_hint != 0;
   }
+  const auto t0 = std::chrono::steady_clock::now();
   const int rc = register_async_impl(c, guess16, trans_start, g3, l3, dtn, dtn1, lam);
   if (rc == ROLO_OK && c->async_pending) { c->n_frames++; count_in_flight(c, true); HIPCHK(hipEventRecord(c->ev_done, c->stream)); }
+  if (c) c->ns_enqueue += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
   return rc;
 }
 
@@ -1413,7 +1425,11 @@ int rolo_register_wait(rolo_ctx* c, float* Tf, double* Td, double* trans_out, ro
   c->async_pending = false;
   count_in_flight(c, false);
   c->device_busy = c->load_hint == 1;   // the choice belongs to the frame that was enqueued: synchronous entry points (rolo_compute_covariances, rolo_align, ...) run alone
+  const auto tw0 = std::chrono::steady_clock::now();
   HIPCHK(hipEventSynchronize(c->ev_done));
+  const auto tw1 = std::chrono::steady_clock::now();
+  c->ns_wait_blocked += std::chrono::duration_cast<std::chrono::nanoseconds>(tw1 - tw0).count();
+  struct WaitTimer { rolo_ctx* c; std::chrono::steady_clock::time_point t; ~WaitTimer() { c->ns_wait_other += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t).count(); } } wt{c, tw1};
   if ((rc = peer_check(c))) return rc;
   if (c->h_counters[1] != 0) { g_err = c->h_counters[1] == ROLO_ENONFINITE ? "non-finite point or covariance in the voxel map build" : "voxel coordinate outside the packed key range"; return c->h_counters[1]; }
   c->n_voxels = c->h_counters[0];
@@ -1432,6 +1448,44 @@ int rolo_register_wait(rolo_ctx* c, float* Tf, double* Td, double* trans_out, ro
   if (trans_out) for (int i = 0; i < 3; i++) trans_out[i] = s->t0[i];
   if (ts) { ts->n_outer = s->trans_outer; ts->converged = s->trans_failed ? 0 : 1; ts->lm_failed = s->trans_failed; ts->n_passes = s->trans_passes; ts->n_correspondences = s->tr_n_corr; ts->n_cost_only = s->trans_cost_only; }
   if (s->error) { g_err = "device-side error during registration"; return s->error; }
+  return ROLO_OK;
+}
+
+// experiment hook (include/rolo_hip.h): a captured chain of launch pairs, replayed `reps` times
+int rolo_debug_chain(rolo_ctx* c, int kind, int n_pairs, int grid, int reps) {
+  if (!c || kind < 0 || kind > 4 || n_pairs < 1 || n_pairs > 256 || grid < 1 || reps < 1) return ROLO_EINVAL;
+  if (c->async_pending) { g_err = "a registration is in flight on this context"; return ROLO_ESTATE; }
+  int rc = set_device(c); if (rc) return rc;
+  if (kind >= 3 && (!c->have_map || !c->src.have_cov)) { g_err = "the real LM chain needs a finished registration on this context"; return ROLO_ESTATE; }
+  if (!c->dbg_chain_exec || c->dbg_chain_key[0] != kind || c->dbg_chain_key[1] != n_pairs || c->dbg_chain_key[2] != grid) {
+    if (c->dbg_chain_exec) { (void)hipGraphExecDestroy(c->dbg_chain_exec); c->dbg_chain_exec = nullptr; }
+    PassArgs a; int pgrid = 0;
+    if (kind >= 3 && (rc = prepare_pass(c, a, pgrid))) return rc;
+    HIPCHK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+    hipError_t e = hipSuccess;
+    const int dof = c->P.optimizer == ROLO_OPT_SO3_LM ? 3 : 6;
+    if (kind >= 3) e = launch_frame_begin(c->state, c->h_args, c->stream);
+    for (int i = 0; i < n_pairs && e == hipSuccess; i++) {
+      if (kind == 0) { e = launch_empty(1, 256, c->stream); if (e == hipSuccess) e = launch_empty(1, 256, c->stream); }
+      else if (kind == 1) { e = launch_empty(grid, 256, c->stream); if (e == hipSuccess) e = launch_empty(grid, 256, c->stream); }
+      else if (kind == 2) { e = launch_empty(grid, 256, c->stream); if (e == hipSuccess) e = launch_empty(1, 256, c->stream); }
+      else if (kind == 3) {   // the first two thirds of the pairs belong to the rotation stage, the rest to the translation stage (a frame's 21 + 10)
+        const int stage = i < (2 * n_pairs + 2) / 3 ? 1 : 2;
+        e = stage == 1 ? launch_rot_pass(dof, a, c->state, pgrid, c->stream) : launch_trans_pass(a, c->state, pgrid, c->stream);
+        if (e == hipSuccess) e = launch_ctrl(c->state, c->partials, pgrid, nullptr, c->trace, stage, c->stream, nullptr, nullptr, dof);
+      } else { e = launch_rot_pass(dof, a, c->state, pgrid, c->stream); if (e == hipSuccess) e = launch_rot_pass(dof, a, c->state, pgrid, c->stream); }
+    }
+    hipGraph_t gph = nullptr;
+    const hipError_t e2 = hipStreamEndCapture(c->stream, &gph);
+    if (e != hipSuccess || e2 != hipSuccess || !gph || hipGraphInstantiate(&c->dbg_chain_exec, gph, nullptr, nullptr, 0) != hipSuccess) {
+      if (gph) (void)hipGraphDestroy(gph);
+      c->dbg_chain_exec = nullptr; (void)hipGetLastError();
+      g_err = "rolo_debug_chain: capture failed"; return ROLO_EHIP;
+    }
+    (void)hipGraphDestroy(gph);
+    c->dbg_chain_key[0] = kind; c->dbg_chain_key[1] = n_pairs; c->dbg_chain_key[2] = grid;
+  }
+  for (int r = 0; r < reps; r++) HIPCHK(hipGraphLaunch(c->dbg_chain_exec, c->stream));
   return ROLO_OK;
 }
 
@@ -1471,8 +1525,9 @@ int rolo_transform_cloud(rolo_ctx* c, const float* in, float* out, int n, int st
 
 int rolo_ctx_counters(rolo_ctx* c, long long* out, int n) {
   if (!c || !out || n < 0) return ROLO_EINVAL;
-  const long long v[9] = {c->n_frames, c->n_replays, c->n_captures, c->n_eager, c->n_topup_frames, c->n_topup_chunks, c->hint_rot, c->hint_trans, c->walk_lanes};
-  for (int i = 0; i < n && i < 9; i++) out[i] = v[i];
+  const long long v[12] = {c->n_frames, c->n_replays, c->n_captures, c->n_eager, c->n_topup_frames, c->n_topup_chunks, c->hint_rot, c->hint_trans, c->walk_lanes,
+                           c->ns_enqueue, c->ns_wait_blocked, c->ns_wait_other};
+  for (int i = 0; i < n && i < 12; i++) out[i] = v[i];
   return ROLO_OK;
 }
 
@@ -1647,7 +1702,7 @@ int rolo_batch_register_async(rolo_batch* b, const float* guess16, const double*
     b->h_args[i].rot = make_rot_begin(c, R, t, 1);
     TransBegin& tb = b->h_args[i].trans;
     for (int d = 0; d < 3; d++) { tb.t0[d] = trans_start ? trans_start[3 * i + d] : 0.0; tb.g[d] = init_guess[3 * i + d]; tb.l[d] = last_t0[3 * i + d]; }
-    tb.dtn = dtn; tb.dtn1 = dtn1; tb.ct_lambda = lam; tb.direct = 0;
+    tb.dtn = dtn; tb.dtn1 = dtn1; tb.ct_lambda = lam; tb.direct = 0; fill_trans_knobs(c, tb);
     graphable = graphable && c->P.use_graph && !c->prof_on && !c->want_knn_lists && !c->src.have_cov && !c->tgt.have_cov;
     keys[i].n_src = c->src.n; keys[i].n_tgt = c->tgt.n; keys[i].src_xyz = c->src.xyz; keys[i].tgt_xyz = c->tgt.xyz; keys[i].P = c->P; keys[i].epoch = g_alloc_epoch;
   }

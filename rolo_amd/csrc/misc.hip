@@ -151,6 +151,12 @@ hipError_t launch_cov_pack(const double* m16, int n, double* soa, hipStream_t s)
   if (n > 0) cov_pack_kernel<<<(n + 255) / 256, 256, 0, s>>>(m16, n, soa);
   return hipGetLastError();
 }
+// rolo_debug_chain (api.hip): a launch that does nothing — its dispatch, its kernel boundary (the L2 write-back / invalidate around it) and nothing else
+__global__ void empty_kernel() {}
+hipError_t launch_empty(int grid, int threads, hipStream_t s) {
+  empty_kernel<<<grid, threads, 0, s>>>();
+  return hipGetLastError();
+}
 hipError_t launch_transform_cloud(const float* in, float* out, int n, int stride, const float*, const float* T16_host, hipStream_t s) {
   Mat4f T;
   for (int i = 0; i < 16; i++) T.m[i] = T16_host[i];

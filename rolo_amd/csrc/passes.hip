@@ -1122,10 +1122,15 @@ __global__ void rot_begin_kernel(LmState* st, RotBegin a) {
   rot_begin_dev(st, a);
 }
 
+ROLO_DEV void trans_knobs(LmState* st, const TransBegin& a) {   // TransBegin: the stage's knobs as they are when computeTranslation is called
+  st->max_iterations = a.max_iterations; st->lm_max = a.lm_max; st->q2_intended = a.q2_intended;
+  st->trans_eps = a.trans_eps; st->inv_trans_eps = 1.0 / a.trans_eps; st->lm_init = a.lm_init;
+}
 __global__ void trans_begin_kernel(LmState* st, TransBegin a) {
   if (threadIdx.x != 0) return;
   for (int i = 0; i < 3; i++) { st->t0[i] = a.t0[i]; st->g[i] = a.g[i]; st->l[i] = a.l[i]; }
   st->dtn = a.dtn; st->dtn1 = a.dtn1; st->ct_lambda = a.ct_lambda; st->pending = 0;
+  trans_knobs(st, a);
   if (a.direct) trans_start(st);
 }
 
@@ -1173,6 +1178,7 @@ __global__ void t3_eval_begin_kernel(LmState* st, TransBegin a, int phase) {
   if (threadIdx.x != 0) return;
   for (int i = 0; i < 3; i++) { st->tt[i] = a.t0[i]; st->t0[i] = a.t0[i]; st->g[i] = a.g[i]; st->l[i] = a.l[i]; }
   st->dtn = a.dtn; st->dtn1 = a.dtn1; st->ct_lambda = a.ct_lambda;
+  trans_knobs(st, a);
   st->lam_over_n = (double)(a.ct_lambda / (float)st->tr_n_corr);
   trans_consts(st);
   st->stage = 2; st->phase = phase; st->lin_skip = 0;

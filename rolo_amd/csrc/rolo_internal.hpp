@@ -243,7 +243,10 @@ hipError_t launch_peer_selftest_fill(const PeerArgs& peer, size_t area_bytes, si
 hipError_t launch_peer_selftest_check(const PeerArgs& peer, size_t area_bytes, size_t seg_doubles, unsigned* bad, hipStream_t s);
 
 struct RotBegin { double R[9], t[3]; int optimizer, max_iterations, fixed_iterations, lm_max, q2_intended; double rot_eps, trans_eps, lm_init; int run_trans; int spec_lin; };
-struct TransBegin { double t0[3], g[3], l[3], dtn, dtn1; float ct_lambda; int direct; /* 1: start now (rotation already done) */ };
+struct TransBegin { double t0[3], g[3], l[3], dtn, dtn1; float ct_lambda; int direct; /* 1: start now (rotation already done) */
+                    // the knobs computeTranslation reads when IT runs (lsq_registration_impl.hpp:63, :98, :142-148 read the members live): a setter called between align and
+                    // computeTranslation counts — until round 6 the stage ran on what the last align had copied into the state
+                    int max_iterations, lm_max, q2_intended; double trans_eps, lm_init; };
 struct FrameArgs { RotBegin rot; TransBegin trans; };
 hipError_t launch_rot_begin(LmState* st, const RotBegin& a, hipStream_t s);
 hipError_t launch_frame_begin(LmState* st, const FrameArgs* a, hipStream_t s);
@@ -263,6 +266,7 @@ hipError_t launch_pack_xyz(const float* in, int stride, float4* out, int n, hipS
 // source (moved by the row-major 4x4 float transform T16 on the way, or nullptr) and target packed by one launch, partial boxes as launch_pack_xyz leaves them
 hipError_t launch_pack_pair(const float* in0, int stride0, float4* out0, int n0, int* bbox0, const float* T16_host_or_null,
                             const float* in1, int stride1, float4* out1, int n1, int* bbox1, hipStream_t s);
+hipError_t launch_empty(int grid, int threads, hipStream_t s);   // rolo_debug_chain: a launch that does nothing
 hipError_t launch_cov_unpack(const double* soa, int n, double* m16, hipStream_t s);   // 6 SoA -> n x 16
 hipError_t launch_cov_pack(const double* m16, int n, double* soa, hipStream_t s);     // n x 16 -> 6 SoA
 

@@ -367,9 +367,21 @@ class RotVGICP:
 
     def counters(self) -> dict:
         """rolo_ctx_counters as a dict"""
-        v = (C.c_longlong * 9)()
-        check(lib().rolo_ctx_counters(self._h, v, 9), "rolo_ctx_counters")
-        return dict(zip(("frames", "graph_replays", "graph_captures", "eager_frames", "topup_frames", "sync_chunks", "hint_rot", "hint_trans", "walk_lanes"), [int(x) for x in v]))
+        v = (C.c_longlong * 12)()
+        check(lib().rolo_ctx_counters(self._h, v, 12), "rolo_ctx_counters")
+        return dict(zip(("frames", "graph_replays", "graph_captures", "eager_frames", "topup_frames", "sync_chunks", "hint_rot", "hint_trans", "walk_lanes",
+                         "host_enqueue_ns", "host_wait_blocked_ns", "host_wait_other_ns"), [int(x) for x in v]))
+
+    def debug_chain(self, kind: int, n_pairs: int, grid: int, reps: int):
+        """experiment hook (rolo_debug_chain): `reps` replays of a captured chain of launch pairs on this context's stream; asynchronous"""
+        check(lib().rolo_debug_chain(self._h, kind, n_pairs, grid, reps), "rolo_debug_chain")
+
+    def synchronize(self):
+        import ctypes as _C
+        hip = _C.CDLL("libamdhip64.so", mode=_C.RTLD_GLOBAL) if not hasattr(RotVGICP, "_hip") else RotVGICP._hip
+        RotVGICP._hip = hip
+        hip.hipStreamSynchronize.argtypes = [_C.c_void_p]
+        return hip.hipStreamSynchronize(_C.c_void_p(self.stream))
 
     @property
     def stream(self) -> int:

@@ -254,11 +254,33 @@ def test_zero_budgets_on_real_clouds(clouds, fused):
     g.close()
 
 
+@pytest.mark.parametrize("fused", [False, True])
+def test_setters_between_align_and_compute_translation_count(clouds, fused):
+    """computeTranslation reads max_iterations_, lm_max_iterations_, transformation_epsilon_ and the lambda factor when IT runs (:63, :98, :142-148): a setter called
+    after align() changes the translation stage — through round 5 the stage ran on the values the last align had copied into the device state"""
+    src, tgt = clouds
+    for knobs, expect in ((dict(lm_max_iterations=3), (1, 2)), (dict(max_iterations=1), (0, 1)), (dict(transformation_epsilon=1.0), (0, 1))):
+        o, g = make_real(src, tgt, fused)
+        assert o.align(None)[0] == 0
+        g.align(None)
+        o.set_driver_params(**knobs)
+        for k, v in knobs.items():
+            setattr(g._p, k, v)
+        g._push()
+        rc_t, t_o, tit_o = o.compute_translation(np.zeros(3), G, L0)
+        t_g = g.computeTranslation(np.zeros(3), G, L0)
+        ts = g.last_translation_stats
+        assert (ts.lm_failed, ts.n_outer) == (rc_t, tit_o) == expect, (knobs, (ts.lm_failed, ts.n_outer), (rc_t, tit_o))
+        assert np.abs(t_g - t_o).max() < 1e-8
+        g.close()
+
+
 def one_point_per_voxel(n_side=14):
-    """a jittered lattice, one point per 1 m voxel, coordinates on a 2^-10 grid: source == target puts every source point exactly on its voxel's mean"""
+    """a jittered lattice, one point per 1 m voxel (UNIFORM voxel k covers [k + 0.5, k + 1.5): the lattice sits on the integers), coordinates on a 2^-10 grid:
+    source == target puts every source point exactly on its voxel's mean"""
     rng = np.random.default_rng(5)
     g = np.stack(np.meshgrid(np.arange(n_side), np.arange(n_side), np.arange(3), indexing="ij"), -1).reshape(-1, 3).astype(np.float64)
-    p = g + 0.5 + np.round(rng.uniform(-0.3, 0.3, g.shape) * 1024) / 1024 - np.array([n_side / 2, n_side / 2, 1.0])
+    p = g + np.round(rng.uniform(-0.3, 0.3, g.shape) * 1024) / 1024 - np.array([n_side / 2, n_side / 2, 1.0])
     return np.ascontiguousarray(np.concatenate([p, np.ones((p.shape[0], 1))], 1).astype(np.float32))
 
 
@@ -276,7 +298,8 @@ def test_nan_gain_ratio_on_a_crafted_scene(fused):
     tr_o = [r for r in o.trace() if r["stage"] == 0]; tr_g = [r for r in g.trace() if r["stage"] == 0]
     assert (rc_o, it_o, cv_o) == (0, 1, True) and (g.last_stats.lm_failed, g.last_stats.n_outer, g.last_stats.converged) == (0, 1, 1)
     assert len(tr_o) == len(tr_g) == 1 and tr_o[0]["accepted"] == tr_g[0]["accepted"] == 1
-    assert math.isnan(tr_o[0]["rho"]) and math.isnan(tr_g[0]["rho"]) and tr_o[0]["y0"] == tr_g[0]["y0"] == 0.0 and tr_g[0]["yi"] == 0.0
+    assert int(g.voxels()[1].max()) == 1                                  # one point per voxel
+    assert math.isnan(tr_o[0]["rho"]) and math.isnan(tr_g[0]["rho"]) and tr_o[0]["y0"] == tr_g[0]["y0"] == 0.0 and tr_g[0]["yi"] == 0.0, (tr_o, tr_g)
     assert np.array_equal(g.final_transformation_d, np.eye(4)) and np.array_equal(Td_o, np.eye(4))
     z = np.zeros(3)
     rc_t, t_o, tit_o = o.compute_translation(z, z, z, ct_lambda=0.0)
