@@ -63,7 +63,10 @@ typedef struct rolo_params {
   int fused_lm;                  /* tuning knob (default 0): 1 = ONE launch per LM trial (the controller runs in the prologue of the next pass,
                                     in every workgroup) instead of a pass launch + a controller launch. Shortest chain for one frame at a
                                     time (the odometry driver turns it on: frame latency -9 %); with several contexts sharing the GPU the
-                                    redundant prologues hold every CU and throughput drops (-22 % with four), so the default is off */
+                                    redundant prologues hold every CU and throughput drops (-22 % with four), so the default is off.
+                                    2 = ONE launch per FRAME (round 6): up to 128 workgroups stay resident for the whole LM chain of both stages and exchange their rows
+                                    through self-validating words between the trials (passes.hip lm_persist_kernel) — no kernel boundary inside the chain, no schedule
+                                    that can fall short; a workgroup that waits longer than ROLO_LM_PERSIST_TIMEOUT_MS (200) ends the frame with ROLO_ECOMM */
 } rolo_params;
 
 typedef struct rolo_stats {

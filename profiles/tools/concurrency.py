@@ -97,6 +97,7 @@ def main():
             r = a_walks(load)
             r["b_us_per_pair_alone"] = alone_us
             out[f"{tag}:{name}"] = r
+            print(f"{tag}:{name}", json.dumps(r), file=sys.stderr, flush=True)
 
         def load_walk(other=other):
             t0 = time.perf_counter()
@@ -107,7 +108,11 @@ def main():
                 return {"b_wall_ms_per_chain": 1e3 * (time.perf_counter() - t0) / N_WALKS}
             return fin
         out[f"{tag}:walk"] = a_walks(load_walk)
-    # two LM chains beside A (B on the other queue, A2 on A's own)
+    # two LM chains beside A (B on the other queue, A2 on A's own); the walk cases above took B's and A2's maps away: register them again
+    for c_ in (B, A2):
+        c_.setInputTargetDevice(d[1].data_ptr(), d[2], 4); c_.setInputSourceDevice(d[0].data_ptr(), d[2], 4)
+        c_.register_async(None, np.zeros(3), GUESS, GUESS * 0.97); c_.register_wait()
+
     def load2():
         t0 = time.perf_counter()
         B.debug_chain(3, PAIRS, 512, 60); A2.debug_chain(3, PAIRS, 512, 60)

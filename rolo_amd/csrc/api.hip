@@ -151,6 +151,8 @@ struct rolo_ctx {
   int* corr[2] = {nullptr, nullptr}; size_t corr_cap[2] = {0, 0};
   double* partials = nullptr; size_t partials_cap = 0;
   int lm_rows = 1;   // workgroups (= partial rows) of one fused LM launch
+  unsigned long long* xbuf = nullptr; size_t xbuf_cap = 0;   // row exchange of the resident LM kernel (fused_lm = 2): header + 2 parities x workgroups x 64 words, zeroed when (re)allocated
+  int lmp_rows = 1, lmp_ppt = 1;   // its grid and the slabs of 512 points per workgroup
   double* sums = nullptr; size_t sums_cap = 0;
   LmState* state = nullptr; size_t state_cap = 0;
   rolo_trace_rec* trace = nullptr; size_t trace_cap = 0;
@@ -462,10 +464,23 @@ int lm_ppt() {
   static const int t = [] { const char* e = getenv("ROLO_LM_PPT"); const int v = e ? atoi(e) : 1; return (v >= 1 && v <= 16) ? v : 1; }();
   return t;
 }
-bool lm_fused(const rolo_ctx* c) {
-  static const int force = [] { const char* e = getenv("ROLO_LM_FUSED"); return e ? atoi(e) : -1; }();   // A/B runs: 0 / 1 overrides the parameter
-  // with a communicator the sums pass through the all-reduce between pass and controller
-  return !c->comm && !peers(c) && (force >= 0 ? force != 0 : c->P.fused_lm != 0);
+// 0: pass + controller launches; 1: one launch per LM trial (lm_kernel); 2: one launch per frame (lm_persist_kernel)
+int lm_mode(const rolo_ctx* c) {
+  static const int force = [] { const char* e = getenv("ROLO_LM_FUSED"); return e ? atoi(e) : -1; }();   // A/B runs: 0 / 1 / 2 overrides the parameter
+  // with a communicator / peers the sums pass through the exchange between pass and controller
+  if (c->comm || peers(c)) return 0;
+  const int m = force >= 0 ? force : c->P.fused_lm;
+  return m == 2 ? 2 : (m != 0 ? 1 : 0);
+}
+bool lm_fused(const rolo_ctx* c) { return lm_mode(c) == 1; }
+bool lm_persist(const rolo_ctx* c) { return lm_mode(c) == 2; }
+int lm_persist_max_wgs() {
+  static const int v = [] { const char* e = getenv("ROLO_LM_PERSIST_WGS"); const int w = e ? atoi(e) : 128; return (w >= 8 && w <= 256) ? w : 128; }();
+  return v;
+}
+unsigned long long lm_persist_timeout_ticks() {   // wall_clock64 runs at 100 MHz
+  static const unsigned long long v = [] { const char* e = getenv("ROLO_LM_PERSIST_TIMEOUT_MS"); const long ms = e ? atol(e) : 200; return (unsigned long long)(ms > 0 ? ms : 200) * 100000ull; }();
+  return v;
 }
 
 void shard(const rolo_ctx* c, int& begin, int& end) { rolo_shard_range(c->src.n, c->rank, c->world, &begin, &end); }
@@ -478,6 +493,16 @@ int prepare_pass(rolo_ctx* c, PassArgs& a, int& grid) {
   grid = std::max(1, (end - begin + PASS_THREADS - 1) / PASS_THREADS);
   c->lm_rows = std::max(1, (end - begin + lm_threads() * lm_ppt() - 1) / (lm_threads() * lm_ppt()));
   if ((rc = ensure(c->partials, c->partials_cap, std::max((size_t)grid, 2 * (size_t)c->lm_rows) * NV_MAX))) return rc;
+  if (lm_persist(c)) {
+    const int npts = std::max(end - begin, 1), maxw = lm_persist_max_wgs();
+    c->lmp_ppt = (npts + 512 * maxw - 1) / (512 * maxw);
+    c->lmp_rows = (npts + 512 * c->lmp_ppt - 1) / (512 * c->lmp_ppt);
+    const size_t need = lm_persist_words(256);   // sized for the largest grid once: the epochs in it must survive a change of the cloud size
+    if (!c->xbuf || c->xbuf_cap < need) {
+      if ((rc = ensure(c->xbuf, c->xbuf_cap, need))) return rc;
+      HIPCHK(hipMemsetAsync(c->xbuf, 0, c->xbuf_cap * sizeof(unsigned long long), c->stream));
+    }
+  }
   a.src = c->src.xyz; a.cov = c->src.cov; a.n_total = c->src.n; a.begin = begin; a.end = end; a.n_off = noff;
   // the source covariances as I - m m^T: only what the library computed itself for THIS cloud under PLANE (ROLO_PASS_NRM=0: the six-entry form always — the A/B)
   static const bool nrm_on = [] { const char* e = getenv("ROLO_PASS_NRM"); return !e || atoi(e) != 0; }();
@@ -520,6 +545,15 @@ int enqueue_lm_chunk(rolo_ctx* c, const PassArgs& a, int k, bool publish = false
   }
   ProfScope ps(c, ROLO_PROF_LM_PASS);
   HIPCHK(launch_lm(dof, T, lm_ppt(), a, sb[k & 1], sb[0], rb[(k + 1) & 1], rb[k & 1], nrows, c->trace, 0, c->stream, publish ? c->h_state : nullptr));
+  return ROLO_OK;
+}
+
+// both stages (or the one the state is in) to completion in ONE launch (passes.hip lm_persist_kernel); the state starts and ends in c->state[0]
+int enqueue_lm_persist(rolo_ctx* c, const PassArgs& a, bool publish = false) {
+  ProfScope ps(c, ROLO_PROF_LM_PASS);
+  const int cap = (std::max(c->P.max_iterations, c->P.fixed_iterations) + 2) * (std::max(c->P.lm_max_iterations, 0) + 2) * 2 + 16;
+  HIPCHK(launch_lm_persist(c->P.optimizer == ROLO_OPT_SO3_LM ? 3 : 6, c->lmp_ppt, a, c->state, c->xbuf, c->lmp_rows, c->trace, publish ? c->h_state : nullptr,
+                           lm_persist_timeout_ticks(), cap, c->stream));
   return ROLO_OK;
 }
 
@@ -589,7 +623,8 @@ int run_stage(rolo_ctx* c, const PassArgs& a, int grid, int stage, int first_chu
   const int hard_cap = (c->P.max_iterations + 2) * (c->P.lm_max_iterations + 1) + 8;
   int issued = 0;
   while (true) {
-    if (lm_fused(c)) { int rc = enqueue_lm_chunk(c, a, chunk); if (rc) return rc; }
+    if (lm_persist(c)) { int rc = enqueue_lm_persist(c, a); if (rc) return rc; }   // runs until the state says the stage (and what follows it) is over
+    else if (lm_fused(c)) { int rc = enqueue_lm_chunk(c, a, chunk); if (rc) return rc; }
     else for (int i = 0; i < chunk; i++) { int rc = enqueue_pass(c, a, grid, stage); if (rc) return rc; }
     issued += chunk;
     c->n_topup_chunks++;
@@ -823,7 +858,7 @@ void rolo_ctx_destroy(rolo_ctx* c) {
                   c->tgt.boxes, c->tgt.knn_idx, c->tgt.knn_d2, c->ks[0].sort_tmp, c->ks[0].keys0, c->ks[0].keys1, c->ks[0].vals0, c->ks[0].vals1, c->ks[0].bbox,
                   c->ks[1].sort_tmp, c->ks[1].keys0, c->ks[1].keys1, c->ks[1].vals0, c->ks[1].vals1, c->ks[1].bbox, c->ks[0].nbr, c->ks[1].nbr, c->ks[0].stage, c->ks[1].stage, c->ks[0].lower, c->ks[1].lower, c->tab.keys,
                   c->tab.rec, c->tab.id_keys, c->tgt_keys, c->tgt_slot, c->counters, c->corr[0], c->corr[1], c->partials, c->sums,
-                  c->state, c->trace, c->stage_in, c->stage_out, c->stage_d, c->stage_i};
+                  c->state, c->trace, c->stage_in, c->stage_out, c->stage_d, c->stage_i, c->xbuf};
   for (void* b : bufs) if (b) (void)hipFree(b);
   if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
   if (c->dbg_chain_exec) (void)hipGraphExecDestroy(c->dbg_chain_exec);
@@ -1320,7 +1355,9 @@ static int enqueue_frame(rolo_ctx* c, bool with_trans) {   // with_trans = false
   STAMP(2);
   int nrot, ntrans; frame_chunks(c, nrot, ntrans);
   if (!with_trans) ntrans = 0;
-  if (lm_fused(c)) {
+  if (lm_persist(c)) {
+    if ((rc = enqueue_lm_persist(c, a, true))) return rc;   // one launch for both stages; it leaves the state in pinned memory
+  } else if (lm_fused(c)) {
     // both stages are the same launches (the device decides which pass a launch evaluates); each hint carries one spare
     if ((rc = enqueue_lm_chunk(c, a, std::max(nrot + ntrans - 1, 2), true))) return rc;   // the closing launch leaves the state in pinned memory
   } else {
@@ -1330,7 +1367,7 @@ static int enqueue_frame(rolo_ctx* c, bool with_trans) {   // with_trans = false
   }
   STAMP(4);
   if (stamp_env()) HIPCHK(hipMemcpyAsync(c->h_stamps, c->stamps, sizeof(unsigned long long) * 8, hipMemcpyDeviceToHost, c->stream));
-  if ((c->comm && !lm_fused(c)) || (!lm_fused(c) && ntrans == 0)) HIPCHK(hipMemcpyAsync(c->h_state, c->state, sizeof(LmState), hipMemcpyDeviceToHost, c->stream));
+  if (!lm_persist(c) && ((c->comm && !lm_fused(c)) || (!lm_fused(c) && ntrans == 0))) HIPCHK(hipMemcpyAsync(c->h_state, c->state, sizeof(LmState), hipMemcpyDeviceToHost, c->stream));
   return ROLO_OK;
 }
 

@@ -1117,6 +1117,162 @@ __global__ __launch_bounds__(THREADS) void lm_kernel(PassArgs a, const LmState* 
   }
 }
 
+// ---- ONE launch per frame: the resident LM kernel (round 6; rolo_params::fused_lm = 2) --------------------------------------------------------------------
+// A frame's LM chain is ~30 trials = ~60 launches of pass + controller: 60 kernel boundaries, each a dispatch, a cold first fetch and an L2 write-back / invalidate
+// that every OTHER kernel on the chip feels (profiles/r06/concurrency.md). Here the whole chain — both stages — is one launch of G <= 128 workgroups that stay
+// resident: per trial every workgroup evaluates the pass over ITS points (the same thread owns the same points in every trial, so the correspondence cache never
+// crosses a workgroup), leaves its row of 1 / 12 / 30 sums in an exchange buffer as self-validating words {epoch : 32 | half a double : 32} — agent-scope relaxed
+// atomic stores, the protocol of the multi-GPU peer exchange (peer_dev.hpp) between workgroups instead of ranks — polls everybody's rows (agent-scope loads: they
+// miss the XCD's L2), adds them in row order (the same bits in every workgroup) and runs the scalar LM step on its own copy of the state in LDS. No fence, no
+// barrier object, no atomic read-modify-write: nothing but the words crosses. Rows are double-buffered by the epoch's parity (a workgroup can be at most one
+// exchange ahead of another); the epoch continues from launch to launch through the buffer's header, so a stale word never matches.
+// A poll that lasts longer than timeout_ticks (wall clock, 100 MHz) gives up: the stage ends with ROLO_ECOMM in the state — a workgroup that never became
+// resident costs a bounded wait, never a hung GPU. Co-residency: G x THREADS threads with ~30 KB of LDS per workgroup fit the chip several times over (256 CUs),
+// and every kernel that can occupy the slots in the meantime terminates by itself.
+constexpr int LMP_HDR = 8;   // words in front of the rows: [0] = last epoch used
+// the scalar step as a CALL: one lane runs ~700 dependent instructions with its own register needs (the LDLT's factors) — inlined into the resident kernel's loop they
+// were live across the pass bodies and spilled (620 bytes of scratch per lane)
+template <int DOF> __device__ __noinline__ void lmp_rot_step(LmState* st, const double* S, rolo_trace_rec* trace) { rot_step_t<DOF>(st, S, trace); }
+__device__ __noinline__ void lmp_trans_step(LmState* st, const double* S, rolo_trace_rec* trace) { trans_step(st, S, trace); }
+
+// publish row[0 .. nv) as words of epoch e, collect all G rows, add them in a fixed order into sums[] (V_* slots). Returns false if a row did not arrive in time.
+template <int THREADS>
+ROLO_DEV bool lmp_exchange(const double* __restrict__ row, int nv, int nh, unsigned e, unsigned long long* __restrict__ xbuf, int G, int wg, unsigned* __restrict__ xw,
+                           double (*part)[NV_MAX], double* __restrict__ sums, int* __restrict__ bad, unsigned long long timeout_ticks) {
+  const int t = (int)threadIdx.x;
+  unsigned long long* rows = xbuf + LMP_HDR + (size_t)(e & 1u) * G * PEER_SLOT_WORDS;
+  const int nw = 2 * nv;
+  if (t < nw) {
+    const double v = row[t >> 1];
+    const unsigned half = (t & 1) ? (unsigned)__double2hiint(v) : (unsigned)__double2loint(v);
+    __hip_atomic_store(rows + (size_t)wg * PEER_SLOT_WORDS + t, ((unsigned long long)e << 32) | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  const int total = G * nw;
+  const long long t0 = wall_clock64();
+  for (int base = t; base < total; base += THREADS * 4) {
+    unsigned long long x[4]; const unsigned long long* q[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int i = min(base + u * THREADS, total - 1);
+      const int r = i / nw, w = i - r * nw;
+      q[u] = rows + (size_t)r * PEER_SLOT_WORDS + w;
+      x[u] = __hip_atomic_load(q[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int i = base + u * THREADS;
+      if (i >= total) continue;
+      while ((unsigned)(x[u] >> 32) != e) {
+        if ((unsigned long long)(wall_clock64() - t0) > timeout_ticks) { *bad = 1; break; }
+        __builtin_amdgcn_s_sleep(1);
+        x[u] = __hip_atomic_load(q[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      xw[i] = (unsigned)x[u];
+    }
+  }
+  __syncthreads();
+  if (*bad) return false;
+  {   // row sums in a fixed order (16 groups of rows, then the groups): the same bits in every workgroup
+    const int v = t & 31, q = t >> 5;
+    double s0 = 0.0;
+    if (v < nv) for (int r = q; r < G; r += 16) s0 += __hiloint2double((int)xw[r * nw + 2 * v + 1], (int)xw[r * nw + 2 * v]);
+    part[q][v] = s0;
+  }
+  __syncthreads();
+  if (t < nv) {
+    double s1 = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) s1 += part[k][t];
+    sums[t < 3 ? t : (t < 3 + nh ? V_H + (t - 3) : V_B + (t - 3 - nh))] = s1;
+  }
+  __syncthreads();
+  return true;
+}
+
+template <int DOF, int THREADS>
+__global__ __launch_bounds__(THREADS) void lm_persist_kernel(PassArgs a, LmState* st_io, unsigned long long* __restrict__ xbuf, rolo_trace_rec* trace, int ppt, LmState* pub,
+                                                            unsigned long long timeout_ticks, int max_trials) {
+  __shared__ LmState sst;
+  __shared__ double row[NV_MAX];
+  __shared__ double sums[NV_MAX];
+  __shared__ double part[16][NV_MAX];
+  __shared__ int bad;
+  extern __shared__ unsigned xw[];   // G x 60 halves
+  static_assert(sizeof(LmState) % sizeof(int) == 0, "LmState must be int-copyable");
+  constexpr int NW = sizeof(LmState) / sizeof(int);
+  constexpr int NHR = DOF * (DOF + 1) / 2, NVR = 3 + NHR + DOF;
+  static_assert(THREADS == 512, "16 summation groups of 32 values");
+  const int G = (int)gridDim.x, wg = (int)blockIdx.x, t = (int)threadIdx.x;
+  ROLO_SHORT_KERNEL_PRIO();
+  {
+    const int* g = reinterpret_cast<const int*>(st_io);
+    int* l = reinterpret_cast<int*>(&sst);
+    for (int w = t; w < NW; w += THREADS) l[w] = g[w];
+  }
+  unsigned e = (unsigned)xbuf[0];   // written by the previous launch on this context (a kernel boundary ago)
+  if (t == 0) bad = 0;
+  __syncthreads();
+  // XCD x (= wg mod 8: the dispatcher deals workgroups round-robin) owns a contiguous eighth of the point blocks — a sector of the cloud whose voxels no other XCD's
+  // L2 has to hold (pass_xcd_block); and with no kernel boundary between the trials that L2 stays warm from the second trial on
+  const int i0 = a.begin + pass_xcd_block(a, wg, G) * ppt * THREADS + t;
+  rolo_trace_rec* tr = wg == 0 ? trace : nullptr;   // without a buffer trace_count still advances
+  int trial = 0;
+  bool ok = true;
+  // ---- rotation / 6-dof stage ----
+  while (ok && uni(sst.stage) == 1) {
+    const bool only_first = uni(sst.phase) == 1 && uni(sst.lin_skip) != 0;
+    {
+      double acc[NVR]; int slot[NVR];
+#pragma unroll
+      for (int v = 0; v < NVR; v++) { acc[v] = 0.0; slot[v] = v; }
+      for (int p = 0; p < ppt; p++) {
+        const int i = i0 + p * THREADS;
+        const bool valid = i < a.end;
+        PtIn in{};
+        if (valid) in = load_pt(a, i);
+        rot_pass_compute<DOF>(a, &sst, i, valid, in, acc);
+      }
+      block_reduce_store<NVR, THREADS>(acc, slot, row, only_first);   // compact: yi, y, n, H lower triangle, b
+    }
+    __syncthreads();
+    ok = lmp_exchange<THREADS>(row, only_first ? 1 : NVR, NHR, ++e, xbuf, G, wg, xw, part, sums, &bad, timeout_ticks) && ++trial <= max_trials;
+    if (ok && t == 0) lmp_rot_step<DOF>(&sst, sums, tr);
+    __syncthreads();
+  }
+  // ---- translation stage ----
+  while (ok && uni(sst.stage) == 2) {
+    const bool only_first = uni(sst.phase) == 1 && uni(sst.lin_skip) != 0;
+    {
+      double acc[30]; int slot[30];
+#pragma unroll
+      for (int v = 0; v < 30; v++) { acc[v] = 0.0; slot[v] = v; }
+      for (int p = 0; p < ppt; p++) {
+        const int i = i0 + p * THREADS;
+        const bool valid = i < a.end;
+        PtIn in{};
+        if (valid) in = load_pt(a, i);
+        trans_pass_compute(a, &sst, i, valid, in, acc);
+      }
+      block_reduce_store<30, THREADS>(acc, slot, row, only_first);
+    }
+    __syncthreads();
+    ok = lmp_exchange<THREADS>(row, only_first ? 1 : 30, 21, ++e, xbuf, G, wg, xw, part, sums, &bad, timeout_ticks) && ++trial <= max_trials;
+    if (ok && t == 0) lmp_trans_step(&sst, sums, tr);
+    __syncthreads();
+  }
+  if (!ok) {   // a row never arrived (or the stages do not end): an error code instead of waiting forever
+    if (t == 0) { sst.error = ROLO_ECOMM; sst.stage = 0; sst.rot_done = 1; sst.rot_failed = 1; sst.trans_done = 1; sst.trans_failed = 1; }
+    __syncthreads();
+  }
+  if (wg == 0) {
+    int* g = reinterpret_cast<int*>(st_io);
+    const int* l = reinterpret_cast<const int*>(&sst);
+    for (int w = t; w < NW; w += THREADS) g[w] = l[w];
+    if (pub) { int* h = reinterpret_cast<int*>(pub); for (int w = t; w < NW; w += THREADS) h[w] = l[w]; }
+    if (t == 0) xbuf[0] = e;   // the next launch's epochs continue here
+  }
+}
+
 __global__ void rot_begin_kernel(LmState* st, RotBegin a) {
   if (threadIdx.x != 0) return;
   rot_begin_dev(st, a);
@@ -1225,6 +1381,14 @@ hipError_t launch_lm(int dof, int threads, int ppt, const PassArgs& a, const LmS
   }
   return hipGetLastError();
 }
+hipError_t launch_lm_persist(int dof, int ppt, const PassArgs& a, LmState* st, unsigned long long* xbuf, int nrows, rolo_trace_rec* trace, LmState* pub, unsigned long long timeout_ticks,
+                             int max_trials, hipStream_t s) {
+  const size_t lds = sizeof(unsigned) * (size_t)nrows * 60;
+  if (dof == 3) lm_persist_kernel<3, 512><<<nrows, 512, lds, s>>>(a, st, xbuf, trace, ppt, pub, timeout_ticks, max_trials);
+  else lm_persist_kernel<6, 512><<<nrows, 512, lds, s>>>(a, st, xbuf, trace, ppt, pub, timeout_ticks, max_trials);
+  return hipGetLastError();
+}
+size_t lm_persist_words(int nrows) { return (size_t)LMP_HDR + 2 * (size_t)nrows * PEER_SLOT_WORDS; }
 hipError_t launch_reduce(const double* partials, int nblocks, double* sums, const LmState* st, int stage, hipStream_t s) {
   reduce_kernel<<<1, 256, 0, s>>>(partials, nblocks, sums, st, stage);
   return hipGetLastError();

@@ -224,6 +224,11 @@ hipError_t launch_trans_pass(const PassArgs& a, const LmState* st, int grid, hip
 // evaluate the next pass into rows_out; threads in {256, 512, 1024}; nrows = workgroups of a pass; do_body = 0: closing launch
 hipError_t launch_lm(int dof, int threads, int ppt /* slabs of `threads` points per workgroup */, const PassArgs& a, const LmState* st_in, LmState* st_out, const double* rows_in, double* rows_out, int nrows,
                      rolo_trace_rec* trace, int do_body, hipStream_t s, LmState* pub = nullptr /* pinned host copy of the state written by workgroup 0 */);
+// one launch per frame (passes.hip lm_persist_kernel): nrows resident workgroups of 512 threads x ppt points, rows exchanged through xbuf (lm_persist_words(nrows) 64-bit words,
+// zeroed once); the state starts and ends in st; timeout_ticks: wall-clock ticks (100 MHz) a poll may last; max_trials: hard cap on the trials of one launch
+hipError_t launch_lm_persist(int dof, int ppt, const PassArgs& a, LmState* st, unsigned long long* xbuf, int nrows, rolo_trace_rec* trace, LmState* pub, unsigned long long timeout_ticks,
+                             int max_trials, hipStream_t s);
+size_t lm_persist_words(int nrows);
 hipError_t launch_reduce(const double* partials, int nblocks, double* sums, const LmState* st, int stage, hipStream_t s);
 // controller: sums the rows of `partials` itself (single GPU) or takes all-reduced `sums` (partials == nullptr)
 // pub != nullptr: also leave the state in that (pinned host) copy, step or no step

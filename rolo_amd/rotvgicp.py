@@ -146,8 +146,9 @@ class RotVGICP:
         """-1 (default): register_async picks its kernels per frame from the device's load; 0 / 1 pin the idle- / busy-device choice (rolo_hip.h)"""
         check(lib().rolo_set_load_hint(self._h, int(mode)), "rolo_set_load_hint")
 
-    def setFusedLm(self, on: bool):
-        """tuning knob: one launch per LM trial (controller in the prologue of the next pass); see rolo_hip.h"""
+    def setFusedLm(self, on):
+        """tuning knob: 0 / False = pass + controller launches, 1 / True = one launch per LM trial (controller in the prologue of the next pass), 2 = one launch per
+        frame (the resident LM kernel); see rolo_hip.h"""
         self._p.fused_lm = int(on)
         self._push()
 

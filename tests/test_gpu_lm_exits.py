@@ -8,7 +8,8 @@ Two kinds of test:
 * real clouds — the exits that real data reaches robustly (the translation stage rejects significantly on every frame: SURVEY Q2), the iteration caps, the
   knobs away from their defaults (rotation / transformation epsilon, initial lambda factor, lm_max_iterations, max_iterations, a 4 degree guess) and a crafted
   one-point-per-voxel scene whose first gain ratio is 0 / 0.
-Every case runs the pass + controller launches and, on real clouds, the one-launch-per-trial form too (ROLO_LM_SPEC_LIN at its default)."""
+Every case runs the pass + controller launches and, on real clouds, the one-launch-per-trial form and the one-launch-per-frame form (the resident LM kernel) too
+(ROLO_LM_SPEC_LIN at its default)."""
 import math
 import os
 import subprocess
@@ -199,7 +200,7 @@ def check_real(o, g, guess=None, trans_start=np.zeros(3), ct_lambda=0.3, expect_
     return tr_g
 
 
-@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("fused", [0, 1, 2])   # pass + controller launches / one launch per trial / one launch per frame (the resident kernel)
 @pytest.mark.parametrize("lm_max", [1, 2, 4, 7, 8])
 def test_translation_lm_failure_on_real_clouds(clouds, fused, lm_max):
     """the translation stage's second outer iteration rejects seven trials in a row on this pair (the as-written CT term; every rejection is 0.3 % of the cost,
@@ -212,7 +213,7 @@ def test_translation_lm_failure_on_real_clouds(clouds, fused, lm_max):
     g.close()
 
 
-@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("fused", [0, 1, 2])   # pass + controller launches / one launch per trial / one launch per frame (the resident kernel)
 @pytest.mark.parametrize("max_it", [1, 2, 3])
 def test_iteration_cap_on_real_clouds(clouds, fused, max_it):
     """max_iterations exhausted without convergence (:161 / :63): converged_ stays false, the last accepted pose comes back — both stages share the knob"""
@@ -223,7 +224,7 @@ def test_iteration_cap_on_real_clouds(clouds, fused, max_it):
     g.close()
 
 
-@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("fused", [0, 1, 2])   # pass + controller launches / one launch per trial / one launch per frame (the resident kernel)
 @pytest.mark.parametrize("knobs", [dict(rotation_epsilon=1e-9, lm_init_lambda_factor=100.0), dict(rotation_epsilon=1e-4, transformation_epsilon=1e-5, lm_init_lambda_factor=1e-3),
                                    dict(lm_init_lambda_factor=1.0, lm_max_iterations=3), dict(rotation_epsilon=5e-2, transformation_epsilon=1e-1)])
 def test_knobs_away_from_defaults_on_real_clouds(clouds, fused, knobs):
@@ -235,7 +236,7 @@ def test_knobs_away_from_defaults_on_real_clouds(clouds, fused, knobs):
     g.close()
 
 
-@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("fused", [0, 1, 2])   # pass + controller launches / one launch per trial / one launch per frame (the resident kernel)
 def test_zero_budgets_on_real_clouds(clouds, fused):
     src, tgt = clouds
     o, g = make_real(src, tgt, fused, lm_max_iterations=0)
@@ -254,7 +255,7 @@ def test_zero_budgets_on_real_clouds(clouds, fused):
     g.close()
 
 
-@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("fused", [0, 1, 2])   # pass + controller launches / one launch per trial / one launch per frame (the resident kernel)
 def test_setters_between_align_and_compute_translation_count(clouds, fused):
     """computeTranslation reads max_iterations_, lm_max_iterations_, transformation_epsilon_ and the lambda factor when IT runs (:63, :98, :142-148): a setter called
     after align() changes the translation stage — through round 5 the stage ran on the values the last align had copied into the device state"""
@@ -284,7 +285,7 @@ def one_point_per_voxel(n_side=14):
     return np.ascontiguousarray(np.concatenate([p, np.ones((p.shape[0], 1))], 1).astype(np.float32))
 
 
-@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("fused", [0, 1, 2])   # pass + controller launches / one launch per trial / one launch per frame (the resident kernel)
 def test_nan_gain_ratio_on_a_crafted_scene(fused):
     """every residual is exactly zero => b = 0, d = 0, yi = y0 = 0: rho = 0 / 0 on both sides, `rho < 0` is false, the step is ACCEPTED (:307) and the stage ends
     converged after one iteration; the translation stage with ct_lambda = 0 does the same"""

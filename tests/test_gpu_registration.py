@@ -789,8 +789,8 @@ def test_fused_lm_equals_pass_plus_controller_launches(guess_deg):
     src, tgt, cfg = make_pair("os64_uniform")
     guess = np.eye(4, dtype=np.float32); guess[:3, :3] = synth.rpy_to_R(0.0, 0.0, np.deg2rad(guess_deg))
     out = []
-    for fused in (0, 1):
-        g = RotVGICP(); g.setResolution(cfg["leaf"]); g.setFusedLm(bool(fused)); g.setUseGraph(False)
+    for fused in (0, 1, 2):   # 2: one launch per FRAME (the resident LM kernel, round 6)
+        g = RotVGICP(); g.setResolution(cfg["leaf"]); g.setFusedLm(fused); g.setUseGraph(False)
         if guess_deg > 0:
             g.setRotationEpsilon(1e-9); g.setInitialLambdaFactor(100.0)   # heavily damped steps, iterated long after the reference's 2e-3 would stop: more passes than the first chunk of 8 holds
         g.setInputTarget(tgt); g.setInputSource(src)
@@ -798,7 +798,7 @@ def test_fused_lm_equals_pass_plus_controller_launches(guess_deg):
         Td = g.final_transformation_d.copy(); st = (g.last_stats.n_outer, g.last_stats.n_passes, g.last_stats.converged)
         t = g.computeTranslation(np.zeros(3), G, L0)
         tr = g.trace()
-        g2 = RotVGICP(); g2.setResolution(cfg["leaf"]); g2.setFusedLm(bool(fused)); g2.setUseGraph(False)
+        g2 = RotVGICP(); g2.setResolution(cfg["leaf"]); g2.setFusedLm(fused); g2.setUseGraph(bool(fused == 2))   # (the resident kernel also through a captured graph: frame 3 replays)
         if guess_deg > 0:
             g2.setRotationEpsilon(1e-9); g2.setInitialLambdaFactor(100.0)
         res = []
@@ -809,13 +809,15 @@ def test_fused_lm_equals_pass_plus_controller_launches(guess_deg):
             res.append((Td2.copy(), t2.copy(), g2.last_stats.n_passes, g2.last_translation_stats.n_passes))
         out.append((Td, st, t, tr, res, g2.counters()))
         g.close(); g2.close()
-    (Ta, sa, ta, tra, ra, ca), (Tb, sb, tb, trb, rb, cb) = out
-    assert sa == sb and len(tra) == len(trb)
-    assert [(r["stage"], r["outer"], r["trial"], r["accepted"]) for r in tra] == [(r["stage"], r["outer"], r["trial"], r["accepted"]) for r in trb]
-    assert np.abs(Ta - Tb).max() < 1e-11 and np.abs(ta - tb).max() < 1e-11
-    for (Tda, t_a, pa, qa), (Tdb, t_b, pb, qb) in zip(ra, rb):
-        assert (pa, qa) == (pb, qb) and np.abs(Tda - Tdb).max() < 1e-11 and np.abs(t_a - t_b).max() < 1e-11
-        assert np.abs(Tda - Ta).max() < 1e-11   # and the asynchronous driver agrees with the synchronous ones
+    (Ta, sa, ta, tra, ra, ca) = out[0]
+    for (Tb, sb, tb, trb, rb, cb) in out[1:]:
+        assert sa == sb and len(tra) == len(trb)
+        assert [(r["stage"], r["outer"], r["trial"], r["accepted"]) for r in tra] == [(r["stage"], r["outer"], r["trial"], r["accepted"]) for r in trb]
+        assert np.abs(Ta - Tb).max() < 1e-11 and np.abs(ta - tb).max() < 1e-11
+        for (Tda, t_a, pa, qa), (Tdb, t_b, pb, qb) in zip(ra, rb):
+            assert (pa, qa) == (pb, qb) and np.abs(Tda - Tdb).max() < 1e-11 and np.abs(t_a - t_b).max() < 1e-11
+            assert np.abs(Tda - Ta).max() < 1e-11   # and the asynchronous driver agrees with the synchronous ones
+    assert out[2][5]["topup_frames"] == 0   # the resident kernel runs until the state says the frame is over: no schedule to fall short of
     if guess_deg > 0:
         assert sa[1] > 8   # the rotation stage did need more than the first chunk: the top-up path ran
 
