@@ -60,13 +60,16 @@ typedef struct rolo_params {
                                     kernel works on the pair) instead of one chain per cloud — both searches start together */
   int use_graph;                 /* tuning knob (default 1): rolo_register_async captures the frame's fixed launch schedule in a
                                     hipGraph on the second frame with unchanged sizes / buffers / parameters and replays it */
-  int fused_lm;                  /* tuning knob (default 0): 1 = ONE launch per LM trial (the controller runs in the prologue of the next pass,
-                                    in every workgroup) instead of a pass launch + a controller launch. Shortest chain for one frame at a
-                                    time (the odometry driver turns it on: frame latency -9 %); with several contexts sharing the GPU the
-                                    redundant prologues hold every CU and throughput drops (-22 % with four), so the default is off.
-                                    2 = ONE launch per FRAME (round 6): up to 128 workgroups stay resident for the whole LM chain of both stages and exchange their rows
-                                    through self-validating words between the trials (passes.hip lm_persist_kernel) — no kernel boundary inside the chain, no schedule
-                                    that can fall short; a workgroup that waits longer than ROLO_LM_PERSIST_TIMEOUT_MS (200) ends the frame with ROLO_ECOMM */
+  int fused_lm;                  /* how the LM chain of a registration is launched (tuning knob, results equal to rounding):
+                                    0 = a pass launch + a controller launch per LM trial (rounds 1-5's default: ~60 launches per frame, predicated on the device state);
+                                    1 = ONE launch per LM trial (the controller runs in the prologue of the next pass, in every workgroup): the shortest chain of rounds 1-5 for
+                                        one frame at a time (the odometry driver turns it on), slower with several contexts in flight (-22 % with four);
+                                    2 = ONE launch per FRAME (round 6, the default): 64 (other contexts' frames in flight) ... 256 (idle device) workgroups stay resident for the
+                                        whole chain of both stages and exchange their rows through self-validating words between the trials (passes.hip lm_persist_kernel) — no
+                                        kernel boundary inside the chain, no schedule that can fall short. Spin-waits are bounded: a launch that cannot get all its workgroups
+                                        onto the chip within ROLO_LM_PERSIST_ADMIT_US (1000) leaves the stage untouched and the frame is finished as with 0
+                                        (rolo_ctx_counters[12]); a later poll longer than ROLO_LM_PERSIST_TIMEOUT_MS (200) ends the frame with ROLO_ECOMM.
+                                        Ranks that share a frame (rolo_peer_*, rolo_comm_*) always run as with 0: their sums cross the exchange between pass and controller */
 } rolo_params;
 
 typedef struct rolo_stats {
@@ -273,8 +276,12 @@ int rolo_peer_info(rolo_ctx* ctx, int* rank, int* world, char* mem_kind16);
  * of the last neighbour search enqueued (1: 64-query packets, 2 / 4: knn_walk_sub_kernel — picked by launch size, ROLO_KNN_SUB overrides),
  * [9] nanoseconds of HOST time spent inside rolo_register_async (graph launch / capture / eager enqueue) since the context was created or recycled,
  * [10] nanoseconds the host was blocked in rolo_register_wait's hipEventSynchronize, [11] nanoseconds of the rest of rolo_register_wait (std::chrono::steady_clock;
- * bench.py's host_enqueue_us_per_frame — round 5's verdict, item 2a). */
+ * bench.py's host_enqueue_us_per_frame — round 5's verdict, item 2a), [12] frames whose resident LM kernel (fused_lm = 2) could not get all its workgroups onto the chip within its
+ * admission time and gave the stage back to the host, which finished it with pass + controller launches. */
 int rolo_ctx_counters(rolo_ctx* ctx, long long* out, int n);
+/* device buffer (re)allocations made so far by the registration contexts of this process (every hipMalloc behind a rolo_ctx's buffers; a captured hipGraph is keyed on it):
+ * a steady-state frame loop must stop moving it */
+long long rolo_alloc_count(void);
 /* experiment hook (profiles/tools/concurrency.py, round 5's verdict item 2b): enqueue `reps` replays of a captured chain of `n_pairs` launch PAIRS on the context's stream —
  * kind 0: empty kernels shaped like a controller (1 workgroup); 1: empty kernels shaped like a pass (`grid` workgroups of 256); 2: empty pass + empty controller
  * alternating (the LM chain's boundaries and dispatches without its instructions or traffic); 3: the context's REAL LM chain (frame begin + predicated pass / controller

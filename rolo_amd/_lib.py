@@ -168,6 +168,7 @@ SYMBOLS = {
     "rolo_peer_info": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p]),
     "rolo_ctx_counters": (C.c_int, [vp, C.POINTER(C.c_longlong), C.c_int]),
     "rolo_debug_chain": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "rolo_alloc_count": (C.c_longlong, []),
     "rolo_prof_enable": (C.c_int, [vp, C.c_int]),
     "rolo_prof_read": (C.c_int, [vp, C.c_int, fp, C.c_int]),
     "rolo_odom_create": (C.c_int, [vp, C.c_float, C.POINTER(vp)]),

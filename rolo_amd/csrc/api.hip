@@ -174,6 +174,7 @@ struct rolo_ctx {
   // async registration bookkeeping
   bool async_pending = false;
   long long n_frames = 0, n_replays = 0, n_captures = 0, n_eager = 0, n_topup_frames = 0, n_topup_chunks = 0;   // rolo_ctx_counters
+  long long n_persist_bails = 0;   // frames whose resident LM kernel gave the stage back to the host (rolo_ctx_counters [12])
   long long ns_enqueue = 0, ns_wait_blocked = 0, ns_wait_other = 0;   // host time inside rolo_register_async / the event wait / the rest of rolo_register_wait (steady_clock)
   hipGraphExec_t dbg_chain_exec = nullptr; int dbg_chain_key[3] = {-1, -1, -1};   // rolo_debug_chain: the captured chain and its (kind, n_pairs, grid)
   // hipGraph of one whole frame (rolo_register_async): captured on the second frame with an unchanged key, replayed after
@@ -374,8 +375,12 @@ int build_clouds(rolo_ctx* c, bool do_src, bool do_tgt, hipStream_t stream, bool
     return ROLO_OK;
   }
   const bool split_tail = !fused_tail_env() || kc > 64;
-  { ProfScope ps(c, ROLO_PROF_KNN_WALK, stream); HIPCHK(launch_knn_walk(A, c->P.k_correspondences, split_tail ? -1 : c->P.regularization, vf, stream, (kc == 20 && split_tail) ? knn_budget_env() : 0, &c->walk_lanes, c->device_busy)); }
-  if (split_tail) { ProfScope ps(c, ROLO_PROF_KNN_TAIL, stream); HIPCHK(launch_knn_tail(A, c->P.k_correspondences, c->P.regularization, vf, stream)); }
+  // default (round 6, k = 20): the walk's epilogue leaves the six centred moments of every neighbourhood, by sorted position, where the index lists used to go, and the tail
+  // finishes them (knn_walk.hpp walk_write_moments); ROLO_KNN_MOMENTS=0: the neighbour indices through A.c[].nbr and the tail's own gather (rounds 1-5, the A/B)
+  static const bool moments_on = [] { const char* e = getenv("ROLO_KNN_MOMENTS"); return !(e && atoi(e) == 0); }();
+  const bool moments = moments_on && kc == 20 && split_tail && knn_budget_env() == 0;
+  { ProfScope ps(c, ROLO_PROF_KNN_WALK, stream); HIPCHK(launch_knn_walk(A, c->P.k_correspondences, split_tail ? -1 : c->P.regularization, vf, stream, (kc == 20 && split_tail) ? knn_budget_env() : 0, &c->walk_lanes, c->device_busy, moments)); }
+  if (split_tail) { ProfScope ps(c, ROLO_PROF_KNN_TAIL, stream); HIPCHK(launch_knn_tail(A, c->P.k_correspondences, c->P.regularization, vf, stream, moments)); }
   if (sharded) {
     const size_t seg = A.c[0].seg;
     if (peers(c)) {   // every rank pushes its segment into every peer's area, flags, and waits for the others' flags (peer.hip)
@@ -474,8 +479,16 @@ int lm_mode(const rolo_ctx* c) {
 }
 bool lm_fused(const rolo_ctx* c) { return lm_mode(c) == 1; }
 bool lm_persist(const rolo_ctx* c) { return lm_mode(c) == 2; }
-int lm_persist_max_wgs() {
-  static const int v = [] { const char* e = getenv("ROLO_LM_PERSIST_WGS"); const int w = e ? atoi(e) : 128; return (w >= 8 && w <= 256) ? w : 128; }();
+// workgroups of the resident LM kernel: on an idle device one 512-thread workgroup per CU (a point per thread at 131 072 points: the shortest trial, 7.8 us), with other
+// contexts' frames in flight 64 — the kernel holds the register files it runs on for the whole chain, and four launches of 64 are what the chip takes at one workgroup per
+// CU (profiles/r06/concurrency.md); ROLO_LM_PERSIST_WGS pins it (A/B)
+int lm_persist_max_wgs(const rolo_ctx* c) {
+  static const int v = [] { const char* e = getenv("ROLO_LM_PERSIST_WGS"); const int w = e ? atoi(e) : 0; return (w >= 8 && w <= 256) ? w : 0; }();
+  return v ? v : (c->device_busy ? 64 : 256);
+}
+unsigned long long lm_persist_admit_ticks() {     // how long the resident kernel's workgroups wait for each other to become resident before they leave the frame to the host
+  // (ROLO_LM_PERSIST_ADMIT_US=0: a test switch — no launch is ever admitted, every frame takes the bail-out path)
+  static const unsigned long long v = [] { const char* e = getenv("ROLO_LM_PERSIST_ADMIT_US"); const long us = e ? atol(e) : 1000; return (unsigned long long)(us >= 0 ? us : 1000) * 100ull; }();
   return v;
 }
 unsigned long long lm_persist_timeout_ticks() {   // wall_clock64 runs at 100 MHz
@@ -494,8 +507,10 @@ int prepare_pass(rolo_ctx* c, PassArgs& a, int& grid) {
   c->lm_rows = std::max(1, (end - begin + lm_threads() * lm_ppt() - 1) / (lm_threads() * lm_ppt()));
   if ((rc = ensure(c->partials, c->partials_cap, std::max((size_t)grid, 2 * (size_t)c->lm_rows) * NV_MAX))) return rc;
   if (lm_persist(c)) {
-    const int npts = std::max(end - begin, 1), maxw = lm_persist_max_wgs();
-    c->lmp_ppt = (npts + 512 * maxw - 1) / (512 * maxw);
+    const int npts = std::max(end - begin, 1), maxw = lm_persist_max_wgs(c);
+    int ppt = (npts + 512 * maxw - 1) / (512 * maxw);
+    if (ppt == 3) ppt = 4;   // (1, 2 and 4 points per thread have the interleaved bodies)
+    c->lmp_ppt = ppt;
     c->lmp_rows = (npts + 512 * c->lmp_ppt - 1) / (512 * c->lmp_ppt);
     const size_t need = lm_persist_words(256);   // sized for the largest grid once: the epochs in it must survive a change of the cloud size
     if (!c->xbuf || c->xbuf_cap < need) {
@@ -553,7 +568,7 @@ int enqueue_lm_persist(rolo_ctx* c, const PassArgs& a, bool publish = false) {
   ProfScope ps(c, ROLO_PROF_LM_PASS);
   const int cap = (std::max(c->P.max_iterations, c->P.fixed_iterations) + 2) * (std::max(c->P.lm_max_iterations, 0) + 2) * 2 + 16;
   HIPCHK(launch_lm_persist(c->P.optimizer == ROLO_OPT_SO3_LM ? 3 : 6, c->lmp_ppt, a, c->state, c->xbuf, c->lmp_rows, c->trace, publish ? c->h_state : nullptr,
-                           lm_persist_timeout_ticks(), cap, c->stream));
+                           lm_persist_timeout_ticks(), lm_persist_admit_ticks(), cap, c->stream));
   return ROLO_OK;
 }
 
@@ -618,12 +633,13 @@ void update_hint(int& hint, rolo_ctx::NeedWindow& w, int used, bool fused) {
 }
 
 // drive a stage to completion: enqueue predicated passes in chunks, look at the device flags between chunks
-int run_stage(rolo_ctx* c, const PassArgs& a, int grid, int stage, int first_chunk) {
+// no_persist: the frame's resident kernel gave the stage back (admission, LmState::lmp_bailed): finish with pass + controller launches
+int run_stage(rolo_ctx* c, const PassArgs& a, int grid, int stage, int first_chunk, bool no_persist = false) {
   int chunk = first_chunk;
   const int hard_cap = (c->P.max_iterations + 2) * (c->P.lm_max_iterations + 1) + 8;
   int issued = 0;
   while (true) {
-    if (lm_persist(c)) { int rc = enqueue_lm_persist(c, a); if (rc) return rc; }   // runs until the state says the stage (and what follows it) is over
+    if (lm_persist(c) && !no_persist) { int rc = enqueue_lm_persist(c, a); if (rc) return rc; }   // runs until the state says the stage (and what follows it) is over
     else if (lm_fused(c)) { int rc = enqueue_lm_chunk(c, a, chunk); if (rc) return rc; }
     else for (int i = 0; i < chunk; i++) { int rc = enqueue_pass(c, a, grid, stage); if (rc) return rc; }
     issued += chunk;
@@ -632,6 +648,7 @@ int run_stage(rolo_ctx* c, const PassArgs& a, int grid, int stage, int first_chu
     if (rc) return rc;
     const bool done = (stage == 1) ? (c->h_state->rot_done != 0) : (c->h_state->trans_done != 0);
     if (done) return ROLO_OK;
+    if (c->h_state->lmp_bailed && !no_persist) { no_persist = true; c->n_persist_bails++; }
     if (issued > hard_cap) { g_err = "LM stage did not terminate"; return ROLO_ESTATE; }
     chunk = 8;
   }
@@ -726,7 +743,7 @@ void rolo_default_params(rolo_params* p) {
   p->q2_intended = 0;
   p->overlap_knn = 1;
   p->use_graph = 1;
-  p->fused_lm = 0;
+  p->fused_lm = 2;
 }
 
 // frames in flight per device (rolo_register_async .. rolo_register_wait): a frame enqueued while OTHER contexts of the device have frames in flight takes the
@@ -896,7 +913,7 @@ void reset_to_fresh(rolo_ctx* c) {
   c->rank = 0; c->world = 1; c->load_hint = -1; c->busy_credit = 0;
   front_reset_object_state(c);   // no projection, armed de-skew or pre-cleared arrays of the previous owner
   c->n_frames = c->n_replays = c->n_captures = c->n_eager = c->n_topup_frames = c->n_topup_chunks = 0;   // rolo_ctx_counters counts per object
-  c->ns_enqueue = c->ns_wait_blocked = c->ns_wait_other = 0;
+  c->ns_enqueue = c->ns_wait_blocked = c->ns_wait_other = 0; c->n_persist_bails = 0;
   // (schedule hints, their windows and the captured graph stay on purpose: they are keyed on sizes, buffers and parameters, not on the object's
   // identity — a frame loop that constructs its operator per frame, src/lidarOdometry.cpp:460, keeps replaying its graph. Drivers created on the
   // context, rolo_odom_create, must be destroyed before the context is released: the pool does not track them.)
@@ -1224,10 +1241,12 @@ int rolo_align(rolo_ctx* c, const float* guess16, float* Tf, double* Td, rolo_st
   c->n_voxels = c->h_counters[0];
   c->n_edge = c->h_counters[2];
   c->have_map = true;
-  if (!c->h_state->rot_done) {   // the first schedule was too short: keep feeding predicated trials
+  if (!c->h_state->rot_done) {   // the first schedule was too short (or the resident kernel gave the stage back): keep feeding predicated trials
     PassArgs a; int grid;
+    const bool bailed = c->h_state->lmp_bailed != 0;
+    if (bailed) c->n_persist_bails++;
     if ((rc = prepare_pass(c, a, grid))) return rc;
-    if ((rc = run_stage(c, a, grid, 1, 8))) return rc;
+    if ((rc = run_stage(c, a, grid, 1, 8, bailed))) return rc;
   }
   c->have_corr = true;
   if (!c->h_state->error) update_hint(c->hint_rot, c->win_rot, c->h_state->rot_passes, lm_fused(c));
@@ -1476,8 +1495,10 @@ int rolo_register_wait(rolo_ctx* c, float* Tf, double* Td, double* trans_out, ro
   if ((rc = prepare_pass(c, a, grid))) return rc;
   // the common case finished inside the first enqueue; otherwise keep feeding predicated passes
   if (!c->h_state->rot_done || (!c->h_state->trans_done && !c->h_state->error)) c->n_topup_frames++;   // the first schedule was too short: host round trips
-  if (!c->h_state->rot_done) { if ((rc = run_stage(c, a, grid, 1, 8))) return rc; }
-  if (!c->h_state->trans_done && !c->h_state->error) { if ((rc = run_stage(c, a, grid, 2, 8))) return rc; }
+  const bool bailed = c->h_state->lmp_bailed != 0;   // (read before the top-ups overwrite the host copy)
+  if (bailed) { c->n_persist_bails++; c->busy_credit = 64; }   // somebody this process cannot see shares the GPU (another process, a foreign workload): the busy-device sizing for the next frames
+  if (!c->h_state->rot_done) { if ((rc = run_stage(c, a, grid, 1, 8, bailed))) return rc; }
+  if (!c->h_state->trans_done && !c->h_state->error) { if ((rc = run_stage(c, a, grid, 2, 8, bailed))) return rc; }
   c->have_corr = true;
   const LmState* s = c->h_state;
   if (!s->error) { update_hint(c->hint_rot, c->win_rot, s->rot_passes, lm_fused(c)); update_hint(c->hint_trans, c->win_trans, s->trans_passes, lm_fused(c)); }
@@ -1562,11 +1583,13 @@ int rolo_transform_cloud(rolo_ctx* c, const float* in, float* out, int n, int st
 
 int rolo_ctx_counters(rolo_ctx* c, long long* out, int n) {
   if (!c || !out || n < 0) return ROLO_EINVAL;
-  const long long v[12] = {c->n_frames, c->n_replays, c->n_captures, c->n_eager, c->n_topup_frames, c->n_topup_chunks, c->hint_rot, c->hint_trans, c->walk_lanes,
-                           c->ns_enqueue, c->ns_wait_blocked, c->ns_wait_other};
-  for (int i = 0; i < n && i < 12; i++) out[i] = v[i];
+  const long long v[13] = {c->n_frames, c->n_replays, c->n_captures, c->n_eager, c->n_topup_frames, c->n_topup_chunks, c->hint_rot, c->hint_trans, c->walk_lanes,
+                           c->ns_enqueue, c->ns_wait_blocked, c->ns_wait_other, c->n_persist_bails};
+  for (int i = 0; i < n && i < 13; i++) out[i] = v[i];
   return ROLO_OK;
 }
+
+long long rolo_alloc_count(void) { return (long long)g_alloc_epoch.load(); }
 
 int rolo_prof_enable(rolo_ctx* c, int on) {
   if (!c) return ROLO_EINVAL;

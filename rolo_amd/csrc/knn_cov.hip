@@ -596,12 +596,10 @@ ROLO_DEV void knn_covariance_finish(double cxx, double cxy, double cxz, double c
   for (int d = 0; d < 6; d++) cov[d * pitch + qi] = c6[d];
 }
 
-// covariance of the neighbourhood + regularisation, one lane per query
+// covariance of the neighbourhood (rot_vgicp_impl.hpp:438-455), fp64, centred two-pass, the neighbours in list order: m6 = xx xy xz yy yz zz
+// the K neighbours are gathered once and stay in registers for both passes
 template <int KMAX>
-ROLO_DEV void knn_covariance_tail(const int (&ki)[KMAX], int kk, const float4* __restrict__ orig, int n, int qi, int reg,
-                                  double* __restrict__ cov, double (&c6)[6], double* __restrict__ nrm = nullptr) {
-  // ---- covariance of the neighbourhood (rot_vgicp_impl.hpp:438-455), fp64, centred two-pass ----
-  // the K neighbours are gathered once and stay in registers for both passes (this kernel is not occupancy-critical)
+ROLO_DEV void knn_neighbourhood_moments(const int (&ki)[KMAX], int kk, const float4* __restrict__ orig, double (&m6)[6]) {
   float px[KMAX], py[KMAX], pz[KMAX];
 #pragma unroll
   for (int u = 0; u < KMAX; u++) {
@@ -618,8 +616,16 @@ ROLO_DEV void knn_covariance_tail(const int (&ki)[KMAX], int kk, const float4* _
     const double ax = (double)px[u] - mx, ay = (double)py[u] - my, az = (double)pz[u] - mz;
     cxx += ax * ax; cxy += ax * ay; cxz += ax * az; cyy += ay * ay; cyz += ay * az; czz += az * az;
   }
-  cxx /= kk; cxy /= kk; cxz /= kk; cyy /= kk; cyz /= kk; czz /= kk;
-  knn_covariance_finish(cxx, cxy, cxz, cyy, cyz, czz, n, qi, reg, cov, c6, nrm);
+  m6[0] = cxx / kk; m6[1] = cxy / kk; m6[2] = cxz / kk; m6[3] = cyy / kk; m6[4] = cyz / kk; m6[5] = czz / kk;
+}
+
+// covariance of the neighbourhood + regularisation, one lane per query
+template <int KMAX>
+ROLO_DEV void knn_covariance_tail(const int (&ki)[KMAX], int kk, const float4* __restrict__ orig, int n, int qi, int reg,
+                                  double* __restrict__ cov, double (&c6)[6], double* __restrict__ nrm = nullptr) {
+  double m6[6];
+  knn_neighbourhood_moments<KMAX>(ki, kk, orig, m6);
+  knn_covariance_finish(m6[0], m6[1], m6[2], m6[3], m6[4], m6[5], n, qi, reg, cov, c6, nrm);
 }
 
 // the same for any number of neighbours (k_correspondences > 64): the neighbours are gathered twice, slot by slot, in the same order
@@ -736,7 +742,7 @@ constexpr int KNN_SUB_MAX_PACKETS = 1792;   // (the pipeline's pair launch is 14
 // against 0.76 ms); with other contexts' frames in flight the packets — half the wavefronts, the same instructions — leave the other frames' short LM kernels more of
 // every SIMD's issue slots: 3.04 against 2.98 k scans/s, and 3.17 against 3.01 k once those kernels run at raised priority (ROLO_SHORT_PRIO). The caller says which
 // case it is (frames in flight on the device when this one is enqueued, api.hip); a captured hipGraph is keyed on it.
-hipError_t launch_knn_walk(const KnnPair& A, int k, int regularization_or_minus1, const VoxelFuse& vf, hipStream_t s, int coop_budget, int* lanes_out, bool device_busy) {
+hipError_t launch_knn_walk(const KnnPair& A, int k, int regularization_or_minus1, const VoxelFuse& vf, hipStream_t s, int coop_budget, int* lanes_out, bool device_busy, bool moments) {
   if (lanes_out) *lanes_out = 1;
   constexpr int QPB = 256;   // queries per workgroup of the plain walk: four wavefronts of 64
   const int n0 = A.c[0].q_end - A.c[0].q_begin, n1 = A.n_clouds > 1 ? A.c[1].q_end - A.c[1].q_begin : 0;
@@ -804,8 +810,11 @@ hipError_t launch_knn_walk(const KnnPair& A, int k, int regularization_or_minus1
         }
         return pad_bytes;
       }();
-      if (lanes == 4) { const int s0 = (n0 + 63) / 64, s1 = (n1 + 63) / 64; knn_walk_sub_kernel<4><<<s0 + s1, 256, walk_pad, s>>>(A, s0); }
-      else if (lanes == 2) { const int s0 = (n0 + 127) / 128, s1 = (n1 + 127) / 128; knn_walk_sub_kernel<2><<<s0 + s1, 256, walk_pad, s>>>(A, s0); }
+      // moments: the walk's epilogue gathers each query's twenty winners once and leaves the six centred second moments of the neighbourhood where its covariance
+      // will go — no 80 B/pt index array to write, read back and gather through again in the tail (round 6)
+      if (lanes == 4) { const int s0 = (n0 + 63) / 64, s1 = (n1 + 63) / 64; if (moments) knn_walk_sub_kernel<4, true><<<s0 + s1, 256, walk_pad, s>>>(A, s0); else knn_walk_sub_kernel<4><<<s0 + s1, 256, walk_pad, s>>>(A, s0); }
+      else if (lanes == 2) { const int s0 = (n0 + 127) / 128, s1 = (n1 + 127) / 128; if (moments) knn_walk_sub_kernel<2, true><<<s0 + s1, 256, walk_pad, s>>>(A, s0); else knn_walk_sub_kernel<2><<<s0 + s1, 256, walk_pad, s>>>(A, s0); }
+      else if (moments) knn_walk_kernel<20, false, false, true><<<g0 + g1, 256, walk_pad, s>>>(A, g0, k, -1);
       else knn_walk_kernel<20, false><<<g0 + g1, 256, walk_pad, s>>>(A, g0, k, -1);
     }
   }
@@ -829,10 +838,11 @@ hipError_t launch_knn_unstage(const KnnPair& A, bool own_slice_only, const Voxel
   return hipGetLastError();
 }
 
-hipError_t launch_knn_tail(const KnnPair& A, int k, int regularization, const VoxelFuse& vf, hipStream_t s) {
+hipError_t launch_knn_tail(const KnnPair& A, int k, int regularization, const VoxelFuse& vf, hipStream_t s, bool moments) {
   const int g0 = slice_blocks(A.c[0]), g1 = A.n_clouds > 1 ? slice_blocks(A.c[1]) : 0;
   if (g0 + g1 == 0) return hipSuccess;
   if (k > 64) knn_tail_loop_kernel<<<g0 + g1, 256, 0, s>>>(A, g0, k, regularization, vf);
+  else if (k == 20 && moments) knn_tail_kernel<20, true><<<g0 + g1, 256, 0, s>>>(A, g0, k, regularization, vf);
   else if (k == 20) knn_tail_kernel<20><<<g0 + g1, 256, 0, s>>>(A, g0, k, regularization, vf);
   else if (k <= 32) knn_tail_kernel<32><<<g0 + g1, 256, 0, s>>>(A, g0, k, regularization, vf);
   else knn_tail_kernel<64><<<g0 + g1, 256, 0, s>>>(A, g0, k, regularization, vf);

@@ -64,6 +64,40 @@ ROLO_DEV void walk_write_lists(const KnnCloud& cl, const double (&K)[KMAX], int 
   for (int u = 0; u < KMAX; u++) nbr[(size_t)(slot0 + u) * cl.n_sorted + j] = ki[u];
 }
 
+// Round 6: a finished query gathers its kk winners ONCE, right here, and leaves the six centred second moments of its neighbourhood (the oracle's order: mean first,
+// then the products summed over the list, rot_vgicp_impl.hpp:438-455) in cov[] — 48 B/pt that the tail finishes in place — instead of 80 B/pt of indices that the tail
+// read back and gathered through again (70 MB of fabric traffic for 6 MB of algorithmic bytes, 202 VGPRs: round 5's verdict, item 4). The light wavefronts do this while
+// the heavy ones still walk; it is the gather and ~250 fp64 instructions, not the SVD (the whole tail inside the walk lost: ROLO_KNN_FUSE_TAIL).
+template <int KMAX>
+ROLO_DEV void walk_write_moments(const KnnCloud& cl, const double (&K)[KMAX], int kk, int qi, int j, int (*s_ki)[256]) {
+  if (cl.knn_idx) {   // the debug lists (rolo_get_knn)
+#pragma unroll
+    for (int u = 0; u < KMAX; u++) if (u < kk) { cl.knn_idx[(size_t)qi * kk + u] = key_idx(K[u]); cl.knn_d2[(size_t)qi * kk + u] = key_d2(K[u]); }
+  }
+  // The indices go to this lane's column of an LDS array and the two passes over the list are REAL loops (five gathers in flight): with the list in registers the loops
+  // must be unrolled, the scheduler hoists all twenty gathers of a pass, and the walk pays for 60 more registers with half its occupancy (8 % of the headline: DEAD_ENDS,
+  // round 6). The second pass finds the points in the caches.
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int u = 0; u < KMAX; u++) s_ki[u][tid] = key_idx(K[u]);
+  const float4* __restrict__ orig = cl.xyz;
+  double mx = 0, my = 0, mz = 0;
+#pragma unroll 5
+  for (int u = 0; u < kk; u++) { const float4 p = orig[s_ki[u][tid]]; mx += (double)p.x; my += (double)p.y; mz += (double)p.z; }
+  mx /= kk; my /= kk; mz /= kk;
+  double cxx = 0, cxy = 0, cxz = 0, cyy = 0, cyz = 0, czz = 0;
+#pragma unroll 5
+  for (int u = 0; u < kk; u++) {
+    const float4 p = orig[s_ki[u][tid]];
+    const double ax = (double)p.x - mx, ay = (double)p.y - my, az = (double)p.z - mz;
+    cxx += ax * ax; cxy += ax * ay; cxz += ax * az; cyy += ay * ay; cyz += ay * az; czz += az * az;
+  }
+  // by SORTED position (coalesced here and in the tail), in the scratch the index lists would have taken: 6 doubles of the 32 int slots per position
+  double* __restrict__ mom = reinterpret_cast<double*>(cl.nbr);
+  const size_t pitch = (size_t)cl.n_sorted;
+  mom[j] = cxx / kk; mom[pitch + j] = cxy / kk; mom[2 * pitch + j] = cxz / kk; mom[3 * pitch + j] = cyy / kk; mom[4 * pitch + j] = cyz / kk; mom[5 * pitch + j] = czz / kk;
+}
+
 // The walk keeps only the 20 packed keys and the query live (58 VGPRs): cut for 8 wavefronts per SIMD. Neighbour indices
 // go to A.c[].nbr, slot-major so every store is coalesced; knn_tail_kernel turns them into covariances.
 #ifndef ROLO_KNN_WALK_OCC
@@ -92,9 +126,10 @@ ROLO_DEV void walk_seeds(const float4* __restrict__ sorted, int g_mine0, int g_o
   }
 }
 
-template <int KMAX, bool FUSE_TAIL, bool LOWER = false>
-__global__ __launch_bounds__(256, KMAX > 32 ? 2 : ROLO_KNN_WALK_OCC) void knn_walk_kernel(KnnPair A, int split, int k, int reg) {   // 64 slots = 128 key registers: 256 VGPRs, 2 waves per SIMD
+template <int KMAX, bool FUSE_TAIL, bool LOWER = false, bool MOMENTS = false>
+__global__ __launch_bounds__(256, KMAX > 32 ? 2 : (MOMENTS ? 6 : ROLO_KNN_WALK_OCC)) void knn_walk_kernel(KnnPair A, int split, int k, int reg) {   // 64 slots = 128 key registers: 256 VGPRs, 2 waves per SIMD
   __shared__ int stk[4][WALK_STACK];
+  __shared__ int s_ki[MOMENTS ? KMAX : 1][256];   // MOMENTS: every lane's neighbour indices for the epilogue's loops (walk_write_moments)
   const int tid = threadIdx.x;
   const int wv = tid >> 6;
   // which cloud of the pair this workgroup searches (wave-uniform: everything below stays in scalar registers)
@@ -159,6 +194,10 @@ __global__ __launch_bounds__(256, KMAX > 32 ? 2 : ROLO_KNN_WALK_OCC) void knn_wa
 
   if (!active) return;
 
+  if (MOMENTS) {   // the neighbourhood's moments instead of its indices (walk_write_moments)
+    walk_write_moments<KMAX>(A.c[which], K, kk, qi, j, s_ki);
+    return;
+  }
   if (!FUSE_TAIL) {   // neighbour indices only (slot-major, coalesced): knn_tail_kernel turns them into covariances
     walk_write_lists<KMAX>(A.c[which], K, kk, bkey, qi, j);
     return;
@@ -225,12 +264,13 @@ template <int ST> ROLO_DEV void merge20(double (&K)[20]) {
 #else
 #define ROLO_KNN_WALK_OCC_ATTR
 #endif
-template <int SUB>
-__global__ __launch_bounds__(256, ROLO_KNN_WALK_OCC) ROLO_KNN_WALK_OCC_ATTR void knn_walk_sub_kernel(KnnPair A, int split /* first block of cloud 1 */) {
+template <int SUB, bool MOMENTS = false>
+__global__ __launch_bounds__(256, MOMENTS ? 6 : ROLO_KNN_WALK_OCC) ROLO_KNN_WALK_OCC_ATTR void knn_walk_sub_kernel(KnnPair A, int split /* first block of cloud 1 */) {
   constexpr int SH = SUB == 2 ? 1 : 2, QPW = 64 / SUB, PPL = KNN_LEAF / SUB, KMAX = 20, E = 4 / SUB /* grandchild boxes per lane */, OWN = QPW / KNN_LEAF;
   static_assert(SUB == 2 || SUB == 4, "lanes per query");
   static_assert(KNN_LEAF == 16, "a wavefront's queries are whole leaves");
   __shared__ int stk_[4][WALK_STACK];
+  __shared__ int s_ki[MOMENTS ? KMAX : 1][256];
   const int tid = threadIdx.x;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, sub = lane & (SUB - 1), ql = lane >> SH;
   const int blk = xcd_contiguous_block((int)blockIdx.x, (int)gridDim.x, 4);
@@ -344,6 +384,10 @@ __global__ __launch_bounds__(256, ROLO_KNN_WALK_OCC) ROLO_KNN_WALK_OCC_ATTR void
   }
   merge20<0>(K);
   if (SUB == 4) merge20<1>(K);   // all the query's lanes hold its list now
+  if (MOMENTS) {   // the first lane of a query gathers its neighbourhood (one lane: the sums must run in list order, as the oracle's do) — walk_write_moments
+    if (active && sub == 0) walk_write_moments<KMAX>(cl, K, KMAX, qi, j, s_ki);
+    return;
+  }
   // every sub-lane writes 20 / SUB of the twenty slots (slot-major index array for knn_tail_kernel: a store covers SUB slots x QPW queries)
   constexpr int NS = KMAX / SUB;
   int ki[NS];
@@ -542,7 +586,7 @@ __global__ __launch_bounds__(64 * NW, ROLO_KNN_WALK_OCC) void knn_walk_coop_kern
 #ifndef ROLO_KNN_TAIL_OCC
 #define ROLO_KNN_TAIL_OCC 2
 #endif
-template <int KMAX>
+template <int KMAX, bool MOMENTS = false>
 __global__ __launch_bounds__(256, ROLO_KNN_TAIL_OCC) void knn_tail_kernel(KnnPair A, int split, int k, int reg, VoxelFuse vf) {
   ROLO_TAIL_KERNEL_PRIO();
   const int blk = xcd_contiguous_block((int)blockIdx.x, (int)gridDim.x);
@@ -558,7 +602,17 @@ __global__ __launch_bounds__(256, ROLO_KNN_TAIL_OCC) void knn_tail_kernel(KnnPai
   const bool act = qi != INT_MAX;
   if (!act && !fuse) return;
   double c6[6] = {0, 0, 0, 0, 0, 0};
-  if (act) {
+  if (act && MOMENTS) {   // the walk left the neighbourhood's six moments in cov[] (walk_write_moments): regularise them in place
+    const size_t pitch = (size_t)n_sorted;
+    const double* __restrict__ cv = reinterpret_cast<const double*>(cl.nbr);   // by sorted position: coalesced
+    const double m0 = cv[j], m1 = cv[pitch + j], m2 = cv[2 * pitch + j], m3 = cv[3 * pitch + j], m4 = cv[4 * pitch + j], m5 = cv[5 * pitch + j];
+    if (cl.stage) {
+      double* o = stage_area(cl, 1) + (size_t)(j / cl.chunk) * cl.seg + cl.stage_off + (size_t)(j % cl.chunk) * 6;
+      knn_covariance_finish(m0, m1, m2, m3, m4, m5, 1, 0, reg, o, c6);
+    } else {
+      knn_covariance_finish(m0, m1, m2, m3, m4, m5, cl.n, qi, reg, cl.cov, c6, cl.nrm);
+    }
+  } else if (act) {
     const int32_t* __restrict__ nbr = cl.nbr;
     int ki[KMAX];
 #pragma unroll

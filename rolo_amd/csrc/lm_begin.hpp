@@ -25,7 +25,7 @@ __device__ inline void rot_begin_dev(LmState* st, const RotBegin& a) {
   st->run_trans = a.run_trans;
   st->rot_done = 0; st->rot_converged = 0; st->rot_failed = 0; st->rot_outer = 0; st->rot_passes = 0; st->rot_ncorr = 0;
   st->trans_done = 0; st->trans_failed = 0; st->trans_outer = 0; st->trans_passes = 0;
-  st->trace_count = 0; st->error = 0; st->pending = 0; st->lin_skip = 0; st->spec_lin = a.spec_lin; st->rot_cost_only = 0; st->trans_cost_only = 0;
+  st->trace_count = 0; st->error = 0; st->pending = 0; st->lin_skip = 0; st->spec_lin = a.spec_lin; st->rot_cost_only = 0; st->trans_cost_only = 0; st->lmp_bailed = 0;
   st->optimizer = a.optimizer; st->max_iterations = a.max_iterations; st->fixed_iterations = a.fixed_iterations;
   st->lm_max = a.lm_max; st->q2_intended = a.q2_intended; st->rot_eps = a.rot_eps; st->trans_eps = a.trans_eps; st->lm_init = a.lm_init;
   st->inv_rot_eps = 1.0 / a.rot_eps; st->inv_trans_eps = 1.0 / a.trans_eps;

@@ -1129,14 +1129,45 @@ __global__ __launch_bounds__(THREADS) void lm_kernel(PassArgs a, const LmState* 
 // A poll that lasts longer than timeout_ticks (wall clock, 100 MHz) gives up: the stage ends with ROLO_ECOMM in the state — a workgroup that never became
 // resident costs a bounded wait, never a hung GPU. Co-residency: G x THREADS threads with ~30 KB of LDS per workgroup fit the chip several times over (256 CUs),
 // and every kernel that can occupy the slots in the meantime terminates by itself.
-constexpr int LMP_HDR = 8;   // words in front of the rows: [0] = last epoch used
+// ADMISSION. Spinning workgroups never give their slots back, so two resident kernels that each got only part of their workgroups onto the chip — two processes sharing
+// the GPU, more contexts in flight than the sizing assumed — would wait for each other forever. Before the first trial the workgroups therefore exchange one EMPTY row under
+// a short timeout (admit_ticks, default 1 ms: longer than any kernel of this library that may hold the slots in the meantime): if every row arrives, all G workgroups are
+// resident and will stay so; if not, the workgroup that ran out of time raises the bail word of this launch, everybody — whoever is polling now, whoever becomes resident
+// later — sees it and leaves, the LM state is untouched (LmState::lmp_bailed = 1 apart), and the host finishes the frame with pass + controller launches. A lost race costs
+// the admission time, never a hung GPU and never an error.
+constexpr int LMP_HDR = 8;   // words in front of the rows: [0] = last epoch used, [2] = bail word (the admission epoch of the launch that gave up)
+#ifdef ROLO_LMP_STATS
+// the phases of a trial as workgroup 0 sees them (wall clock, 100 MHz ticks, summed): [0] pass body + block reduction, [1] exchange (publish, poll, row sums), [2] the scalar step, [7] trials
+__device__ unsigned long long g_lmp_t[8];
+extern "C" int rolo_debug_lmp_times(unsigned long long* out8, int reset) {
+  (void)hipDeviceSynchronize();
+  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_lmp_t), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+  if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_lmp_t), z, sizeof(z)) != hipSuccess) return -1; }
+  return 0;
+}
+#define LMP_STAMP(k) const long long lt##k = wall_clock64()
+#define LMP_ACC() do { if (wg == 0 && t == 0) { const long long lt3 = wall_clock64(); atomicAdd(&g_lmp_t[0], (unsigned long long)(lt1 - lt0)); atomicAdd(&g_lmp_t[1], (unsigned long long)(lt2 - lt1)); \
+                       atomicAdd(&g_lmp_t[2], (unsigned long long)(lt3 - lt2)); atomicAdd(&g_lmp_t[7], 1ull); } } while (0)
+#else
+#define LMP_STAMP(k)
+#define LMP_ACC()
+#endif
 // the scalar step as a CALL: one lane runs ~700 dependent instructions with its own register needs (the LDLT's factors) — inlined into the resident kernel's loop they
 // were live across the pass bodies and spilled (620 bytes of scratch per lane)
-template <int DOF> __device__ __noinline__ void lmp_rot_step(LmState* st, const double* S, rolo_trace_rec* trace) { rot_step_t<DOF>(st, S, trace); }
-__device__ __noinline__ void lmp_trans_step(LmState* st, const double* S, rolo_trace_rec* trace) { trans_step(st, S, trace); }
+// (state and sums live in LDS: the round trip through an address_space(3) pointer tells the compiler so — a call boundary hides it, and generic pointers would make every
+// one of the step's ~150 state accesses a flat instruction)
+template <typename T> ROLO_DEV T* lds_ptr(T* p) { return (T*)(__attribute__((address_space(3))) T*)p; }
+template <int DOF> __device__ __noinline__ void lmp_rot_step(LmState* st, const double* S, rolo_trace_rec* trace) { rot_step_t<DOF>(lds_ptr(st), lds_ptr(S), trace); }
+__device__ __noinline__ void lmp_trans_step(LmState* st, const double* S, rolo_trace_rec* trace) { trans_step(lds_ptr(st), lds_ptr(S), trace); }
 
 // publish row[0 .. nv) as words of epoch e, collect all G rows, add them in a fixed order into sums[] (V_* slots). Returns false if a row did not arrive in time.
-template <int THREADS>
+#ifndef ROLO_LMP_SPIN_PRIO
+#define ROLO_LMP_SPIN_PRIO 1   // issue priority while a workgroup polls the others' rows (A/B: 0 = the spinning wavefronts step back behind everything else on their SIMD)
+#endif
+#ifndef ROLO_LMP_SPIN_SLEEP
+#define ROLO_LMP_SPIN_SLEEP 1  // s_sleep argument between two polls of a missing word (x 64 clocks)
+#endif
+template <int THREADS, bool ADMIT = false>
 ROLO_DEV bool lmp_exchange(const double* __restrict__ row, int nv, int nh, unsigned e, unsigned long long* __restrict__ xbuf, int G, int wg, unsigned* __restrict__ xw,
                            double (*part)[NV_MAX], double* __restrict__ sums, int* __restrict__ bad, unsigned long long timeout_ticks) {
   const int t = (int)threadIdx.x;
@@ -1149,6 +1180,7 @@ ROLO_DEV bool lmp_exchange(const double* __restrict__ row, int nv, int nh, unsig
   }
   const int total = G * nw;
   const long long t0 = wall_clock64();
+  if (ROLO_LMP_SPIN_PRIO != ROLO_SHORT_PRIO) __builtin_amdgcn_s_setprio(ROLO_LMP_SPIN_PRIO);
   for (int base = t; base < total; base += THREADS * 4) {
     unsigned long long x[4]; const unsigned long long* q[4];
 #pragma unroll
@@ -1163,15 +1195,23 @@ ROLO_DEV bool lmp_exchange(const double* __restrict__ row, int nv, int nh, unsig
       const int i = base + u * THREADS;
       if (i >= total) continue;
       while ((unsigned)(x[u] >> 32) != e) {
-        if ((unsigned long long)(wall_clock64() - t0) > timeout_ticks) { *bad = 1; break; }
-        __builtin_amdgcn_s_sleep(1);
+        if ((unsigned long long)(wall_clock64() - t0) > timeout_ticks) {
+          *bad = 1;
+          if (ADMIT) __hip_atomic_store(xbuf + 2, (unsigned long long)e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // this launch gives up: tell everybody
+          break;
+        }
+        if (ADMIT && (unsigned)__hip_atomic_load(xbuf + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == e) { *bad = 1; break; }   // somebody gave up
+        __builtin_amdgcn_s_sleep(ADMIT ? 8 : ROLO_LMP_SPIN_SLEEP);
         x[u] = __hip_atomic_load(q[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       xw[i] = (unsigned)x[u];
     }
   }
+  if (ROLO_LMP_SPIN_PRIO != ROLO_SHORT_PRIO) __builtin_amdgcn_s_setprio(ROLO_SHORT_PRIO);
+  if (ADMIT && t == 0 && (unsigned)__hip_atomic_load(xbuf + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == e) *bad = 1;   // (a workgroup that found every row may still be the last to hear)
   __syncthreads();
   if (*bad) return false;
+  if (ADMIT) return true;
   {   // row sums in a fixed order (16 groups of rows, then the groups): the same bits in every workgroup
     const int v = t & 31, q = t >> 5;
     double s0 = 0.0;
@@ -1189,9 +1229,168 @@ ROLO_DEV bool lmp_exchange(const double* __restrict__ row, int nv, int nh, unsig
   return true;
 }
 
-template <int DOF, int THREADS>
-__global__ __launch_bounds__(THREADS) void lm_persist_kernel(PassArgs a, LmState* st_io, unsigned long long* __restrict__ xbuf, rolo_trace_rec* trace, int ppt, LmState* pub,
-                                                            unsigned long long timeout_ticks, int max_trials) {
+// The pass bodies of the resident kernel: PPT points per thread, INTERLEAVED — all the record fetches of half (A) first, the first hash probes of half (B) behind them,
+// then (A)'s arithmetic while the probes are in flight, (B)'s record fetches, (B)'s arithmetic: a trial costs two dependent round trips whatever PPT is, where a loop over
+// the points costs two per point (one launch per trial with 2 / 4 / 8 points per thread: +70 us of frame latency per doubling, DEAD_ENDS rounds 2-3). A thread owns the same
+// points in every trial, so the float coordinates, the covariance (as m) and BOTH correspondence ids of a point stay in registers for the whole chain; the ids are still
+// written to corr[] — the getters and a later rolo_compute_translation read them there.
+struct PtReg { float x, y, z; Vec3 m; };   // m.x is NaN for a point whose covariance is not of the plane form (or when the pass has no m at all): six entries from memory
+template <int PPT>
+ROLO_DEV void lmp_load_points(const PassArgs& a, int i0, int threads, PtReg (&pt)[PPT], int (&cid)[PPT][2], bool (&valid)[PPT]) {
+  const size_t pitch = (size_t)a.n_total;
+#pragma unroll
+  for (int p = 0; p < PPT; p++) {
+    const int i = i0 + p * threads;
+    valid[p] = i < a.end;
+    pt[p] = PtReg{0.f, 0.f, 0.f, Vec3{__builtin_nan(""), 0.0, 0.0}};
+    cid[p][0] = cid[p][1] = -1;
+    if (valid[p]) {
+      const float4 pf = a.src[i];
+      pt[p].x = pf.x; pt[p].y = pf.y; pt[p].z = pf.z;
+      if (a.nrm) pt[p].m = Vec3{a.nrm[i], a.nrm[pitch + i], a.nrm[2 * pitch + i]};
+      if (a.n_off == 1) { cid[p][0] = a.corr[0][i]; cid[p][1] = a.corr[1][i]; }
+    }
+  }
+}
+ROLO_DEV Sym3 lmp_rotated_cov(const PassArgs& a, const double* R, const double* __restrict__ S6, const PtReg& q, int i) {
+  if (q.m.x == q.m.x) {
+    const Sym3 S{uni(S6[0]), uni(S6[1]), uni(S6[2]), uni(S6[3]), uni(S6[4]), uni(S6[5])};
+    const Vec3 r = mat3_mulv(R, q.m);
+    return Sym3{S.xx - r.x * r.x, S.xy - r.x * r.y, S.xz - r.x * r.z, S.yy - r.y * r.y, S.yz - r.y * r.z, S.zz - r.z * r.z};
+  }
+  const size_t pitch = (size_t)a.n_total;
+  return sym3_rotate(R, Sym3{a.cov[i], a.cov[pitch + i], a.cov[2 * pitch + i], a.cov[3 * pitch + i], a.cov[4 * pitch + i], a.cov[5 * pitch + i]});
+}
+template <int DOF, int PPT>
+ROLO_DEV void lmp_rot_body(const PassArgs& a, const LmState* __restrict__ st, int i0, int threads, const PtReg* pt, int (*cid)[2], const bool* valid,
+                           double (&acc)[3 + DOF * (DOF + 1) / 2 + DOF]) {
+  constexpr int NH = DOF * (DOF + 1) / 2;
+  const int phase = uni(st->phase), cur = uni(st->cur);
+  const bool skip_lin = phase == 1 && uni(st->lin_skip) != 0;
+  const int newb = phase == 0 ? cur : (cur ^ 1);
+  double R0[9], R1[9], t1[3];
+#pragma unroll
+  for (int k = 0; k < 9; k++) { R0[k] = uni(st->x0_R[k]); R1[k] = uni(st->xt_R[k]); }
+#pragma unroll
+  for (int k = 0; k < 3; k++) t1[k] = uni(st->xt_t[k]);
+  Vec3 tp[PPT];
+#pragma unroll
+  for (int p = 0; p < PPT; p++) {
+    tp[p] = mat3_mulv(R1, Vec3{(double)pt[p].x, (double)pt[p].y, (double)pt[p].z});
+    tp[p].x += t1[0]; tp[p].y += t1[1]; tp[p].z += t1[2];
+  }
+  // (A) compute_error(xi): the records of the cached correspondences — their ids are in registers, so these fetches depend on nothing this trial computed
+  Rec ra[PPT]; bool ha[PPT];
+#pragma unroll
+  for (int p = 0; p < PPT; p++) {
+    const int v = cur ? cid[p][1] : cid[p][0];
+    ha[p] = phase == 1 && valid[p] && v >= 0;
+    if (ha[p]) ra[p] = load_rec(a.tab.rec, v);
+  }
+  // (B) first probe of every point's voxel
+  unsigned long long key[PPT]; unsigned h[PPT]; ulonglong2 sl[PPT]; bool ok[PPT];
+  if (!skip_lin) {
+#pragma unroll
+    for (int p = 0; p < PPT; p++) {
+      int kx, ky, kz;
+      voxel_coord_dev(a.tab, tp[p].x, tp[p].y, tp[p].z, kx, ky, kz);
+      ok[p] = valid[p] && pack_key(kx, ky, kz, key[p]);
+      h[p] = hash_key(key[p]) & a.tab.mask;
+      if (ok[p]) sl[p] = *reinterpret_cast<const ulonglong2*>(a.tab.keys + 2 * (size_t)h[p]);
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < PPT; p++) {
+    if (ha[p]) {
+      const Sym3 M = sym3_inverse(sym3_add(ra[p].cov, lmp_rotated_cov(a, R0, st->x0_S, pt[p], i0 + p * threads)));
+      const Vec3 e{ra[p].mean.x - tp[p].x, ra[p].mean.y - tp[p].y, ra[p].mean.z - tp[p].z};
+      acc[0] += ra[p].w * dot3(e, sym3_mulv(M, e));
+    }
+  }
+  if (skip_lin) return;
+  int vid[PPT];
+  int* __restrict__ corr_new = a.corr[newb];
+#pragma unroll
+  for (int p = 0; p < PPT; p++) {
+    vid[p] = -1;
+    if (ok[p]) {
+      while (true) {   // (the table is at most half full: the first probe answers almost always)
+        if (sl[p].x == key[p]) { vid[p] = (int)(unsigned)sl[p].y; break; }
+        if (sl[p].x == KEY_EMPTY) break;
+        h[p] = (h[p] + 1) & a.tab.mask;
+        sl[p] = *reinterpret_cast<const ulonglong2*>(a.tab.keys + 2 * (size_t)h[p]);
+      }
+    }
+    if (newb) cid[p][1] = vid[p]; else cid[p][0] = vid[p];
+    if (valid[p]) corr_new[i0 + p * threads] = vid[p];
+  }
+  Rec rb[PPT];
+#pragma unroll
+  for (int p = 0; p < PPT; p++) if (vid[p] >= 0) rb[p] = load_rec(a.tab.rec, vid[p]);
+#pragma unroll
+  for (int p = 0; p < PPT; p++) {
+    if (vid[p] >= 0) {
+      const Sym3 M = sym3_inverse(sym3_add(rb[p].cov, lmp_rotated_cov(a, R1, st->xt_S, pt[p], i0 + p * threads)));
+      const Vec3 e{rb[p].mean.x - tp[p].x, rb[p].mean.y - tp[p].y, rb[p].mean.z - tp[p].z};
+      const Vec3 Me = sym3_mulv(M, e);
+      acc[1] += rb[p].w * dot3(e, Me);
+      acc[2] += 1.0;
+      const Vec3 wMe{rb[p].w * Me.x, rb[p].w * Me.y, rb[p].w * Me.z};
+      accumulate_hb<DOF>(M, tp[p], rb[p].w, 0.0, wMe, &acc[3], &acc[3 + NH]);
+    }
+  }
+}
+template <int PPT>
+ROLO_DEV void lmp_trans_body(const PassArgs& a, const LmState* __restrict__ st, int i0, int threads, const PtReg* pt, const int (*cid)[2], const bool* valid, double (&acc)[30]) {
+  constexpr int NH = 21;
+  const int phase = uni(st->phase);
+  const bool skip_lin = phase == 1 && uni(st->lin_skip) != 0;
+  const int tr_cur = uni(st->tr_cur);
+  double R[9];
+#pragma unroll
+  for (int k = 0; k < 9; k++) R[k] = uni(st->tr_R[k]);
+  const Vec3 tt{uni(st->tt[0]), uni(st->tt[1]), uni(st->tt[2])};
+  const Vec3 g{uni(st->g[0]), uni(st->g[1]), uni(st->g[2])};
+  const double lam_n = uni(st->lam_over_n);
+  const Vec3 lAq{uni(st->lastA_q[0]), uni(st->lastA_q[1]), uni(st->lastA_q[2])}, lBq{uni(st->lastB_q[0]), uni(st->lastB_q[1]), uni(st->lastB_q[2])};
+  const double inv_dtn = uni(st->inv_dtn);
+  Rec r[PPT]; bool has[PPT];
+#pragma unroll
+  for (int p = 0; p < PPT; p++) {
+    const int v = tr_cur ? cid[p][1] : cid[p][0];
+    has[p] = valid[p] && v >= 0;
+    if (has[p]) r[p] = load_rec(a.tab.rec, v);
+  }
+#pragma unroll
+  for (int p = 0; p < PPT; p++) {
+    if (!has[p]) continue;
+    const Vec3 q{(double)pt[p].x, (double)pt[p].y, (double)pt[p].z};
+    const Vec3 tp{q.x + tt.x, q.y + tt.y, q.z + tt.z};
+    const Vec3 ba{q.x - g.x, q.y - g.y, q.z - g.z};
+    const Vec3 dv{(ba.x - tp.x) * inv_dtn, (ba.y - tp.y) * inv_dtn, (ba.z - tp.z) * inv_dtn};
+    const Vec3 ctA{dv.x - lAq.x, dv.y - lAq.y, dv.z - lAq.z};
+    const Vec3 ctB{dv.x - lBq.x, dv.y - lBq.y, dv.z - lBq.z};
+    const Sym3 M = sym3_inverse(sym3_add(r[p].cov, lmp_rotated_cov(a, R, st->tr_S, pt[p], i0 + p * threads)));
+    const Vec3 e{r[p].mean.x - tp.x, r[p].mean.y - tp.y, r[p].mean.z - tp.z};
+    const Vec3 Me = sym3_mulv(M, e);
+    const double eMe = dot3(e, Me), w = r[p].w;
+    if (phase == 1) acc[0] += w * (eMe + lam_n * dot3(ctA, sym3_mulv(M, ctA)));
+    if (skip_lin) continue;
+    const Vec3 McB = sym3_mulv(M, ctB);
+    acc[1] += w * (eMe + lam_n * dot3(ctB, McB));
+    acc[2] += 1.0;
+    const double s1 = lam_n * inv_dtn;
+    const Vec3 vb{w * (Me.x + s1 * McB.x), w * (Me.y + s1 * McB.y), w * (Me.z + s1 * McB.z)};
+    accumulate_hb<6>(M, tp, w * (1.0 + lam_n * inv_dtn * inv_dtn), 0.0, vb, &acc[3], &acc[3 + NH]);
+  }
+}
+
+// PPT > 0: the interleaved bodies above (DIRECT1 only: one correspondence per point); PPT = 0: any number of points per thread and any neighbour search, one point after the other
+// BATCH = points of a thread that go through a body together (interleaved); OCC = wavefronts per SIMD the register budget must allow (2: 256 registers, 4: 128 — then a
+// walk's wavefronts fit on the same SIMDs and use the issue slots the resident kernel leaves idle while it exchanges and steps)
+template <int DOF, int THREADS, int PPT, int BATCH = (PPT > 0 ? PPT : 1), int OCC = 2>
+__global__ __launch_bounds__(THREADS, OCC) void lm_persist_kernel(PassArgs a, LmState* st_io, unsigned long long* __restrict__ xbuf, rolo_trace_rec* trace, int ppt, LmState* pub,
+                                                                             unsigned long long timeout_ticks, unsigned long long admit_ticks, int max_trials) {
   __shared__ LmState sst;
   __shared__ double row[NV_MAX];
   __shared__ double sums[NV_MAX];
@@ -1201,8 +1400,10 @@ __global__ __launch_bounds__(THREADS) void lm_persist_kernel(PassArgs a, LmState
   static_assert(sizeof(LmState) % sizeof(int) == 0, "LmState must be int-copyable");
   constexpr int NW = sizeof(LmState) / sizeof(int);
   constexpr int NHR = DOF * (DOF + 1) / 2, NVR = 3 + NHR + DOF;
+  constexpr int NP = PPT > 0 ? PPT : 1;
   static_assert(THREADS == 512, "16 summation groups of 32 values");
   const int G = (int)gridDim.x, wg = (int)blockIdx.x, t = (int)threadIdx.x;
+  if (PPT > 0) ppt = PPT;
   ROLO_SHORT_KERNEL_PRIO();
   {
     const int* g = reinterpret_cast<const int*>(st_io);
@@ -1211,54 +1412,85 @@ __global__ __launch_bounds__(THREADS) void lm_persist_kernel(PassArgs a, LmState
   }
   unsigned e = (unsigned)xbuf[0];   // written by the previous launch on this context (a kernel boundary ago)
   if (t == 0) bad = 0;
-  __syncthreads();
   // XCD x (= wg mod 8: the dispatcher deals workgroups round-robin) owns a contiguous eighth of the point blocks — a sector of the cloud whose voxels no other XCD's
   // L2 has to hold (pass_xcd_block); and with no kernel boundary between the trials that L2 stays warm from the second trial on
   const int i0 = a.begin + pass_xcd_block(a, wg, G) * ppt * THREADS + t;
+  PtReg pt[NP]; int cid[NP][2]; bool valid[NP];
+  if (PPT > 0) lmp_load_points<NP>(a, i0, THREADS, pt, cid, valid);
+  __syncthreads();
+  // admission (above): one empty row per workgroup under the short timeout
+  if (t == 0) row[0] = 0.0;
+  __syncthreads();
+  if (admit_ticks == 0 /* test switch: nobody is admitted */ || !lmp_exchange<THREADS, true>(row, 1, 0, ++e, xbuf, G, wg, xw, part, sums, &bad, admit_ticks)) {
+    // not everybody is resident: leave the stage to the host, exactly as it was (every leaving workgroup writes the same words)
+    if (t == 0) {
+      xbuf[0] = admit_ticks == 0 ? e + 1 : e;
+      st_io->lmp_bailed = 1;
+      if (pub) { int* h = reinterpret_cast<int*>(pub); const int* l = reinterpret_cast<const int*>(&sst); for (int w = 0; w < NW; w++) h[w] = l[w]; pub->lmp_bailed = 1; }
+    }
+    return;
+  }
+  if (t == 0) sst.lmp_bailed = 0;
   rolo_trace_rec* tr = wg == 0 ? trace : nullptr;   // without a buffer trace_count still advances
   int trial = 0;
   bool ok = true;
   // ---- rotation / 6-dof stage ----
   while (ok && uni(sst.stage) == 1) {
     const bool only_first = uni(sst.phase) == 1 && uni(sst.lin_skip) != 0;
+    LMP_STAMP(0);
     {
       double acc[NVR]; int slot[NVR];
 #pragma unroll
       for (int v = 0; v < NVR; v++) { acc[v] = 0.0; slot[v] = v; }
-      for (int p = 0; p < ppt; p++) {
+      if (PPT > 0) {
+#pragma unroll
+        for (int p0 = 0; p0 < NP; p0 += BATCH) lmp_rot_body<DOF, BATCH>(a, &sst, i0 + p0 * THREADS, THREADS, pt + p0, cid + p0, valid + p0, acc);
+      }
+      else for (int p = 0; p < ppt; p++) {
         const int i = i0 + p * THREADS;
-        const bool valid = i < a.end;
+        const bool vl = i < a.end;
         PtIn in{};
-        if (valid) in = load_pt(a, i);
-        rot_pass_compute<DOF>(a, &sst, i, valid, in, acc);
+        if (vl) in = load_pt(a, i);
+        rot_pass_compute<DOF>(a, &sst, i, vl, in, acc);
       }
       block_reduce_store<NVR, THREADS>(acc, slot, row, only_first);   // compact: yi, y, n, H lower triangle, b
     }
     __syncthreads();
+    LMP_STAMP(1);
     ok = lmp_exchange<THREADS>(row, only_first ? 1 : NVR, NHR, ++e, xbuf, G, wg, xw, part, sums, &bad, timeout_ticks) && ++trial <= max_trials;
+    LMP_STAMP(2);
     if (ok && t == 0) lmp_rot_step<DOF>(&sst, sums, tr);
     __syncthreads();
+    LMP_ACC();
   }
   // ---- translation stage ----
   while (ok && uni(sst.stage) == 2) {
     const bool only_first = uni(sst.phase) == 1 && uni(sst.lin_skip) != 0;
+    LMP_STAMP(0);
     {
       double acc[30]; int slot[30];
 #pragma unroll
       for (int v = 0; v < 30; v++) { acc[v] = 0.0; slot[v] = v; }
-      for (int p = 0; p < ppt; p++) {
+      if (PPT > 0) {
+#pragma unroll
+        for (int p0 = 0; p0 < NP; p0 += BATCH) lmp_trans_body<BATCH>(a, &sst, i0 + p0 * THREADS, THREADS, pt + p0, cid + p0, valid + p0, acc);
+      }
+      else for (int p = 0; p < ppt; p++) {
         const int i = i0 + p * THREADS;
-        const bool valid = i < a.end;
+        const bool vl = i < a.end;
         PtIn in{};
-        if (valid) in = load_pt(a, i);
-        trans_pass_compute(a, &sst, i, valid, in, acc);
+        if (vl) in = load_pt(a, i);
+        trans_pass_compute(a, &sst, i, vl, in, acc);
       }
       block_reduce_store<30, THREADS>(acc, slot, row, only_first);
     }
     __syncthreads();
+    LMP_STAMP(1);
     ok = lmp_exchange<THREADS>(row, only_first ? 1 : 30, 21, ++e, xbuf, G, wg, xw, part, sums, &bad, timeout_ticks) && ++trial <= max_trials;
+    LMP_STAMP(2);
     if (ok && t == 0) lmp_trans_step(&sst, sums, tr);
     __syncthreads();
+    LMP_ACC();
   }
   if (!ok) {   // a row never arrived (or the stages do not end): an error code instead of waiting forever
     if (t == 0) { sst.error = ROLO_ECOMM; sst.stage = 0; sst.rot_done = 1; sst.rot_failed = 1; sst.trans_done = 1; sst.trans_failed = 1; }
@@ -1285,7 +1517,7 @@ ROLO_DEV void trans_knobs(LmState* st, const TransBegin& a) {   // TransBegin: t
 __global__ void trans_begin_kernel(LmState* st, TransBegin a) {
   if (threadIdx.x != 0) return;
   for (int i = 0; i < 3; i++) { st->t0[i] = a.t0[i]; st->g[i] = a.g[i]; st->l[i] = a.l[i]; }
-  st->dtn = a.dtn; st->dtn1 = a.dtn1; st->ct_lambda = a.ct_lambda; st->pending = 0;
+  st->dtn = a.dtn; st->dtn1 = a.dtn1; st->ct_lambda = a.ct_lambda; st->pending = 0; st->lmp_bailed = 0;
   trans_knobs(st, a);
   if (a.direct) trans_start(st);
 }
@@ -1382,10 +1614,22 @@ hipError_t launch_lm(int dof, int threads, int ppt, const PassArgs& a, const LmS
   return hipGetLastError();
 }
 hipError_t launch_lm_persist(int dof, int ppt, const PassArgs& a, LmState* st, unsigned long long* xbuf, int nrows, rolo_trace_rec* trace, LmState* pub, unsigned long long timeout_ticks,
-                             int max_trials, hipStream_t s) {
+                             unsigned long long admit_ticks, int max_trials, hipStream_t s) {
   const size_t lds = sizeof(unsigned) * (size_t)nrows * 60;
-  if (dof == 3) lm_persist_kernel<3, 512><<<nrows, 512, lds, s>>>(a, st, xbuf, trace, ppt, pub, timeout_ticks, max_trials);
-  else lm_persist_kernel<6, 512><<<nrows, 512, lds, s>>>(a, st, xbuf, trace, ppt, pub, timeout_ticks, max_trials);
+  // the interleaved bodies (1, 2 or 4 points per thread in registers) for the reference's own configuration — SO(3) optimiser, DIRECT1; everything else one point after the other
+  static const bool interleave = [] { const char* e = getenv("ROLO_LM_PERSIST_INTERLEAVE"); return !(e && atoi(e) == 0); }();
+  const int sp = (interleave && dof == 3 && a.n_off == 1 && (ppt == 1 || ppt == 2 || ppt == 4)) ? ppt : 0;
+  // ROLO_LM_PERSIST_LEAN=1 (an A/B): the kernels built for four wavefronts per SIMD — 128 registers, the points of a thread one after the other
+  static const bool lean = [] { const char* e = getenv("ROLO_LM_PERSIST_LEAN"); return e && atoi(e) != 0; }();
+  if (dof == 3) {
+    if (sp == 1 && lean) lm_persist_kernel<3, 512, 1, 1, 4><<<nrows, 512, lds, s>>>(a, st, xbuf, trace, ppt, pub, timeout_ticks, admit_ticks, max_trials);
+    else if (sp == 2 && lean) lm_persist_kernel<3, 512, 2, 1, 4><<<nrows, 512, lds, s>>>(a, st, xbuf, trace, ppt, pub, timeout_ticks, admit_ticks, max_trials);
+    else if (sp == 4 && lean) lm_persist_kernel<3, 512, 4, 1, 4><<<nrows, 512, lds, s>>>(a, st, xbuf, trace, ppt, pub, timeout_ticks, admit_ticks, max_trials);
+    else if (sp == 1) lm_persist_kernel<3, 512, 1><<<nrows, 512, lds, s>>>(a, st, xbuf, trace, ppt, pub, timeout_ticks, admit_ticks, max_trials);
+    else if (sp == 2) lm_persist_kernel<3, 512, 2><<<nrows, 512, lds, s>>>(a, st, xbuf, trace, ppt, pub, timeout_ticks, admit_ticks, max_trials);
+    else if (sp == 4) lm_persist_kernel<3, 512, 4><<<nrows, 512, lds, s>>>(a, st, xbuf, trace, ppt, pub, timeout_ticks, admit_ticks, max_trials);
+    else lm_persist_kernel<3, 512, 0><<<nrows, 512, lds, s>>>(a, st, xbuf, trace, ppt, pub, timeout_ticks, admit_ticks, max_trials);
+  } else lm_persist_kernel<6, 512, 0><<<nrows, 512, lds, s>>>(a, st, xbuf, trace, ppt, pub, timeout_ticks, admit_ticks, max_trials);
   return hipGetLastError();
 }
 size_t lm_persist_words(int nrows) { return (size_t)LMP_HDR + 2 * (size_t)nrows * PEER_SLOT_WORDS; }

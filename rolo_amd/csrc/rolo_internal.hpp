@@ -122,6 +122,8 @@ struct LmState {
   // linearises at the accepted pose: the state after it is the one the full pass would have left, one launch later. spec_lin = 0 (ROLO_LM_SPEC_LIN=0) never skips.
   int lin_skip, spec_lin;
   int rot_cost_only, trans_cost_only;   // passes of rot_passes / trans_passes that ran with lin_skip set (counted by the step that consumes them): rolo_stats::n_cost_only
+  int lmp_bailed;   // the resident LM kernel (fused_lm = 2) did not get all its workgroups resident within the admission time and left WITHOUT touching the stage: the host
+                    // finishes the frame with pass + controller launches (passes.hip lm_persist_kernel, api.hip run_stage)
   // parameters
   int optimizer, max_iterations, fixed_iterations, lm_max, q2_intended;
   double rot_eps, trans_eps, lm_init;
@@ -203,8 +205,11 @@ constexpr int KNN_WALK_STACK = 48;
 // coop_budget > 0 (k = 20, own covariance launch): the cooperative walk — a packet that has scored that many leaves with sub-trees left publishes them to the
 // idle wavefronts of its workgroup (knn_walk.hpp); 0: the plain walk, every wavefront for itself
 // device_busy: other contexts have frames in flight on this device — large launches then take the 64-query packets (half the wavefronts: shares the chip better) instead of two lanes per query (finishes sooner alone)
-hipError_t launch_knn_walk(const KnnPair& A, int k, int regularization_or_minus1, const VoxelFuse& vf, hipStream_t s, int coop_budget = 0, int* lanes_out = nullptr, bool device_busy = false);
-hipError_t launch_knn_tail(const KnnPair& A, int k, int regularization, const VoxelFuse& vf, hipStream_t s);   // covariances from A.c[].nbr
+// moments (k = 20, plain and sub-lane walks, regularization -1): the walk's epilogue leaves the six centred second moments of every query's neighbourhood in A.c[].cov
+// (SoA, by original index) instead of the neighbour indices in A.c[].nbr; launch_knn_tail(..., moments = true) finishes them in place
+hipError_t launch_knn_walk(const KnnPair& A, int k, int regularization_or_minus1, const VoxelFuse& vf, hipStream_t s, int coop_budget = 0, int* lanes_out = nullptr, bool device_busy = false,
+                           bool moments = false);
+hipError_t launch_knn_tail(const KnnPair& A, int k, int regularization, const VoxelFuse& vf, hipStream_t s, bool moments = false);   // covariances from A.c[].nbr (or from the moments in A.c[].cov)
 // multi-GPU: exchange buffer (sorted order, all ranks' slices after the all-gather, or [q_begin, q_end) only) -> cov[] by original index
 // vf.enabled: the target's points are accumulated into the voxel map by this scatter (sharded VoxelFuse)
 hipError_t launch_knn_unstage(const KnnPair& A, bool own_slice_only, const VoxelFuse& vf, hipStream_t s);
@@ -225,9 +230,10 @@ hipError_t launch_trans_pass(const PassArgs& a, const LmState* st, int grid, hip
 hipError_t launch_lm(int dof, int threads, int ppt /* slabs of `threads` points per workgroup */, const PassArgs& a, const LmState* st_in, LmState* st_out, const double* rows_in, double* rows_out, int nrows,
                      rolo_trace_rec* trace, int do_body, hipStream_t s, LmState* pub = nullptr /* pinned host copy of the state written by workgroup 0 */);
 // one launch per frame (passes.hip lm_persist_kernel): nrows resident workgroups of 512 threads x ppt points, rows exchanged through xbuf (lm_persist_words(nrows) 64-bit words,
-// zeroed once); the state starts and ends in st; timeout_ticks: wall-clock ticks (100 MHz) a poll may last; max_trials: hard cap on the trials of one launch
+// zeroed once); the state starts and ends in st; admit_ticks: wall-clock ticks (100 MHz) the workgroups wait for each other to become resident before they leave the stage to the
+// host (LmState::lmp_bailed); timeout_ticks: what a poll may last after that (a bug guard: ROLO_ECOMM); max_trials: hard cap on the trials of one launch
 hipError_t launch_lm_persist(int dof, int ppt, const PassArgs& a, LmState* st, unsigned long long* xbuf, int nrows, rolo_trace_rec* trace, LmState* pub, unsigned long long timeout_ticks,
-                             int max_trials, hipStream_t s);
+                             unsigned long long admit_ticks, int max_trials, hipStream_t s);
 size_t lm_persist_words(int nrows);
 hipError_t launch_reduce(const double* partials, int nblocks, double* sums, const LmState* st, int stage, hipStream_t s);
 // controller: sums the rows of `partials` itself (single GPU) or takes all-reduced `sums` (partials == nullptr)

@@ -330,3 +330,40 @@ def test_cpp_operator_prints_lm_not_converged(tmp_path, clouds):
         assert o.align(None)[0] == 0
         rc, t_o, it = o.compute_translation(np.zeros(3), g3, g3)
         assert rc == fails and np.abs(np.array(v[:3]) - t_o).max() < 1e-8 and int(v[4]) == src.shape[0]
+
+
+_BAIL = r"""
+import sys, json, numpy as np
+sys.path.insert(0, sys.argv[1])
+from rolo_amd import synth
+from rolo_amd.rotvgicp import RotVGICP
+G = -np.asarray(synth.PREV_STEP_T); L0 = G * 0.97
+src, tgt, _ = synth.dense_pair("vlp16", col_stride=2)
+out = {}
+for mode in (0, 2):
+    g = RotVGICP(); g.setPolarResolution(0.175, 0.175, 2.0); g.setFusedLm(mode)
+    res = []
+    for k in range(4):   # eager, eager, captured graph, replay
+        g.setInputTarget(tgt.copy()); g.setInputSource(src.copy())
+        g.register_async(None, np.zeros(3), G, L0); Tf, Td, t = g.register_wait()
+        res.append((Td.ravel().tolist(), np.asarray(t).tolist(), g.last_stats.n_outer, g.last_translation_stats.n_outer, g.last_stats.n_passes))
+    g.align(None); Ta = g.final_transformation_d.ravel().tolist(); ta = g.computeTranslation(np.zeros(3), G, L0).tolist()
+    out[str(mode)] = dict(res=res, align=Ta, trans=ta, counters=g.counters())
+print(json.dumps(out))
+"""
+
+
+def test_resident_lm_kernel_gives_the_stage_back_when_it_cannot_become_resident():
+    """fused_lm = 2 with nobody admitted (ROLO_LM_PERSIST_ADMIT_US=0, the test switch of the admission time-out): every launch of the resident kernel leaves WITHOUT touching the
+    stage (LmState::lmp_bailed), the host finishes every frame with pass + controller launches — same poses as fused_lm = 0 to rounding, no error, the bails counted.
+    This is the path two processes sharing a GPU (or more contexts in flight than fit) take instead of spinning on each other."""
+    import json
+    r = subprocess.run([sys.executable, "-c", _BAIL, ROOT], capture_output=True, text=True, env=dict(os.environ, ROLO_LM_PERSIST_ADMIT_US="0"), cwd=ROOT, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    a, b = out["0"], out["2"]
+    assert b["counters"]["persist_bails"] >= 5 and a["counters"]["persist_bails"] == 0          # four frames + align (+ computeTranslation) all bailed
+    for (Ta, ta, ia, ja, pa), (Tb, tb, ib, jb, pb) in zip(a["res"], b["res"]):
+        assert (ia, ja, pa) == (ib, jb, pb)
+        assert np.abs(np.array(Ta) - np.array(Tb)).max() < 1e-11 and np.abs(np.array(ta) - np.array(tb)).max() < 1e-11
+    assert np.abs(np.array(a["align"]) - np.array(b["align"])).max() < 1e-11 and np.abs(np.array(a["trans"]) - np.array(b["trans"])).max() < 1e-11

@@ -255,3 +255,69 @@ def test_submit_from_pointcloud2_payload(kind):
     with pytest.raises(RoloError) as ei:
         msgs.submit_msg(fg, 101.0, payload, CloudLayout(L.point_step, 0, 4, L.point_step - 2, L.off_ring, L.ring_bytes, L.off_time, L.time_kind))
     assert ei.value.code == -1
+
+
+def long_trajectory(n):
+    """a closed curve through the hall with changing speed and turn rate (0.15 ... 0.45 m and 1.5 ... 4 degrees per frame, a little roll / pitch): the view, and with it
+    the number of corner / surface features, changes every frame"""
+    poses = []
+    R = np.eye(3); t = np.array([-4.0, -3.0, 0.0])
+    for k in range(n):
+        poses.append((R.copy(), t.copy()))
+        step = 0.30 + 0.15 * np.sin(0.37 * k)
+        yaw = np.deg2rad(2.75 + 1.25 * np.cos(0.23 * k))
+        dR = synth.rpy_to_R(np.deg2rad(0.4 * np.sin(0.5 * k)), np.deg2rad(-0.3 * np.cos(0.31 * k)), yaw)
+        t = t + R @ np.array([step, 0.03 * np.sin(0.9 * k), 0.0])
+        R = R @ dR
+    return poses
+
+
+def test_pipeline_50_frames():
+    from rolo_amd._lib import lib
+    """A LONG sequence (round 5's verdict, item 5): 50 raw VLP-16 frames along a curved trajectory, feature counts changing every frame, through the staged node cores and
+    the fused submit / collect path against the oracle chain (src/lidarOdometry.cpp:503-626): every state identical, every pose within the bars, and what only a long run
+    shows — device buffers stop growing, the frame's hipGraph is re-captured a handful of times (the feature counts are part of its key), no top-up storms, and the
+    schedule hints settle."""
+    cfg = dict(n_scan=16, horizon_scan=1800)
+    n = 50
+    poses = long_trajectory(n)
+    fo = pyorc.front_params(**cfg); fg = front_params(**cfg)
+    oo = pyorc.Odom(pyorc.default_params(polar_resolution=(0.175, 0.175, 2.0)), 0.3)
+    staged = LidarOdometry(0, 0.3); fe = FrontEnd(staged.reg, fg)
+    fused = LidarOdometry(0, 0.3)
+    frames = [synth.make_frame("vlp16", R, t, synth.SEED + 7 * k) for k, (R, t) in enumerate(poses)]
+    fused.submit(fg, 100.0, frames[0].xyz, frames[0].ring)
+    counts, counters = [], []
+    worst = np.zeros(4)
+    for k in range(n):
+        fr = frames[k]; stamp = 100.0 + 0.1 * k
+        if k >= 2:   # the back end answers every frame from the third on (SURVEY Q4)
+            oo.backend_odometry(stamp - 0.05); staged.odometryHandler(stamp - 0.05); fused.odometryHandler(stamp - 0.05)
+        eo = pyorc.extract_features(fo, pyorc.project(fo, fr.xyz, fr.ring))
+        rco, pose_o, R_o, t_o = oo.cloud(stamp, eo["corner"], eo["surface"])
+        pg = fe.project(fr.xyz, fr.ring); eg = fe.extract(pg["n"])
+        assert np.array_equal(eg["corner"], eo["corner"]) and np.array_equal(eg["surface"], eo["surface"])
+        rcs, pose_s, R_s, t_s = staged.cloudHandler(stamp, eg["corner"], eg["surface"])
+        if k + 1 < n:
+            fused.submit(fg, stamp + 0.1, frames[k + 1].xyz, frames[k + 1].ring)
+        rcf, pose_f, R_f, t_f, cnt = fused.collect()
+        assert rcs == rcf == rco, (k, rcs, rcf, rco)
+        assert cnt == (pg["n"], eg["corner"].shape[0], eg["surface"].shape[0])
+        for (p_, R_, t_) in ((pose_s, R_s, t_s), (pose_f, R_f, t_f)):
+            assert np.abs(p_[:3] - pose_o[:3]).max() <= 1e-4 and np.abs(p_[3:] - pose_o[3:]).max() <= 1e-5, k
+            assert np.abs(R_ - R_o).max() <= 1e-5 and np.abs(t_ - t_o).max() <= 1e-4, k
+            worst = np.maximum(worst, [np.abs(p_[:3] - pose_o[:3]).max(), np.abs(p_[3:] - pose_o[3:]).max(), np.abs(R_ - R_o).max(), np.abs(t_ - t_o).max()])
+        counts.append(cnt[1] + cnt[2])
+        counters.append((staged.reg.counters(), fused.reg.counters(), int(lib().rolo_alloc_count())))
+    assert len(set(counts)) > 25          # the feature counts did change from frame to frame
+    assert worst.max() < 5e-6, worst      # what we actually get over 50 frames (float32 pose chain): no drift between the chains
+    for which in (0, 1):
+        c = [cc[which] for cc in counters]
+        assert c[-1]["frames"] == n - 2                       # the first frame is only stored, the second waits for the back end's first odometry (SURVEY Q4)
+        # a frame's hipGraph is keyed on its cloud sizes: with feature counts changing every frame almost nothing is replayed — but nothing may storm either
+        assert c[-1]["topup_frames"] <= 3, c[-1]
+        assert c[-1]["sync_chunks"] <= 8, c[-1]
+        assert c[-1]["hint_rot"] == c[20]["hint_rot"] and c[-1]["hint_trans"] <= c[20]["hint_trans"] + 2   # the schedule hints settled in the first twenty frames
+    # device allocations stop: buffers grow by a quarter beyond what a frame needs, so the count of (re)allocations is the same after frame 25 and after frame 50
+    assert counters[-1][2] == counters[25][2], (counters[25][2], counters[-1][2])
+    staged.close(); fused.close()
