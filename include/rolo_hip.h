@@ -235,7 +235,9 @@ int rolo_debug_lm_script_translation(rolo_ctx* ctx, const rolo_lm_script* script
 /* Which kernels rolo_register_async picks where the best one depends on whether the GPU is shared (not in the reference: its operator owns its CPU threads).
  * -1 (default): decided per frame — other contexts of the device have frames in flight when this one is enqueued => the kernels that share the chip best
  * (throughput); an idle device => the ones that finish soonest (latency). 0 / 1 pin the idle- / busy-device choice (profiling runs, callers that know their
- * load). Today this selects the neighbour search of large launches: 64-query packets (busy) or two lanes per query (idle); results are bit-identical. */
+ * load). It selects the neighbour search of large launches — 64-query packets (busy) or two lanes per query (idle): the same lists, bit for bit — and, since round 6, the
+ * size of the resident LM kernel (fused_lm = 2: 64 workgroups busy, 256 idle): the sums of a pass then run over other groups of points and poses agree to rounding
+ * (1e-12), not bit for bit. A caller that needs run-to-run identical bits under changing load pins the hint (or sets fused_lm = 0). */
 int rolo_set_load_hint(rolo_ctx* ctx, int mode);
 int rolo_comm_unique_id(void* unique_id128);
 int rolo_comm_init(rolo_ctx* ctx, const void* unique_id128, int rank, int world);
@@ -385,9 +387,9 @@ int rolo_odom_submit_msg(rolo_odom* o, const rolo_front_params* P, double stamp,
 int rolo_odom_get_features(rolo_odom* o, float* features, int cap_points, int* n_corner, int* n_surface);
 /* options of the fused path: ROLO_ODOM_REUSE_COVARIANCES (default 0) = rolo_adopt_target_covariances between frames */
 #define ROLO_ODOM_REUSE_COVARIANCES 1
-/* ROLO_ODOM_FUSED_LM (default 1): the driver's registrations use one launch per LM trial (rolo_params.fused_lm) — it registers one frame at a
- * time, where that is the shortest chain (frame latency -9 %). The driver asserts the option on its context right before each registration it
- * enqueues; it does not depend on, and is not reverted by, the parameter block the caller hands to rolo_set_params. */
+/* ROLO_ODOM_FUSED_LM (default 2; values 0 / 1 / 2 = rolo_params.fused_lm): how the driver's registrations launch their LM chain — it registers one frame at a
+ * time, where the shortest chain wins: one launch per frame since round 6 (one launch per trial, 1, through round 5). The driver asserts the option on its context right
+ * before each registration it enqueues; it does not depend on, and is not reverted by, the parameter block the caller hands to rolo_set_params. */
 #define ROLO_ODOM_FUSED_LM 2
 /* ROLO_ODOM_EARLY_SOURCE (default 0): when a frame is submitted with nothing else in flight (rolo_odom_frame, or submit / collect one frame at
  * a time), the propagated previous features — the SOURCE of the coming registration, known at submit time — are moved and searched on the

@@ -1447,7 +1447,7 @@ __global__ __launch_bounds__(THREADS, OCC) void lm_persist_kernel(PassArgs a, Lm
       for (int v = 0; v < NVR; v++) { acc[v] = 0.0; slot[v] = v; }
       if (PPT > 0) {
 #pragma unroll
-        for (int p0 = 0; p0 < NP; p0 += BATCH) lmp_rot_body<DOF, BATCH>(a, &sst, i0 + p0 * THREADS, THREADS, pt + p0, cid + p0, valid + p0, acc);
+        for (int p0 = 0; p0 < NP; p0 += BATCH) { lmp_rot_body<DOF, BATCH>(a, &sst, i0 + p0 * THREADS, THREADS, pt + p0, cid + p0, valid + p0, acc); if (BATCH < NP) { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } }
       }
       else for (int p = 0; p < ppt; p++) {
         const int i = i0 + p * THREADS;
@@ -1476,7 +1476,7 @@ __global__ __launch_bounds__(THREADS, OCC) void lm_persist_kernel(PassArgs a, Lm
       for (int v = 0; v < 30; v++) { acc[v] = 0.0; slot[v] = v; }
       if (PPT > 0) {
 #pragma unroll
-        for (int p0 = 0; p0 < NP; p0 += BATCH) lmp_trans_body<BATCH>(a, &sst, i0 + p0 * THREADS, THREADS, pt + p0, cid + p0, valid + p0, acc);
+        for (int p0 = 0; p0 < NP; p0 += BATCH) { lmp_trans_body<BATCH>(a, &sst, i0 + p0 * THREADS, THREADS, pt + p0, cid + p0, valid + p0, acc); if (BATCH < NP) { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } }
       }
       else for (int p = 0; p < ppt; p++) {
         const int i = i0 + p * THREADS;
@@ -1577,6 +1577,7 @@ __global__ void t3_eval_begin_kernel(LmState* st, TransBegin a, int phase) {
 
 }  // namespace
 
+static void* _inst_probe[] = { (void*)&lm_persist_kernel<3,512,4,2,3>, (void*)&lm_persist_kernel<3,512,4,1,3>, (void*)&lm_persist_kernel<3,512,2,2,3>, (void*)&lm_persist_kernel<3,512,2,1,3>, (void*)&lm_persist_kernel<3,512,1,1,3> };
 hipError_t launch_rot_pass(int dof, const PassArgs& a, const LmState* st, int grid, hipStream_t s) {
   if (dof == 3) rot_pass_kernel<3><<<grid, PASS_THREADS, 0, s>>>(a, st);
   else rot_pass_kernel<6><<<grid, PASS_THREADS, 0, s>>>(a, st);

@@ -687,7 +687,7 @@ unsigned long long ctx_cloud_epoch(rolo_ctx* c) { return c->cloud_epoch; }
 hipStream_t ctx_stream(rolo_ctx* c) { return c->stream; }
 int ctx_device(rolo_ctx* c) { return c->device; }
 void ctx_set_error(const char* msg) { g_err = msg ? msg : ""; }
-void ctx_set_fused_lm(rolo_ctx* c, int on) { c->P.fused_lm = on ? 1 : 0; }
+void ctx_set_fused_lm(rolo_ctx* c, int mode) { c->P.fused_lm = mode < 0 ? 0 : (mode > 2 ? 2 : mode); }
 // rolo_set_source_device(T * src) + rolo_set_target_device(tgt) as ONE launch (the odometry driver's per-frame hand-over; both clouds on the device)
 int ctx_set_pair_device(rolo_ctx* c, const float* d_src, int n_src, int stride_src, const float* T16_host_or_null, const float* d_tgt, int n_tgt, int stride_tgt) {
   if (!c) return ROLO_EINVAL;

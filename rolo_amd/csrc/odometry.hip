@@ -95,7 +95,7 @@ struct rolo_odom {
   // registration stream while K1-K4 of the new frame run on the front-end stream; collect only has the target left to search.
   bool early_src = false; double early_stamp = 0; Aff early_T = aff_identity();
   bool early_source_enabled = false;  // ROLO_ODOM_EARLY_SOURCE (off: measured slower, see rolo_hip.h)
-  bool fused_lm = true;   // ROLO_ODOM_FUSED_LM: one launch per LM trial for this driver's registrations (one frame at a time: the shortest chain)
+  int fused_lm = 2;       // ROLO_ODOM_FUSED_LM: rolo_params.fused_lm of this driver's registrations (one frame at a time: the shortest chain — 2, one launch per frame, since round 6; 1, one launch per trial, before)
   rolo_stats last_rot{}, last_trans{};
 };
 
@@ -178,7 +178,7 @@ int rolo_odom_set_deskew(rolo_odom* o, const rolo_deskew* d, const float* rel_ti
 int rolo_odom_set_option(rolo_odom* o, int option, int value) {
   if (!o) return ROLO_EINVAL;
   if (option == ROLO_ODOM_REUSE_COVARIANCES) { o->reuse_cov = value != 0; o->cov_chain = false; return ROLO_OK; }
-  if (option == ROLO_ODOM_FUSED_LM) { o->fused_lm = value != 0; return ROLO_OK; }
+  if (option == ROLO_ODOM_FUSED_LM) { if (value < 0 || value > 2) return ROLO_EINVAL; o->fused_lm = value; return ROLO_OK; }
   if (option == ROLO_ODOM_EARLY_SOURCE) { o->early_source_enabled = value != 0; return ROLO_OK; }
   return ROLO_EINVAL;
 }
@@ -226,7 +226,7 @@ int rolo_odom_cloud(rolo_odom* o, double stamp, const float* corner, int n_corne
     double guess_t[3];  // Translation after the rotation stage = translation of T_interp * T_rot = that of T_interp
     for (int i = 0; i < 3; i++) guess_t[i] = (double)o->transformation_interpolated.m[i * 4 + 3];
     const double zero3[3] = {0, 0, 0};
-    rolo::ctx_set_fused_lm(o->ctx, o->fused_lm ? 1 : 0);
+    rolo::ctx_set_fused_lm(o->ctx, o->fused_lm);
     if ((rc = rolo_register_async(o->ctx, nullptr, zero3, guess_t, o->TranslationOld, 0.1, 0.1, o->ct_lambda))) return rc;
     float Tf[16]; double reg_t[3];
     if ((rc = rolo_register_wait(o->ctx, Tf, nullptr, reg_t, &o->last_rot, &o->last_trans))) return rc;
@@ -352,7 +352,7 @@ int rolo_odom_collect(rolo_odom* o, float* pose6, double* rot9, double* trans3, 
     for (int i = 0; i < 3; i++) guess_t[i] = (double)o->transformation_interpolated.m[i * 4 + 3];
     const double zero3[3] = {0, 0, 0};
     o->cov_chain = false;
-    rolo::ctx_set_fused_lm(o->ctx, o->fused_lm ? 1 : 0);
+    rolo::ctx_set_fused_lm(o->ctx, o->fused_lm);
     if ((rc = rolo_register_async(o->ctx, nullptr, zero3, guess_t, o->TranslationOld, 0.1, 0.1, o->ct_lambda))) return rc;
     float Tf[16]; double reg_t[3];
     if ((rc = rolo_register_wait(o->ctx, Tf, nullptr, reg_t, &o->last_rot, &o->last_trans))) return rc;

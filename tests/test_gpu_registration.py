@@ -875,29 +875,36 @@ def test_speculative_linearisation_skipping_changes_no_bit():
 def test_load_hint_picks_the_walk_and_the_result_does_not_depend_on_it():
     """rolo_set_load_hint / the per-frame choice of round 5: a large launch takes the 64-query packet walk (rolo_ctx_counters "walk_lanes" = 1) when the device is
     busy and two lanes per query when it is idle; pinned by the hint, decided from the frames other contexts have in flight otherwise (sticky for a few frames).
-    Both walks return the same lists, so poses and translations are the same BITS."""
+    Both walks return the same lists, so the covariances are the same BITS. Since round 6 the hint also sizes the resident LM kernel (256 workgroups on an idle device,
+    64 beside other frames): the rows of a pass are then summed over other groups of points, and poses agree to rounding (1e-12) instead of bit for bit — with
+    fused_lm = 0 they still are the same bits."""
     src, tgt, _ = synth.dense_pair("os1-128")
     assert src.shape[0] == 131072
     z = np.zeros(3)
 
-    def ctx(hint):
-        g = RotVGICP(); g.setResolution(0.5); g.setFixedIterations(20); g.setUseGraph(False); g.setLoadHint(hint)
+    def ctx(hint, fused=2):
+        g = RotVGICP(); g.setResolution(0.5); g.setFixedIterations(20); g.setUseGraph(False); g.setLoadHint(hint); g.setFusedLm(fused)
         g.setInputTarget(tgt); g.setInputSource(src)
         return g
     res = {}
-    for hint in (0, 1):
-        g = ctx(hint)
-        g.register_async(None, z, G, L0); Tf, Td, t = g.register_wait()
-        res[hint] = (Td.copy(), np.asarray(t).copy(), g.counters()["walk_lanes"]); g.close()
-    assert res[0][2] == 2 and res[1][2] == 1
-    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+    for fused in (0, 2):
+        for hint in (0, 1):
+            g = ctx(hint, fused)
+            g.register_async(None, z, G, L0); Tf, Td, t = g.register_wait()
+            res[fused, hint] = (Td.copy(), np.asarray(t).copy(), g.counters()["walk_lanes"], g.getSourceCovariances().copy()); g.close()
+        assert res[fused, 0][2] == 2 and res[fused, 1][2] == 1
+        assert np.array_equal(res[fused, 0][3], res[fused, 1][3])                      # the search's results do not depend on the walk
+    assert np.array_equal(res[0, 0][0], res[0, 1][0]) and np.array_equal(res[0, 0][1], res[0, 1][1])   # pass + controller launches: the same bits
+    for a_, b_ in ((res[2, 0], res[2, 1]), (res[2, 0], res[0, 0])):
+        assert np.abs(a_[0] - b_[0]).max() < 1e-12 and np.abs(a_[1] - b_[1]).max() < 1e-12
+    res = {0: res[2, 0], 1: res[2, 1]}
     # automatic: a alone -> the idle-device walk; b enqueued while a's frame is in flight -> the busy-device walk; b stays with it for its next frames (no flip per caller barrier)
     a, b = ctx(-1), ctx(-1)
     a.register_async(None, z, G, L0)
     b.register_async(None, z, G, L0)
     Ta = a.register_wait()[1]; Tb = b.register_wait()[1]
     assert a.counters()["walk_lanes"] == 2 and b.counters()["walk_lanes"] == 1
-    assert np.array_equal(Ta, res[0][0]) and np.array_equal(Tb, res[0][0])
+    assert np.array_equal(Ta, res[0][0]) and np.array_equal(Tb, res[1][0])   # a: the idle-device sizes, b: the busy-device ones
     b.setInputTarget(tgt); b.setInputSource(src)
     b.register_async(None, z, G, L0); b.register_wait()
     assert b.counters()["walk_lanes"] == 1
