@@ -279,7 +279,8 @@ int rolo_peer_info(rolo_ctx* ctx, int* rank, int* world, char* mem_kind16);
  * [9] nanoseconds of HOST time spent inside rolo_register_async (graph launch / capture / eager enqueue) since the context was created or recycled,
  * [10] nanoseconds the host was blocked in rolo_register_wait's hipEventSynchronize, [11] nanoseconds of the rest of rolo_register_wait (std::chrono::steady_clock;
  * bench.py's host_enqueue_us_per_frame — round 5's verdict, item 2a), [12] frames whose resident LM kernel (fused_lm = 2) could not get all its workgroups onto the chip within its
- * admission time and gave the stage back to the host, which finished it with pass + controller launches. */
+ * admission time and gave the stage back to the host, which finished it with pass + controller launches, [13] what the context has LEARNED about load it cannot count (another
+ * process on the GPU): 0 = its frames last what they last alone (idle-device kernels), 1 = trying the busy-device kernels, 2 = keeping them (rolo_set_load_hint -1 only). */
 int rolo_ctx_counters(rolo_ctx* ctx, long long* out, int n);
 /* device buffer (re)allocations made so far by the registration contexts of this process (every hipMalloc behind a rolo_ctx's buffers; a captured hipGraph is keyed on it):
  * a steady-state frame loop must stop moving it */

@@ -66,11 +66,16 @@ def run(n_proc, hint, foreign, seconds=4.0):
 
 def main():
     res = {}
+    if len(sys.argv) > 1 and sys.argv[1] == "--two-auto":
+        r2 = run(2, -1, 0, seconds=float(sys.argv[2]) if len(sys.argv) > 2 else 8.0)
+        print(json.dumps({"scans_per_s_each": [r["scans_per_s"] for r in r2], "counters": [r["counters"] for r in r2]}))
+        return
     for hint in (0, 1, -1):
         r1 = run(1, hint, 0)
-        res[f"one_process_alone_hint{hint}"] = {"scans_per_s": r1[0]["scans_per_s"], "persist_bails": r1[0]["counters"]["persist_bails"]}
+        res[f"one_process_alone_hint{hint}"] = {"scans_per_s": r1[0]["scans_per_s"], "persist_bails": r1[0]["counters"]["persist_bails"], "load_mode_at_end": r1[0]["counters"].get("load_mode")}
         r2 = run(2, hint, 0)
-        res[f"two_processes_hint{hint}"] = {"scans_per_s_each": [r["scans_per_s"] for r in r2], "sum": sum(r["scans_per_s"] for r in r2), "persist_bails": [r["counters"]["persist_bails"] for r in r2]}
+        res[f"two_processes_hint{hint}"] = {"scans_per_s_each": [r["scans_per_s"] for r in r2], "sum": sum(r["scans_per_s"] for r in r2), "persist_bails": [r["counters"]["persist_bails"] for r in r2],
+                                            "load_mode_at_end": [r["counters"].get("load_mode") for r in r2], "graph_captures": [r["counters"]["graph_captures"] for r in r2]}
         rf = run(1, hint, 1)
         res[f"beside_foreign_copies_hint{hint}"] = {"scans_per_s": rf[0]["scans_per_s"], "copy_GBps": rf[0]["copy_GBps"], "persist_bails": rf[0]["counters"]["persist_bails"]}
         print(hint, json.dumps({k: v for k, v in res.items() if k.endswith(str(hint))}), file=sys.stderr, flush=True)

@@ -129,6 +129,20 @@ struct rolo_ctx {
     double* lower = nullptr; size_t lower_cap = 0;  // k_correspondences > 64: the key the next round of 64 starts above, per sorted position
   } ks[2];
   hipEvent_t ev_done = nullptr;    // end of the frame rolo_register_async enqueued (the stream may carry other contexts' frames behind it)
+  hipEvent_t ev_start = nullptr;   // its start (both with timing: the frame's duration on the DEVICE is the load signal of LoadLearner below)
+  // What the per-process count of frames in flight cannot see — another PROCESS on the same GPU — learned from the device's own signal (round 5's verdict, item 7): while this
+  // context believes the device idle it remembers the shortest frame it has seen at the current sizes; frames that last a quarter longer than that for a while mean somebody
+  // else is using the chip, and the context tries the busy-device kernels: if its frames get shorter it keeps them (and looks again every 512 frames), if not it goes back.
+  // (Two processes with one context each: 2 x 1 066 scans/s on the idle-device kernels, 2 x 1 376 on the busy-device ones; beside a stream of 1 GiB copies the idle-device
+  // kernels stay the right choice — profiles/r06/load_regimes.json.)
+  struct LoadLearner {
+    int mode = 0;              // 0: idle-device kernels, 1: trying the busy-device kernels, 2: keeping them
+    int frames = 0;            // frames in this mode
+    double best_idle = 0, ema = 0, idle_at_switch = 0;
+    int n_src = 0, n_tgt = 0;  // the sizes best_idle belongs to
+    int holdoff = 0;           // frames before the next try after one that did not pay
+  } learn;
+  bool frame_auto_idle = false;   // the frame in flight was sized by the learner (load_hint < 0, nobody else of this process in flight, not sharded)
   hipStream_t stream2 = nullptr;   // second stream for the eager (uncaptured) path of rolo_batch_*; stream and stream2 are a PAIR of the device's stream bank
                                    // (below): main streams on every other stream of a burst = two hardware queues, alternating — measured the best layout for
                                    // frames of several contexts in flight on MI355X (2930 scans/s; one queue per context 2140, three
@@ -195,6 +209,9 @@ struct rolo_ctx {
   hipGraph_t graph = nullptr;
   hipGraphExec_t graph_exec = nullptr;
   bool graph_nrm_written = false;   // the captured build_clouds left the PLANE covariances as I - m m^T too (CloudDev::have_nrm after a replay)
+  // the captured frame of the OTHER load regime (GraphKey::busy): a context whose load estimate flips — the learner's periodic second look, a second context that comes and
+  // goes — swaps its two graphs instead of capturing again (42 captures in 11 000 frames of the two-process run before this slot existed)
+  struct GraphSlot { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; GraphKey key{}; bool nrm = false; } galt;
   // per-kernel event timing (rolo_prof_*)
   bool prof_on = false;
   struct ProfEv { int slot; hipEvent_t a, b; };
@@ -665,6 +682,7 @@ void peer_disconnect_impl(rolo_ctx* c) {
   if (P.connected) { c->rank = 0; c->world = 1; c->have_corr = false; c->src.have_cov = false; c->tgt.have_cov = false; c->have_map = false; }
   P.connected = false; P.args = PeerArgs{};
   if (c->graph_exec) { (void)hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }   // a captured schedule holds the peers' pointers
+  if (c->galt.exec) { (void)hipGraphExecDestroy(c->galt.exec); c->galt.exec = nullptr; }
   c->gseen_valid = false;
 }
 void peer_release(rolo_ctx* c) {
@@ -841,7 +859,7 @@ static int ctx_create_impl(int device, bool high_priority, rolo_ctx** out) {
          hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) == hipSuccess;
   } else if (ok) ok = bank_acquire_pair(device, &c->stream, &c->stream2, &c->bank_slot) == ROLO_OK;
   if (!ok || hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming) != hipSuccess) { rolo_ctx_destroy(c); g_err = "hipStreamCreate failed"; return ROLO_EHIP; }
+      hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess || hipEventCreate(&c->ev_done) != hipSuccess || hipEventCreate(&c->ev_start) != hipSuccess) { rolo_ctx_destroy(c); g_err = "hipStreamCreate failed"; return ROLO_EHIP; }
   if (hipHostMalloc((void**)&c->h_state, sizeof(LmState)) != hipSuccess || hipHostMalloc((void**)&c->h_sums, sizeof(double) * NV_MAX) != hipSuccess ||
       hipHostMalloc((void**)&c->h_counters, sizeof(int) * 4) != hipSuccess || hipHostMalloc((void**)&c->h_args, sizeof(FrameArgs)) != hipSuccess) { rolo_ctx_destroy(c); g_err = "hipHostMalloc failed"; return ROLO_EHIP; }
   memset(c->h_state, 0, sizeof(LmState));
@@ -878,6 +896,8 @@ void rolo_ctx_destroy(rolo_ctx* c) {
                   c->state, c->trace, c->stage_in, c->stage_out, c->stage_d, c->stage_i, c->xbuf};
   for (void* b : bufs) if (b) (void)hipFree(b);
   if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
+  if (c->galt.exec) (void)hipGraphExecDestroy(c->galt.exec);
+  if (c->galt.graph) (void)hipGraphDestroy(c->galt.graph);
   if (c->dbg_chain_exec) (void)hipGraphExecDestroy(c->dbg_chain_exec);
   if (c->graph) (void)hipGraphDestroy(c->graph);
   if (c->h_args) (void)hipHostFree(c->h_args);
@@ -889,6 +909,7 @@ void rolo_ctx_destroy(rolo_ctx* c) {
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   if (c->ev_done) (void)hipEventDestroy(c->ev_done);
+  if (c->ev_start) (void)hipEventDestroy(c->ev_start);
   if (c->stream && c->bank_slot < 0) (void)hipStreamDestroy(c->stream);
   if (c->bank_slot >= 0) bank_release_pair(c->device, c->bank_slot);
   delete c;
@@ -1420,6 +1441,9 @@ static int register_async_impl(rolo_ctx* c, const float* guess16, const double* 
       return a.n_src == b.n_src && a.n_tgt == b.n_tgt && a.src_xyz == b.src_xyz && a.tgt_xyz == b.tgt_xyz && a.epoch == b.epoch &&
              a.nrot == b.nrot && a.ntrans == b.ntrans && a.rank == b.rank && a.world == b.world && a.busy == b.busy && memcmp(&a.P, &b.P, sizeof(rolo_params)) == 0;
     };
+    if (c->galt.exec && same(key, c->galt.key) && !(c->graph_exec && same(key, c->gkey))) {   // the other regime's frame is cached: swap
+      std::swap(c->graph, c->galt.graph); std::swap(c->graph_exec, c->galt.exec); std::swap(c->gkey, c->galt.key); std::swap(c->graph_nrm_written, c->galt.nrm);
+    }
     if (c->graph_exec && same(key, c->gkey)) {
       HIPCHK(hipGraphLaunch(c->graph_exec, c->stream));
       c->n_replays++;
@@ -1429,6 +1453,12 @@ static int register_async_impl(rolo_ctx* c, const float* guess16, const double* 
       return ROLO_OK;
     }
     if (c->gseen_valid && same(key, c->gseen)) {
+      if (c->graph_exec && c->gkey.busy != key.busy) {   // keep the other regime's frame in the second slot (whatever was there goes)
+        if (c->galt.exec) (void)hipGraphExecDestroy(c->galt.exec);
+        if (c->galt.graph) (void)hipGraphDestroy(c->galt.graph);
+        c->galt.graph = c->graph; c->galt.exec = c->graph_exec; c->galt.key = c->gkey; c->galt.nrm = c->graph_nrm_written;
+        c->graph = nullptr; c->graph_exec = nullptr;
+      }
       if (c->graph_exec) { (void)hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
       if (c->graph) { (void)hipGraphDestroy(c->graph); c->graph = nullptr; }
       HIPCHK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
@@ -1466,6 +1496,14 @@ int rolo_register_async(rolo_ctx* c, const float* guess16, const double* trans_s
     // (ranks that share ONE frame — peers, a communicator, a shard range — always have each other's frames "in flight": that is cooperation, not load)
     const bool sharded_ctx = c->comm != nullptr || peers(c) || c->world > 1;
     c->device_busy = c->load_hint < 0 ? (!sharded_ctx && c->busy_credit > 0) : c->load_hint != 0;
+    // nobody of this process in flight: the learner decides (it may know of load this process cannot count)
+    c->frame_auto_idle = c->load_hint < 0 && !sharded_ctx && c->busy_credit == 0 && !c->async_pending;
+    if (c->frame_auto_idle) {
+      rolo_ctx::LoadLearner& L = c->learn;
+      if (L.n_src != c->src.n || L.n_tgt != c->tgt.n) { L = rolo_ctx::LoadLearner{}; L.n_src = c->src.n; L.n_tgt = c->tgt.n; }
+      c->device_busy = L.mode != 0;
+    }
+    if (!c->async_pending && set_device(c) == ROLO_OK) (void)hipEventRecord(c->ev_start, c->stream);
   }
   const auto t0 = std::chrono::steady_clock::now();
   const int rc = register_async_impl(c, guess16, trans_start, g3, l3, dtn, dtn1, lam);
@@ -1485,6 +1523,25 @@ int rolo_register_wait(rolo_ctx* c, float* Tf, double* Td, double* trans_out, ro
   HIPCHK(hipEventSynchronize(c->ev_done));
   const auto tw1 = std::chrono::steady_clock::now();
   c->ns_wait_blocked += std::chrono::duration_cast<std::chrono::nanoseconds>(tw1 - tw0).count();
+  if (c->frame_auto_idle) {   // the learner's signal: how long the frame took on the device (rolo_ctx::LoadLearner)
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, c->ev_start, c->ev_done) == hipSuccess && ms > 0.f) {
+      rolo_ctx::LoadLearner& L = c->learn;
+      L.frames++;
+      L.ema = L.frames <= 2 ? (double)ms : 0.8 * L.ema + 0.2 * (double)ms;   // (frames 1-2 of a mode: eager launches and the graph capture — the average restarts behind them)
+      if (L.frames == 3) L.ema = ms;
+      if (L.mode == 0) {
+        if (L.frames >= 3 && (L.best_idle == 0 || ms < L.best_idle)) L.best_idle = ms;
+        if (L.holdoff > 0) L.holdoff--;
+        if (L.frames >= 12 && L.holdoff == 0 && L.best_idle > 0 && L.ema > 1.25 * L.best_idle) { L.idle_at_switch = L.ema; L.mode = 1; L.frames = 0; }
+      } else if (L.mode == 1) {
+        if (L.frames >= 12) {
+          if (L.ema < 0.95 * L.idle_at_switch) { L.mode = 2; L.frames = 0; }
+          else { L.mode = 0; L.frames = 0; L.holdoff = 512; }
+        }
+      } else if (L.frames >= 512) { L.mode = 0; L.frames = 0; L.holdoff = 0; }   // look again: is the other user still there?
+    } else (void)hipGetLastError();
+  }
   struct WaitTimer { rolo_ctx* c; std::chrono::steady_clock::time_point t; ~WaitTimer() { c->ns_wait_other += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t).count(); } } wt{c, tw1};
   if ((rc = peer_check(c))) return rc;
   if (c->h_counters[1] != 0) { g_err = c->h_counters[1] == ROLO_ENONFINITE ? "non-finite point or covariance in the voxel map build" : "voxel coordinate outside the packed key range"; return c->h_counters[1]; }
@@ -1583,9 +1640,9 @@ int rolo_transform_cloud(rolo_ctx* c, const float* in, float* out, int n, int st
 
 int rolo_ctx_counters(rolo_ctx* c, long long* out, int n) {
   if (!c || !out || n < 0) return ROLO_EINVAL;
-  const long long v[13] = {c->n_frames, c->n_replays, c->n_captures, c->n_eager, c->n_topup_frames, c->n_topup_chunks, c->hint_rot, c->hint_trans, c->walk_lanes,
-                           c->ns_enqueue, c->ns_wait_blocked, c->ns_wait_other, c->n_persist_bails};
-  for (int i = 0; i < n && i < 13; i++) out[i] = v[i];
+  const long long v[14] = {c->n_frames, c->n_replays, c->n_captures, c->n_eager, c->n_topup_frames, c->n_topup_chunks, c->hint_rot, c->hint_trans, c->walk_lanes,
+                           c->ns_enqueue, c->ns_wait_blocked, c->ns_wait_other, c->n_persist_bails, c->learn.mode};
+  for (int i = 0; i < n && i < 14; i++) out[i] = v[i];
   return ROLO_OK;
 }
 
@@ -1842,6 +1899,7 @@ int rolo_set_shard(rolo_ctx* c, int rank, int world) {
   c->rank = rank; c->world = world; c->have_corr = false;
   if (c->shard_knn) { c->src.have_cov = false; c->tgt.have_cov = false; c->have_map = false; }
   if (c->graph_exec) { (void)hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }   // the captured schedule bakes the shard range in
+  if (c->galt.exec) { (void)hipGraphExecDestroy(c->galt.exec); c->galt.exec = nullptr; }
   c->gseen_valid = false;
   return ROLO_OK;
 }

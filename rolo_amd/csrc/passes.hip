@@ -1447,7 +1447,10 @@ __global__ __launch_bounds__(THREADS, OCC) void lm_persist_kernel(PassArgs a, Lm
       for (int v = 0; v < NVR; v++) { acc[v] = 0.0; slot[v] = v; }
       if (PPT > 0) {
 #pragma unroll
-        for (int p0 = 0; p0 < NP; p0 += BATCH) lmp_rot_body<DOF, BATCH>(a, &sst, i0 + p0 * THREADS, THREADS, pt + p0, cid + p0, valid + p0, acc);
+        for (int p0 = 0; p0 < NP; p0 += BATCH) {
+          lmp_rot_body<DOF, BATCH>(a, &sst, i0 + p0 * THREADS, THREADS, pt + p0, cid + p0, valid + p0, acc);
+          if (BATCH < NP) { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }   // one batch after the other: left alone, the compiler interleaves them all (and spills)
+        }
       }
       else for (int p = 0; p < ppt; p++) {
         const int i = i0 + p * THREADS;
@@ -1476,7 +1479,10 @@ __global__ __launch_bounds__(THREADS, OCC) void lm_persist_kernel(PassArgs a, Lm
       for (int v = 0; v < 30; v++) { acc[v] = 0.0; slot[v] = v; }
       if (PPT > 0) {
 #pragma unroll
-        for (int p0 = 0; p0 < NP; p0 += BATCH) lmp_trans_body<BATCH>(a, &sst, i0 + p0 * THREADS, THREADS, pt + p0, cid + p0, valid + p0, acc);
+        for (int p0 = 0; p0 < NP; p0 += BATCH) {
+          lmp_trans_body<BATCH>(a, &sst, i0 + p0 * THREADS, THREADS, pt + p0, cid + p0, valid + p0, acc);
+          if (BATCH < NP) { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
+        }
       }
       else for (int p = 0; p < ppt; p++) {
         const int i = i0 + p * THREADS;
@@ -1624,12 +1630,15 @@ hipError_t launch_lm_persist(int dof, int ppt, const PassArgs& a, LmState* st, u
   const int sp = (interleave && dof == 3 && a.n_off == 1 && (ppt == 1 || ppt == 2 || ppt == 4)) ? ppt : 0;
   // ROLO_LM_PERSIST_LEAN=1 (an A/B): the kernels built for four wavefronts per SIMD — 128 registers, the points of a thread one after the other
   static const bool lean = [] { const char* e = getenv("ROLO_LM_PERSIST_LEAN"); return e && atoi(e) != 0; }();
+  static const int batch4 = [] { const char* e = getenv("ROLO_LM_PERSIST_BATCH"); const int v = e ? atoi(e) : 2; return (v == 1 || v == 4) ? v : 2; }();   // four points per thread go through the bodies in batches of 2 (default: 3 636 scans/s with four contexts) / 1 (3 630) / 4 (3 519: 136 spilled registers)
   if (dof == 3) {
     if (sp == 1 && lean) lm_persist_kernel<3, 512, 1, 1, 4><<<nrows, 512, lds, s>>>(a, st, xbuf, trace, ppt, pub, timeout_ticks, admit_ticks, max_trials);
     else if (sp == 2 && lean) lm_persist_kernel<3, 512, 2, 1, 4><<<nrows, 512, lds, s>>>(a, st, xbuf, trace, ppt, pub, timeout_ticks, admit_ticks, max_trials);
     else if (sp == 4 && lean) lm_persist_kernel<3, 512, 4, 1, 4><<<nrows, 512, lds, s>>>(a, st, xbuf, trace, ppt, pub, timeout_ticks, admit_ticks, max_trials);
     else if (sp == 1) lm_persist_kernel<3, 512, 1><<<nrows, 512, lds, s>>>(a, st, xbuf, trace, ppt, pub, timeout_ticks, admit_ticks, max_trials);
     else if (sp == 2) lm_persist_kernel<3, 512, 2><<<nrows, 512, lds, s>>>(a, st, xbuf, trace, ppt, pub, timeout_ticks, admit_ticks, max_trials);
+    else if (sp == 4 && batch4 == 1) lm_persist_kernel<3, 512, 4, 1><<<nrows, 512, lds, s>>>(a, st, xbuf, trace, ppt, pub, timeout_ticks, admit_ticks, max_trials);
+    else if (sp == 4 && batch4 == 2) lm_persist_kernel<3, 512, 4, 2><<<nrows, 512, lds, s>>>(a, st, xbuf, trace, ppt, pub, timeout_ticks, admit_ticks, max_trials);
     else if (sp == 4) lm_persist_kernel<3, 512, 4><<<nrows, 512, lds, s>>>(a, st, xbuf, trace, ppt, pub, timeout_ticks, admit_ticks, max_trials);
     else lm_persist_kernel<3, 512, 0><<<nrows, 512, lds, s>>>(a, st, xbuf, trace, ppt, pub, timeout_ticks, admit_ticks, max_trials);
   } else lm_persist_kernel<6, 512, 0><<<nrows, 512, lds, s>>>(a, st, xbuf, trace, ppt, pub, timeout_ticks, admit_ticks, max_trials);

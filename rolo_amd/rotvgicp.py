@@ -368,10 +368,10 @@ class RotVGICP:
 
     def counters(self) -> dict:
         """rolo_ctx_counters as a dict"""
-        v = (C.c_longlong * 13)()
-        check(lib().rolo_ctx_counters(self._h, v, 13), "rolo_ctx_counters")
+        v = (C.c_longlong * 14)()
+        check(lib().rolo_ctx_counters(self._h, v, 14), "rolo_ctx_counters")
         return dict(zip(("frames", "graph_replays", "graph_captures", "eager_frames", "topup_frames", "sync_chunks", "hint_rot", "hint_trans", "walk_lanes",
-                         "host_enqueue_ns", "host_wait_blocked_ns", "host_wait_other_ns", "persist_bails"), [int(x) for x in v]))
+                         "host_enqueue_ns", "host_wait_blocked_ns", "host_wait_other_ns", "persist_bails", "load_mode"), [int(x) for x in v]))
 
     def debug_chain(self, kind: int, n_pairs: int, grid: int, reps: int):
         """experiment hook (rolo_debug_chain): `reps` replays of a captured chain of launch pairs on this context's stream; asynchronous"""
