@@ -38,11 +38,20 @@ def code_objects(path):
         pos = q
 
 
-def short(name):
-    m = re.search(r"\d+([a-z_0-9]+_kernel)", name)
-    base = m.group(1) if m else name
-    t = re.search(r"_kernel(I[A-Za-z0-9_]+?E)E?v", name)
-    return base + ("<" + t.group(1) + ">" if t else "")
+def demangle(names):
+    """c++filt in one go; falls back to the mangled names"""
+    try:
+        out = subprocess.run(["c++filt"], input="\n".join(names), capture_output=True, text=True, check=True).stdout.splitlines()
+        return dict(zip(names, out)) if len(out) == len(names) else {n: n for n in names}
+    except Exception:
+        return {n: n for n in names}
+
+
+def short(dem):
+    """`knn_walk_kernel<20, false, false, true>` from `void rolo::(anonymous namespace)::knn_walk_kernel<20, false, false, true>(rolo::KnnPair, int, int, int)` — the same
+    form summarize_sq.py makes of rocprofv3's Kernel_Name"""
+    m = re.search(r"([A-Za-z_0-9]+)(<[^()]*>)?\(", dem)
+    return (m.group(1) + (m.group(2) or "")) if m else dem
 
 
 def kernels(elf_bytes):
@@ -53,7 +62,7 @@ def kernels(elf_bytes):
         blk = ".agpr_count:" + blk
         g = lambda k, d="0": (re.search(r"\." + k + r":\s*(\S+)", blk) or [None, d])[1]
         name = g("name", "?")
-        yield dict(kernel=short(name), mangled=name, vgpr=int(g("vgpr_count")), agpr=int(g("agpr_count")), sgpr=int(g("sgpr_count")), vgpr_spill=int(g("vgpr_spill_count")),
+        yield dict(kernel=name, mangled=name, vgpr=int(g("vgpr_count")), agpr=int(g("agpr_count")), sgpr=int(g("sgpr_count")), vgpr_spill=int(g("vgpr_spill_count")),
                    sgpr_spill=int(g("sgpr_spill_count")), lds_bytes=int(g("group_segment_fixed_size")), scratch_bytes_per_lane=int(g("private_segment_fixed_size")),
                    max_workgroup=int(g("max_flat_workgroup_size")))
 
@@ -64,6 +73,9 @@ def main():
     for triple, elf in code_objects(path):
         for k in kernels(elf):
             rows[k["mangled"]] = k
+    dm = demangle(list(rows))
+    for m_, k in rows.items():
+        k["kernel"] = short(dm[m_])
     w = csv.writer(sys.stdout)
     w.writerow(["kernel", "vgpr_count", "agpr_count", "sgpr_count", "vgpr_spill", "sgpr_spill", "lds_bytes", "scratch_bytes_per_lane", "max_workgroup", "waves_per_simd_by_registers", "mangled"])
     for k in sorted(rows.values(), key=lambda r: r["kernel"]):
