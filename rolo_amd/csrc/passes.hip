@@ -1628,14 +1628,11 @@ hipError_t launch_lm_persist(int dof, int ppt, const PassArgs& a, LmState* st, u
   // the interleaved bodies (1, 2 or 4 points per thread in registers) for the reference's own configuration — SO(3) optimiser, DIRECT1; everything else one point after the other
   static const bool interleave = [] { const char* e = getenv("ROLO_LM_PERSIST_INTERLEAVE"); return !(e && atoi(e) == 0); }();
   const int sp = (interleave && dof == 3 && a.n_off == 1 && (ppt == 1 || ppt == 2 || ppt == 4)) ? ppt : 0;
-  // ROLO_LM_PERSIST_LEAN=1 (an A/B): the kernels built for four wavefronts per SIMD — 128 registers, the points of a thread one after the other
-  static const bool lean = [] { const char* e = getenv("ROLO_LM_PERSIST_LEAN"); return e && atoi(e) != 0; }();
+  // (builds for four wavefronts per SIMD — 128 registers, so that a walk's wavefronts could share the SIMDs — spill 85 / 159 / 270 registers at 1 / 2 / 4 points per thread and are
+  // not instantiated: lm_persist_kernel<3, 512, PPT, 1, 4>, profiles/DEAD_ENDS.md round 6)
   static const int batch4 = [] { const char* e = getenv("ROLO_LM_PERSIST_BATCH"); const int v = e ? atoi(e) : 2; return (v == 1 || v == 4) ? v : 2; }();   // four points per thread go through the bodies in batches of 2 (default: 3 636 scans/s with four contexts) / 1 (3 630) / 4 (3 519: 136 spilled registers)
   if (dof == 3) {
-    if (sp == 1 && lean) lm_persist_kernel<3, 512, 1, 1, 4><<<nrows, 512, lds, s>>>(a, st, xbuf, trace, ppt, pub, timeout_ticks, admit_ticks, max_trials);
-    else if (sp == 2 && lean) lm_persist_kernel<3, 512, 2, 1, 4><<<nrows, 512, lds, s>>>(a, st, xbuf, trace, ppt, pub, timeout_ticks, admit_ticks, max_trials);
-    else if (sp == 4 && lean) lm_persist_kernel<3, 512, 4, 1, 4><<<nrows, 512, lds, s>>>(a, st, xbuf, trace, ppt, pub, timeout_ticks, admit_ticks, max_trials);
-    else if (sp == 1) lm_persist_kernel<3, 512, 1><<<nrows, 512, lds, s>>>(a, st, xbuf, trace, ppt, pub, timeout_ticks, admit_ticks, max_trials);
+    if (sp == 1) lm_persist_kernel<3, 512, 1><<<nrows, 512, lds, s>>>(a, st, xbuf, trace, ppt, pub, timeout_ticks, admit_ticks, max_trials);
     else if (sp == 2) lm_persist_kernel<3, 512, 2><<<nrows, 512, lds, s>>>(a, st, xbuf, trace, ppt, pub, timeout_ticks, admit_ticks, max_trials);
     else if (sp == 4 && batch4 == 1) lm_persist_kernel<3, 512, 4, 1><<<nrows, 512, lds, s>>>(a, st, xbuf, trace, ppt, pub, timeout_ticks, admit_ticks, max_trials);
     else if (sp == 4 && batch4 == 2) lm_persist_kernel<3, 512, 4, 2><<<nrows, 512, lds, s>>>(a, st, xbuf, trace, ppt, pub, timeout_ticks, admit_ticks, max_trials);
