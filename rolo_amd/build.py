@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librolo_hip.so")
 SOURCES = ["api.hip", "knn_cov.hip", "voxelmap.hip", "passes.hip", "misc.hip", "front.hip", "odometry.hip", "fusion.hip", "scan2map.hip", "peer.hip"]
-HEADERS = ["rolo_internal.hpp", "dev_math.hpp", "voxel_dev.hpp", "knn_walk.hpp", "knn_packet.hpp", "polar_exact.hpp", "polar_exact_consts.hpp", "peer_dev.hpp", "polar_f32.hpp", "lm_begin.hpp", os.path.join("..", "..", "include", "rolo_hip.h"),
+HEADERS = ["rolo_internal.hpp", "dev_math.hpp", "voxel_dev.hpp", "knn_walk.hpp", "knn_packet.hpp", "polar_exact.hpp", "polar_exact_consts.hpp", "peer_dev.hpp", "polar_f32.hpp", "lm_begin.hpp", "load_learner.hpp", os.path.join("..", "..", "include", "rolo_hip.h"),
            os.path.join("..", "..", "include", "rolo_fusion.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = os.environ.get("ROLO_EXTRA_FLAGS", "").split() + ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function",

@@ -4,6 +4,7 @@
 // (include/rot_gicp/gicp/rot_vgicp.hpp:72-104, impl/rot_vgicp_impl.hpp:20-169, impl/lsq_registration_impl.hpp:55-80,
 // 152-179). No CPU fallback exists: every entry point fails with ROLO_EHIP if the HIP runtime does.
 #include "rolo_internal.hpp"
+#include "load_learner.hpp"
 #include <dlfcn.h>
 #include <cstdio>
 #include <cstring>
@@ -130,18 +131,7 @@ struct rolo_ctx {
   } ks[2];
   hipEvent_t ev_done = nullptr;    // end of the frame rolo_register_async enqueued (the stream may carry other contexts' frames behind it)
   hipEvent_t ev_start = nullptr;   // its start (both with timing: the frame's duration on the DEVICE is the load signal of LoadLearner below)
-  // What the per-process count of frames in flight cannot see — another PROCESS on the same GPU — learned from the device's own signal (round 5's verdict, item 7): while this
-  // context believes the device idle it remembers the shortest frame it has seen at the current sizes; frames that last a quarter longer than that for a while mean somebody
-  // else is using the chip, and the context tries the busy-device kernels: if its frames get shorter it keeps them (and looks again every 512 frames), if not it goes back.
-  // (Two processes with one context each: 2 x 1 066 scans/s on the idle-device kernels, 2 x 1 376 on the busy-device ones; beside a stream of 1 GiB copies the idle-device
-  // kernels stay the right choice — profiles/r06/load_regimes.json.)
-  struct LoadLearner {
-    int mode = 0;              // 0: idle-device kernels, 1: trying the busy-device kernels, 2: keeping them
-    int frames = 0;            // frames in this mode
-    double best_idle = 0, ema = 0, idle_at_switch = 0;
-    int n_src = 0, n_tgt = 0;  // the sizes best_idle belongs to
-    int holdoff = 0;           // frames before the next try after one that did not pay
-  } learn;
+  rolo::LoadLearner learn;     // load this process cannot count (another process on the GPU), learned from the frames' device time: load_learner.hpp
   bool frame_auto_idle = false;   // the frame in flight was sized by the learner (load_hint < 0, nobody else of this process in flight, not sharded)
   hipStream_t stream2 = nullptr;   // second stream for the eager (uncaptured) path of rolo_batch_*; stream and stream2 are a PAIR of the device's stream bank
                                    // (below): main streams on every other stream of a burst = two hardware queues, alternating — measured the best layout for
@@ -1499,9 +1489,8 @@ int rolo_register_async(rolo_ctx* c, const float* guess16, const double* trans_s
     // nobody of this process in flight: the learner decides (it may know of load this process cannot count)
     c->frame_auto_idle = c->load_hint < 0 && !sharded_ctx && c->busy_credit == 0 && !c->async_pending;
     if (c->frame_auto_idle) {
-      rolo_ctx::LoadLearner& L = c->learn;
-      if (L.n_src != c->src.n || L.n_tgt != c->tgt.n) { L = rolo_ctx::LoadLearner{}; L.n_src = c->src.n; L.n_tgt = c->tgt.n; }
-      c->device_busy = L.mode != 0;
+      c->learn.sizes(c->src.n, c->tgt.n);
+      c->device_busy = c->learn.busy();
     }
     if (!c->async_pending && set_device(c) == ROLO_OK) (void)hipEventRecord(c->ev_start, c->stream);
   }
@@ -1526,20 +1515,7 @@ int rolo_register_wait(rolo_ctx* c, float* Tf, double* Td, double* trans_out, ro
   if (c->frame_auto_idle) {   // the learner's signal: how long the frame took on the device (rolo_ctx::LoadLearner)
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, c->ev_start, c->ev_done) == hipSuccess && ms > 0.f) {
-      rolo_ctx::LoadLearner& L = c->learn;
-      L.frames++;
-      L.ema = L.frames <= 2 ? (double)ms : 0.8 * L.ema + 0.2 * (double)ms;   // (frames 1-2 of a mode: eager launches and the graph capture — the average restarts behind them)
-      if (L.frames == 3) L.ema = ms;
-      if (L.mode == 0) {
-        if (L.frames >= 3 && (L.best_idle == 0 || ms < L.best_idle)) L.best_idle = ms;
-        if (L.holdoff > 0) L.holdoff--;
-        if (L.frames >= 12 && L.holdoff == 0 && L.best_idle > 0 && L.ema > 1.25 * L.best_idle) { L.idle_at_switch = L.ema; L.mode = 1; L.frames = 0; }
-      } else if (L.mode == 1) {
-        if (L.frames >= 12) {
-          if (L.ema < 0.95 * L.idle_at_switch) { L.mode = 2; L.frames = 0; }
-          else { L.mode = 0; L.frames = 0; L.holdoff = 512; }
-        }
-      } else if (L.frames >= 512) { L.mode = 0; L.frames = 0; L.holdoff = 0; }   // look again: is the other user still there?
+      c->learn.frame((double)ms);
     } else (void)hipGetLastError();
   }
   struct WaitTimer { rolo_ctx* c; std::chrono::steady_clock::time_point t; ~WaitTimer() { c->ns_wait_other += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t).count(); } } wt{c, tw1};
