@@ -156,7 +156,7 @@ struct rolo_ctx {
   double* partials = nullptr; size_t partials_cap = 0;
   int lm_rows = 1;   // workgroups (= partial rows) of one fused LM launch
   unsigned long long* xbuf = nullptr; size_t xbuf_cap = 0;   // row exchange of the resident LM kernel (fused_lm = 2): header + 2 parities x workgroups x 64 words, zeroed when (re)allocated
-  int lmp_rows = 1, lmp_ppt = 1;   // its grid and the slabs of 512 points per workgroup
+  int lmp_rows = 1, lmp_ppt = 1, lmp_threads = 512;   // its grid, the points per thread and the workgroup size
   double* sums = nullptr; size_t sums_cap = 0;
   LmState* state = nullptr; size_t state_cap = 0;
   rolo_trace_rec* trace = nullptr; size_t trace_cap = 0;
@@ -514,11 +514,20 @@ int prepare_pass(rolo_ctx* c, PassArgs& a, int& grid) {
   c->lm_rows = std::max(1, (end - begin + lm_threads() * lm_ppt() - 1) / (lm_threads() * lm_ppt()));
   if ((rc = ensure(c->partials, c->partials_cap, std::max((size_t)grid, 2 * (size_t)c->lm_rows) * NV_MAX))) return rc;
   if (lm_persist(c)) {
-    const int npts = std::max(end - begin, 1), maxw = lm_persist_max_wgs(c);
-    int ppt = (npts + 512 * maxw - 1) / (512 * maxw);
+    // ROLO_LM_PERSIST_BUSY_THREADS=256 (A/B): with other frames in flight twice the workgroups of half the size — the same registers held, on twice the CUs, half of each
+    static const int busy_threads = [] { const char* e = getenv("ROLO_LM_PERSIST_BUSY_THREADS"); return (e && atoi(e) == 256) ? 256 : 512; }();
+    int T = c->device_busy ? busy_threads : 512;
+    const int npts = std::max(end - begin, 1);
+    int maxw = std::min(256, lm_persist_max_wgs(c) * (512 / T));
+    int ppt = (npts + T * maxw - 1) / (T * maxw);
     if (ppt == 3) ppt = 4;   // (1, 2 and 4 points per thread have the interleaved bodies)
-    c->lmp_ppt = ppt;
-    c->lmp_rows = (npts + 512 * c->lmp_ppt - 1) / (512 * c->lmp_ppt);
+    if (T == 256 && !(ppt == 4 && c->P.optimizer == ROLO_OPT_SO3_LM && noff == 1)) {   // the A/B form exists for the headline's case only
+      T = 512; maxw = lm_persist_max_wgs(c);
+      ppt = (npts + T * maxw - 1) / (T * maxw);
+      if (ppt == 3) ppt = 4;
+    }
+    c->lmp_ppt = ppt; c->lmp_threads = T;
+    c->lmp_rows = (npts + T * c->lmp_ppt - 1) / (T * c->lmp_ppt);
     const size_t need = lm_persist_words(256);   // sized for the largest grid once: the epochs in it must survive a change of the cloud size
     if (!c->xbuf || c->xbuf_cap < need) {
       if ((rc = ensure(c->xbuf, c->xbuf_cap, need))) return rc;
@@ -574,7 +583,7 @@ int enqueue_lm_chunk(rolo_ctx* c, const PassArgs& a, int k, bool publish = false
 int enqueue_lm_persist(rolo_ctx* c, const PassArgs& a, bool publish = false) {
   ProfScope ps(c, ROLO_PROF_LM_PASS);
   const int cap = (std::max(c->P.max_iterations, c->P.fixed_iterations) + 2) * (std::max(c->P.lm_max_iterations, 0) + 2) * 2 + 16;
-  HIPCHK(launch_lm_persist(c->P.optimizer == ROLO_OPT_SO3_LM ? 3 : 6, c->lmp_ppt, a, c->state, c->xbuf, c->lmp_rows, c->trace, publish ? c->h_state : nullptr,
+  HIPCHK(launch_lm_persist(c->P.optimizer == ROLO_OPT_SO3_LM ? 3 : 6, c->lmp_threads, c->lmp_ppt, a, c->state, c->xbuf, c->lmp_rows, c->trace, publish ? c->h_state : nullptr,
                            lm_persist_timeout_ticks(), lm_persist_admit_ticks(), cap, c->stream));
   return ROLO_OK;
 }

@@ -1213,10 +1213,12 @@ ROLO_DEV bool lmp_exchange(const double* __restrict__ row, int nv, int nh, unsig
   if (*bad) return false;
   if (ADMIT) return true;
   {   // row sums in a fixed order (16 groups of rows, then the groups): the same bits in every workgroup
-    const int v = t & 31, q = t >> 5;
-    double s0 = 0.0;
-    if (v < nv) for (int r = q; r < G; r += 16) s0 += __hiloint2double((int)xw[r * nw + 2 * v + 1], (int)xw[r * nw + 2 * v]);
-    part[q][v] = s0;
+    const int v = t & 31;
+    for (int q = t >> 5; q < 16; q += THREADS / 32) {
+      double s0 = 0.0;
+      if (v < nv) for (int r = q; r < G; r += 16) s0 += __hiloint2double((int)xw[r * nw + 2 * v + 1], (int)xw[r * nw + 2 * v]);
+      part[q][v] = s0;
+    }
   }
   __syncthreads();
   if (t < nv) {
@@ -1404,7 +1406,7 @@ __global__ __launch_bounds__(THREADS, OCC) void lm_persist_kernel(PassArgs a, Lm
   constexpr int NW = sizeof(LmState) / sizeof(int);
   constexpr int NHR = DOF * (DOF + 1) / 2, NVR = 3 + NHR + DOF;
   constexpr int NP = PPT > 0 ? PPT : 1;
-  static_assert(THREADS == 512, "16 summation groups of 32 values");
+  static_assert(THREADS == 512 || THREADS == 256, "16 summation groups of 32 values, dealt over the workgroup's 32-lane halves");
   const int G = (int)gridDim.x, wg = (int)blockIdx.x, t = (int)threadIdx.x;
   if (PPT > 0) ppt = PPT;
   ROLO_SHORT_KERNEL_PRIO();
@@ -1622,7 +1624,7 @@ hipError_t launch_lm(int dof, int threads, int ppt, const PassArgs& a, const LmS
   }
   return hipGetLastError();
 }
-hipError_t launch_lm_persist(int dof, int ppt, const PassArgs& a, LmState* st, unsigned long long* xbuf, int nrows, rolo_trace_rec* trace, LmState* pub, unsigned long long timeout_ticks,
+hipError_t launch_lm_persist(int dof, int threads, int ppt, const PassArgs& a, LmState* st, unsigned long long* xbuf, int nrows, rolo_trace_rec* trace, LmState* pub, unsigned long long timeout_ticks,
                              unsigned long long admit_ticks, int max_trials, hipStream_t s) {
   const size_t lds = sizeof(unsigned) * (size_t)nrows * 60;
   // the interleaved bodies (1, 2 or 4 points per thread in registers) for the reference's own configuration — SO(3) optimiser, DIRECT1; everything else one point after the other
@@ -1631,6 +1633,13 @@ hipError_t launch_lm_persist(int dof, int ppt, const PassArgs& a, LmState* st, u
   // (builds for four wavefronts per SIMD — 128 registers, so that a walk's wavefronts could share the SIMDs — spill 85 / 159 / 270 registers at 1 / 2 / 4 points per thread and are
   // not instantiated: lm_persist_kernel<3, 512, PPT, 1, 4>, profiles/DEAD_ENDS.md round 6)
   static const int batch4 = [] { const char* e = getenv("ROLO_LM_PERSIST_BATCH"); const int v = e ? atoi(e) : 2; return (v == 1 || v == 4) ? v : 2; }();   // four points per thread go through the bodies in batches of 2 (default: 3 636 scans/s with four contexts) / 1 (3 630) / 4 (3 519: 136 spilled registers)
+  // (A/B, ROLO_LM_PERSIST_BUSY_THREADS=256: 128 workgroups of 256 threads — one wavefront per SIMD at 256 registers, so that other kernels' wavefronts share the SIMDs
+  // instead of finding 64 CUs closed: 3 353 / 3 339 against 3 639 / 3 635 scans/s, profiles/DEAD_ENDS.md round 6)
+  if (threads == 256) {
+    if (!(dof == 3 && sp == 4)) return hipErrorInvalidValue;
+    lm_persist_kernel<3, 256, 4, 2><<<nrows, 256, lds, s>>>(a, st, xbuf, trace, ppt, pub, timeout_ticks, admit_ticks, max_trials);
+    return hipGetLastError();
+  }
   if (dof == 3) {
     if (sp == 1) lm_persist_kernel<3, 512, 1><<<nrows, 512, lds, s>>>(a, st, xbuf, trace, ppt, pub, timeout_ticks, admit_ticks, max_trials);
     else if (sp == 2) lm_persist_kernel<3, 512, 2><<<nrows, 512, lds, s>>>(a, st, xbuf, trace, ppt, pub, timeout_ticks, admit_ticks, max_trials);

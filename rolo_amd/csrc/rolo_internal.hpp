@@ -232,7 +232,7 @@ hipError_t launch_lm(int dof, int threads, int ppt /* slabs of `threads` points 
 // one launch per frame (passes.hip lm_persist_kernel): nrows resident workgroups of 512 threads x ppt points, rows exchanged through xbuf (lm_persist_words(nrows) 64-bit words,
 // zeroed once); the state starts and ends in st; admit_ticks: wall-clock ticks (100 MHz) the workgroups wait for each other to become resident before they leave the stage to the
 // host (LmState::lmp_bailed); timeout_ticks: what a poll may last after that (a bug guard: ROLO_ECOMM); max_trials: hard cap on the trials of one launch
-hipError_t launch_lm_persist(int dof, int ppt, const PassArgs& a, LmState* st, unsigned long long* xbuf, int nrows, rolo_trace_rec* trace, LmState* pub, unsigned long long timeout_ticks,
+hipError_t launch_lm_persist(int dof, int threads, int ppt, const PassArgs& a, LmState* st, unsigned long long* xbuf, int nrows, rolo_trace_rec* trace, LmState* pub, unsigned long long timeout_ticks,
                              unsigned long long admit_ticks, int max_trials, hipStream_t s);
 size_t lm_persist_words(int nrows);
 hipError_t launch_reduce(const double* partials, int nblocks, double* sums, const LmState* st, int stage, hipStream_t s);
