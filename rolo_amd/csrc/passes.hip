@@ -1263,9 +1263,43 @@ ROLO_DEV Sym3 lmp_rotated_cov(const PassArgs& a, const double* R, const double* 
   const size_t pitch = (size_t)a.n_total;
   return sym3_rotate(R, Sym3{a.cov[i], a.cov[pitch + i], a.cov[2 * pitch + i], a.cov[3 * pitch + i], a.cov[4 * pitch + i], a.cov[5 * pitch + i]});
 }
-template <int DOF, int PPT>
+// The reference's per-correspondence Mahalanobis cache (rot_vgicp_impl.hpp:204-222: update_correspondences leaves M = (C_B + R C_A R^T)^-1 of the linearisation point with
+// every correspondence, compute_error reads it) — in LDS: mc[k * ms + slot], k = the six entries, slot = this thread's p-th point; a thread only ever touches its own slots.
+// The (B) half writes it, the (A) half of the trials that follow reads it (m_hit: wave-uniform, lm_persist_kernel) instead of fetching the voxel covariance, rotating C_A and
+// inverting again: a cost-only trial is 26 instead of ~100 fp64 instructions per point. As global memory this cache LOST (48 B written + read per point and pass: DEAD_ENDS
+// round 5, entry 1); the resident kernel keeps a thread's points for the whole chain, so it costs no traffic here.
+typedef __attribute__((address_space(3))) double lds_f64;
+ROLO_DEV void mc_store(lds_f64* mc, int ms, int slot, const Sym3& M) {
+  mc[slot] = M.xx; mc[ms + slot] = M.xy; mc[2 * ms + slot] = M.xz; mc[3 * ms + slot] = M.yy; mc[4 * ms + slot] = M.yz; mc[5 * ms + slot] = M.zz;
+}
+ROLO_DEV Sym3 mc_load(const lds_f64* mc, int ms, int slot) { return Sym3{mc[slot], mc[ms + slot], mc[2 * ms + slot], mc[3 * ms + slot], mc[4 * ms + slot], mc[5 * ms + slot]}; }
+struct RecMW { Vec3 mean; double w; };
+ROLO_DEV RecMW load_rec_mw(const double* __restrict__ rec, int id) {
+  const double* r = rec + (size_t)id * REC_DOUBLES;
+  return RecMW{Vec3{r[0], r[1], r[2]}, r[9]};
+}
+// M of every point of this thread for the pose (R, S6 = R R^T) and the correspondences of buffer `buf`, one point after the other: what a (B) half would have left, had
+// it not been overwritten by a rejected trial's speculation (once per rejection), and the translation stage's constant matrices (once per stage)
+template <int NP>
+ROLO_DEV void lmp_fill_cache(const PassArgs& a, const double* R9, const double* S6, int buf, int i0, int threads, const PtReg* pt, const int (*cid)[2], const bool* valid,
+                             lds_f64* mc, int ms, int slot0) {
+  double R[9];
+#pragma unroll
+  for (int k = 0; k < 9; k++) R[k] = uni(R9[k]);
+#pragma unroll
+  for (int p = 0; p < NP; p++) {
+    const int v = buf ? cid[p][1] : cid[p][0];
+    if (valid[p] && v >= 0) {
+      const double* r = a.tab.rec + (size_t)v * REC_DOUBLES;
+      const Sym3 cb{r[3], r[4], r[5], r[6], r[7], r[8]};
+      mc_store(mc, ms, slot0 + p * threads, sym3_inverse(sym3_add(cb, lmp_rotated_cov(a, R, S6, pt[p], i0 + p * threads))));
+    }
+    asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
+  }
+}
+template <int DOF, int PPT, bool MC>
 ROLO_DEV void lmp_rot_body(const PassArgs& a, const LmState* __restrict__ st, int i0, int threads, const PtReg* pt, int (*cid)[2], const bool* valid,
-                           double (&acc)[3 + DOF * (DOF + 1) / 2 + DOF]) {
+                           double (&acc)[3 + DOF * (DOF + 1) / 2 + DOF], lds_f64* mc, int ms, int slot0) {
   constexpr int NH = DOF * (DOF + 1) / 2;
   const int phase = uni(st->phase), cur = uni(st->cur);
   const bool skip_lin = phase == 1 && uni(st->lin_skip) != 0;
@@ -1282,12 +1316,16 @@ ROLO_DEV void lmp_rot_body(const PassArgs& a, const LmState* __restrict__ st, in
     tp[p].x += t1[0]; tp[p].y += t1[1]; tp[p].z += t1[2];
   }
   // (A) compute_error(xi): the records of the cached correspondences — their ids are in registers, so these fetches depend on nothing this trial computed
+  // (with the cache — mc, filled for x0 by whoever ran before: lm_persist_kernel — only the mean and the weight of a record are fetched here)
   Rec ra[PPT]; bool ha[PPT];
 #pragma unroll
   for (int p = 0; p < PPT; p++) {
     const int v = cur ? cid[p][1] : cid[p][0];
     ha[p] = phase == 1 && valid[p] && v >= 0;
-    if (ha[p]) ra[p] = load_rec(a.tab.rec, v);
+    if (ha[p]) {
+      if (MC) { const RecMW l = load_rec_mw(a.tab.rec, v); ra[p].mean = l.mean; ra[p].w = l.w; }
+      else ra[p] = load_rec(a.tab.rec, v);
+    }
   }
   // (B) first probe of every point's voxel
   unsigned long long key[PPT]; unsigned h[PPT]; ulonglong2 sl[PPT]; bool ok[PPT];
@@ -1304,11 +1342,13 @@ ROLO_DEV void lmp_rot_body(const PassArgs& a, const LmState* __restrict__ st, in
 #pragma unroll
   for (int p = 0; p < PPT; p++) {
     if (ha[p]) {
-      const Sym3 M = sym3_inverse(sym3_add(ra[p].cov, lmp_rotated_cov(a, R0, st->x0_S, pt[p], i0 + p * threads)));
+      Sym3 M;
+      if constexpr (MC) M = mc_load(mc, ms, slot0 + p * threads);
+      else M = sym3_inverse(sym3_add(ra[p].cov, lmp_rotated_cov(a, R0, st->x0_S, pt[p], i0 + p * threads)));
       const Vec3 e{ra[p].mean.x - tp[p].x, ra[p].mean.y - tp[p].y, ra[p].mean.z - tp[p].z};
       acc[0] += ra[p].w * dot3(e, sym3_mulv(M, e));
     }
-    if (PPT > 1) __builtin_amdgcn_sched_barrier(0);   // the FETCHES of the points are batched, their arithmetic is not: interleaved, four inverses' temporaries are 250 registers
+    if (PPT > 1 && !MC) __builtin_amdgcn_sched_barrier(0);   // the FETCHES of the points are batched, their arithmetic is not: interleaved, four inverses' temporaries are 250 registers
   }
   if (skip_lin) return;
   int vid[PPT];
@@ -1334,6 +1374,7 @@ ROLO_DEV void lmp_rot_body(const PassArgs& a, const LmState* __restrict__ st, in
   for (int p = 0; p < PPT; p++) {
     if (vid[p] >= 0) {
       const Sym3 M = sym3_inverse(sym3_add(rb[p].cov, lmp_rotated_cov(a, R1, st->xt_S, pt[p], i0 + p * threads)));
+      if (MC) mc_store(mc, ms, slot0 + p * threads, M);
       const Vec3 e{rb[p].mean.x - tp[p].x, rb[p].mean.y - tp[p].y, rb[p].mean.z - tp[p].z};
       const Vec3 Me = sym3_mulv(M, e);
       acc[1] += rb[p].w * dot3(e, Me);
@@ -1344,8 +1385,9 @@ ROLO_DEV void lmp_rot_body(const PassArgs& a, const LmState* __restrict__ st, in
     if (PPT > 1) __builtin_amdgcn_sched_barrier(0);
   }
 }
-template <int PPT>
-ROLO_DEV void lmp_trans_body(const PassArgs& a, const LmState* __restrict__ st, int i0, int threads, const PtReg* pt, const int (*cid)[2], const bool* valid, double (&acc)[30]) {
+template <int PPT, bool MC>
+ROLO_DEV void lmp_trans_body(const PassArgs& a, const LmState* __restrict__ st, int i0, int threads, const PtReg* pt, const int (*cid)[2], const bool* valid, double (&acc)[30],
+                             lds_f64* mc, int ms, int slot0) {
   constexpr int NH = 21;
   const int phase = uni(st->phase);
   const bool skip_lin = phase == 1 && uni(st->lin_skip) != 0;
@@ -1363,7 +1405,10 @@ ROLO_DEV void lmp_trans_body(const PassArgs& a, const LmState* __restrict__ st, 
   for (int p = 0; p < PPT; p++) {
     const int v = tr_cur ? cid[p][1] : cid[p][0];
     has[p] = valid[p] && v >= 0;
-    if (has[p]) r[p] = load_rec(a.tab.rec, v);
+    if (has[p]) {
+      if (MC) { const RecMW l = load_rec_mw(a.tab.rec, v); r[p].mean = l.mean; r[p].w = l.w; }
+      else r[p] = load_rec(a.tab.rec, v);
+    }
   }
 #pragma unroll
   for (int p = 0; p < PPT; p++) {
@@ -1374,7 +1419,10 @@ ROLO_DEV void lmp_trans_body(const PassArgs& a, const LmState* __restrict__ st, 
     const Vec3 dv{(ba.x - tp.x) * inv_dtn, (ba.y - tp.y) * inv_dtn, (ba.z - tp.z) * inv_dtn};
     const Vec3 ctA{dv.x - lAq.x, dv.y - lAq.y, dv.z - lAq.z};
     const Vec3 ctB{dv.x - lBq.x, dv.y - lBq.y, dv.z - lBq.z};
-    const Sym3 M = sym3_inverse(sym3_add(r[p].cov, lmp_rotated_cov(a, R, st->tr_S, pt[p], i0 + p * threads)));
+    // (the stage's Mahalanobis matrices are those of the LAST rotation linearisation: constant over all its passes — lm_persist_kernel fills the cache once)
+    Sym3 M;
+    if constexpr (MC) M = mc_load(mc, ms, slot0 + p * threads);
+    else M = sym3_inverse(sym3_add(r[p].cov, lmp_rotated_cov(a, R, st->tr_S, pt[p], i0 + p * threads)));
     const Vec3 e{r[p].mean.x - tp.x, r[p].mean.y - tp.y, r[p].mean.z - tp.z};
     const Vec3 Me = sym3_mulv(M, e);
     const double eMe = dot3(e, Me), w = r[p].w;
@@ -1393,7 +1441,8 @@ ROLO_DEV void lmp_trans_body(const PassArgs& a, const LmState* __restrict__ st, 
 // PPT > 0: the interleaved bodies above (DIRECT1 only: one correspondence per point); PPT = 0: any number of points per thread and any neighbour search, one point after the other
 // BATCH = points of a thread that go through a body together (interleaved); OCC = wavefronts per SIMD the register budget must allow (2: 256 registers, 4: 128 — then a
 // walk's wavefronts fit on the same SIMDs and use the issue slots the resident kernel leaves idle while it exchanges and steps)
-template <int DOF, int THREADS, int PPT, int BATCH = (PPT > 0 ? PPT : 1), int OCC = 2>
+// MC: the Mahalanobis cache of lmp_rot_body in LDS (the interleaved bodies only)
+template <int DOF, int THREADS, int PPT, int BATCH = (PPT > 0 ? PPT : 1), int OCC = 2, bool MC = (PPT > 0)>
 __global__ __launch_bounds__(THREADS, OCC) void lm_persist_kernel(PassArgs a, LmState* st_io, unsigned long long* __restrict__ xbuf, rolo_trace_rec* trace, int ppt, LmState* pub,
                                                                              unsigned long long timeout_ticks, unsigned long long admit_ticks, int max_trials) {
   __shared__ LmState sst;
@@ -1422,6 +1471,11 @@ __global__ __launch_bounds__(THREADS, OCC) void lm_persist_kernel(PassArgs a, Lm
   const int i0 = a.begin + pass_xcd_block(a, wg, G) * ppt * THREADS + t;
   PtReg pt[NP]; int cid[NP][2]; bool valid[NP];
   if (PPT > 0) lmp_load_points<NP>(a, i0, THREADS, pt, cid, valid);
+  // the Mahalanobis cache (lmp_rot_body) behind the G rows of xw: 6 x THREADS x PPT doubles
+  constexpr int MS = THREADS * NP;
+  static_assert(!MC || PPT > 0, "the cache belongs to the interleaved bodies");
+  lds_f64* mc = MC ? (lds_f64*)(__attribute__((address_space(3))) void*)(xw + (size_t)G * 60) : nullptr;
+  bool m_valid = false;   // the cache holds M(x0) for the correspondences of buffer `cur` (rotation stage) / M(tr_R) for those of `tr_cur` (translation stage)
   __syncthreads();
   // admission (above): one empty row per workgroup under the short timeout
   if (t == 0) row[0] = 0.0;
@@ -1442,7 +1496,9 @@ __global__ __launch_bounds__(THREADS, OCC) void lm_persist_kernel(PassArgs a, Lm
   // ---- rotation / 6-dof stage ----
   while (ok && uni(sst.stage) == 1) {
     const bool only_first = uni(sst.phase) == 1 && uni(sst.lin_skip) != 0;
+    const int phase_in = uni(sst.phase), cur_in = uni(sst.cur);
     LMP_STAMP(0);
+    if (MC && !m_valid && phase_in == 1) lmp_fill_cache<NP>(a, sst.x0_R, sst.x0_S, cur_in, i0, THREADS, pt, cid, valid, mc, MS, t);
     {
       double acc[NVR]; int slot[NVR];
 #pragma unroll
@@ -1450,7 +1506,7 @@ __global__ __launch_bounds__(THREADS, OCC) void lm_persist_kernel(PassArgs a, Lm
       if (PPT > 0) {
 #pragma unroll
         for (int p0 = 0; p0 < NP; p0 += BATCH) {
-          lmp_rot_body<DOF, BATCH>(a, &sst, i0 + p0 * THREADS, THREADS, pt + p0, cid + p0, valid + p0, acc);
+          lmp_rot_body<DOF, BATCH, MC>(a, &sst, i0 + p0 * THREADS, THREADS, pt + p0, cid + p0, valid + p0, acc, mc, MS, p0 * THREADS + t);
           if (BATCH < NP) { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }   // one batch after the other: left alone, the compiler interleaves them all (and spills)
         }
       }
@@ -1469,12 +1525,17 @@ __global__ __launch_bounds__(THREADS, OCC) void lm_persist_kernel(PassArgs a, Lm
     LMP_STAMP(2);
     if (ok && t == 0) lmp_rot_step<DOF>(&sst, sums, tr);
     __syncthreads();
+    // what the cache holds now (rot_step_t): a linearisation pass (phase 0) left M(x0); a trial WITH a (B) half overwrote it with M(xt) — M(x0) of the next trial exactly if
+    // the step accepted and took the speculated linearisation (cur flipped); a cost-only trial only read it (if it was accepted, a phase-0 pass follows and writes)
+    m_valid = phase_in == 0 || only_first || uni(sst.cur) != cur_in;
     LMP_ACC();
   }
+  m_valid = false;   // (tr_R is the LAST linearisation point, not always x0: the first translation pass fills the cache)
   // ---- translation stage ----
   while (ok && uni(sst.stage) == 2) {
     const bool only_first = uni(sst.phase) == 1 && uni(sst.lin_skip) != 0;
     LMP_STAMP(0);
+    if (MC && !m_valid) lmp_fill_cache<NP>(a, sst.tr_R, sst.tr_S, uni(sst.tr_cur), i0, THREADS, pt, cid, valid, mc, MS, t);
     {
       double acc[30]; int slot[30];
 #pragma unroll
@@ -1482,7 +1543,7 @@ __global__ __launch_bounds__(THREADS, OCC) void lm_persist_kernel(PassArgs a, Lm
       if (PPT > 0) {
 #pragma unroll
         for (int p0 = 0; p0 < NP; p0 += BATCH) {
-          lmp_trans_body<BATCH>(a, &sst, i0 + p0 * THREADS, THREADS, pt + p0, cid + p0, valid + p0, acc);
+          lmp_trans_body<BATCH, MC>(a, &sst, i0 + p0 * THREADS, THREADS, pt + p0, cid + p0, valid + p0, acc, mc, MS, p0 * THREADS + t);
           if (BATCH < NP) { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
         }
       }
@@ -1501,6 +1562,7 @@ __global__ __launch_bounds__(THREADS, OCC) void lm_persist_kernel(PassArgs a, Lm
     LMP_STAMP(2);
     if (ok && t == 0) lmp_trans_step(&sst, sums, tr);
     __syncthreads();
+    m_valid = true;
     LMP_ACC();
   }
   if (!ok) {   // a row never arrived (or the stages do not end): an error code instead of waiting forever
@@ -1624,31 +1686,43 @@ hipError_t launch_lm(int dof, int threads, int ppt, const PassArgs& a, const LmS
   }
   return hipGetLastError();
 }
+// one launch of an instantiation: dynamic LDS = the G rows of the exchange (+ the Mahalanobis cache); above 64 KB the function's limit has to be raised once
+template <typename K, typename... Args>
+hipError_t lmp_launch(K kern, int nrows, int threads, size_t lds, hipStream_t s, Args... args) {
+  static const bool raised = [kern] {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+    if (e != hipSuccess) (void)hipGetLastError();
+    return e == hipSuccess;
+  }();
+  if (lds > 64 * 1024 && !raised) return hipErrorInvalidValue;
+  kern<<<nrows, threads, lds, s>>>(args...);
+  return hipGetLastError();
+}
 hipError_t launch_lm_persist(int dof, int threads, int ppt, const PassArgs& a, LmState* st, unsigned long long* xbuf, int nrows, rolo_trace_rec* trace, LmState* pub, unsigned long long timeout_ticks,
                              unsigned long long admit_ticks, int max_trials, hipStream_t s) {
-  const size_t lds = sizeof(unsigned) * (size_t)nrows * 60;
   // the interleaved bodies (1, 2 or 4 points per thread in registers) for the reference's own configuration — SO(3) optimiser, DIRECT1; everything else one point after the other
   static const bool interleave = [] { const char* e = getenv("ROLO_LM_PERSIST_INTERLEAVE"); return !(e && atoi(e) == 0); }();
   const int sp = (interleave && dof == 3 && a.n_off == 1 && (ppt == 1 || ppt == 2 || ppt == 4)) ? ppt : 0;
+  // ROLO_LM_PERSIST_MCACHE=0 (A/B): no Mahalanobis cache in LDS — every trial inverts again, as the pass kernels do
+  static const int mcache_on = [] { const char* e = getenv("ROLO_LM_PERSIST_MCACHE"); return (e && atoi(e) == 0) ? 0 : 1; }();
+  const bool mcache = sp > 0 && !(sp == 4 && threads == 512 && !mcache_on);   // (the A/B form exists for the headline's case)
+  const size_t lds = sizeof(unsigned) * (size_t)nrows * 60 + (mcache ? sizeof(double) * 6 * (size_t)threads * sp : 0);
   // (builds for four wavefronts per SIMD — 128 registers, so that a walk's wavefronts could share the SIMDs — spill 85 / 159 / 270 registers at 1 / 2 / 4 points per thread and are
   // not instantiated: lm_persist_kernel<3, 512, PPT, 1, 4>, profiles/DEAD_ENDS.md round 6)
   static const int batch4 = [] { const char* e = getenv("ROLO_LM_PERSIST_BATCH"); const int v = e ? atoi(e) : 2; return (v == 1 || v == 4) ? v : 2; }();   // four points per thread go through the bodies in batches of 2 (default: 3 636 scans/s with four contexts) / 1 (3 630) / 4 (3 519: 136 spilled registers)
+#define LMP_GO(...) lmp_launch(&lm_persist_kernel<__VA_ARGS__>, nrows, threads, lds, s, a, st, xbuf, trace, ppt, pub, timeout_ticks, admit_ticks, max_trials)
   // (A/B, ROLO_LM_PERSIST_BUSY_THREADS=256: 128 workgroups of 256 threads — one wavefront per SIMD at 256 registers, so that other kernels' wavefronts share the SIMDs
   // instead of finding 64 CUs closed: 3 353 / 3 339 against 3 639 / 3 635 scans/s, profiles/DEAD_ENDS.md round 6)
-  if (threads == 256) {
-    if (!(dof == 3 && sp == 4)) return hipErrorInvalidValue;
-    lm_persist_kernel<3, 256, 4, 2><<<nrows, 256, lds, s>>>(a, st, xbuf, trace, ppt, pub, timeout_ticks, admit_ticks, max_trials);
-    return hipGetLastError();
-  }
-  if (dof == 3) {
-    if (sp == 1) lm_persist_kernel<3, 512, 1><<<nrows, 512, lds, s>>>(a, st, xbuf, trace, ppt, pub, timeout_ticks, admit_ticks, max_trials);
-    else if (sp == 2) lm_persist_kernel<3, 512, 2><<<nrows, 512, lds, s>>>(a, st, xbuf, trace, ppt, pub, timeout_ticks, admit_ticks, max_trials);
-    else if (sp == 4 && batch4 == 1) lm_persist_kernel<3, 512, 4, 1><<<nrows, 512, lds, s>>>(a, st, xbuf, trace, ppt, pub, timeout_ticks, admit_ticks, max_trials);
-    else if (sp == 4 && batch4 == 2) lm_persist_kernel<3, 512, 4, 2><<<nrows, 512, lds, s>>>(a, st, xbuf, trace, ppt, pub, timeout_ticks, admit_ticks, max_trials);
-    else if (sp == 4) lm_persist_kernel<3, 512, 4><<<nrows, 512, lds, s>>>(a, st, xbuf, trace, ppt, pub, timeout_ticks, admit_ticks, max_trials);
-    else lm_persist_kernel<3, 512, 0><<<nrows, 512, lds, s>>>(a, st, xbuf, trace, ppt, pub, timeout_ticks, admit_ticks, max_trials);
-  } else lm_persist_kernel<6, 512, 0><<<nrows, 512, lds, s>>>(a, st, xbuf, trace, ppt, pub, timeout_ticks, admit_ticks, max_trials);
-  return hipGetLastError();
+  if (threads == 256) return (dof == 3 && sp == 4) ? LMP_GO(3, 256, 4, 2) : hipErrorInvalidValue;
+  if (dof != 3) return LMP_GO(6, 512, 0);
+  if (sp == 1) return LMP_GO(3, 512, 1);
+  if (sp == 2) return LMP_GO(3, 512, 2);
+  if (sp == 4 && batch4 == 1) return LMP_GO(3, 512, 4, 1);
+  if (sp == 4 && !mcache) return LMP_GO(3, 512, 4, 2, 2, false);
+  if (sp == 4 && batch4 == 2) return LMP_GO(3, 512, 4, 2);
+  if (sp == 4) return LMP_GO(3, 512, 4);
+  return LMP_GO(3, 512, 0);
+#undef LMP_GO
 }
 size_t lm_persist_words(int nrows) { return (size_t)LMP_HDR + 2 * (size_t)nrows * PEER_SLOT_WORDS; }
 hipError_t launch_reduce(const double* partials, int nblocks, double* sums, const LmState* st, int stage, hipStream_t s) {
