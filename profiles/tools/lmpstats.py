@@ -26,4 +26,7 @@ for it in range(12):
 f(buf, 0)
 n = max(buf[7], 1)
 print("trials", buf[7], "per trial us: body+reduce %.2f  exchange %.2f  step %.2f  total %.2f" % (buf[0] / n / 100, buf[1] / n / 100, buf[2] / n / 100, (buf[0] + buf[1] + buf[2]) / n / 100),
+      "| cost-only trials %d: body+reduce %.2f  exchange %.2f  step %.2f | the others: body+reduce %.2f  exchange %.2f  step %.2f |" % (
+          buf[6], buf[3] / max(buf[6], 1) / 100, buf[4] / max(buf[6], 1) / 100, buf[5] / max(buf[6], 1) / 100,
+          (buf[0] - buf[3]) / max(n - buf[6], 1) / 100, (buf[1] - buf[4]) / max(n - buf[6], 1) / 100, (buf[2] - buf[5]) / max(n - buf[6], 1) / 100),
       "passes", g.last_stats.n_passes, g.last_translation_stats.n_passes, "cost-only", g.last_stats.n_cost_only + g.last_translation_stats.n_cost_only)

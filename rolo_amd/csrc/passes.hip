@@ -1147,7 +1147,9 @@ extern "C" int rolo_debug_lmp_times(unsigned long long* out8, int reset) {
 }
 #define LMP_STAMP(k) const long long lt##k = wall_clock64()
 #define LMP_ACC() do { if (wg == 0 && t == 0) { const long long lt3 = wall_clock64(); atomicAdd(&g_lmp_t[0], (unsigned long long)(lt1 - lt0)); atomicAdd(&g_lmp_t[1], (unsigned long long)(lt2 - lt1)); \
-                       atomicAdd(&g_lmp_t[2], (unsigned long long)(lt3 - lt2)); atomicAdd(&g_lmp_t[7], 1ull); } } while (0)
+                       atomicAdd(&g_lmp_t[2], (unsigned long long)(lt3 - lt2)); atomicAdd(&g_lmp_t[7], 1ull); \
+                       if (only_first) { atomicAdd(&g_lmp_t[3], (unsigned long long)(lt1 - lt0)); atomicAdd(&g_lmp_t[4], (unsigned long long)(lt2 - lt1)); \
+                                         atomicAdd(&g_lmp_t[5], (unsigned long long)(lt3 - lt2)); atomicAdd(&g_lmp_t[6], 1ull); } } } while (0)   /* [3..6]: the cost-only trials among them */
 #else
 #define LMP_STAMP(k)
 #define LMP_ACC()
@@ -1156,9 +1158,13 @@ extern "C" int rolo_debug_lmp_times(unsigned long long* out8, int reset) {
 // were live across the pass bodies and spilled (620 bytes of scratch per lane)
 // (state and sums live in LDS: the round trip through an address_space(3) pointer tells the compiler so — a call boundary hides it, and generic pointers would make every
 // one of the step's ~150 state accesses a flat instruction)
-template <typename T> ROLO_DEV T* lds_ptr(T* p) { return (T*)(__attribute__((address_space(3))) T*)p; }
-template <int DOF> __device__ __noinline__ void lmp_rot_step(LmState* st, const double* S, rolo_trace_rec* trace) { rot_step_t<DOF>(lds_ptr(st), lds_ptr(S), trace); }
-__device__ __noinline__ void lmp_trans_step(LmState* st, const double* S, rolo_trace_rec* trace) { trans_step(lds_ptr(st), lds_ptr(S), trace); }
+// (round 6, second form: state and sums are FILE-scope LDS variables, so that the step — a function of its own — names them directly: every access is a ds_ instruction
+// with a constant address. As pointer arguments they arrived generic, and the cast back to LDS cost a null check of three instructions per access — ~1 300 of the
+// step's 4 300 instructions, all issued by one lane at four cycles each)
+__shared__ LmState lmp_sst;
+__shared__ double lmp_sums[NV_MAX];
+template <int DOF> __device__ __noinline__ void lmp_rot_step(rolo_trace_rec* trace) { rot_step_t<DOF>(&lmp_sst, lmp_sums, trace); }
+__device__ __noinline__ void lmp_trans_step(rolo_trace_rec* trace) { trans_step(&lmp_sst, lmp_sums, trace); }
 
 // publish row[0 .. nv) as words of epoch e, collect all G rows, add them in a fixed order into sums[] (V_* slots). Returns false if a row did not arrive in time.
 #ifndef ROLO_LMP_SPIN_PRIO
@@ -1445,9 +1451,9 @@ ROLO_DEV void lmp_trans_body(const PassArgs& a, const LmState* __restrict__ st, 
 template <int DOF, int THREADS, int PPT, int BATCH = (PPT > 0 ? PPT : 1), int OCC = 2, bool MC = (PPT > 0)>
 __global__ __launch_bounds__(THREADS, OCC) void lm_persist_kernel(PassArgs a, LmState* st_io, unsigned long long* __restrict__ xbuf, rolo_trace_rec* trace, int ppt, LmState* pub,
                                                                              unsigned long long timeout_ticks, unsigned long long admit_ticks, int max_trials) {
-  __shared__ LmState sst;
+  LmState& sst = lmp_sst;
+  double* const sums = lmp_sums;
   __shared__ double row[NV_MAX];
-  __shared__ double sums[NV_MAX];
   __shared__ double part[16][NV_MAX];
   __shared__ int bad;
   extern __shared__ unsigned xw[];   // G x 60 halves
@@ -1523,7 +1529,7 @@ __global__ __launch_bounds__(THREADS, OCC) void lm_persist_kernel(PassArgs a, Lm
     LMP_STAMP(1);
     ok = lmp_exchange<THREADS>(row, only_first ? 1 : NVR, NHR, ++e, xbuf, G, wg, xw, part, sums, &bad, timeout_ticks) && ++trial <= max_trials;
     LMP_STAMP(2);
-    if (ok && t == 0) lmp_rot_step<DOF>(&sst, sums, tr);
+    if (ok && t == 0) lmp_rot_step<DOF>(tr);
     __syncthreads();
     // what the cache holds now (rot_step_t): a linearisation pass (phase 0) left M(x0); a trial WITH a (B) half overwrote it with M(xt) — M(x0) of the next trial exactly if
     // the step accepted and took the speculated linearisation (cur flipped); a cost-only trial only read it (if it was accepted, a phase-0 pass follows and writes)
@@ -1560,7 +1566,7 @@ __global__ __launch_bounds__(THREADS, OCC) void lm_persist_kernel(PassArgs a, Lm
     LMP_STAMP(1);
     ok = lmp_exchange<THREADS>(row, only_first ? 1 : 30, 21, ++e, xbuf, G, wg, xw, part, sums, &bad, timeout_ticks) && ++trial <= max_trials;
     LMP_STAMP(2);
-    if (ok && t == 0) lmp_trans_step(&sst, sums, tr);
+    if (ok && t == 0) lmp_trans_step(tr);
     __syncthreads();
     m_valid = true;
     LMP_ACC();
