@@ -621,10 +621,12 @@ ROLO_DEV void unpack_hb(LmState* __restrict__ st, const double* __restrict__ S) 
   st->n_corr = (int)(S[V_N] + 0.5);
 }
 
-template <int DOF>
+// ONE: `trace` is a single record (the resident kernel's LDS slot: a wavefront other than the stepping one copies it to the buffer, lm_persist_kernel)
+template <int DOF, bool ONE = false>
 ROLO_DEV void trace_push(LmState* __restrict__ st, rolo_trace_rec* __restrict__ trace, int stage, int accepted, double yi, double rho) {
   if (!trace || st->trace_count >= TRACE_CAP) { st->trace_count++; return; }
-  rolo_trace_rec& r = trace[st->trace_count++];
+  rolo_trace_rec& r = trace[ONE ? 0 : st->trace_count];
+  st->trace_count++;
   r.stage = stage; r.outer = st->outer; r.trial = st->trial; r.accepted = accepted;
   r.y0 = st->y0; r.yi = yi; r.rho = rho; r.lambda = st->lambda;
   double dn = 0;
@@ -728,7 +730,7 @@ ROLO_DEV void rot_finish(LmState* st, bool converged, bool failed) {
   else st->stage = 0;
 }
 
-template <int DOF>
+template <int DOF, bool ONE = false>
 ROLO_DEV void rot_step_t(LmState* __restrict__ st, const double* __restrict__ S, rolo_trace_rec* __restrict__ trace) {
   constexpr int dof = DOF;
   st->rot_passes++;
@@ -758,7 +760,7 @@ ROLO_DEV void rot_step_t(LmState* __restrict__ st, const double* __restrict__ S,
   const bool gn = st->optimizer == ROLO_OPT_GN;
   if (!gn && rho < 0) {
     if (delta_converged(st, dof == 3)) {  // returns true without moving x0
-      trace_push<DOF>(st, trace, 0, 2, yi, rho);
+      trace_push<DOF, ONE>(st, trace, 0, 2, yi, rho);
       st->outer++;
       const bool done = st->fixed_iterations > 0 ? (st->outer >= st->fixed_iterations) : true;
       if (done) { rot_finish(st, true, false); return; }
@@ -768,7 +770,7 @@ ROLO_DEV void rot_step_t(LmState* __restrict__ st, const double* __restrict__ S,
       st->lin_skip = st->spec_lin;   // a rejected trial: the next pass evaluates its trial's cost alone (LmState::lin_skip)
       return;
     }
-    trace_push<DOF>(st, trace, 0, 0, yi, rho);
+    trace_push<DOF, ONE>(st, trace, 0, 0, yi, rho);
     st->lambda = st->nu * st->lambda; st->nu = 2 * st->nu;
     st->trial++;
     if (st->trial >= st->lm_max) { rot_finish(st, false, true); return; }  // "lm not converged!!"
@@ -776,7 +778,7 @@ ROLO_DEV void rot_step_t(LmState* __restrict__ st, const double* __restrict__ S,
     st->lin_skip = st->spec_lin;
     return;
   }
-  trace_push<DOF>(st, trace, 0, 1, gn ? NAN : yi, gn ? NAN : rho);
+  trace_push<DOF, ONE>(st, trace, 0, 1, gn ? NAN : yi, gn ? NAN : rho);
   for (int i = 0; i < 9; i++) st->x0_R[i] = st->xt_R[i];
   for (int i = 0; i < 6; i++) st->x0_S[i] = st->xt_S[i];
   for (int i = 0; i < 3; i++) st->x0_t[i] = st->xt_t[i];
@@ -816,6 +818,7 @@ ROLO_DEV void trans_finish(LmState* st, bool failed) {
   st->trans_done = 1; st->trans_failed = failed ? 1 : 0; st->trans_outer = st->outer + (failed ? 1 : 0) /* iterations started: rot_finish */; st->stage = 0;
 }
 
+template <bool ONE = false>
 ROLO_DEV void trans_step(LmState* __restrict__ st, const double* __restrict__ S, rolo_trace_rec* __restrict__ trace) {
   st->trans_passes++;
   if (st->phase == 1 && st->lin_skip) st->trans_cost_only++;
@@ -835,8 +838,8 @@ ROLO_DEV void trans_step(LmState* __restrict__ st, const double* __restrict__ S,
   for (int i = 0; i < 6; i++) den += st->d[i] * (st->lambda * st->d[i] - st->b[i]);
   const double rho = (st->y0 - yi) / den;
   if (rho < 0) {
-    if (t_converged(st)) { trace_push<6>(st, trace, 1, 2, yi, rho); st->outer++; trans_finish(st, false); return; }
-    trace_push<6>(st, trace, 1, 0, yi, rho);
+    if (t_converged(st)) { trace_push<6, ONE>(st, trace, 1, 2, yi, rho); st->outer++; trans_finish(st, false); return; }
+    trace_push<6, ONE>(st, trace, 1, 0, yi, rho);
     st->lambda = st->nu * st->lambda; st->nu = 2 * st->nu;
     st->trial++;
     if (st->trial >= st->lm_max) { trans_finish(st, true); return; }
@@ -844,7 +847,7 @@ ROLO_DEV void trans_step(LmState* __restrict__ st, const double* __restrict__ S,
     st->lin_skip = st->spec_lin;   // a rejected trial: the next pass evaluates its trial's cost alone
     return;
   }
-  trace_push<6>(st, trace, 1, 1, yi, rho);
+  trace_push<6, ONE>(st, trace, 1, 1, yi, rho);
   for (int i = 0; i < 3; i++) st->t0[i] = st->tt[i];
   st->lambda = lm_lambda_after_accept(st->lambda, rho);
   st->outer++;
@@ -1163,8 +1166,22 @@ extern "C" int rolo_debug_lmp_times(unsigned long long* out8, int reset) {
 // step's 4 300 instructions, all issued by one lane at four cycles each)
 __shared__ LmState lmp_sst;
 __shared__ double lmp_sums[NV_MAX];
-template <int DOF> __device__ __noinline__ void lmp_rot_step(rolo_trace_rec* trace) { rot_step_t<DOF>(&lmp_sst, lmp_sums, trace); }
-__device__ __noinline__ void lmp_trans_step(rolo_trace_rec* trace) { trans_step(&lmp_sst, lmp_sums, trace); }
+// (a trial's trace record goes to an LDS slot: written to the buffer by the stepping lane, the store's acknowledgement — the function returns behind s_waitcnt vmcnt(0) — was
+// ~0.4 us of workgroup 0's step, for which all the others then wait in the next exchange)
+__shared__ rolo_trace_rec lmp_trace_slot;
+template <int DOF> __device__ __noinline__ void lmp_rot_step(bool want_trace) { rot_step_t<DOF, true>(&lmp_sst, lmp_sums, want_trace ? &lmp_trace_slot : nullptr); }
+__device__ __noinline__ void lmp_trans_step(bool want_trace) { trans_step<true>(&lmp_sst, lmp_sums, want_trace ? &lmp_trace_slot : nullptr); }
+// after the barrier behind a step: the last wavefront of workgroup 0 copies the record the step left (if it left one) — plain stores nobody waits for before the kernel ends
+template <int THREADS>
+ROLO_DEV void lmp_trace_flush(rolo_trace_rec* __restrict__ trace, int count_before) {
+  static_assert(sizeof(rolo_trace_rec) % sizeof(int) == 0, "record copied in dwords");
+  constexpr int NWORD = sizeof(rolo_trace_rec) / sizeof(int);
+  const int t = (int)threadIdx.x - (THREADS - 64);
+  if (t < 0 || t >= NWORD) return;
+  const int count = lmp_sst.trace_count;
+  if (count == count_before || count_before >= TRACE_CAP) return;
+  reinterpret_cast<int*>(trace + count_before)[t] = reinterpret_cast<const int*>(&lmp_trace_slot)[t];
+}
 
 // publish row[0 .. nv) as words of epoch e, collect all G rows, add them in a fixed order into sums[] (V_* slots). Returns false if a row did not arrive in time.
 #ifndef ROLO_LMP_SPIN_PRIO
@@ -1502,7 +1519,7 @@ __global__ __launch_bounds__(THREADS, OCC) void lm_persist_kernel(PassArgs a, Lm
   // ---- rotation / 6-dof stage ----
   while (ok && uni(sst.stage) == 1) {
     const bool only_first = uni(sst.phase) == 1 && uni(sst.lin_skip) != 0;
-    const int phase_in = uni(sst.phase), cur_in = uni(sst.cur);
+    const int phase_in = uni(sst.phase), cur_in = uni(sst.cur), tc_in = uni(sst.trace_count);
     LMP_STAMP(0);
     if (MC && !m_valid && phase_in == 1) lmp_fill_cache<NP>(a, sst.x0_R, sst.x0_S, cur_in, i0, THREADS, pt, cid, valid, mc, MS, t);
     {
@@ -1529,8 +1546,9 @@ __global__ __launch_bounds__(THREADS, OCC) void lm_persist_kernel(PassArgs a, Lm
     LMP_STAMP(1);
     ok = lmp_exchange<THREADS>(row, only_first ? 1 : NVR, NHR, ++e, xbuf, G, wg, xw, part, sums, &bad, timeout_ticks) && ++trial <= max_trials;
     LMP_STAMP(2);
-    if (ok && t == 0) lmp_rot_step<DOF>(tr);
+    if (ok && t == 0) lmp_rot_step<DOF>(tr != nullptr);
     __syncthreads();
+    if (ok && tr) lmp_trace_flush<THREADS>(tr, tc_in);
     // what the cache holds now (rot_step_t): a linearisation pass (phase 0) left M(x0); a trial WITH a (B) half overwrote it with M(xt) — M(x0) of the next trial exactly if
     // the step accepted and took the speculated linearisation (cur flipped); a cost-only trial only read it (if it was accepted, a phase-0 pass follows and writes)
     m_valid = phase_in == 0 || only_first || uni(sst.cur) != cur_in;
@@ -1540,6 +1558,7 @@ __global__ __launch_bounds__(THREADS, OCC) void lm_persist_kernel(PassArgs a, Lm
   // ---- translation stage ----
   while (ok && uni(sst.stage) == 2) {
     const bool only_first = uni(sst.phase) == 1 && uni(sst.lin_skip) != 0;
+    const int tc_in = uni(sst.trace_count);
     LMP_STAMP(0);
     if (MC && !m_valid) lmp_fill_cache<NP>(a, sst.tr_R, sst.tr_S, uni(sst.tr_cur), i0, THREADS, pt, cid, valid, mc, MS, t);
     {
@@ -1566,8 +1585,9 @@ __global__ __launch_bounds__(THREADS, OCC) void lm_persist_kernel(PassArgs a, Lm
     LMP_STAMP(1);
     ok = lmp_exchange<THREADS>(row, only_first ? 1 : 30, 21, ++e, xbuf, G, wg, xw, part, sums, &bad, timeout_ticks) && ++trial <= max_trials;
     LMP_STAMP(2);
-    if (ok && t == 0) lmp_trans_step(tr);
+    if (ok && t == 0) lmp_trans_step(tr != nullptr);
     __syncthreads();
+    if (ok && tr) lmp_trace_flush<THREADS>(tr, tc_in);
     m_valid = true;
     LMP_ACC();
   }
