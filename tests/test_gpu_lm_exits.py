@@ -367,3 +367,68 @@ def test_resident_lm_kernel_gives_the_stage_back_when_it_cannot_become_resident(
         assert (ia, ja, pa) == (ib, jb, pb)
         assert np.abs(np.array(Ta) - np.array(Tb)).max() < 1e-11 and np.abs(np.array(ta) - np.array(tb)).max() < 1e-11
     assert np.abs(np.array(a["align"]) - np.array(b["align"])).max() < 1e-11 and np.abs(np.array(a["trans"]) - np.array(b["trans"])).max() < 1e-11
+
+
+# ---- the resident kernel's forms and its Mahalanobis cache -------------------------------------------------------------------------------------------
+_FORMS = r"""
+import sys, json, numpy as np
+sys.path.insert(0, sys.argv[1])
+from rolo_amd import synth
+from rolo_amd.rotvgicp import RotVGICP
+sensor, leaf, hint = sys.argv[2], float(sys.argv[3]), int(sys.argv[4])
+src, tgt, _ = synth.dense_pair(sensor, seed=synth.SEED)
+G = -np.asarray(synth.PREV_STEP_T, np.float64)
+guess = np.eye(4, dtype=np.float32); guess[:3, :3] = synth.rpy_to_R(0.01, -0.015, np.radians(3.0))
+out = {}
+for fused in (0, 2):
+    rows = []
+    for knobs in (dict(fixed_iterations=20), dict(), dict(lm_init_lambda_factor=1e-3, rotation_epsilon=1e-9), dict(lm_init_lambda_factor=100.0, lm_max_iterations=4)):
+        g = RotVGICP(0); g.setResolution(leaf); g.setLoadHint(hint)
+        for k, v in knobs.items():
+            setattr(g._p, k, v)
+        g._p.fused_lm = fused; g._push()
+        g.setInputTarget(tgt); g.setInputSource(src)
+        g.register_async(guess, np.zeros(3), G, G * 0.97)
+        _, _, t = g.register_wait()
+        st, ts = g.last_stats, g.last_translation_stats
+        tr = [(r["stage"], r["outer"], r["trial"], r["accepted"], r["y0"], r["yi"]) for r in g.trace()]
+        rows.append(dict(T=np.asarray(g.final_transformation_d).tolist(), t=np.asarray(t).tolist(), rot=[st.lm_failed, st.n_outer, int(st.converged), st.n_passes, st.n_cost_only, st.n_correspondences],
+                         trans=[ts.lm_failed, ts.n_outer, ts.n_passes, ts.n_cost_only], trace=tr))
+        g.close()
+    out[str(fused)] = rows
+print(json.dumps(out))
+"""
+
+
+@pytest.mark.parametrize("sensor,leaf,hint,wgs", [("os1-128", 0.5, 1, None), ("os1-64", 1.0, 1, None), ("os1-128", 0.5, 0, None), ("os1-128", 0.5, 1, "128")])
+def test_resident_kernel_forms_and_cache_follow_the_pass_launches(sensor, leaf, hint, wgs):
+    """The resident LM kernel in the forms the load picks — 64 workgroups x 4 points per thread (the headline's), x 2 (65 536-point clouds; 128 workgroups forced), 256 x 1 on an
+    idle device — with its Mahalanobis cache (passes.hip lmp_rot_body: written by the (B) halves, read by the (A) halves and the translation passes, refilled after a rejected
+    speculation) against pass + controller launches, which invert per trial: forced iterations (the cost-only run after convergence), the reference's own loop, a small initial
+    damping (rejections early in the stage) and a large one with four trials per iteration (LM failure). Same exits, counts, cost-only passes and decisions; costs to 1e-9,
+    poses to 1e-10 (the rows are sums over other groups of points)."""
+    import json
+    env = dict(os.environ)
+    if wgs:
+        env["ROLO_LM_PERSIST_WGS"] = wgs
+    r = subprocess.run([sys.executable, "-c", _FORMS, ROOT, sensor, str(leaf), str(hint)], capture_output=True, text=True, env=env, cwd=ROOT, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    for a, b in zip(out["0"], out["2"]):
+        # (cost-only passes, index 4 / 3: whether the pass after a trial is cost-only follows the trial's decision — where a stage goes on past convergence its decisions are
+        # rounding noise of the sums, and the count with them; it is compared when no decision of the stage was noise)
+        noisy = [any(r[0] == stage and abs(r[4] - r[5]) <= 1e-7 * abs(r[4]) for r in a["trace"]) for stage in (0, 1)]
+        assert a["rot"][:4] + a["rot"][5:] == b["rot"][:4] + b["rot"][5:] and a["trans"][:3] == b["trans"][:3], (a["rot"], b["rot"], a["trans"], b["trans"])
+        assert noisy[0] or a["rot"][4] == b["rot"][4], (a["rot"], b["rot"])
+        assert noisy[1] or a["trans"][3] == b["trans"][3], (a["trans"], b["trans"])
+        assert np.abs(np.array(a["T"]) - np.array(b["T"])).max() < 1e-10 and np.abs(np.array(a["t"]) - np.array(b["t"])).max() < 1e-10
+        assert len(a["trace"]) == len(b["trace"])
+        for ra, rb in zip(a["trace"], b["trace"]):
+            if abs(ra[4] - ra[5]) <= 1e-7 * abs(ra[4]):      # a decision inside the rounding noise of the sums: the records after it may differ legitimately
+                break
+            assert ra[:4] == rb[:4], (ra, rb)
+            assert same(ra[4], rb[4], 1e-9) and same(ra[5], rb[5], 1e-9), (ra, rb)
+    # the scenarios do what they are there for: a cost-only run, rejections, an LM failure
+    forced, own, small, large = out["2"]
+    assert forced["rot"][1] == 20 and forced["rot"][4] >= 5
+    assert any(r[3] == 0 for r in small["trace"]) or any(r[3] == 0 for r in own["trace"])
