@@ -1,4 +1,4 @@
-# usage: bash profiles/tools/_ab.sh <outdir> NAME:ENV=VAL,ENV=VAL ...   (alternating bench runs, short form; scratch helper for A/B measurements)
+# usage: bash profiles/tools/ab.sh <outdir> NAME:ENV=VAL,ENV=VAL ...   (alternating bench runs, short form; alternating A/B runs of the short bench form)
 out=$1; shift; mkdir -p gpurun_out/$out
 B="python bench.py --steps 20 --warmup 5 --no-cpu --no-config5 --no-pipeline --no-layout-check --no-side-legs"
 for rep in 1 2; do

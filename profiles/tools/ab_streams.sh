@@ -1,4 +1,4 @@
-# usage: bash profiles/tools/_ab2.sh <outdir> NAME:STREAMS:ENV=VAL,... ...
+# usage: bash profiles/tools/ab_streams.sh <outdir> NAME:STREAMS:ENV=VAL,... ...
 out=$1; shift; mkdir -p gpurun_out/$out
 for spec in "$@"; do
   name=${spec%%:*}; rest=${spec#*:}; st=${rest%%:*}; envs=${rest#*:}; envs=${envs//,/ }
