@@ -18,6 +18,7 @@
 // are predicated on the device-side state, so a fixed schedule of launches can be enqueued (or graph-captured)
 // without knowing how many trials the data will need.
 #include "rolo_internal.hpp"
+#include <atomic>
 #include "lm_begin.hpp"
 #include "dev_math.hpp"
 #include "voxel_dev.hpp"
@@ -1712,16 +1713,22 @@ hipError_t launch_lm(int dof, int threads, int ppt, const PassArgs& a, const LmS
   }
   return hipGetLastError();
 }
-// one launch of an instantiation: dynamic LDS = the G rows of the exchange (+ the Mahalanobis cache); above 64 KB the function's limit has to be raised once
-template <typename K, typename... Args>
-hipError_t lmp_launch(K kern, int nrows, int threads, size_t lds, hipStream_t s, Args... args) {
-  static const bool raised = [kern] {
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
-    if (e != hipSuccess) (void)hipGetLastError();
-    return e == hipSuccess;
-  }();
-  if (lds > 64 * 1024 && !raised) return hipErrorInvalidValue;
-  kern<<<nrows, threads, lds, s>>>(args...);
+// one launch of an instantiation: dynamic LDS = the G rows of the exchange (+ the Mahalanobis cache); above 64 KB the function's limit is raised first — once per
+// instantiation (KERN is a template argument: a static per kernel, not per signature) and per device of the process
+template <auto KERN, typename... Args>
+hipError_t lmp_launch(int nrows, int threads, size_t lds, hipStream_t s, Args... args) {
+  if (lds > 64 * 1024) {
+    static std::atomic<unsigned long long> raised{0};   // bit d: done on device d
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return hipGetLastError();
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(raised.load(std::memory_order_relaxed) & bit)) {
+      const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(KERN), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+      if (e != hipSuccess) return e;
+      raised.fetch_or(bit, std::memory_order_relaxed);
+    }
+  }
+  KERN<<<nrows, threads, lds, s>>>(args...);
   return hipGetLastError();
 }
 hipError_t launch_lm_persist(int dof, int threads, int ppt, const PassArgs& a, LmState* st, unsigned long long* xbuf, int nrows, rolo_trace_rec* trace, LmState* pub, unsigned long long timeout_ticks,
@@ -1736,7 +1743,7 @@ hipError_t launch_lm_persist(int dof, int threads, int ppt, const PassArgs& a, L
   // (builds for four wavefronts per SIMD — 128 registers, so that a walk's wavefronts could share the SIMDs — spill 85 / 159 / 270 registers at 1 / 2 / 4 points per thread and are
   // not instantiated: lm_persist_kernel<3, 512, PPT, 1, 4>, profiles/DEAD_ENDS.md round 6)
   static const int batch4 = [] { const char* e = getenv("ROLO_LM_PERSIST_BATCH"); const int v = e ? atoi(e) : 2; return (v == 1 || v == 4) ? v : 2; }();   // four points per thread go through the bodies in batches of 2 (default: 3 636 scans/s with four contexts) / 1 (3 630) / 4 (3 519: 136 spilled registers)
-#define LMP_GO(...) lmp_launch(&lm_persist_kernel<__VA_ARGS__>, nrows, threads, lds, s, a, st, xbuf, trace, ppt, pub, timeout_ticks, admit_ticks, max_trials)
+#define LMP_GO(...) lmp_launch<&lm_persist_kernel<__VA_ARGS__>>(nrows, threads, lds, s, a, st, xbuf, trace, ppt, pub, timeout_ticks, admit_ticks, max_trials)
   // (A/B, ROLO_LM_PERSIST_BUSY_THREADS=256: 128 workgroups of 256 threads — one wavefront per SIMD at 256 registers, so that other kernels' wavefronts share the SIMDs
   // instead of finding 64 CUs closed: 3 353 / 3 339 against 3 639 / 3 635 scans/s, profiles/DEAD_ENDS.md round 6)
   if (threads == 256) return (dof == 3 && sp == 4) ? LMP_GO(3, 256, 4, 2) : hipErrorInvalidValue;
