@@ -1143,6 +1143,12 @@ constexpr int LMP_HDR = 8;   // words in front of the rows: [0] = last epoch use
 #ifdef ROLO_LMP_STATS
 // the phases of a trial as workgroup 0 sees them (wall clock, 100 MHz ticks, summed): [0] pass body + block reduction, [1] exchange (publish, poll, row sums), [2] the scalar step, [7] trials
 __device__ unsigned long long g_lmp_t[8];
+__device__ unsigned long long g_lmp_adm[4];   // admission as workgroup 0 sees it: [0] ticks from its start to everybody admitted, [1] launches, [2] the longest one, [3] ticks from its start to the kernel's end
+extern "C" int rolo_debug_lmp_admission(unsigned long long* out4, int reset) {
+  if (hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_lmp_adm), sizeof(unsigned long long) * 4) != hipSuccess) return -1;
+  if (reset) { unsigned long long z[4] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_lmp_adm), z, sizeof(z)) != hipSuccess) return -1; }
+  return 0;
+}
 extern "C" int rolo_debug_lmp_times(unsigned long long* out8, int reset) {
   (void)hipDeviceSynchronize();
   if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_lmp_t), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
@@ -1483,6 +1489,9 @@ __global__ __launch_bounds__(THREADS, OCC) void lm_persist_kernel(PassArgs a, Lm
   const int G = (int)gridDim.x, wg = (int)blockIdx.x, t = (int)threadIdx.x;
   if (PPT > 0) ppt = PPT;
   ROLO_SHORT_KERNEL_PRIO();
+#ifdef ROLO_LMP_STATS
+  const long long lt_entry = wall_clock64();
+#endif
   {
     const int* g = reinterpret_cast<const int*>(st_io);
     int* l = reinterpret_cast<int*>(&sst);
@@ -1514,6 +1523,9 @@ __global__ __launch_bounds__(THREADS, OCC) void lm_persist_kernel(PassArgs a, Lm
     return;
   }
   if (t == 0) sst.lmp_bailed = 0;
+#ifdef ROLO_LMP_STATS
+  if (wg == 0 && t == 0) { const unsigned long long dta = (unsigned long long)(wall_clock64() - lt_entry); atomicAdd(&g_lmp_adm[0], dta); atomicAdd(&g_lmp_adm[1], 1ull); atomicMax(&g_lmp_adm[2], dta); }
+#endif
   rolo_trace_rec* tr = wg == 0 ? trace : nullptr;   // without a buffer trace_count still advances
   int trial = 0;
   bool ok = true;
@@ -1602,6 +1614,9 @@ __global__ __launch_bounds__(THREADS, OCC) void lm_persist_kernel(PassArgs a, Lm
     for (int w = t; w < NW; w += THREADS) g[w] = l[w];
     if (pub) { int* h = reinterpret_cast<int*>(pub); for (int w = t; w < NW; w += THREADS) h[w] = l[w]; }
     if (t == 0) xbuf[0] = e;   // the next launch's epochs continue here
+#ifdef ROLO_LMP_STATS
+    if (t == 0) atomicAdd(&g_lmp_adm[3], (unsigned long long)(wall_clock64() - lt_entry));
+#endif
   }
 }
 
