@@ -264,7 +264,7 @@ ROLO_DEV void rot_pass_compute(const PassArgs& a, const LmState* __restrict__ st
     // (A) compute_error(xi): cached correspondences, Mahalanobis of the linearisation pose x0
     // (round 5 measured the reference's per-correspondence Mahalanobis cache here — six fp64 of M(x0) per point, written by the (B) half, read by the next
     // trial's (A) half, rot_vgicp_impl.hpp:204-222 — and it LOST: 96 B per point and pass of extra traffic cost more than the ~100 instructions saved,
-    // 2694 against 2875 scans/s; profiles/DEAD_ENDS.md. Neither stage caches M: the translation stage's cache, whose M is constant, measured neutral and is not kept either.)
+    // 2694 against 2875 scans/s; profiles/DEAD_ENDS.md. Neither stage of these PASS kernels caches M: the translation stage's cache, whose M is constant, measured neutral and is not kept either. The resident kernel does — in LDS, where it costs no traffic: lmp_rot_body.)
     if (phase == 1) {
       const Sym3 RCA0 = rotated_cov(a, R0, st->x0_S, in);
       for (int o = 0; o < n_off; o++) {
