@@ -1753,7 +1753,10 @@ hipError_t launch_lm_persist(int dof, int threads, int ppt, const PassArgs& a, L
   const int sp = (interleave && dof == 3 && a.n_off == 1 && (ppt == 1 || ppt == 2 || ppt == 4)) ? ppt : 0;
   // ROLO_LM_PERSIST_MCACHE=0 (A/B): no Mahalanobis cache in LDS — every trial inverts again, as the pass kernels do
   static const int mcache_on = [] { const char* e = getenv("ROLO_LM_PERSIST_MCACHE"); return (e && atoi(e) == 0) ? 0 : 1; }();
-  const bool mcache = sp > 0 && !(sp == 4 && threads == 512 && !mcache_on);   // (the A/B form exists for the headline's case)
+  // (the A/B form exists for the headline's case; it is also the form of a launch whose rows + cache would not fit a CU's LDS: four points per thread AND more than ~220
+  // workgroups — a cloud of more than 450 000 points on an idle device — is 60 KB of rows + 96 KB of cache + 10 KB of state)
+  const bool fits = sizeof(unsigned) * (size_t)nrows * 60 + sizeof(double) * 6 * (size_t)threads * sp <= (size_t)(160 - 12) * 1024;
+  const bool mcache = sp > 0 && !(sp == 4 && threads == 512 && (!mcache_on || !fits));
   const size_t lds = sizeof(unsigned) * (size_t)nrows * 60 + (mcache ? sizeof(double) * 6 * (size_t)threads * sp : 0);
   // (builds for four wavefronts per SIMD — 128 registers, so that a walk's wavefronts could share the SIMDs — spill 85 / 159 / 270 registers at 1 / 2 / 4 points per thread and are
   // not instantiated: lm_persist_kernel<3, 512, PPT, 1, 4>, profiles/DEAD_ENDS.md round 6)
