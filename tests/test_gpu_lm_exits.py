@@ -432,3 +432,40 @@ def test_resident_kernel_forms_and_cache_follow_the_pass_launches(sensor, leaf, 
     forced, own, small, large = out["2"]
     assert forced["rot"][1] == 20 and forced["rot"][4] >= 5
     assert any(r[3] == 0 for r in small["trace"]) or any(r[3] == 0 for r in own["trace"])
+
+
+_BIG = r"""
+import sys, json, numpy as np
+sys.path.insert(0, sys.argv[1])
+from rolo_amd import synth
+from rolo_amd.rotvgicp import RotVGICP
+src, tgt, _ = synth.dense_pair("os1-128x2048", seed=synth.SEED)          # 262 144 points per cloud
+j = np.array([0.013, -0.007, 0.011, 0.0], np.float32)
+src = np.concatenate([src, src + j]); tgt = np.concatenate([tgt, tgt + j])   # 524 288: four points per thread on 256 workgroups of the resident kernel
+G = -np.asarray(synth.PREV_STEP_T, np.float64)
+out = {}
+for fused in (0, 2):
+    g = RotVGICP(0); g.setResolution(0.5); g.setLoadHint(0); g._p.fused_lm = fused; g._push()
+    g.setInputTarget(tgt); g.setInputSource(src)
+    g.register_async(None, np.zeros(3), G, G * 0.97)
+    _, _, t = g.register_wait()
+    st, ts = g.last_stats, g.last_translation_stats
+    out[str(fused)] = dict(T=np.asarray(g.final_transformation_d).tolist(), t=np.asarray(t).tolist(), rot=[st.lm_failed, st.n_outer, int(st.converged), st.n_correspondences],
+                           trans=[ts.lm_failed, ts.n_outer], bails=g.counters()["persist_bails"], n=int(src.shape[0]))
+    g.close()
+print(json.dumps(out))
+"""
+
+
+def test_resident_kernel_on_a_cloud_beyond_the_cache_capacity():
+    """524 288 points per cloud on an idle device: 256 workgroups x 4 points per thread — 60 KB of exchange rows + 96 KB of Mahalanobis cache would not fit a CU's 160 KB of LDS
+    beside the state, so the launch takes the form without the cache (passes.hip launch_lm_persist: `fits`). Same exits and counts as pass + controller launches, poses to 1e-10,
+    no bail-out."""
+    import json
+    r = subprocess.run([sys.executable, "-c", _BIG, ROOT], capture_output=True, text=True, cwd=ROOT, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    a, b = out["0"], out["2"]
+    assert a["n"] == 524288 and b["bails"] == 0
+    assert a["rot"] == b["rot"] and a["trans"] == b["trans"], (a, b)
+    assert np.abs(np.array(a["T"]) - np.array(b["T"])).max() < 1e-10 and np.abs(np.array(a["t"]) - np.array(b["t"])).max() < 1e-10
