@@ -469,3 +469,15 @@ def test_resident_kernel_on_a_cloud_beyond_the_cache_capacity():
     assert a["n"] == 524288 and b["bails"] == 0
     assert a["rot"] == b["rot"] and a["trans"] == b["trans"], (a, b)
     assert np.abs(np.array(a["T"]) - np.array(b["T"])).max() < 1e-10 and np.abs(np.array(a["t"]) - np.array(b["t"])).max() < 1e-10
+
+
+@pytest.mark.parametrize("fused", [0, 2])
+@pytest.mark.parametrize("reg", [1, 2, 4])   # MIN_EIG, NORMALIZED_MIN_EIG, FROBENIUS (rot_vgicp.hpp RegularizationMethod): no I - m m^T form — the passes read six entries per covariance
+def test_solve_with_six_entry_covariances(clouds, fused, reg):
+    """the regularisations whose covariance is not of the plane form: the passes (and the resident kernel's Mahalanobis cache, lmp_rotated_cov) rotate the six entries read
+    from memory instead of I - m m^T — exits, counts, poses and the significant trace records against the oracle, a 3 degree guess"""
+    src, tgt = clouds
+    o, g = make_real(src, tgt, fused, regularization=reg)
+    guess = np.eye(4, dtype=np.float32); guess[:3, :3] = synth.rpy_to_R(0.0, 0.01, math.radians(3.0))
+    check_real(o, g, guess)
+    g.close()
