@@ -601,6 +601,9 @@ __global__ __launch_bounds__(256, ROLO_KNN_TAIL_OCC) void knn_tail_kernel(KnnPai
   if (j < cl.q_end) { sp = cl.sorted[j]; qi = __float_as_int(sp.w); }
   const bool act = qi != INT_MAX;
   if (!act && !fuse) return;
+  // (the voxel of a target point: two dependent gathers — slot by original index, id by slot — issued HERE, so that they travel while the SVD runs)
+  int vox_id = -1;
+  if (fuse && act) { const int slot = vf.tgt_slot[qi]; if (slot >= 0) vox_id = slot_id(vf.tab, (unsigned)slot); }
   double c6[6] = {0, 0, 0, 0, 0, 0};
   if (act && MOMENTS) {   // the walk left the neighbourhood's six moments in cov[] (walk_write_moments): regularise them in place
     const size_t pitch = (size_t)n_sorted;
@@ -624,11 +627,7 @@ __global__ __launch_bounds__(256, ROLO_KNN_TAIL_OCC) void knn_tail_kernel(KnnPai
       knn_covariance_tail<KMAX>(ki, (KMAX == 20) ? 20 : k, cl.xyz, cl.n, qi, reg, cl.cov, c6, cl.nrm);
     }
   }
-  if (fuse) {   // every lane of the wavefront takes part in the segmented fold
-    int id = -1;
-    if (act) { const int slot = vf.tgt_slot[qi]; if (slot >= 0) id = slot_id(vf.tab, (unsigned)slot); }
-    accumulate_point(vf.tab, id, sp, c6, fix_scales(cl.n, vf.counters), true, const_cast<int*>(vf.counters) + 1);
-  }
+  if (fuse) accumulate_point(vf.tab, vox_id, sp, c6, fix_scales(cl.n, vf.counters), true, const_cast<int*>(vf.counters) + 1);   // every lane of the wavefront takes part in the segmented fold
 }
 
 // k_correspondences > 64: the same kernel with the neighbour slots walked in a loop (knn_covariance_tail_loop) — correct, not tuned
