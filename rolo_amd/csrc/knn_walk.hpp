@@ -627,7 +627,11 @@ __global__ __launch_bounds__(256, ROLO_KNN_TAIL_OCC) void knn_tail_kernel(KnnPai
       knn_covariance_tail<KMAX>(ki, (KMAX == 20) ? 20 : k, cl.xyz, cl.n, qi, reg, cl.cov, c6, cl.nrm);
     }
   }
+#ifdef ROLO_VOXEL_ACCUM_WAVE   // (A/B: one set of atomics per RUN of a wavefront, rounds 2-5)
   if (fuse) accumulate_point(vf.tab, vox_id, sp, c6, fix_scales(cl.n, vf.counters), true, const_cast<int*>(vf.counters) + 1);   // every lane of the wavefront takes part in the segmented fold
+#else
+  if (fuse) accumulate_point_wg<256>(vf.tab, vox_id, sp, c6, fix_scales(cl.n, vf.counters), const_cast<int*>(vf.counters) + 1);   // every thread of the workgroup takes part (fuse is workgroup-uniform)
+#endif
 }
 
 // k_correspondences > 64: the same kernel with the neighbour slots walked in a loop (knn_covariance_tail_loop) — correct, not tuned
