@@ -658,7 +658,7 @@ __global__ __launch_bounds__(256) void knn_tail_loop_kernel(KnnPair A, int split
   if (fuse) {
     int id = -1;
     if (act) { const int slot = vf.tgt_slot[qi]; if (slot >= 0) id = slot_id(vf.tab, (unsigned)slot); }
-    accumulate_point(vf.tab, id, sp, c6, fix_scales(cl.n, vf.counters), true, const_cast<int*>(vf.counters) + 1);
+    accumulate_point_wg<256>(vf.tab, id, sp, c6, fix_scales(cl.n, vf.counters), const_cast<int*>(vf.counters) + 1);
   }
 }
 
@@ -686,7 +686,7 @@ __global__ __launch_bounds__(256) void knn_unstage_kernel(KnnPair A, int split, 
   if (fuse) {   // every lane of the wavefront takes part in the segmented fold
     int id = -1;
     if (act) { const int slot = vf.tgt_slot[qi]; if (slot >= 0) id = slot_id(vf.tab, (unsigned)slot); }
-    accumulate_point(vf.tab, id, sp, c6, fix_scales(cl.n, vf.counters), true, const_cast<int*>(vf.counters) + 1);
+    accumulate_point_wg<256>(vf.tab, id, sp, c6, fix_scales(cl.n, vf.counters), const_cast<int*>(vf.counters) + 1);
   }
 }
 

@@ -63,7 +63,9 @@ __global__ __launch_bounds__(256) void voxel_accum_kernel(const float4* __restri
       for (int d = 0; d < 6; d++) c[d] = cov[(size_t)d * n + i];
     }
   }
-  accumulate_point(tab, id, p, c, fix_scales(n, counters), fixed_cov != 0, counters + 1);
+  // (fixed_cov is a kernel argument: uniform — every thread of the workgroup takes the same call; the workgroup form meets the runs' sums in LDS first, voxel_dev.hpp)
+  if (fixed_cov) accumulate_point_wg<256>(tab, id, p, c, fix_scales(n, counters), counters + 1);
+  else accumulate_point(tab, id, p, c, fix_scales(n, counters), false, counters + 1);
 }
 
 // ---- the same two kernels over the target in MORTON order (CloudDev::sorted of the neighbour search) -----------------
@@ -135,7 +137,8 @@ __global__ __launch_bounds__(256) void voxel_accum_sorted_kernel(const float4* _
       for (int d = 0; d < 6; d++) c[d] = cov[(size_t)d * n + i];
     }
   }
-  accumulate_point(tab, id, p, c, fix_scales(n, counters), fixed_cov != 0, counters + 1);
+  if (fixed_cov) accumulate_point_wg<256>(tab, id, p, c, fix_scales(n, counters), counters + 1);
+  else accumulate_point(tab, id, p, c, fix_scales(n, counters), false, counters + 1);
 }
 
 __global__ __launch_bounds__(256) void voxel_finalize_kernel(VoxelTable tab, const int* counters, int n_pts, int fixed_cov, int* pub_counters, LmState* lm_state, const FrameArgs* lm_args) {
