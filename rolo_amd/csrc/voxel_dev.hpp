@@ -265,19 +265,27 @@ ROLO_DEV void voxel_insert_point(const VoxelTable& tab, const float4* __restrict
   unsigned long long key;
   if (!pack_key(kx, ky, kz, key)) { atomicMin(&counters[1], ROLO_EKEYRANGE); tgt_slot[i] = -1; tgt_keys[i] = KEY_EMPTY; return; }
   unsigned h = hash_key(key) & tab.mask;
+  bool claimed = false;
   while (true) {
     unsigned long long prev = atomicCAS(slot_key(tab, h), KEY_EMPTY, key);
-    if (prev == KEY_EMPTY) {
-      int id = atomicAdd(&counters[0], 1);
-      set_slot_id(tab, h, id);
-      tab.id_keys[id] = key;
-      double* r = tab.rec + (size_t)id * REC_DOUBLES;
-#pragma unroll
-      for (int d = 0; d < REC_DOUBLES; d++) r[d] = 0.0;
-      break;
-    }
+    if (prev == KEY_EMPTY) { claimed = true; break; }
     if (prev == key) break;
     h = (h + 1) & tab.mask;
+  }
+  if (claimed) {
+    // the compact ids come from ONE counter: the lanes of a wavefront that claimed a slot take theirs with one atomic between them (every claim its own atomic on the one
+    // address: ~5 500 serialised device-scope atomics per launch of the frame's three)
+    const unsigned long long m = __ballot(true);   // (the lanes inside this branch)
+    const int lane = threadIdx.x & 63, leader = __ffsll((long long)m) - 1;
+    int base = 0;
+    if (lane == leader) base = atomicAdd(&counters[0], __popcll(m));
+    base = __shfl(base, leader, 64);
+    const int id = base + __popcll(m & ((1ull << lane) - 1ull));
+    set_slot_id(tab, h, id);
+    tab.id_keys[id] = key;
+    double* r = tab.rec + (size_t)id * REC_DOUBLES;
+#pragma unroll
+    for (int d = 0; d < REC_DOUBLES; d++) r[d] = 0.0;
   }
   tgt_slot[i] = (int)h;
   tgt_keys[i] = key;
