@@ -1760,7 +1760,7 @@ hipError_t launch_lm_persist(int dof, int threads, int ppt, const PassArgs& a, L
   const size_t lds = sizeof(unsigned) * (size_t)nrows * 60 + (mcache ? sizeof(double) * 6 * (size_t)threads * sp : 0);
   // (builds for four wavefronts per SIMD — 128 registers, so that a walk's wavefronts could share the SIMDs — spill 85 / 159 / 270 registers at 1 / 2 / 4 points per thread and are
   // not instantiated: lm_persist_kernel<3, 512, PPT, 1, 4>, profiles/DEAD_ENDS.md round 6)
-  static const int batch4 = [] { const char* e = getenv("ROLO_LM_PERSIST_BATCH"); const int v = e ? atoi(e) : 2; return (v == 1 || v == 4) ? v : 2; }();   // four points per thread go through the bodies in batches of 2 (default: 3 636 scans/s with four contexts) / 1 (3 630) / 4 (3 519: 136 spilled registers)
+  static const int batch4 = [] { const char* e = getenv("ROLO_LM_PERSIST_BATCH"); const int v = e ? atoi(e) : 2; return (v == 1 || v == 4) ? v : 2; }();   // four points per thread go through the bodies in batches of 2 (default: 4 087 scans/s with four contexts, final kernels) / 1 (4 046: twice the dependent round trips and the same 6.6 us per linearising body — the bodies are bound by their fp64 issue at two wavefronts per SIMD, not by their fetches) / 4 (3 761: 144 spilled registers)
 #define LMP_GO(...) lmp_launch<&lm_persist_kernel<__VA_ARGS__>>(nrows, threads, lds, s, a, st, xbuf, trace, ppt, pub, timeout_ticks, admit_ticks, max_trials)
   // (A/B, ROLO_LM_PERSIST_BUSY_THREADS=256: 128 workgroups of 256 threads — one wavefront per SIMD at 256 registers, so that other kernels' wavefronts share the SIMDs
   // instead of finding 64 CUs closed: 3 353 / 3 339 against 3 639 / 3 635 scans/s, profiles/DEAD_ENDS.md round 6)
