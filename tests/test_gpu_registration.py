@@ -1215,3 +1215,42 @@ def test_polar_keys_at_planted_bin_edges():
                        env=dict(os.environ, ROLO_POLAR_EXACT="0"), capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-1500:]
     print("fast device atan2 / acos alone among the planted points (wrong keys, then lookups that miss their own voxel):", r.stdout.strip().split("EDGEDIFF")[-1].strip())
+
+
+@pytest.mark.parametrize("kind", ["sparse", "clumped"])
+def test_voxel_map_through_the_workgroup_table(kind):
+    """K6's accumulation lets the sums of a workgroup's 256 curve-consecutive points meet in a 128-entry LDS table before they go to the records (voxel_dev.hpp
+    accumulate_point_wg). sparse: 8 192 points, (almost) every one a voxel of its own — more distinct voxels per workgroup than the table holds, so runs overflow straight to the
+    records; clumped: 16 384 points in 24 voxels — every table entry collects hundreds of points. Both the staged build (buildVoxelMap) and the map a frame builds inside the
+    search's launches (register_async: VoxelFuse) against the oracle's map: keys and counts equal, means to 1e-12, covariances to 1e-9."""
+    rng = np.random.default_rng(20261001)
+    if kind == "sparse":
+        n = 8192
+        p = rng.uniform(-90.0, 90.0, size=(n, 3))
+    else:
+        n = 16384
+        centres = rng.integers(-20, 20, size=(24, 3)).astype(np.float64) * 0.5 + 0.5   # voxel k covers [k + 0.5, k + 1.5) * leaf: centres sit mid-voxel
+        p = centres[rng.integers(0, 24, size=n)] + rng.uniform(-0.2, 0.2, size=(n, 3))
+    tgt = np.c_[p, np.zeros(n)].astype(np.float32)
+    src = (tgt + np.array([0.01, -0.02, 0.015, 0.0], np.float32)).astype(np.float32)
+    cfg = dict(voxel_type=1, leaf=0.5, polar=(0.175, 0.175, 2.0))
+    o, g = make_both(src, tgt, cfg)
+    assert o.compute_covariances() == 0 and o.build_voxelmap() == 0
+    ko, co, mo, vo = o.voxels()
+    so = np.lexsort(ko.T[::-1])
+    if kind == "sparse":
+        assert len(ko) > 0.98 * n
+    else:
+        assert len(ko) <= 24 * 8
+    def check():
+        kg, cg, mg, vg = g.voxels()
+        sg = np.lexsort(kg.T[::-1])
+        assert kg.shape == ko.shape and np.array_equal(kg[sg], ko[so]) and np.array_equal(cg[sg], co[so])
+        assert np.abs(mg[sg] - mo[so]).max() < 1e-12 and np.abs(vg[sg] - vo[so]).max() < 1e-9
+    g.buildVoxelMap(); check()                       # the staged build: voxel_accum_sorted_kernel
+    g2 = RotVGICP(); g2.setResolution(0.5); g2.setInputTarget(tgt); g2.setInputSource(src)
+    G = np.zeros(3)
+    g2.register_async(None, np.zeros(3), G, G); g2.register_wait()
+    g_keep, g = g, g2
+    check()                                          # the frame's own build: the tail's accumulation
+    g_keep.close(); g2.close()
