@@ -593,7 +593,9 @@ __global__ __launch_bounds__(256, ROLO_KNN_TAIL_OCC) void knn_tail_kernel(KnnPai
   // other some CUs held four of them (tail 42.8 -> 40.5 us); the tail has no reuse between neighbouring workgroups that an XCD-contiguous order would serve
   int which, blk;
   {
-    const int b = (int)blockIdx.x, nb0 = split, nb1 = (int)gridDim.x - split, m = nb0 < nb1 ? nb0 : nb1;
+    // (the alternating order is laid over the XCD-contiguous one: neighbouring workgroups of a cloud still share an XCD, whose L2 merges their scattered stores — dealt
+    // over the XCDs directly the tail wrote 32 instead of 26 MB)
+    const int b = xcd_contiguous_block((int)blockIdx.x, (int)gridDim.x), nb0 = split, nb1 = (int)gridDim.x - split, m = nb0 < nb1 ? nb0 : nb1;
     if (b < 2 * m) { which = b & 1; blk = (b >> 1) + (which ? split : 0); }
     else { which = nb0 > nb1 ? 0 : 1; blk = m + (b - 2 * m) + (which ? split : 0); }
   }
